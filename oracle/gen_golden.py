@@ -1,0 +1,165 @@
+"""Generate tests/golden/*.npz by running the REAL reference on CPU (fp32).
+
+Build-container only (needs /root/reference).  Usage:  python oracle/gen_golden.py
+
+The reference ships no tests or golden vectors, so the fixtures the
+parity tests use are outputs of the reference's own classes on seeded inputs:
+
+  dit_tiny.npz      DiffusionTransformer.forward (dit...:1452-1587) incl. per-layer hidden
+                    states, 2-layer / 128-dim config, weights = oracle.make_state_dict(seed)
+  dit_tiny_sp.npz   the same network evaluated the way sequence-parallel rank r of 2 sees it
+                    for the *embedding/rope* part (rope_H_shift, dit...:1578-1585)
+  rope_tiny.npz     Rotary3DPositionEmbeddingMixin.rotary/_ref/_pose on a random tensor
+  sampler_tiny.npz  RFSampler + Denoiser(RFScaling) + VanillaCFG + OpenAIWrapper, 2 steps
+  sigmas50.npz      50-step schedule (sampling.py:888-903)
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import ref_shims  # noqa: E402
+from oracle import scail_oracle as O  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def bf16r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def tiny_inputs(seed=7, B=2, T=4, H=8, W=8, Lt=12, n_clip=5, text_dim=64):
+    g = torch.Generator().manual_seed(seed)
+    x = bf16r(torch.randn(B, T, 16, H, W, generator=g))
+    ctx = bf16r(torch.randn(B, Lt, text_dim, generator=g))
+    ctx[:, Lt // 2:] = 0            # zeroed padding rows, umt5.py:516-522
+    ref = bf16r(torch.randn(1, 1, 16, H, W, generator=g))
+    pose = bf16r(torch.randn(1, T, 16, H // 2, W // 2, generator=g))
+    clip = bf16r(torch.randn(1, n_clip, 1280, generator=g))
+    t = torch.tensor([731.0, 731.0])
+    return dict(x=x, ctx=ctx, ref=ref, pose=pose, clip=clip, t=t)
+
+
+def gen_dit_tiny():
+    cfg = O.DiTConfig(**O.TINY)
+    sd = O.make_state_dict(cfg, seed=1234)
+    net = ref_shims.build_reference_dit(cfg, sd)
+    inp = tiny_inputs()
+    hidden = []
+    mix = net.mixins["adaln_layer"]
+    orig = mix.layer_forward
+
+    def tap(*a, **k):           # SAT calls the mixin hook directly (transformer.py:712-719)
+        o = orig(*a, **k)
+        hidden.append(o.detach().clone())
+        return o
+
+    mix.layer_forward = tap
+    net.collect_hooks_()        # hooks are snapshotted at add_mixin time (base_model.py:140-176)
+    with torch.no_grad():
+        out = net(inp["x"], timesteps=inp["t"], context=inp["ctx"],
+                  concat_images=torch.zeros(1, *inp["x"].shape[1:]), ref_concat=inp["ref"],
+                  concat_smpl_render=inp["pose"], image_clip_features=inp["clip"])
+    del mix.layer_forward
+    net.collect_hooks_()
+    assert len(hidden) == cfg.num_layers
+    np.savez_compressed(os.path.join(OUT, "dit_tiny.npz"), seed=1234,
+                        **{k: v.numpy() for k, v in inp.items()}, out=out.numpy(),
+                        **{f"hidden{i + 1}": h.numpy() for i, h in enumerate(hidden)})
+    print("dit_tiny: out", tuple(out.shape), "abs-mean", float(out.abs().mean()))
+
+    # sequence-parallel view: rank r of 2 holds rows [r*H/2, (r+1)*H/2) of every latent and
+    # shifts its RoPE window by r*(H/2/patch) (diffusion_video.py:495-503, dit...:1578-1585).
+    # The reference mixin is driven directly (no process group of size 2 needed) to pin the
+    # shifted rope tables + patch embedding for a shard.
+    ref = ref_shims.load_reference()
+    pos = net.mixins["pos_embed"]
+    g = torch.Generator().manual_seed(11)
+    H = inp["x"].shape[3]
+    res = {}
+    for r in range(2):
+        hs = H // 2
+        kw = dict(rope_T=4, rope_H=hs // 2, rope_W=4, rope_H_shift=r * (hs // 2), rope_W_shift=0,
+                  global_rope_H=0, global_rope_W=120)
+        Lr, Ln, Lp = kw["rope_H"] * 4, 4 * kw["rope_H"] * 4, 4 * (kw["rope_H"] // 2) * 2
+        q = torch.randn(1, 4, Lr + Ln + Lp, cfg.head_dim, generator=g)
+        with torch.no_grad():
+            qr = torch.cat([pos.rotary_ref(q[:, :, :Lr], **kw), pos.rotary(q[:, :, Lr:Lr + Ln], **kw),
+                            pos.rotary_pose(q[:, :, -Lp:], **kw)], dim=2)
+        res[f"q{r}"] = q.numpy()
+        res[f"qr{r}"] = qr.numpy()
+    np.savez_compressed(os.path.join(OUT, "rope_tiny_sp.npz"), **res)
+    return cfg, sd, net, inp
+
+
+def gen_rope(cfg, net):
+    pos = net.mixins["pos_embed"]
+    g = torch.Generator().manual_seed(3)
+    kw = dict(rope_T=3, rope_H=6, rope_W=4, rope_H_shift=0, rope_W_shift=0, global_rope_H=0, global_rope_W=120)
+    Lr, Ln, Lp = 6 * 4, 3 * 6 * 4, 3 * 3 * 2
+    q = torch.randn(2, 4, Lr + Ln + Lp, cfg.head_dim, generator=g)
+    with torch.no_grad():
+        qr = torch.cat([pos.rotary_ref(q[:, :, :Lr], **kw), pos.rotary(q[:, :, Lr:Lr + Ln], **kw),
+                        pos.rotary_pose(q[:, :, -Lp:], **kw)], dim=2)
+    np.savez_compressed(os.path.join(OUT, "rope_tiny.npz"), q=q.numpy(), qr=qr.numpy(),
+                        rope_T=3, rope_H=6, rope_W=4)
+    print("rope_tiny:", tuple(qr.shape))
+
+
+def gen_sampler(cfg, sd, net, inp):
+    ref = ref_shims.load_reference()
+    sampling, denoiser_mod, wrappers, guiders = ref["sampling"], ref["denoiser"], ref["wrappers"], ref["guiders"]
+    from sgm.modules.diffusionmodules.denoiser_scaling import RFScaling
+    from sgm.modules.diffusionmodules.denoiser_weighting import EpsWeighting
+
+    class _Den(denoiser_mod.Denoiser):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.weighting = EpsWeighting()
+            self.scaling = RFScaling()
+
+    den = _Den()
+    wrapped = wrappers.OpenAIWrapper(net, compile_model=False, dtype=torch.float32)
+    sampler = sampling.RFSampler(
+        schedule_shift=False, hunyuan_schedule=True, shift_scale=5, mode="normal", num_steps=2, verbose=False,
+        device="cpu",
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.RFDiscretization",
+                               "params": {"reverse": False}},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 4}})
+    g = torch.Generator().manual_seed(21)
+    x0 = torch.randn(1, *inp["x"].shape[1:], generator=g)
+    uc_ctx = torch.zeros_like(inp["ctx"][:1])
+    uc_ctx[:, :1] = bf16r(torch.randn(1, 1, inp["ctx"].shape[-1], generator=g))
+    c_ctx = inp["ctx"][1:2]
+    shared = dict(concat_images=torch.zeros(1, *inp["x"].shape[1:]), ref_concat=inp["ref"],
+                  concat_smpl_render=inp["pose"], image_clip_features=inp["clip"])
+    c = dict(crossattn=c_ctx.clone(), **{k: v.clone() for k, v in shared.items()})
+    uc = dict(crossattn=uc_ctx.clone(), **{k: v.clone() for k, v in shared.items()})
+    # diffusion_video.py:555-563
+    fn = lambda inp_, sigma, cc, **kw: den(wrapped, inp_, sigma, cc, concat_images=None, chunk_dim=None, **kw)
+    with torch.no_grad():
+        xT = sampler(fn, x0.clone(), c, uc=uc)
+    sig = sampling.make_flow_timesteps(0, 2, verbose=False, shift_scale=5, mode="normal")
+    np.savez_compressed(os.path.join(OUT, "sampler_tiny.npz"), x0=x0.numpy(), uc_ctx=uc_ctx.numpy(),
+                        c_ctx=c_ctx.numpy(), xT=xT.numpy(), sigmas=sig.numpy())
+    sig50 = sampling.make_flow_timesteps(0, 50, verbose=False, shift_scale=5, mode="normal")
+    np.savez_compressed(os.path.join(OUT, "sigmas50.npz"), sigmas=sig50.numpy())
+    print("sampler_tiny: xT abs-mean", float(xT.abs().mean()), "sigmas", sig.tolist())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    cfg, sd, net, inp = gen_dit_tiny()
+    gen_rope(cfg, net)
+    gen_sampler(cfg, sd, net, inp)
+
+
+if __name__ == "__main__":
+    main()

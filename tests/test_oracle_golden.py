@@ -1,0 +1,63 @@
+"""Pin the CPU oracle (oracle/scail_oracle.py) to outputs of the REAL reference
+(tests/golden/*.npz, produced by oracle/gen_golden.py in the build container)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import scail_oracle as O
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def test_state_dict_spec_matches_survey_count():
+    cfg = O.DiTConfig(**O.TINY)
+    assert len(O.state_dict_spec(cfg)) == 73           # SURVEY.md Appendix B [probe]
+    n = sum(int(np.prod(s)) for s in O.state_dict_spec(cfg).values())
+    assert n == 2474432                                 # reference parameter count for this config
+
+
+def test_dit_forward_matches_reference(golden_dir):
+    g = _load(golden_dir, "dit_tiny.npz")
+    cfg = O.DiTConfig(**O.TINY)
+    sd = O.make_state_dict(cfg, seed=int(g["seed"]))
+    out, hidden = O.dit_forward(cfg, sd, g["x"], g["t"], g["ctx"], g["ref"], g["pose"], g["clip"], return_hidden=True)
+    for i in range(cfg.num_layers):
+        torch.testing.assert_close(hidden[i + 1], g[f"hidden{i + 1}"], rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(out, g["out"], rtol=2e-5, atol=2e-5)
+
+
+def test_rope_tables_match_reference(golden_dir):
+    g = _load(golden_dir, "rope_tiny.npz")
+    cfg = O.DiTConfig(**O.TINY)
+    cos, sin = O.rope_tables(cfg, int(g["rope_T"]), int(g["rope_H"]), int(g["rope_W"]))
+    torch.testing.assert_close(O.apply_rope(g["q"], cos, sin), g["qr"], rtol=1e-5, atol=2e-6)
+    # interleaved pairs share one angle, pooled or not: the HIP path stores (L, hd/2) tables
+    assert torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2])
+
+
+def test_rope_tables_sequence_parallel_shift(golden_dir):
+    g = _load(golden_dir, "rope_tiny_sp.npz")
+    cfg = O.DiTConfig(**O.TINY)
+    for r in range(2):
+        cos, sin = O.rope_tables(cfg, 4, 2, 4, H_shift=r * 2)
+        torch.testing.assert_close(O.apply_rope(g[f"q{r}"], cos, sin), g[f"qr{r}"], rtol=1e-5, atol=2e-6)
+
+
+def test_sampler_matches_reference(golden_dir):
+    g = _load(golden_dir, "sampler_tiny.npz")
+    d = _load(golden_dir, "dit_tiny.npz")
+    cfg = O.DiTConfig(**O.TINY)
+    sd = O.make_state_dict(cfg, seed=int(d["seed"]))
+    torch.testing.assert_close(O.flow_sigmas(2), g["sigmas"], rtol=0, atol=0)
+    xT, _ = O.sample(cfg, sd, g["x0"], g["c_ctx"], g["uc_ctx"], d["ref"], d["pose"], d["clip"], num_steps=2)
+    torch.testing.assert_close(xT, g["xT"], rtol=5e-5, atol=5e-5)
+
+
+def test_sigmas50(golden_dir):
+    g = _load(golden_dir, "sigmas50.npz")
+    s = O.flow_sigmas(50)
+    assert torch.equal(s, g["sigmas"])
+    assert s[0] == 1.0 and s[-1] == 0.0 and abs(float(s[1]) - 0.9959) < 1e-4
