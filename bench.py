@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): denoising-step latent tokens/sec, SCAIL-14B, 512p x 81 f.
+
+One "step" = one full sampler step of the reference (sampling.py:960-963): a batch-2 (uncond, cond)
+DiT forward over the L = 48 832 token sequence [ref | noise | pose] + CFG combine + Euler update on
+the fp32 state.  value = 37 632 noise tokens / t_step, whole job.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Inputs are synthetic and already resident in HBM when the timed region starts; weights
+are random-init bf16 of the 14B architecture (no checkpoint offline).  Nothing is skipped inside the
+timed region: the step-invariant text/CLIP K,V cache of the engine is DISABLED here, so every step
+recomputes text_embedding / clip_proj / 40x K,V projections exactly like the reference does.
+
+N > 1 shards the token axis (sequence parallel, K/V all-gather over xGMI) -> "scaling": "strong".
+The JSON line also carries
+  roofline     MFMA roofline of the dominant kernel (self-attention flash kernel): algorithmic
+               4*Lq*Lk*128*heads*B FLOP per launch / mean launch time measured with HIP events on the
+               launch stream inside the timed region; peak 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md);
+  cpu_baseline the CPU oracle (fp32 port of the reference block) timed on this box's host cores on a
+               bounded sample, converted to the metric by algorithmic FLOPs (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (network params, latent T,H,W, text tokens, clip tokens)
+    "14b": (dict(hidden_size=5120, num_layers=40, num_attention_heads=40, inner_hidden_size=13824, text_dim=4096,
+                 time_freq_dim=256, time_embed_dim=5120), (21, 64, 112), 512, 257),
+    "1.3b": (dict(hidden_size=1536, num_layers=30, num_attention_heads=12, inner_hidden_size=8960, text_dim=4096,
+                  time_freq_dim=256, time_embed_dim=1536), (21, 64, 112), 512, 257),
+    "tiny": (dict(hidden_size=256, num_layers=2, num_attention_heads=2, inner_hidden_size=512, text_dim=64,
+                  time_freq_dim=256, time_embed_dim=256), (4, 8, 8), 12, 5),
+}
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def step_flops(p, L, Lt, Lc, B=2):
+    """Algorithmic FLOPs of one sampler step."""
+    D, FF, nl = p["hidden_size"], p["inner_hidden_size"], p["num_layers"]
+    per = 8 * L * D * D + 4 * L * D * D + 4 * (Lt + Lc) * D * D + 4 * L * D * FF + 4 * L * L * D + 4 * L * (Lt + Lc) * D
+    return per * nl * B
+
+
+class KernelTimer:
+    """HIP-event bracket around tagged launches on the current (launch) stream."""
+
+    def __init__(self):
+        self.events = {}
+        self.enabled = False
+
+    def run(self, tag, fn, *a, **k):
+        if not self.enabled:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        self.events.setdefault(tag, []).append((e0, e1))
+        return r
+
+    def mean_ms(self, tag):
+        ev = self.events.get(tag, [])
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
+
+
+def cpu_baseline(p, n_threads=None):
+    """Time the CPU oracle (fp32 restatement of the reference block, oracle/scail_oracle.py) on a bounded
+    sample: ONE transformer block at the real width on a (5, 32, 56) latent (L = 3 248 tokens, B = 2)."""
+    from oracle import scail_oracle as O
+    n_threads = n_threads or os.cpu_count()
+    torch.set_num_threads(n_threads)
+    cfg = O.DiTConfig(hidden_size=p["hidden_size"], num_layers=1, num_attention_heads=p["num_attention_heads"],
+                      inner_hidden_size=p["inner_hidden_size"], text_dim=64, time_embed_dim=p["hidden_size"])
+    g = torch.Generator().manual_seed(0)
+    D = cfg.hidden_size
+    sd = {k: torch.randn(s, generator=g) * 0.02 for k, s in O.state_dict_spec(cfg).items()
+          if ".layers.0." in k or "adaln_layer" in k}
+    T, H, W, Lt, Lc = 5, 32, 56, 512, 257
+    cos, sin = O.rope_tables(cfg, T, H // 2, W // 2)
+    Ls = cos.shape[0]
+    h = torch.randn(2, Ls, D, generator=g)
+    adaln, text, clip = torch.randn(2, 6 * D, generator=g), torch.randn(2, Lt, D, generator=g), torch.randn(2, Lc, D, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.block(cfg, sd, 0, h, adaln, text, clip, cos, sin)
+        dt = time.perf_counter() - t0
+    fl = step_flops(dict(p, num_layers=1), Ls, Lt, Lc)
+    return dt, fl, Ls, n_threads
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=os.environ.get("SCAIL_BENCH_CONFIG", "14b"), choices=list(CONFIGS))
+    ap.add_argument("--layers", type=int, default=None, help="DEBUG ONLY: fewer layers (result flagged invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg-scale", type=float, default=4.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from scail_amd import lib, ops, parallel
+    from scail_amd.dit import DiffusionTransformer
+    from scail_amd.sampler import make_flow_timesteps
+    lib.load()
+    sp = parallel.init_from_env("nccl") if world > 1 else None
+    import torch.distributed as dist
+
+    p, (T, H, W), Lt, Lc = CONFIGS[args.config]
+    p = dict(p)
+    if args.layers is not None:
+        p["num_layers"] = args.layers
+    net = DiffusionTransformer(transformer_args=dict(model_parallel_size=1), num_frames=81, latent_width=300,
+                               latent_height=300, share_adaln=True, use_i2v_clip=True, device=dev, init_seed=1234, **p)
+    net.cache_conditioning = False          # recompute text/CLIP K,V every step like the reference
+    net.sp = sp
+    timer = KernelTimer()
+    net.kernel_timer = timer
+
+    # ---- synthetic inputs, identical on every rank, already on the GPU ----
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, T, 16, H, W, generator=g).to(dev)
+    ref = torch.randn(1, 1, 16, H, W, generator=g).to(dev).to(torch.bfloat16)
+    pose = torch.randn(1, T, 16, H // 2, W // 2, generator=g).to(dev).to(torch.bfloat16)
+    c_ctx = torch.randn(1, Lt, p["text_dim"], generator=g)
+    c_ctx[:, 64:] = 0                        # zeroed padding rows (umt5.py:516-522)
+    uc_ctx = torch.zeros(1, Lt, p["text_dim"])
+    uc_ctx[:, :1] = torch.randn(1, 1, p["text_dim"], generator=g)
+    ctx = torch.cat([uc_ctx, c_ctx], 0).to(dev).to(torch.bfloat16)
+    clip = torch.randn(1, Lc, 1280, generator=g).to(dev).to(torch.bfloat16)
+    chunk_dim = None
+    if sp is not None:
+        chunk_dim = 3 if H < W else 4
+        sp.check_latent(H, W, chunk_dim)
+        x, ref, pose = sp.chunk(x, chunk_dim), sp.chunk(ref, chunk_dim), sp.chunk(pose, chunk_dim)
+    sig = make_flow_timesteps(0, 50, shift_scale=5, mode="normal")
+    dummy = torch.zeros(1, device=dev)
+
+    def step(i):
+        xin = torch.cat([x, x], 0)
+        t = (sig[i] * 1000.0).repeat(2).to(dev)
+        v = net.forward_f32(xin, t, ctx, None, concat_images=dummy, ref_concat=ref, concat_smpl_render=pose,
+                            image_clip_features=clip, chunk_dim=chunk_dim)
+        ops.cfg_euler_(x, v, args.cfg_scale, float(sig[i + 1] - sig[i]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    timer.enabled = True
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    finite = bool(torch.isfinite(x).all().item())
+
+    hp, wp = H // 2, W // 2
+    Lnoise = T * hp * wp
+    L = hp * wp + Lnoise + T * (H // 4) * (W // 4)
+    t_step = elapsed / args.steps
+    nh = p["num_attention_heads"]
+    attn_ms = timer.mean_ms("self_attn")
+    attn_flops = 4.0 * (L // world) * L * 128 * nh * 2
+    ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms else None
+    fl = step_flops(p, L, Lt, Lc)
+    out = {
+        "metric": "denoising-step latent tokens/sec", "value": Lnoise / t_step, "unit": "latent tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SCAIL-{args.config} DiT sampler step (batch-2 CFG forward + Euler), 512x896x81f latent "
+                               f"({T},16,{H},{W}), L={L} tokens (ref+noise+pose), text {Lt}, clip {Lc}, "
+                               f"{p['num_layers']} layers, random-init bf16 weights",
+                   "parallelism": f"sp{world}", "cond_cache": False, "noise_tokens": Lnoise, "all_tokens_x_batch": 2 * L,
+                   "step_tflop": fl / 1e12, "step_mfma_frac": fl / t_step / (world * PEAK_BF16_TFLOPS * 1e12),
+                   "finite": finite},
+        "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel (self-attention)", "achieved": ach,
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
+                     "traffic": None, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,
+                     "launches_timed": len(timer.events.get("self_attn", []))},
+    }
+    if args.layers is not None:
+        out["config"]["INVALID_debug_layers"] = args.layers
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        dt, cfl, Ls, nt = cpu_baseline(p)
+        rate = cfl / dt
+        out["cpu_baseline"] = {
+            "value": Lnoise / (fl / rate), "unit": "latent tokens/s", "cores": nt, "kind": "port",
+            "sample": f"oracle block (fp32, torch CPU, {nt} threads) at full width D={p['hidden_size']}, B=2, L={Ls} tokens "
+                      f"(latent 5x32x56): {dt:.2f} s for {cfl / 1e12:.2f} TFLOP = {rate / 1e12:.3f} TFLOP/s; value = "
+                      f"noise tokens / (step FLOPs / that rate), i.e. EXTRAPOLATED by algorithmic FLOPs"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,8 +5,9 @@ Build-container only (needs /root/reference).  Usage:  python oracle/gen_golden.
 The reference ships no tests or golden vectors, so the fixtures the
 parity tests use are outputs of the reference's own classes on seeded inputs:
 
-  dit_tiny.npz      DiffusionTransformer.forward (dit...:1452-1587) incl. per-layer hidden
-                    states, 2-layer / 128-dim config, weights = oracle.make_state_dict(seed)
+  dit_tiny.npz      DiffusionTransformer.forward (dit...:1452-1587) incl. per-layer hidden states,
+                    2-layer / 256-dim / 2-head config, weights = oracle.make_state_dict(seed)
+  dit_config1.npz   the same for BASELINE.json configs[0] (2-layer / 128-dim / 1 head)
   dit_tiny_sp.npz   the same network evaluated the way sequence-parallel rank r of 2 sees it
                     for the *embedding/rope* part (rope_H_shift, dit...:1578-1585)
   rope_tiny.npz     Rotary3DPositionEmbeddingMixin.rotary/_ref/_pose on a random tensor
@@ -46,8 +47,8 @@ def tiny_inputs(seed=7, B=2, T=4, H=8, W=8, Lt=12, n_clip=5, text_dim=64):
     return dict(x=x, ctx=ctx, ref=ref, pose=pose, clip=clip, t=t)
 
 
-def gen_dit_tiny():
-    cfg = O.DiTConfig(**O.TINY)
+def gen_dit_tiny(name="dit_tiny", cfgd=None):
+    cfg = O.DiTConfig(**(cfgd or O.TINY))
     sd = O.make_state_dict(cfg, seed=1234)
     net = ref_shims.build_reference_dit(cfg, sd)
     inp = tiny_inputs()
@@ -69,11 +70,13 @@ def gen_dit_tiny():
     del mix.layer_forward
     net.collect_hooks_()
     assert len(hidden) == cfg.num_layers
-    np.savez_compressed(os.path.join(OUT, "dit_tiny.npz"), seed=1234,
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=1234,
                         **{k: v.numpy() for k, v in inp.items()}, out=out.numpy(),
                         **{f"hidden{i + 1}": h.numpy() for i, h in enumerate(hidden)})
-    print("dit_tiny: out", tuple(out.shape), "abs-mean", float(out.abs().mean()))
+    print(name + ": out", tuple(out.shape), "abs-mean", float(out.abs().mean()))
 
+    if name != "dit_tiny":
+        return cfg, sd, net, inp
     # sequence-parallel view: rank r of 2 holds rows [r*H/2, (r+1)*H/2) of every latent and
     # shifts its RoPE window by r*(H/2/patch) (diffusion_video.py:495-503, dit...:1578-1585).
     # The reference mixin is driven directly (no process group of size 2 needed) to pin the
@@ -88,7 +91,7 @@ def gen_dit_tiny():
         kw = dict(rope_T=4, rope_H=hs // 2, rope_W=4, rope_H_shift=r * (hs // 2), rope_W_shift=0,
                   global_rope_H=0, global_rope_W=120)
         Lr, Ln, Lp = kw["rope_H"] * 4, 4 * kw["rope_H"] * 4, 4 * (kw["rope_H"] // 2) * 2
-        q = torch.randn(1, 4, Lr + Ln + Lp, cfg.head_dim, generator=g)
+        q = torch.randn(1, 2, Lr + Ln + Lp, cfg.head_dim, generator=g)
         with torch.no_grad():
             qr = torch.cat([pos.rotary_ref(q[:, :, :Lr], **kw), pos.rotary(q[:, :, Lr:Lr + Ln], **kw),
                             pos.rotary_pose(q[:, :, -Lp:], **kw)], dim=2)
@@ -103,7 +106,7 @@ def gen_rope(cfg, net):
     g = torch.Generator().manual_seed(3)
     kw = dict(rope_T=3, rope_H=6, rope_W=4, rope_H_shift=0, rope_W_shift=0, global_rope_H=0, global_rope_W=120)
     Lr, Ln, Lp = 6 * 4, 3 * 6 * 4, 3 * 3 * 2
-    q = torch.randn(2, 4, Lr + Ln + Lp, cfg.head_dim, generator=g)
+    q = torch.randn(2, 2, Lr + Ln + Lp, cfg.head_dim, generator=g)
     with torch.no_grad():
         qr = torch.cat([pos.rotary_ref(q[:, :, :Lr], **kw), pos.rotary(q[:, :, Lr:Lr + Ln], **kw),
                         pos.rotary_pose(q[:, :, -Lp:], **kw)], dim=2)
@@ -156,6 +159,7 @@ def gen_sampler(cfg, sd, net, inp):
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
+    gen_dit_tiny("dit_config1", O.CONFIG1)
     cfg, sd, net, inp = gen_dit_tiny()
     gen_rope(cfg, net)
     gen_sampler(cfg, sd, net, inp)

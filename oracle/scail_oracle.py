@@ -65,9 +65,15 @@ class DiTConfig:
         return t, self.latent_height // self.patch_size[1], self.latent_width // self.patch_size[2]
 
 
-TINY = dict(hidden_size=128, num_layers=2, num_attention_heads=4, inner_hidden_size=256,
-            text_dim=64, time_freq_dim=256, time_embed_dim=128, latent_height=32, latent_width=32,
+# Test-size configs.  head_dim is 128 in both (the shipped 14B and 1.3B configs both use 128 and
+# the HIP attention kernel is specialised for it).  TINY has two heads so head indexing is
+# exercised; CONFIG1 is BASELINE.json configs[0] ("2-layer/128-dim ... 4x8x8 latent").
+TINY = dict(hidden_size=256, num_layers=2, num_attention_heads=2, inner_hidden_size=512,
+            text_dim=64, time_freq_dim=256, time_embed_dim=256, latent_height=32, latent_width=32,
             num_frames=13)
+CONFIG1 = dict(hidden_size=128, num_layers=2, num_attention_heads=1, inner_hidden_size=256,
+               text_dim=64, time_freq_dim=256, time_embed_dim=128, latent_height=32, latent_width=32,
+               num_frames=13)
 
 
 def state_dict_spec(cfg: DiTConfig) -> Dict[str, Tuple[int, ...]]:

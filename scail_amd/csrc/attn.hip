@@ -1,0 +1,255 @@
+// Flash attention (no mask, head_dim 128) for the SCAIL DiT on gfx950: self-attention over the
+// concatenated [ref | noise | pose] token sequence (L = 48 832 at 512p x 81 f) and the two short
+// cross-attentions (512 text / 257 CLIP keys).
+//
+// Work decomposition: one 512-thread workgroup (8 waves) per (256 query rows, head, batch); each
+// wave owns 32 query rows.  K and V^T tiles of 64 keys are staged through registers into a
+// double-buffered LDS ring shared by the 8 waves (one barrier per tile; the global loads of tile
+// t+1 are issued before the MFMAs of tile t and written to the other buffer after them).
+//
+// MFMA formulation (v_mfma_f32_32x32x16_bf16), chosen so that NO cross-lane data movement is
+// needed between the two GEMMs:
+//   S^T = K . Q^T    A = K fragment  (rows = keys, from LDS), B = Q fragment (registers, loaded once)
+//                    -> lane (q = lane & 31, g = lane >> 5) holds, for its query row q, the scores of
+//                       keys 32 f + (r & 3) + 8 (r >> 2) + 4 g,  f = 0..1, r = 0..15
+//   O^T += V^T . P^T A = V^T fragment (rows = d, from LDS),  B = P^T fragment = the SAME lane's 8
+//                       consecutive score registers packed to bf16.  The MFMA contraction only needs
+//                       A and B to agree on which key sits in k-slot (g, j); V^T is stored with key
+//                       bits 2 and 3 swapped inside each 16-key group (scail_transpose_v), which makes
+//                       the 8 keys of slot group (ks, g) one contiguous 16-byte LDS read.
+// Online softmax in fp32 (running max m, running sum l per query row, exp2 with the scale folded
+// in); a row's two lanes (g = 0, 1) keep the same m and separate partial l that are added once at
+// the end.  LDS rows are padded (K: 272 B, V^T: 144 B) so every ds_read_b128 service group touches
+// 16 distinct 16-byte slots.
+#include "common.h"
+
+#define HD 128
+#define QBLK 256
+#define KVBLK 64
+#define ATT_THREADS 512
+#define K_LD (HD + 8)      // elements per K row in LDS (272 B)
+#define V_LD (KVBLK + 8)   // elements per V^T row in LDS (144 B)
+#define ATT_LDS_BYTES (2 * (KVBLK * K_LD + HD * V_LD) * 2)
+
+struct AttnParams {
+    const u16* q; int64_t q_bs, q_rs;
+    const u16* k; int64_t k_ss, k_bs, k_rs;
+    const u16* vt; int64_t vt_ss, vt_bs;
+    u16* o; int64_t o_bs, o_rs;
+    int heads, Lq, Lk, Lkp, n_seg;
+    float sl2;  // scale * log2(e)
+    int accumulate;
+};
+
+__global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Ks = smem;                       // [2][KVBLK][K_LD]
+    u16* Vs = smem + 2 * KVBLK * K_LD;    // [2][HD][V_LD]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ql = lane & 31, g = lane >> 5;
+    const int h = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int q0 = blockIdx.x * QBLK + wave * 32;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16 ks + 8 g .. +7] ----
+    bf16x8 qf[HD / 16];
+    {
+        const int qrow = min(q0 + ql, p.Lq - 1);
+        const u16* qp = p.q + b * p.q_bs + (int64_t)qrow * p.q_rs + (int64_t)h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    }
+
+    // ---- staging coordinates (2 K chunks + 2 V^T chunks of 16 B per thread per tile) ----
+    const int krow = tid >> 4, kcc = tid & 15;  // K chunk c = tid + 512 i: row = (tid>>4) + 32 i
+    const int vrow = tid >> 3, vcc = tid & 7;   // V chunk c = tid + 512 i: row = (tid>>3) + 64 i
+    const u16* kbase = p.k + b * p.k_bs + (int64_t)h * HD + kcc * 8;
+    const u16* vbase = p.vt + b * p.vt_bs + (int64_t)h * HD * p.Lkp + vcc * 8;
+    const int tps = p.Lkp / KVBLK;          // tiles per segment
+    const int ntiles = tps * p.n_seg;
+    uint4 kr0, kr1, vr0, vr1;  // named scalars (register arrays written under a branch go to scratch)
+#define G_LOAD(tt_)                                                                               \
+    {                                                                                             \
+        const int seg_ = (tt_) / tps, t_ = (tt_) - seg_ * tps;                                    \
+        const int key0_ = t_ * KVBLK;                                                             \
+        const u16* kp_ = kbase + (int64_t)seg_ * p.k_ss;                                          \
+        const u16* vp_ = vbase + (int64_t)seg_ * p.vt_ss + key0_;                                 \
+        kr0 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow, p.Lk - 1) * p.k_rs);       \
+        kr1 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + 32, p.Lk - 1) * p.k_rs);  \
+        vr0 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)vrow * p.Lkp);                       \
+        vr1 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + 64) * p.Lkp);                \
+    }
+#define S_STORE(buf_)                                                                             \
+    {                                                                                             \
+        *reinterpret_cast<uint4*>(Ks + ((buf_) * KVBLK + krow) * K_LD + kcc * 8) = kr0;           \
+        *reinterpret_cast<uint4*>(Ks + ((buf_) * KVBLK + krow + 32) * K_LD + kcc * 8) = kr1;      \
+        *reinterpret_cast<uint4*>(Vs + ((buf_) * HD + vrow) * V_LD + vcc * 8) = vr0;              \
+        *reinterpret_cast<uint4*>(Vs + ((buf_) * HD + vrow + 64) * V_LD + vcc * 8) = vr1;         \
+    }
+
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl2 = p.sl2;
+    const int tail = p.Lk - (tps - 1) * KVBLK;  // valid keys in the last tile of a segment (1..64)
+
+    G_LOAD(0)
+    // drain the Q-fragment loads here: otherwise hipcc's in-order vmcnt bookkeeping makes the first
+    // QK^T MFMAs of EVERY iteration wait for the freshly issued tile t+1 loads (vmcnt(3..0))
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
+    S_STORE(0)
+    __syncthreads();
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int cur = tt & 1;
+        if (tt + 1 < ntiles) G_LOAD(tt + 1)
+
+        // ---- S^T = K Q^T ----
+        f32x16 s[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[f][e] = 0.f;
+        const u16* ks_ = Ks + (cur * KVBLK + ql) * K_LD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + f * 32 * K_LD + ks * 16);
+                s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[f], 0, 0, 0);
+            }
+        }
+        // ---- mask the padded keys of a segment's last tile ----
+        if (tail < KVBLK) {
+            const int t = tt % tps;
+            if (t == tps - 1) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        if (key >= tail) s[f][r] = -INFINITY;
+                    }
+            }
+        }
+        // ---- online softmax ----
+        float mx = s[0][0];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[f][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+        const float msc = m_new * sl2;
+        float rs = 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[f][r] * sl2 - msc);
+                s[f][r] = pv;
+                rs += pv;
+            }
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        // ---- P^T fragments: k-slot group ks <-> score registers s[ks>>1][8 (ks&1) .. +7] ----
+        bf16x8 pf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 u;
+            const int f = ks >> 1, r0 = (ks & 1) * 8;
+            u.x = pack_bf16x2(s[f][r0 + 0], s[f][r0 + 1]);
+            u.y = pack_bf16x2(s[f][r0 + 2], s[f][r0 + 3]);
+            u.z = pack_bf16x2(s[f][r0 + 4], s[f][r0 + 5]);
+            u.w = pack_bf16x2(s[f][r0 + 6], s[f][r0 + 7]);
+            pf[ks] = __builtin_bit_cast(bf16x8, u);
+        }
+        // ---- O^T += V^T P^T ----
+        const u16* vs_ = Vs + (cur * HD + ql) * V_LD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int d = 0; d < HD / 32; ++d) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * V_LD + ks * 16);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[d], 0, 0, 0);
+            }
+        }
+        if (tt + 1 < ntiles) { S_STORE(cur ^ 1) }
+        __syncthreads();
+    }
+
+    // ---- epilogue: O[q][32 d + 8 rr + 4 g + e] ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + ql;
+    if (qrow < p.Lq) {
+        u16* op = p.o + b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * HD + 4 * g;
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * rr + e] * inv;
+                uint2* dst = reinterpret_cast<uint2*>(op + d * 32 + rr * 8);
+                if (p.accumulate) {
+                    const uint2 old = *dst;
+                    v[0] += bf_lo(old.x); v[1] += bf_hi(old.x);
+                    v[2] += bf_lo(old.y); v[3] += bf_hi(old.y);
+                }
+                uint2 w;
+                w.x = pack_bf16x2(v[0], v[1]);
+                w.y = pack_bf16x2(v[2], v[3]);
+                *dst = w;
+            }
+        }
+    }
+}
+
+extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t q_rs,
+                                     const scail_bf16* k, int64_t k_ss, int64_t k_bs, int64_t k_rs,
+                                     const scail_bf16* vt, int64_t vt_ss, int64_t vt_bs,
+                                     scail_bf16* o, int64_t o_bs, int64_t o_rs,
+                                     int64_t n_batch, int64_t heads, int64_t Lq, int64_t Lk, int64_t n_seg,
+                                     float scale, int accumulate, void* stream) {
+    SCAIL_REQUIRE(Lk >= 1 && n_seg >= 1, "need at least one key");
+    SCAIL_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && o_rs % 4 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 &&
+                      k_ss % 8 == 0 && vt_ss % 8 == 0 && o_bs % 4 == 0,
+                  "strides must keep 16-byte (q,k,vt) / 8-byte (o) alignment");
+    SCAIL_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(k) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(vt) & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 7) == 0,
+                  "pointer alignment");
+    const int64_t Lkp = (Lk + 63) / 64 * 64;
+    SCAIL_REQUIRE(vt_bs == 0 || vt_bs == heads * HD * Lkp, "vt batch stride must be 0 or heads*128*ceil64(Lk)");
+    SCAIL_REQUIRE(Lq < (1ll << 31) && Lkp * n_seg < (1ll << 31), "sequence too long");
+    if (Lq == 0 || n_batch == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("flash_attn: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    AttnParams p;
+    p.q = q; p.q_bs = q_bs; p.q_rs = q_rs;
+    p.k = k; p.k_ss = k_ss; p.k_bs = k_bs; p.k_rs = k_rs;
+    p.vt = vt; p.vt_ss = vt_ss; p.vt_bs = vt_bs;
+    p.o = o; p.o_bs = o_bs; p.o_rs = o_rs;
+    p.heads = (int)heads; p.Lq = (int)Lq; p.Lk = (int)Lk; p.Lkp = (int)Lkp; p.n_seg = (int)n_seg;
+    p.sl2 = scale * 1.4426950408889634f;
+    p.accumulate = accumulate;
+    dim3 grid((unsigned)((Lq + QBLK - 1) / QBLK), (unsigned)heads, (unsigned)n_batch);
+    hipLaunchKernelGGL(flash_attn_kernel, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p);
+    return scail_check_launch("flash_attn");
+}

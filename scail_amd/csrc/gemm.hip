@@ -1,0 +1,209 @@
+// bf16 GEMM  y = epilogue(x . W^T + bias)  on MFMA 32x32x16 (gfx950), fp32 accumulate.
+//
+// Tile 128(m) x 128(n) x 64(k), 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA fragments.
+// Both operands are K-contiguous in HBM (x rows, torch-Linear W rows), so both tiles are staged
+// row-major into LDS through registers (16-byte global loads, 16-byte ds_write), rows padded to
+// 144 B so that the 16-lane service groups of ds_read_b128 hit 16 distinct 16-byte slots (no bank
+// conflicts), double-buffered with ONE barrier per k-tile: the global loads of tile t+1 are issued
+// before the MFMAs of tile t and written to the other buffer after them.
+//
+// The MFMA is issued "transposed" (A operand = W fragment, B operand = x fragment), so a lane's
+// accumulator registers run along n: 4 consecutive output columns per register quad -> 8-byte
+// stores and float4 bias / gate loads in the epilogue.
+//
+// Block -> tile map: XCD-aware remap (block b runs on XCD b % 8; give each XCD a contiguous range
+// of tiles so neighbours share operand panels in that XCD's L2), then grouped ordering (8 m-tiles
+// per group, m fastest) so the 64 co-resident tiles of an XCD touch 8 + 8 operand panels.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define LDT 72  // padded LDS row, elements (144 B)
+#define GEMM_THREADS 256
+#define GEMM_LDS_BYTES (2 * (BM + BN) * LDT * 2)
+#define GROUP_M 8
+
+struct GemmParams {
+    const u16* x; int64_t lda;
+    const u16* w;
+    const float* bias;
+    u16* y; int64_t ldc;
+    int M, N, K;
+    const u16* resid; int64_t ldr;
+    const float* gate; int64_t gate_stride; int64_t rows_per_batch;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Xs = smem;                  // [2][BM][LDT]
+    u16* Ws = smem + 2 * BM * LDT;   // [2][BN][LDT]
+
+    // ---- tile mapping ----
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nb = tiles_m * tiles_n;
+    int wg;
+    {
+        const int id = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = id & 7, loc = id >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int in_group = GROUP_M * tiles_n;
+    const int gid = wg / in_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int pid_m = first_m + (wg % in_group) % gsz;
+    const int pid_n = (wg % in_group) / gsz;
+    const int m0 = pid_m * BM, n0 = pid_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, g = lane >> 5;
+
+    // ---- staging coordinates: chunk = tid + 256 i  -> row = (tid >> 3) + 32 i, kc = tid & 7 ----
+    const int srow = tid >> 3, kc = tid & 7;
+    // (named scalars, not arrays: hipcc sends register arrays written under a branch to scratch)
+#define ROWPTR(i_)                                                                              \
+    const u16* xptr##i_ = p.x + (int64_t)min(m0 + srow + 32 * i_, p.M - 1) * p.lda + kc * 8;    \
+    const u16* wptr##i_ = p.w + (int64_t)min(n0 + srow + 32 * i_, p.N - 1) * p.K + kc * 8;      \
+    uint4 xr##i_, wr##i_;
+    ROWPTR(0) ROWPTR(1) ROWPTR(2) ROWPTR(3)
+#define G_LOAD1(i_, k0_)                                              \
+    xr##i_ = *reinterpret_cast<const uint4*>(xptr##i_ + (k0_));       \
+    wr##i_ = *reinterpret_cast<const uint4*>(wptr##i_ + (k0_));
+#define G_LOAD(k0_) G_LOAD1(0, k0_) G_LOAD1(1, k0_) G_LOAD1(2, k0_) G_LOAD1(3, k0_)
+#define S_STORE1(i_, buf_)                                                                        \
+    *reinterpret_cast<uint4*>(Xs + ((buf_) * BM + srow + 32 * i_) * LDT + kc * 8) = xr##i_;       \
+    *reinterpret_cast<uint4*>(Ws + ((buf_) * BN + srow + 32 * i_) * LDT + kc * 8) = wr##i_;
+#define S_STORE(buf_) S_STORE1(0, buf_) S_STORE1(1, buf_) S_STORE1(2, buf_) S_STORE1(3, buf_)
+
+    f32x16 acc[2][2];  // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int nk = p.K / BK;
+    G_LOAD(0)
+    S_STORE(0)
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) { G_LOAD((t + 1) * BK) }
+        const u16* xs = Xs + (cur * BM + wm * 64 + l31) * LDT + g * 8;
+        const u16* ws = Ws + (cur * BN + wn * 64 + l31) * LDT + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * LDT + ks * 16);
+                xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * LDT + ks * 16);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (t + 1 < nk) { S_STORE(cur ^ 1) }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column m, rows n = nbase + 8 rr + 4 g + e ----
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = m0 + wm * 64 + mi * 32 + l31;
+        if (m >= p.M) continue;
+        int64_t bidx = 0;
+        if (EPI == SCAIL_EPI_RESID && p.gate != nullptr) bidx = (int64_t)m / p.rows_per_batch;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int n = n0 + wn * 64 + ni * 32 + 8 * rr + 4 * g;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * rr + e];
+                if (p.bias != nullptr) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (EPI == SCAIL_EPI_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                } else if (EPI == SCAIL_EPI_GELU_ERF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                } else if (EPI == SCAIL_EPI_RESID) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(p.resid + (int64_t)m * p.ldr + n);
+                    float gt[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (p.gate != nullptr) {
+                        const float4 gg = *reinterpret_cast<const float4*>(p.gate + bidx * p.gate_stride + n);
+                        gt[0] = gg.x; gt[1] = gg.y; gt[2] = gg.z; gt[3] = gg.w;
+                    }
+                    v[0] = bf_lo(rv.x) + gt[0] * v[0];
+                    v[1] = bf_hi(rv.x) + gt[1] * v[1];
+                    v[2] = bf_lo(rv.y) + gt[2] * v[2];
+                    v[3] = bf_hi(rv.y) + gt[3] * v[3];
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(p.y + (int64_t)m * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("gemm: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((unsigned)tiles), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, p);
+    return scail_check_launch("gemm_bf16");
+}
+
+extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf16* w, const float* bias,
+                               scail_bf16* y, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                               const scail_bf16* resid, int64_t ldr, const float* gate, int64_t gate_stride,
+                               int64_t rows_per_batch, void* stream) {
+    SCAIL_REQUIRE(K > 0 && K % BK == 0, "K must be a positive multiple of 64");
+    SCAIL_REQUIRE(N % 8 == 0, "N must be a multiple of 8");
+    SCAIL_REQUIRE(lda % 8 == 0 && ldc % 4 == 0, "lda must be a multiple of 8, ldc of 4");
+    SCAIL_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "dimension too large");
+    SCAIL_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0,
+                  "pointer alignment");
+    if (M == 0 || N == 0) return 0;
+    GemmParams p;
+    p.x = x; p.lda = lda; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.resid = resid; p.ldr = ldr; p.gate = gate; p.gate_stride = gate_stride; p.rows_per_batch = rows_per_batch;
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case SCAIL_EPI_BIAS: return launch_gemm<SCAIL_EPI_BIAS>(p, s);
+        case SCAIL_EPI_GELU_TANH: return launch_gemm<SCAIL_EPI_GELU_TANH>(p, s);
+        case SCAIL_EPI_GELU_ERF: return launch_gemm<SCAIL_EPI_GELU_ERF>(p, s);
+        case SCAIL_EPI_RESID:
+            SCAIL_REQUIRE(resid != nullptr && ldr % 4 == 0, "RESID epilogue needs resid with ldr % 4 == 0");
+            SCAIL_REQUIRE(gate == nullptr || (rows_per_batch > 0 && gate_stride % 4 == 0), "gate needs rows_per_batch > 0, gate_stride % 4 == 0");
+            return launch_gemm<SCAIL_EPI_RESID>(p, s);
+        default:
+            scail_set_error("scail_gemm_bf16: unknown epilogue");
+            return 1;
+    }
+}

@@ -1,0 +1,456 @@
+// Row-wise / elementwise kernels of the SCAIL DiT hot path (all HBM-bound): fused
+// LayerNorm+modulate, affine LayerNorm, full-width RMSNorm (+3D RoPE), V transpose staging,
+// timestep embedding, tiny linears, AdaLN tables, patchify / unpatchify, CFG+Euler.
+// One 256-thread workgroup per row for the norm kernels; every bf16 access is a 16-byte vector.
+#include "common.h"
+
+#define ROW_THREADS 256
+#define ROW_MAXV 3  // D <= 256 * 8 * 3 = 6144 kept in registers
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (+ modulate | + affine)
+// ------------------------------------------------------------------------------------------------
+template <int MODE>  // 0: modulate (shift/scale per batch), 1: affine (w, b)
+__global__ __launch_bounds__(ROW_THREADS) void ln_kernel(
+    const u16* __restrict__ x, int64_t ldx, u16* __restrict__ y, int64_t ldy,
+    const float* __restrict__ p0, const float* __restrict__ p1, int64_t mod_stride,
+    int64_t rows_out, int64_t src_rows_per_batch, int64_t src_row_offset, int D, float eps) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const int64_t b = r / rows_out;
+    const int64_t i = r - b * rows_out;
+    const u16* xr = x + (b * src_rows_per_batch + src_row_offset + i) * ldx;
+    u16* yr = y + r * ldy;
+    const int nvec = D >> 3;
+    float v[ROW_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < ROW_MAXV; ++j) {
+        const int c = threadIdx.x + j * ROW_THREADS;
+        if (c < nvec) {
+            uint4 u = *reinterpret_cast<const uint4*>(xr + (int64_t)c * 8);
+            unpack8(u, v[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[j][e];
+        }
+    }
+    const float mean = block_sum_256(s, red) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < ROW_MAXV; ++j) {
+        const int c = threadIdx.x + j * ROW_THREADS;
+        if (c < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[j][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = block_sum_256(q, red) / (float)D;
+    const float rstd = rsqrtf(var + eps);
+    const float* a0 = (MODE == 0) ? p0 + b * mod_stride : p0;  // shift | weight
+    const float* a1 = (MODE == 0) ? p1 + b * mod_stride : p1;  // scale | bias
+#pragma unroll
+    for (int j = 0; j < ROW_MAXV; ++j) {
+        const int c = threadIdx.x + j * ROW_THREADS;
+        if (c < nvec) {
+            float o[8];
+            const float4 s0 = *reinterpret_cast<const float4*>(a0 + c * 8);
+            const float4 s1 = *reinterpret_cast<const float4*>(a0 + c * 8 + 4);
+            const float4 t0 = *reinterpret_cast<const float4*>(a1 + c * 8);
+            const float4 t1 = *reinterpret_cast<const float4*>(a1 + c * 8 + 4);
+            const float A0[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float A1[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float n = (v[j][e] - mean) * rstd;
+                o[e] = (MODE == 0) ? n * (1.0f + A1[e]) + A0[e] : n * A0[e] + A1[e];
+            }
+            *reinterpret_cast<uint4*>(yr + (int64_t)c * 8) = pack8(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm over D (+ optional interleaved RoPE with per-token pair tables)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
+    const u16* __restrict__ x, int64_t ldx, u16* __restrict__ y, int64_t ldy,
+    const float* __restrict__ w, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+    int64_t rows_per_batch, int D, int head_dim, float eps) {
+    __shared__ float red[4];
+    const int64_t r = blockIdx.x;
+    const u16* xr = x + r * ldx;
+    u16* yr = y + r * ldy;
+    const int nvec = D >> 3;
+    float v[ROW_MAXV][8];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < ROW_MAXV; ++j) {
+        const int c = threadIdx.x + j * ROW_THREADS;
+        if (c < nvec) {
+            uint4 u = *reinterpret_cast<const uint4*>(xr + (int64_t)c * 8);
+            unpack8(u, v[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q += v[j][e] * v[j][e];
+        }
+    }
+    const float var = block_sum_256(q, red) / (float)D;
+    const float rstd = rsqrtf(var + eps);
+    const int half = head_dim >> 1;
+    const int64_t tok = r % rows_per_batch;
+#pragma unroll
+    for (int j = 0; j < ROW_MAXV; ++j) {
+        const int c = threadIdx.x + j * ROW_THREADS;
+        if (c < nvec) {
+            float n[8], o[8];
+            const float4 w0 = *reinterpret_cast<const float4*>(w + c * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(w + c * 8 + 4);
+            const float W[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) n[e] = W[e] * (v[j][e] * rstd);
+            if (cos_tab != nullptr) {
+                // columns c*8 .. c*8+7 lie in one head; pair index inside the head:
+                const int p0 = ((c * 8) % head_dim) >> 1;
+                const float4 cs = *reinterpret_cast<const float4*>(cos_tab + tok * half + p0);
+                const float4 sn = *reinterpret_cast<const float4*>(sin_tab + tok * half + p0);
+                const float C[4] = {cs.x, cs.y, cs.z, cs.w};
+                const float S[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // out[2i] = x[2i] cos - x[2i+1] sin ; out[2i+1] = x[2i+1] cos + x[2i] sin
+                    o[2 * e] = n[2 * e] * C[e] - n[2 * e + 1] * S[e];
+                    o[2 * e + 1] = n[2 * e + 1] * C[e] + n[2 * e] * S[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = n[e];
+            }
+            *reinterpret_cast<uint4*>(yr + (int64_t)c * 8) = pack8(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// V -> V^T staging (64 keys x head_dim tile through LDS)
+// ------------------------------------------------------------------------------------------------
+#define TV_KEYS 64
+__global__ __launch_bounds__(256) void transpose_v_kernel(
+    const u16* __restrict__ v, int64_t ldv, int64_t v_bs, u16* __restrict__ vt, int heads,
+    int head_dim, int64_t Lk, int64_t Lkp) {
+    extern __shared__ __attribute__((aligned(16))) u16 tile[];  // [64][head_dim + 8]
+    const int ldt = head_dim + 8;
+    const int64_t key0 = (int64_t)blockIdx.x * TV_KEYS;
+    const int h = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int cpr = head_dim >> 3;  // 16-byte chunks per row
+    const u16* src = v + b * v_bs + (int64_t)h * head_dim;
+    for (int c = threadIdx.x; c < TV_KEYS * cpr; c += 256) {
+        const int kr = c / cpr, cc = c - kr * cpr;
+        uint4 u = make_uint4(0, 0, 0, 0);
+        if (key0 + kr < Lk) u = *reinterpret_cast<const uint4*>(src + (key0 + kr) * ldv + cc * 8);
+        *reinterpret_cast<uint4*>(tile + kr * ldt + cc * 8) = u;
+    }
+    __syncthreads();
+    u16* dst = vt + ((b * heads + h) * (int64_t)head_dim) * Lkp + key0;
+    for (int o = threadIdx.x; o < head_dim * (TV_KEYS / 8); o += 256) {
+        const int d = o >> 3, ch = o & 7;
+        u16 e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = ch * 8 + j;  // position inside the 64-key tile
+            const int key = (p & ~12) | (((p >> 3) & 1) << 2) | (((p >> 2) & 1) << 3);  // swap bits 2,3
+            e[j] = tile[key * ldt + d];
+        }
+        uint4 u;
+        u.x = e[0] | ((uint32_t)e[1] << 16);
+        u.y = e[2] | ((uint32_t)e[3] << 16);
+        u.z = e[4] | ((uint32_t)e[5] << 16);
+        u.w = e[6] | ((uint32_t)e[7] << 16);
+        *reinterpret_cast<uint4*>(dst + (int64_t)d * Lkp + ch * 8) = u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small stuff
+// ------------------------------------------------------------------------------------------------
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int dim) {
+    const int b = blockIdx.x;
+    const int half = dim >> 1;
+    for (int j = threadIdx.x; j < half; j += blockDim.x) {
+        const double f = exp(-log(10000.0) * (double)j / (double)half);
+        const double a = (double)t[b] * f;
+        out[(int64_t)b * dim + j] = (float)cos(a);
+        out[(int64_t)b * dim + half + j] = (float)sin(a);
+    }
+    if ((dim & 1) && threadIdx.x == 0) out[(int64_t)b * dim + dim - 1] = 0.f;
+}
+
+__device__ __forceinline__ float act_f(float x, int a) {
+    return a == 1 ? silu_f(x) : (a == 2 ? gelu_tanh_f(x) : x);
+}
+
+#define SL_MAXM 8
+// one wave per output column n; lanes stride over K in 8-element chunks
+__global__ __launch_bounds__(256) void small_linear_kernel(
+    const float* __restrict__ x, const u16* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ y, int M, int N, int K, int act_in, int act_out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc[SL_MAXM];
+#pragma unroll
+    for (int m = 0; m < SL_MAXM; ++m) acc[m] = 0.f;
+    const u16* wr = w + (int64_t)n * K;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        float wf[8];
+        unpack8(*reinterpret_cast<const uint4*>(wr + k), wf);
+#pragma unroll
+        for (int m = 0; m < SL_MAXM; ++m) {
+            if (m < M) {
+                const float4 x0 = *reinterpret_cast<const float4*>(x + (int64_t)m * K + k);
+                const float4 x1 = *reinterpret_cast<const float4*>(x + (int64_t)m * K + k + 4);
+                const float X[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[m] += act_f(X[e], act_in) * wf[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < SL_MAXM; ++m) {
+        if (m < M) {
+            const float s = wave_sum(acc[m]);
+            if (lane == 0) y[(int64_t)m * N + n] = act_f(s + (bias ? bias[n] : 0.f), act_out);
+        }
+    }
+}
+
+__global__ void adaln_table_kernel(const float* __restrict__ emb, const float* __restrict__ table,
+                                   float* __restrict__ out, int64_t n_batch, int64_t width, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t j = i % width;
+    const int64_t b = (i / width) % n_batch;
+    const int64_t l = i / (width * n_batch);
+    out[i] = emb[b * width + j] + table[l * width + j];
+}
+
+// one thread per (token, 8-column chunk) of the im2col matrix
+__global__ void patchify_kernel(const float* __restrict__ x, const u16* __restrict__ ref,
+                                const u16* __restrict__ pose, u16* __restrict__ tok, int64_t n_batch,
+                                int64_t n_ref, int64_t n_pose, int T, int H, int W, int kpad, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cpr = kpad >> 3;
+    const int ch = (int)(i % cpr);
+    const int64_t row = i / cpr;
+    const int h2 = H >> 1, w2 = W >> 1, h4 = H >> 2, w4 = W >> 2;
+    const int64_t Lref = (int64_t)h2 * w2, Lnoise = (int64_t)T * h2 * w2, Lpose = (int64_t)T * h4 * w4;
+    const int64_t L = Lref + Lnoise + Lpose;
+    const int64_t b = row / L;
+    int64_t l = row - b * L;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = ch * 8 + e;
+        float val = 0.f;
+        if (k < 80) {
+            const int c = k >> 2, p = (k >> 1) & 1, q = k & 1;
+            if (l < Lref) {
+                const int hh = (int)(l / w2), ww = (int)(l % w2);
+                if (c >= 16) val = 1.f;
+                else {
+                    const int64_t bb = (n_ref == 1) ? 0 : b;
+                    val = bf2f(ref[((bb * 16 + c) * H + (2 * hh + p)) * W + 2 * ww + q]);
+                }
+            } else if (l < Lref + Lnoise) {
+                const int64_t ll = l - Lref;
+                const int t = (int)(ll / (h2 * w2));
+                const int rem = (int)(ll % (h2 * w2));
+                const int hh = rem / w2, ww = rem % w2;
+                if (c >= 16) val = 0.f;
+                else val = bf2f(f2bf(x[(((b * T + t) * 16 + c) * H + (2 * hh + p)) * W + 2 * ww + q]));
+            } else {
+                const int64_t ll = l - Lref - Lnoise;
+                const int t = (int)(ll / (h4 * w4));
+                const int rem = (int)(ll % (h4 * w4));
+                const int hh = rem / w4, ww = rem % w4;
+                if (c >= 16) val = 1.f;
+                else {
+                    const int64_t bb = (n_pose == 1) ? 0 : b;
+                    val = bf2f(pose[(((bb * T + t) * 16 + c) * h2 + (2 * hh + p)) * w2 + 2 * ww + q]);
+                }
+            }
+        }
+        o[e] = val;
+    }
+    *reinterpret_cast<uint4*>(tok + row * kpad + ch * 8) = pack8(o);
+}
+
+// out[b][t][c][2h+p][2w+q] = tok[b][(t,h,w)][p*32 + q*16 + c]
+__global__ void unpatchify_kernel(const u16* __restrict__ tok, float* __restrict__ out, int T, int H,
+                                  int W, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ww = (int)(i % W);
+    const int hh = (int)((i / W) % H);
+    const int c = (int)((i / ((int64_t)W * H)) % 16);
+    const int t = (int)((i / ((int64_t)W * H * 16)) % T);
+    const int64_t b = i / ((int64_t)W * H * 16 * T);
+    const int h2 = H >> 1, w2 = W >> 1;
+    const int64_t row = (b * T + t) * (int64_t)(h2 * w2) + (int64_t)(hh >> 1) * w2 + (ww >> 1);
+    out[i] = bf2f(tok[row * 64 + (hh & 1) * 32 + (ww & 1) * 16 + c]);
+}
+
+__global__ void cfg_euler_kernel(float* __restrict__ x, const float* __restrict__ v, int64_t n,
+                                 float cfg, float dsigma) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float vu = v[i], vc = v[n + i];
+    x[i] = x[i] + dsigma * (vu + cfg * (vc - vu));
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, u16* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = f2bf(x[i]);
+}
+__global__ void bf16_to_f32_kernel(const u16* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = bf2f(x[i]);
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int scail_ln_modulate(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t ldy,
+                                 const float* shift, const float* scale, int64_t mod_stride,
+                                 int64_t n_batch, int64_t rows_out, int64_t src_rows_per_batch,
+                                 int64_t src_row_offset, int64_t D, float eps, void* stream) {
+    SCAIL_REQUIRE(D % 8 == 0 && D <= ROW_THREADS * 8 * ROW_MAXV, "D must be a multiple of 8 and <= 6144");
+    SCAIL_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && mod_stride % 4 == 0, "strides must keep 16-byte alignment");
+    SCAIL_REQUIRE(aligned16(x) && aligned16(y) && aligned16(shift) && aligned16(scale), "pointers must be 16-byte aligned");
+    const int64_t rows = n_batch * rows_out;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(ln_kernel<0>, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream, x, ldx,
+                       y, ldy, shift, scale, mod_stride, rows_out, src_rows_per_batch, src_row_offset,
+                       (int)D, eps);
+    return scail_check_launch("ln_modulate");
+}
+
+extern "C" int scail_layernorm_affine(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t ldy,
+                                      const float* w, const float* b, int64_t rows, int64_t D, float eps,
+                                      void* stream) {
+    SCAIL_REQUIRE(D % 8 == 0 && D <= ROW_THREADS * 8 * ROW_MAXV, "D must be a multiple of 8 and <= 6144");
+    SCAIL_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "strides must keep 16-byte alignment");
+    SCAIL_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && aligned16(b), "pointers must be 16-byte aligned");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream, x, ldx,
+                       y, ldy, w, b, (int64_t)0, rows, rows, (int64_t)0, (int)D, eps);
+    return scail_check_launch("layernorm_affine");
+}
+
+extern "C" int scail_rmsnorm_rope(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t ldy,
+                                  const float* w, const float* cos_tab, const float* sin_tab,
+                                  int64_t rows, int64_t rows_per_batch, int64_t D, int64_t head_dim,
+                                  float eps, void* stream) {
+    SCAIL_REQUIRE(D % 8 == 0 && D <= ROW_THREADS * 8 * ROW_MAXV, "D must be a multiple of 8 and <= 6144");
+    SCAIL_REQUIRE(head_dim % 8 == 0 && D % head_dim == 0, "head_dim must be a multiple of 8 dividing D");
+    SCAIL_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "strides must keep 16-byte alignment");
+    SCAIL_REQUIRE((cos_tab == nullptr) == (sin_tab == nullptr), "cos and sin tables go together");
+    SCAIL_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && aligned16(cos_tab) && aligned16(sin_tab),
+                  "pointers must be 16-byte aligned");
+    SCAIL_REQUIRE(rows_per_batch > 0, "rows_per_batch must be positive");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
+                       x, ldx, y, ldy, w, cos_tab, sin_tab, rows_per_batch, (int)D, (int)head_dim, eps);
+    return scail_check_launch("rmsnorm_rope");
+}
+
+extern "C" int scail_transpose_v(const scail_bf16* v, int64_t ldv, int64_t v_batch_stride,
+                                 scail_bf16* vt, int64_t n_batch, int64_t heads, int64_t head_dim,
+                                 int64_t Lk, void* stream) {
+    SCAIL_REQUIRE(head_dim % 8 == 0 && head_dim <= 512, "head_dim must be a multiple of 8, <= 512");
+    SCAIL_REQUIRE(ldv % 8 == 0 && v_batch_stride % 8 == 0 && aligned16(v) && aligned16(vt), "16-byte alignment");
+    if (Lk == 0 || n_batch == 0) return 0;
+    const int64_t Lkp = (Lk + 63) / 64 * 64;
+    const size_t lds = (size_t)TV_KEYS * (head_dim + 8) * sizeof(u16);
+    hipLaunchKernelGGL(transpose_v_kernel, dim3((unsigned)(Lkp / 64), (unsigned)heads, (unsigned)n_batch),
+                       dim3(256), lds, (hipStream_t)stream, v, ldv, v_batch_stride, vt, (int)heads,
+                       (int)head_dim, Lk, Lkp);
+    return scail_check_launch("transpose_v");
+}
+
+extern "C" int scail_timestep_embedding(const float* t, float* out, int64_t n, int64_t dim, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((unsigned)n), dim3(128), 0, (hipStream_t)stream, t, out,
+                       (int)dim);
+    return scail_check_launch("timestep_embedding");
+}
+
+extern "C" int scail_small_linear(const float* x, const scail_bf16* w, const float* b, float* y, int64_t M,
+                                  int64_t N, int64_t K, int act_in, int act_out, void* stream) {
+    SCAIL_REQUIRE(M >= 0 && M <= SL_MAXM, "M must be <= 8");
+    SCAIL_REQUIRE(K % 8 == 0, "K must be a multiple of 8");
+    SCAIL_REQUIRE(aligned16(x) && aligned16(w), "16-byte alignment");
+    if (M == 0 || N == 0) return 0;
+    hipLaunchKernelGGL(small_linear_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       w, b, y, (int)M, (int)N, (int)K, act_in, act_out);
+    return scail_check_launch("small_linear");
+}
+
+extern "C" int scail_adaln_table(const float* emb, const float* table, float* out, int64_t n_layers,
+                                 int64_t n_batch, int64_t width, void* stream) {
+    const int64_t total = n_layers * n_batch * width;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(adaln_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, emb, table, out, n_batch, width, total);
+    return scail_check_launch("adaln_table");
+}
+
+extern "C" int scail_patchify(const float* x, const scail_bf16* ref, const scail_bf16* pose,
+                              scail_bf16* tok, int64_t n_batch, int64_t n_ref, int64_t n_pose, int64_t T,
+                              int64_t H, int64_t W, int64_t kpad, void* stream) {
+    SCAIL_REQUIRE(H % 4 == 0 && W % 4 == 0, "latent H and W must be multiples of 4 (pose is half size, patch 2)");
+    SCAIL_REQUIRE(kpad >= 80 && kpad % 8 == 0, "kpad must be >= 80 and a multiple of 8");
+    SCAIL_REQUIRE((n_ref == 1 || n_ref == n_batch) && (n_pose == 1 || n_pose == n_batch), "cond batch must be 1 or n_batch");
+    const int64_t L = (1 + T) * (H / 2) * (W / 2) + T * (H / 4) * (W / 4);
+    const int64_t total = n_batch * L * (kpad / 8);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, ref, pose, tok, n_batch, n_ref, n_pose, (int)T, (int)H, (int)W,
+                       (int)kpad, total);
+    return scail_check_launch("patchify");
+}
+
+extern "C" int scail_unpatchify(const scail_bf16* tok, float* out, int64_t n_batch, int64_t T, int64_t H,
+                                int64_t W, void* stream) {
+    const int64_t total = n_batch * T * 16 * H * W;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, tok, out, (int)T, (int)H, (int)W, total);
+    return scail_check_launch("unpatchify");
+}
+
+extern "C" int scail_cfg_euler(float* x, const float* v, int64_t n, float cfg_scale, float dsigma,
+                               void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, v, n, cfg_scale, dsigma);
+    return scail_check_launch("cfg_euler");
+}
+
+extern "C" int scail_f32_to_bf16(const float* x, scail_bf16* y, int64_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, n);
+    return scail_check_launch("f32_to_bf16");
+}
+extern "C" int scail_bf16_to_f32(const scail_bf16* x, float* y, int64_t n, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, n);
+    return scail_check_launch("bf16_to_f32");
+}

@@ -1,0 +1,75 @@
+"""ctypes binding of libscail_hip.so (include/scail_hip.h).  Fails loudly when the library is
+missing -- there is deliberately no fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscail_hip.so")
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i = C.c_int
+_f = C.c_float
+
+# name -> argtypes; must list EVERY symbol declared in include/scail_hip.h (tests/test_abi.py
+# cross-checks this table against the header).
+SIGNATURES = {
+    "scail_gemm_bf16": [_p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _i64, _p, _i64, _i64, _p],
+    "scail_ln_modulate": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _f, _p],
+    "scail_layernorm_affine": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _f, _p],
+    "scail_rmsnorm_rope": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _p],
+    "scail_transpose_v": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _p],
+    "scail_flash_attn_bf16": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
+                              _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
+    "scail_timestep_embedding": [_p, _p, _i64, _i64, _p],
+    "scail_small_linear": [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
+    "scail_adaln_table": [_p, _p, _p, _i64, _i64, _i64, _p],
+    "scail_patchify": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
+    "scail_unpatchify": [_p, _p, _i64, _i64, _i64, _i64, _p],
+    "scail_cfg_euler": [_p, _p, _i64, _f, _f, _p],
+    "scail_f32_to_bf16": [_p, _p, _i64, _p],
+    "scail_bf16_to_f32": [_p, _p, _i64, _p],
+}
+
+EPI_BIAS, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2
+ABI_VERSION = 1
+
+_lib = None
+
+
+class ScailHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built (``python -m scail_amd.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ScailHipError(
+            f"{LIB_PATH} not found: build it with `python -m scail_amd.build` (hipcc, gfx950). "
+            "scail_amd has no CPU/torch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.scail_last_error.restype = C.c_char_p
+    lib.scail_last_error.argtypes = []
+    lib.scail_abi_version.restype = C.c_int
+    lib.scail_abi_version.argtypes = []
+    if lib.scail_abi_version() != ABI_VERSION:
+        raise ScailHipError(f"ABI mismatch: library {lib.scail_abi_version()} vs binding {ABI_VERSION}")
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise ScailHipError(f"{name} failed ({rc}): {lib.scail_last_error().decode()}")

@@ -1,0 +1,242 @@
+"""Tensor-level wrappers over the C ABI (include/scail_hip.h).
+
+PyTorch is used for device memory and the current HIP stream only; every function enqueues one
+HIP kernel of libscail_hip.so on ``torch.cuda.current_stream()``.  All tensors must live on the
+GPU -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise L.ScailHipError(f"{name}: tensor must be on the GPU (scail_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise L.ScailHipError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rowmajor2d(t: torch.Tensor, name: str):
+    """(rows, cols, row_stride) of a tensor whose last dim is contiguous and whose leading dims
+    collapse to ONE uniformly strided row index (contiguous tensors and column-slice views do)."""
+    if t.stride(-1) != 1:
+        raise L.ScailHipError(f"{name}: last dim must be contiguous")
+    cols = t.shape[-1]
+    if t.dim() == 1:
+        return 1, cols, cols
+    ld = t.stride(-2)
+    rows, exp = 1, ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise L.ScailHipError(f"{name}: leading dims are not uniformly strided {tuple(t.shape)} {t.stride()}")
+        exp *= t.shape[d]
+        rows *= t.shape[d]
+    return rows, cols, ld
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(x, w, bias=None, out=None, epilogue=L.EPI_BIAS, resid=None, gate=None, rows_per_batch=0):
+    """y = epilogue(x @ w.T + bias).  x (..., K) bf16 (rows may be strided), w (N, K) bf16 contiguous,
+    bias fp32 (N).  RESID: y = resid + gate[b] * (.), gate fp32 (n_batch, N) view with row stride."""
+    _chk(x, bf16, "gemm.x"); _chk(w, bf16, "gemm.w")
+    M, K, lda = _rowmajor2d(x, "gemm.x")
+    N = w.shape[0]
+    if w.shape[1] != K or not w.is_contiguous():
+        raise L.ScailHipError("gemm: w must be contiguous (N, K)")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=bf16)
+    _chk(out, bf16, "gemm.out")
+    Mo, No, ldc = _rowmajor2d(out, "gemm.out")
+    assert Mo == M and No == N, (Mo, M, No, N)
+    ldr = 0
+    if resid is not None:
+        _chk(resid, bf16, "gemm.resid")
+        Mr, Nr, ldr = _rowmajor2d(resid, "gemm.resid")
+        assert Mr == M and Nr == N
+    gs = 0
+    if gate is not None:
+        _chk(gate, f32, "gemm.gate")
+        assert gate.dim() == 2 and gate.shape[1] == N and gate.stride(1) == 1
+        gs = gate.stride(0)
+    if bias is not None:
+        _chk(bias, f32, "gemm.bias")
+    L.call("scail_gemm_bf16", x.data_ptr(), lda, w.data_ptr(), _ptr(bias), out.data_ptr(), ldc, M, N, K,
+           epilogue, _ptr(resid), ldr, _ptr(gate), gs, rows_per_batch, _stream())
+    return out
+
+
+def ln_modulate(x, shift, scale, out=None, eps=1e-6, rows_out=None, src_rows_per_batch=None, src_row_offset=0):
+    """x (B, Ls, D) bf16; shift/scale fp32 (B, D) views (same row stride).  Output (B, rows_out, D)."""
+    _chk(x, bf16, "ln_modulate.x"); _chk(shift, f32, "shift"); _chk(scale, f32, "scale")
+    B, Ls, D = x.shape
+    assert x.stride(2) == 1 and x.stride(0) == Ls * x.stride(1)
+    rows_out = Ls if rows_out is None else rows_out
+    src_rows_per_batch = Ls if src_rows_per_batch is None else src_rows_per_batch
+    if out is None:
+        out = torch.empty(B, rows_out, D, device=x.device, dtype=bf16)
+    assert shift.shape == (B, D) and scale.shape == (B, D) and shift.stride(0) == scale.stride(0)
+    assert shift.stride(1) == 1 and scale.stride(1) == 1
+    L.call("scail_ln_modulate", x.data_ptr(), x.stride(1), out.data_ptr(), out.stride(-2), shift.data_ptr(),
+           scale.data_ptr(), shift.stride(0), B, rows_out, src_rows_per_batch, src_row_offset, D, eps, _stream())
+    return out
+
+
+def layernorm_affine(x, w, b, out=None, eps=1e-6):
+    _chk(x, bf16, "layernorm_affine.x"); _chk(w, f32, "w"); _chk(b, f32, "b")
+    rows, D, ldx = _rowmajor2d(x, "layernorm_affine.x")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=bf16)
+    _, _, ldy = _rowmajor2d(out, "layernorm_affine.out")
+    L.call("scail_layernorm_affine", x.data_ptr(), ldx, out.data_ptr(), ldy, w.data_ptr(), b.data_ptr(), rows, D,
+           eps, _stream())
+    return out
+
+
+def rmsnorm_rope(x, w, cos=None, sin=None, out=None, rows_per_batch=None, head_dim=128, eps=1e-6):
+    """RMSNorm over the last dim (+RoPE with (L, head_dim/2) fp32 tables).  In place when out is None."""
+    _chk(x, bf16, "rmsnorm_rope.x"); _chk(w, f32, "w")
+    rows, D, ldx = _rowmajor2d(x, "rmsnorm_rope.x")
+    out = x if out is None else out
+    _, _, ldy = _rowmajor2d(out, "rmsnorm_rope.out")
+    if cos is not None:
+        _chk(cos, f32, "cos"); _chk(sin, f32, "sin")
+        assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[1] == head_dim // 2
+        rows_per_batch = cos.shape[0] if rows_per_batch is None else rows_per_batch
+        assert rows_per_batch <= cos.shape[0]
+    else:
+        rows_per_batch = rows if rows_per_batch is None else rows_per_batch
+    L.call("scail_rmsnorm_rope", x.data_ptr(), ldx, out.data_ptr(), ldy, w.data_ptr(), _ptr(cos), _ptr(sin), rows,
+           rows_per_batch, D, head_dim, eps, _stream())
+    return out
+
+
+def transpose_v(v, heads, head_dim=128, out=None):
+    """v (B, Lk, heads*head_dim) bf16 (strided view ok) -> vt (B, heads, head_dim, ceil64(Lk))."""
+    _chk(v, bf16, "transpose_v.v")
+    B, Lk, D = v.shape
+    assert D == heads * head_dim and v.stride(2) == 1
+    Lkp = (Lk + 63) // 64 * 64
+    if out is None:
+        out = torch.empty(B, heads, head_dim, Lkp, device=v.device, dtype=bf16)
+    assert out.is_contiguous() and out.shape == (B, heads, head_dim, Lkp)
+    L.call("scail_transpose_v", v.data_ptr(), v.stride(1), v.stride(0), out.data_ptr(), B, heads, head_dim, Lk,
+           _stream())
+    return out
+
+
+def flash_attn(q, k, vt, out=None, scale=None, accumulate=False, n_seg=1, k_seg_stride=0, vt_seg_stride=0,
+               k_broadcast=False):
+    """q (B, Lq, H*128) view; k (B|1, Lk, H*128) view [per segment]; vt (B|1, H, 128, Lkp) [per segment].
+    Output (B, Lq, H*128) view.  ``k_broadcast``: K/V have batch 1 and are shared by all B queries."""
+    _chk(q, bf16, "flash_attn.q"); _chk(k, bf16, "k"); _chk(vt, bf16, "vt")
+    B, Lq, D = q.shape
+    H = D // 128
+    assert D == H * 128 and q.stride(2) == 1 and k.stride(2) == 1
+    Lk = k.shape[1]
+    Lkp = (Lk + 63) // 64 * 64
+    assert vt.shape[-1] == Lkp and vt.shape[-2] == 128 and vt.shape[-3] == H, (vt.shape, Lkp, H)
+    assert vt[0].is_contiguous()
+    if out is None:
+        out = torch.empty(B, Lq, D, device=q.device, dtype=bf16)
+    _chk(out, bf16, "flash_attn.out")
+    assert out.stride(2) == 1
+    k_bs = 0 if (k_broadcast or k.shape[0] == 1) else k.stride(0)
+    vt_bs = 0 if (k_broadcast or vt.shape[0] == 1) else vt.stride(0)
+    if scale is None:
+        scale = 1.0 / math.sqrt(128)
+    L.call("scail_flash_attn_bf16", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride, k_bs,
+           k.stride(1), vt.data_ptr(), vt_seg_stride, vt_bs, out.data_ptr(), out.stride(0), out.stride(1), B, H, Lq,
+           Lk, n_seg, scale, 1 if accumulate else 0, _stream())
+    return out
+
+
+def timestep_embedding(t, dim):
+    _chk(t, f32, "timestep_embedding.t")
+    out = torch.empty(t.shape[0], dim, device=t.device, dtype=f32)
+    L.call("scail_timestep_embedding", t.data_ptr(), out.data_ptr(), t.shape[0], dim, _stream())
+    return out
+
+
+def small_linear(x, w, b=None, act_in=L.ACT_NONE, act_out=L.ACT_NONE):
+    _chk(x, f32, "small_linear.x"); _chk(w, bf16, "small_linear.w")
+    assert x.is_contiguous() and w.is_contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=f32)
+    L.call("scail_small_linear", x.data_ptr(), w.data_ptr(), _ptr(b), y.data_ptr(), M, N, K, act_in, act_out,
+           _stream())
+    return y
+
+
+def adaln_table(emb, table):
+    """out[l, b, :] = emb[b, :] + table[l, :]; emb (B, W) fp32, table (layers, W) fp32."""
+    _chk(emb, f32, "adaln_table.emb"); _chk(table, f32, "adaln_table.table")
+    assert emb.is_contiguous() and table.is_contiguous()
+    out = torch.empty(table.shape[0], emb.shape[0], emb.shape[1], device=emb.device, dtype=f32)
+    L.call("scail_adaln_table", emb.data_ptr(), table.data_ptr(), out.data_ptr(), table.shape[0], emb.shape[0],
+           emb.shape[1], _stream())
+    return out
+
+
+def patchify(x, ref, pose, kpad=128, out=None):
+    """x fp32 (B,T,16,H,W); ref bf16 (1|B,1,16,H,W); pose bf16 (1|B,T,16,H/2,W/2) -> (B, L, kpad) bf16."""
+    _chk(x, f32, "patchify.x"); _chk(ref, bf16, "patchify.ref"); _chk(pose, bf16, "patchify.pose")
+    assert x.is_contiguous() and ref.is_contiguous() and pose.is_contiguous()
+    B, T, C, H, W = x.shape
+    assert C == 16 and ref.shape[1:] == (1, 16, H, W) and pose.shape[1:] == (T, 16, H // 2, W // 2)
+    Ltok = (1 + T) * (H // 2) * (W // 2) + T * (H // 4) * (W // 4)
+    if out is None:
+        out = torch.empty(B, Ltok, kpad, device=x.device, dtype=bf16)
+    L.call("scail_patchify", x.data_ptr(), ref.data_ptr(), pose.data_ptr(), out.data_ptr(), B, ref.shape[0],
+           pose.shape[0], T, H, W, kpad, _stream())
+    return out
+
+
+def unpatchify(tok, T, H, W, out=None):
+    _chk(tok, bf16, "unpatchify.tok")
+    assert tok.is_contiguous() and tok.shape[-1] == 64
+    B = tok.shape[0]
+    if out is None:
+        out = torch.empty(B, T, 16, H, W, device=tok.device, dtype=f32)
+    L.call("scail_unpatchify", tok.data_ptr(), out.data_ptr(), B, T, H, W, _stream())
+    return out
+
+
+def cfg_euler_(x, v, cfg_scale, dsigma):
+    """In place: x += dsigma * (v[0] + cfg * (v[1] - v[0])).  x fp32 (1, ...), v fp32 (2, ...)."""
+    _chk(x, f32, "cfg_euler.x"); _chk(v, f32, "cfg_euler.v")
+    assert x.is_contiguous() and v.is_contiguous() and v.numel() == 2 * x.numel()
+    L.call("scail_cfg_euler", x.data_ptr(), v.data_ptr(), x.numel(), float(cfg_scale), float(dsigma), _stream())
+    return x
+
+
+def to_bf16(x):
+    _chk(x, f32, "to_bf16.x")
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=bf16)
+    L.call("scail_f32_to_bf16", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+    return y
+
+
+def to_f32(x):
+    _chk(x, bf16, "to_f32.x")
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=f32)
+    L.call("scail_bf16_to_f32", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+    return y

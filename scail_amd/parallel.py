@@ -1,0 +1,189 @@
+"""Sequence parallelism over the token axis for the SCAIL DiT.
+
+Reference behaviour being replaced: DeepSpeed-Ulysses (sat/mpu/ulysses_attn_layer.py:41-110,
+all_to_all.py:15-108) over an H- or W-split of the latent (diffusion_video.py:495-552), with the
+RoPE window shifted by the rank (dit_video_crossattn_sc_xc.py:1578-1585) and a final gather to
+SP rank 0 (diffusion_video.py:571-585).
+
+MI355X design: the same latent split and rank-shifted RoPE (so a rank's tokens are an aligned slab
+of ref, noise and pose tokens), but instead of 4 all-to-alls per attention (12 per layer, also for
+the two cross-attentions whose K/V are replicated anyway) each layer does ONE exchange: an
+all-gather of the post-norm, post-RoPE K and of the V^T staging buffer over xGMI (RCCL; direct
+peer links, no ring dependence), after which every rank runs full attention of its local queries
+against the n_seg gathered key segments (``scail_flash_attn_bf16`` n_seg > 1).  Softmax is
+permutation invariant over keys, so rank-major key order is harmless.  Everything else in the
+block is per-token and needs no communication; weights are replicated (32 GB << 288 GB HBM).
+The K/V projection is issued first so the all-gather overlaps the Q projection + Q norm/RoPE.
+"""
+from __future__ import annotations
+
+import threading
+from typing import List, Optional
+
+import torch
+
+from . import lib as L
+from . import ops
+
+
+class _Handle:
+    def __init__(self, work=None):
+        self.work = work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+
+
+class TorchDistBackend:
+    """torch.distributed process group (backend 'nccl' == RCCL on ROCm; 'gloo' in CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self._src = dist.get_global_rank(group, 0) if group is not None else 0
+
+    def broadcast(self, t):
+        self.dist.broadcast(t, src=self._src, group=self.group)
+
+    def all_gather_into(self, out, inp, async_op=True):
+        """out: (size, *inp.shape) contiguous."""
+        w = self.dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1), group=self.group, async_op=async_op)
+        return _Handle(w if async_op else None)
+
+    def gather_cat(self, t, dim):
+        """Concatenate along ``dim`` on group rank 0 (reference: dist.gather + concat, :578-585);
+        other ranks get their own shard back."""
+        if self.rank == 0:
+            lst = [torch.zeros_like(t) for _ in range(self.size)]
+        else:
+            lst = None
+        self.dist.gather(t, gather_list=lst, dst=self._src, group=self.group)
+        return torch.cat(lst, dim=dim) if self.rank == 0 else t
+
+
+class ThreadBackend:
+    """N virtual ranks as threads of ONE process sharing one GPU (or the CPU): lets the multi-rank
+    data path -- including the multi-segment attention kernel -- be exercised on a 1-GPU box."""
+
+    class Shared:
+        def __init__(self, size):
+            self.size = size
+            self.barrier = threading.Barrier(size)
+            self.slots: List[Optional[torch.Tensor]] = [None] * size
+
+    def __init__(self, shared: "ThreadBackend.Shared", rank: int):
+        self.shared, self.rank, self.size = shared, rank, shared.size
+
+    def _sync(self):
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+        self.shared.barrier.wait()
+
+    def broadcast(self, t):
+        if self.rank == 0:
+            self.shared.slots[0] = t
+        self._sync()
+        if self.rank != 0:
+            t.copy_(self.shared.slots[0])
+        self._sync()
+
+    def all_gather_into(self, out, inp, async_op=True):
+        self.shared.slots[self.rank] = inp
+        self._sync()
+        for r in range(self.size):
+            out[r].copy_(self.shared.slots[r].reshape(out[r].shape))
+        self._sync()
+        return _Handle(None)
+
+    def gather_cat(self, t, dim):
+        self.shared.slots[self.rank] = t
+        self._sync()
+        res = torch.cat([s for s in self.shared.slots], dim=dim) if self.rank == 0 else t
+        self._sync()
+        return res
+
+
+class SequenceParallel:
+    """What the engine and the DiT need from a sequence-parallel group."""
+
+    def __init__(self, backend):
+        self.backend = backend
+        self.rank, self.size = backend.rank, backend.size
+        self._buf = {}
+
+    # ---- host-side sharding (diffusion_video.py:495-552) ----
+    @staticmethod
+    def chunk_dim_for(shape_hw) -> int:
+        h, w = shape_hw
+        return 3 if h < w else 4
+
+    def chunk(self, t: torch.Tensor, dim: int) -> torch.Tensor:
+        if t.shape[dim] % self.size:
+            raise ValueError(f"dim {dim} of size {t.shape[dim]} does not split over {self.size} ranks")
+        return torch.chunk(t, self.size, dim=dim)[self.rank].contiguous()
+
+    def check_latent(self, H: int, W: int, chunk_dim: int):
+        """Each rank needs an even number of patch rows/cols of the half-size pose latent:
+        (H / size) % 4 == 0 along the split axis (reference needs the same for avg_pool2d, :630)."""
+        ext = H if chunk_dim == 3 else W
+        if ext % (4 * self.size):
+            raise ValueError(f"latent extent {ext} along the split axis must be a multiple of 4*sp_size={4 * self.size}")
+
+    def broadcast(self, t):
+        self.backend.broadcast(t)
+
+    def gather_to_rank0(self, t, dim):
+        return self.backend.gather_cat(t.contiguous(), dim)
+
+    # ---- the one per-layer exchange ----
+    def self_attention(self, net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps):
+        """xn (B, Lloc, D) -> att (B, Lloc, D): K/V projection, K norm+RoPE, V^T staging, all-gather
+        of both, (overlapped) Q projection + norm + RoPE, attention over all ranks' keys."""
+        D, nh = net.hidden_size, net.num_attention_heads
+        B = xn.shape[0]
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        key = (B, Ltok)
+        if key not in self._buf:
+            Lp = vt_loc.shape[-1]
+            dev = xn.device
+            self._buf = {key: dict(
+                kloc=torch.empty(B, Ltok, D, device=dev, dtype=torch.bfloat16),
+                kg=torch.empty(self.size, B, Ltok, D, device=dev, dtype=torch.bfloat16),
+                vtg=torch.empty(self.size, B, nh, 128, Lp, device=dev, dtype=torch.bfloat16))}
+        bufs = self._buf[key]
+        ops.gemm(xn, lw["qkv_w"][D:], lw["qkv_b"][D:], out=qkv[..., D:])           # K and V columns
+        ops.rmsnorm_rope(k, lw["kn"], cos, sin, out=bufs["kloc"], rows_per_batch=Ltok, eps=eps)
+        ops.transpose_v(v, nh, out=vt_loc)
+        h1 = self.backend.all_gather_into(bufs["kg"], bufs["kloc"])
+        h2 = self.backend.all_gather_into(bufs["vtg"], vt_loc)
+        ops.gemm(xn, lw["qkv_w"][:D], lw["qkv_b"][:D], out=q)                       # overlaps the exchange
+        ops.rmsnorm_rope(q, lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
+        h1.wait()
+        h2.wait()
+        kg, vtg = bufs["kg"], bufs["vtg"]
+        net._timed("self_attn", ops.flash_attn, q, kg[0], vtg[0], out=att, n_seg=self.size,
+                   k_seg_stride=kg.stride(0), vt_seg_stride=vtg.stride(0))
+        return att
+
+
+def init_from_env(backend: str = "nccl") -> Optional[SequenceParallel]:
+    """One process per GPU, launched by torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* from the environment.  The whole world is one sequence-parallel group (the reference's
+    CLI asserts dp == 1, sample_video.py:229).  Returns None for a single process."""
+    import os
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return None
+    if not dist.is_initialized():
+        if backend == "nccl":
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return SequenceParallel(TorchDistBackend(None))

@@ -1,0 +1,99 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds, loads without a GPU and exports
+every symbol include/scail_hip.h declares; the ctypes table covers the same set; the product path
+refuses to run without a GPU instead of silently falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "scail_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scail_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from scail_amd import build
+    return build.build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    lib = ctypes.CDLL(libpath)
+    syms = _header_symbols()
+    assert len(syms) >= 16
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/scail_hip.h but not exported"
+
+
+def test_ctypes_table_matches_header(libpath):
+    from scail_amd import lib as L
+    declared = set(_header_symbols()) - {"scail_last_error", "scail_abi_version"}
+    assert set(L.SIGNATURES) == declared
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "scail_hip.h")).read(), flags=re.S)
+    for name, args in L.SIGNATURES.items():
+        m = re.search(r"int\s+" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        assert len([a for a in m.group(1).split(",") if a.strip()]) == len(args), name
+    lib = L.load()
+    assert lib.scail_abi_version() == L.ABI_VERSION
+
+
+def test_argument_validation_without_gpu(libpath):
+    """Pure host-side checks of the ABI fire before any launch, so they are testable on CPU."""
+    from scail_amd import lib as L
+    L.load()
+    with pytest.raises(L.ScailHipError, match="multiple of 64"):
+        L.call("scail_gemm_bf16", None, 72, None, None, None, 16, 8, 16, 72, 0, None, 0, None, 0, 0, None)
+    with pytest.raises(L.ScailHipError, match="M must be <= 8"):
+        L.call("scail_small_linear", None, None, None, None, 9, 8, 8, 0, 0, None)
+    with pytest.raises(L.ScailHipError, match="unknown epilogue"):
+        L.call("scail_gemm_bf16", None, 64, None, None, None, 16, 8, 16, 64, 99, None, 0, None, 0, 0, None)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_no_silent_cpu_fallback():
+    from scail_amd import lib as L, ops
+    x = torch.zeros(8, 64, dtype=torch.bfloat16)
+    with pytest.raises(L.ScailHipError, match="GPU"):
+        ops.gemm(x, x)
+    from scail_amd.dit import DiffusionTransformer
+    net = DiffusionTransformer(transformer_args=dict(model_parallel_size=1), hidden_size=128, num_layers=1,
+                               num_attention_heads=1, text_dim=64, time_embed_dim=128, time_freq_dim=256,
+                               inner_hidden_size=256, share_adaln=True, use_i2v_clip=True, device="cpu")
+    with pytest.raises(L.ScailHipError, match="GPU"):
+        net(torch.zeros(2, 1, 16, 4, 4), timesteps=torch.zeros(2), context=torch.zeros(2, 4, 64),
+            concat_images=torch.zeros(1), ref_concat=torch.zeros(1, 1, 16, 4, 4),
+            concat_smpl_render=torch.zeros(1, 1, 16, 2, 2), image_clip_features=torch.zeros(1, 3, 1280))
+
+
+def test_state_dict_keys_match_reference_layout():
+    """Key names/shapes equal the reference's (oracle.state_dict_spec is pinned to the real reference by
+    a strict load in oracle/gen_golden.py)."""
+    from oracle import scail_oracle as O
+    from scail_amd.dit import DiffusionTransformer
+    cfg = O.DiTConfig(**O.TINY)
+    net = DiffusionTransformer(transformer_args=dict(model_parallel_size=1), num_frames=13, latent_width=32,
+                               latent_height=32, hidden_size=256, text_dim=64, num_layers=2, num_attention_heads=2,
+                               time_freq_dim=256, time_embed_dim=256, share_adaln=True, inner_hidden_size=512,
+                               use_i2v_clip=True, device="cpu")
+    spec = O.state_dict_spec(cfg)
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in spec.items()}
+    with pytest.raises(NotImplementedError, match="SwiGLU"):
+        DiffusionTransformer(use_SwiGLU=True, share_adaln=True, use_i2v_clip=True, device="cpu", num_layers=1)
+
+
+def test_reference_yaml_targets_resolve():
+    from scail_amd import config, sampler
+    assert config.get_obj_from_str("sgm.modules.diffusionmodules.sampling.RFSampler") is sampler.RFSampler
+    s = config.instantiate_from_config({"target": "sgm.modules.diffusionmodules.sampling.RFSampler", "params": dict(
+        hunyuan_schedule=True, shift_scale=5, num_steps=50,
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 4}})})
+    sig = s.sigmas()
+    assert sig.shape == (51,) and sig[0] == 1 and sig[-1] == 0 and s.guider.scale == 4

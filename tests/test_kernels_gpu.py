@@ -1,0 +1,270 @@
+"""GPU parity tests, op level: every HIP kernel of libscail_hip.so (called through the C ABI via
+scail_amd.ops) against the CPU oracle (oracle/scail_oracle.py) on seeded inputs.
+
+Tolerances: bf16 storage + fp32 accumulate vs the fp32 oracle ->
+rtol 2e-2 / atol 2e-2 on O(1) activations; tighter where only one rounding separates the two."""
+import math
+
+import pytest
+import torch
+
+from oracle import scail_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from scail_amd import lib, ops as _ops
+    lib.load()          # loud failure when the HIP library is missing
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def bfr(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return bfr(torch.randn(*shape, generator=g) * scale)
+
+
+def gpu_bf16(x):
+    return x.to(torch.bfloat16).to(DEV)
+
+
+def close(a, b, rtol=2e-2, atol=2e-2, msg=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), f"{msg} mismatches={int(bad.sum())}/{bad.numel()} max_err={float(err.max()):.4g} " \
+                          f"at {tuple(torch.nonzero(bad)[0].tolist()) if bad.any() else None} ref_absmax={float(b.abs().max()):.4g}"
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 128), (1000, 384, 256), (77, 64, 320), (256, 512, 5120)])
+@pytest.mark.parametrize("epi", ["bias", "gelu_tanh", "gelu_erf"])
+def test_gemm(ops, M, N, K, epi):
+    from scail_amd import lib as L
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
+    ref = x @ w.t() + b
+    code = {"bias": L.EPI_BIAS, "gelu_tanh": L.EPI_GELU_TANH, "gelu_erf": L.EPI_GELU_ERF}[epi]
+    if epi == "gelu_tanh":
+        ref = O.gelu_tanh(ref)
+    elif epi == "gelu_erf":
+        ref = torch.nn.functional.gelu(ref)
+    y = ops.gemm(gpu_bf16(x), gpu_bf16(w), b.to(DEV), epilogue=code)
+    close(y, ref, rtol=1e-2, atol=1e-2, msg=f"gemm {M}x{N}x{K} {epi}")
+
+
+def test_gemm_transpose_detecting(ops):
+    """A = I with an asymmetric W catches an output written transposed (guide rule 16)."""
+    K = N = 128
+    x = torch.eye(K)
+    w = bfr(torch.arange(N * K, dtype=torch.float32).reshape(N, K) / (N * K))
+    y = ops.gemm(gpu_bf16(x), gpu_bf16(w))
+    close(y, w.t(), rtol=1e-2, atol=1e-3, msg="gemm identity")
+
+
+def test_gemm_strided_and_residual(ops):
+    from scail_amd import lib as L
+    B, Lr, K, N = 2, 150, 128, 256
+    xbig = rnd(B, Lr, 3 * K, seed=4)
+    x = xbig[..., K:2 * K]                                   # column-slice view, lda = 3K
+    w, b = rnd(N, K, seed=5, scale=0.1), rnd(N, seed=6)
+    resid = rnd(B, Lr, N, seed=7)
+    gate = rnd(B, 6 * N, seed=8)
+    ref = resid + gate[:, None, 2 * N:3 * N] * (x @ w.t() + b)
+    xg = gpu_bf16(xbig)[..., K:2 * K]
+    h = gpu_bf16(resid)
+    g = gate.to(DEV)
+    ops.gemm(xg, gpu_bf16(w), b.to(DEV), out=h, epilogue=L.EPI_RESID, resid=h, gate=g[:, 2 * N:3 * N], rows_per_batch=Lr)
+    close(h, ref, msg="gemm resid+gate in place")
+    h2 = gpu_bf16(resid)
+    ops.gemm(xg, gpu_bf16(w), b.to(DEV), out=h2, epilogue=L.EPI_RESID, resid=h2)
+    close(h2, resid + (x @ w.t() + b), msg="gemm ungated residual")
+
+
+def test_gemm_errors_are_loud(ops):
+    from scail_amd import lib as L
+    x, w = gpu_bf16(rnd(8, 72)), gpu_bf16(rnd(16, 72))
+    with pytest.raises(L.ScailHipError, match="multiple of 64"):
+        ops.gemm(x, w)
+    with pytest.raises(L.ScailHipError, match="GPU"):
+        ops.gemm(rnd(8, 64).to(torch.bfloat16), rnd(16, 64).to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [128, 256, 5120])
+def test_ln_modulate(ops, D):
+    B, Ls = 2, 37
+    x, sh, sc = rnd(B, Ls, D, seed=1, scale=2.0) + 0.5, rnd(B, D, seed=2), rnd(B, D, seed=3, scale=0.3)
+    ref = O.modulate(O.layer_norm(x, 1e-6), sh[:, None], sc[:, None])
+    y = ops.ln_modulate(gpu_bf16(x), sh.to(DEV), sc.to(DEV))
+    close(y, ref, msg=f"ln_modulate D={D}")
+    # noise-token slice variant used by the final layer
+    y2 = ops.ln_modulate(gpu_bf16(x), sh.to(DEV), sc.to(DEV), rows_out=20, src_row_offset=5)
+    close(y2, ref[:, 5:25], msg="ln_modulate slice")
+
+
+def test_layernorm_affine(ops):
+    rows, D = 53, 1280
+    x, w, b = rnd(rows, D, seed=1, scale=3.0), 1 + 0.1 * rnd(D, seed=2), rnd(D, seed=3)
+    y = ops.layernorm_affine(gpu_bf16(x), w.to(DEV), b.to(DEV), eps=1e-5)
+    close(y, O.layer_norm(x, 1e-5, w, b), msg="layernorm_affine")
+
+
+@pytest.mark.parametrize("heads", [1, 2, 40])
+def test_rmsnorm_rope(ops, heads):
+    cfg = O.DiTConfig(hidden_size=128 * heads, num_attention_heads=heads, latent_height=32, latent_width=32, num_frames=13)
+    T, Hp, Wp = 3, 6, 4
+    cos, sin = O.rope_tables(cfg, T, Hp, Wp)
+    Ltok = cos.shape[0]
+    B, D = 2, 128 * heads
+    x, w = rnd(B, Ltok, 3 * D, seed=1), 1 + 0.1 * rnd(D, seed=2)
+    q = x[..., D:2 * D]
+    ref = O.rms_norm(q, w, 1e-6)
+    ref_rope = O._merge(O.apply_rope(O._heads(ref, heads), cos, sin))
+    xg = gpu_bf16(x)
+    out = torch.empty(B, Ltok, D, device=DEV, dtype=torch.bfloat16)
+    ops.rmsnorm_rope(xg[..., D:2 * D], w.to(DEV), out=out)
+    close(out, ref, msg="rmsnorm (no rope)")
+    ops.rmsnorm_rope(xg[..., D:2 * D], w.to(DEV), cos[:, 0::2].contiguous().to(DEV), sin[:, 0::2].contiguous().to(DEV))
+    close(xg[..., D:2 * D], ref_rope, msg="rmsnorm+rope in place")
+    close(xg[..., :D], x[..., :D], rtol=0, atol=0, msg="neighbour columns untouched")
+
+
+def test_rope_tables_match_oracle():
+    from scail_amd import rope
+    cfg = O.DiTConfig(**O.TINY)
+    for hs in (0, 2):
+        cos, sin = rope.build_tables(128, 4, 4, 6, H_shift=hs)
+        oc, os_ = O.rope_tables(cfg, 4, 4, 6, H_shift=hs)
+        assert torch.equal(cos, oc[:, 0::2]) and torch.equal(sin, os_[:, 0::2])
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, heads):
+    return O._merge(O.sdpa(O._heads(q, heads), O._heads(k, heads), O._heads(v, heads)))
+
+
+@pytest.mark.parametrize("Lq,Lk", [(64, 64), (300, 300), (257, 512), (1000, 257), (96, 96), (40, 1)])
+def test_flash_attn(ops, Lq, Lk):
+    B, H = 2, 2
+    D = H * 128
+    q, k, v = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3)
+    ref = _attn_ref(q, k, v, H)
+    vt = ops.transpose_v(gpu_bf16(v), H)
+    o = ops.flash_attn(gpu_bf16(q), gpu_bf16(k), vt)
+    close(o, ref, rtol=2e-2, atol=1e-2, msg=f"flash_attn Lq={Lq} Lk={Lk}")
+
+
+def test_flash_attn_strided_qkv_and_accumulate(ops):
+    B, H, Lt = 2, 2, 200
+    D = H * 128
+    qkv = rnd(B, Lt, 3 * D, seed=1)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    ref = _attn_ref(q, k, v, H)
+    g = gpu_bf16(qkv)
+    vt = ops.transpose_v(g[..., 2 * D:], H)
+    o = ops.flash_attn(g[..., :D], g[..., D:2 * D], vt)
+    close(o, ref, atol=1e-2, msg="strided views into the qkv buffer")
+    # second key set accumulated on top, batch-broadcast (text + CLIP cross attention)
+    k2, v2 = rnd(1, 70, D, seed=5), rnd(1, 70, D, seed=6)
+    ref2 = ref + _attn_ref(q, k2.expand(B, -1, -1), v2.expand(B, -1, -1), H)
+    ops.flash_attn(g[..., :D], gpu_bf16(k2), ops.transpose_v(gpu_bf16(v2), H), out=o, accumulate=True)
+    close(o, ref2, atol=2e-2, msg="accumulate + broadcast K/V")
+
+
+def test_flash_attn_segments(ops):
+    """n_seg > 1: keys of 3 equally sized segments (sequence-parallel all-gather layout)."""
+    B, H, Lq, Ls, S = 1, 2, 130, 100, 3
+    D = H * 128
+    q = rnd(B, Lq, D, seed=1)
+    ks, vs = rnd(S, B, Ls, D, seed=2), rnd(S, B, Ls, D, seed=3)
+    ref = _attn_ref(q, torch.cat(list(ks), 1), torch.cat(list(vs), 1), H)
+    kg = gpu_bf16(ks)
+    vtg = torch.stack([ops.transpose_v(gpu_bf16(vs[s]), H) for s in range(S)])
+    o = ops.flash_attn(gpu_bf16(q), kg[0], vtg[0], n_seg=S, k_seg_stride=kg.stride(0), vt_seg_stride=vtg.stride(0))
+    close(o, ref, atol=1e-2, msg="segmented keys")
+
+
+def test_flash_attn_rescale_branch(ops):
+    """A key that dominates late in the sequence forces the online-softmax running max to jump
+    (guide rule 26): the result must still match the fp32 oracle."""
+    B, H, Lq, Lk = 1, 1, 64, 320
+    q, k, v = rnd(B, Lq, 128, seed=1), rnd(B, Lk, 128, seed=2), rnd(B, Lk, 128, seed=3)
+    k[0, 250] = bfr(q[0, 7] * 4.0)
+    k[0, 100] = bfr(q[0, 9] * 2.0)
+    ref = _attn_ref(q, k, v, H)
+    o = ops.flash_attn(gpu_bf16(q), gpu_bf16(k), ops.transpose_v(gpu_bf16(v), H))
+    close(o, ref, atol=1e-2, msg="spiked keys")
+
+
+def test_flash_attn_properties_long(ops):
+    """Size-independent properties at a long sequence (one head of the config-2 length):
+    rows of softmax sum to one (V = 1 -> O = 1), linearity in V, key-permutation invariance."""
+    B, H, Lt = 1, 1, 48832
+    g = torch.Generator(device=DEV).manual_seed(0)
+    q = torch.randn(B, 2048, 128, device=DEV, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, Lt, 128, device=DEV, generator=g).to(torch.bfloat16)
+    v1 = torch.randn(B, Lt, 128, device=DEV, generator=g).to(torch.bfloat16)
+    ones = torch.ones(B, Lt, 128, device=DEV, dtype=torch.bfloat16)
+    o1 = ops.flash_attn(q, k, ops.transpose_v(ones, H)).float()
+    assert (o1 - 1).abs().max() < 1e-2
+    oa = ops.flash_attn(q, k, ops.transpose_v(v1, H)).float()
+    ob = ops.flash_attn(q, k, ops.transpose_v((2 * v1.float()).to(torch.bfloat16), H)).float()
+    assert (ob - 2 * oa).abs().max() < 2e-2 * max(1.0, float(oa.abs().max()))
+    perm = torch.randperm(Lt, device=DEV, generator=g)
+    oc = ops.flash_attn(q, k[:, perm].contiguous(), ops.transpose_v(v1[:, perm].contiguous(), H)).float()
+    assert (oc - oa).abs().max() < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------
+def test_small_ops(ops):
+    from scail_amd import lib as L
+    t = torch.tensor([0.0, 1000.0, 731.0, 995.9])
+    e = ops.timestep_embedding(t.to(DEV), 256)
+    close(e, O.timestep_embedding(t, 256), rtol=0, atol=2e-6, msg="timestep_embedding")
+    x, w, b = torch.randn(2, 256), rnd(384, 256, seed=1, scale=0.05), rnd(384, seed=2)
+    y = ops.small_linear(x.to(DEV), gpu_bf16(w), b.to(DEV), act_in=L.ACT_SILU, act_out=L.ACT_SILU)
+    ref = torch.nn.functional.silu(torch.nn.functional.silu(x) @ w.t() + b)
+    close(y, ref, rtol=1e-4, atol=1e-4, msg="small_linear")
+    emb, tab = torch.randn(2, 96), torch.randn(5, 96)
+    close(ops.adaln_table(emb.to(DEV), tab.to(DEV)), emb[None] + tab[:, None], rtol=0, atol=0, msg="adaln_table")
+    xx, v = torch.randn(1, 3, 16, 8, 8), torch.randn(2, 3, 16, 8, 8)
+    xg = xx.clone().to(DEV)
+    ops.cfg_euler_(xg, v.to(DEV), 4.0, -0.25)
+    close(xg, xx + (-0.25) * O.cfg_combine(v[:1], v[1:], 4.0), rtol=1e-6, atol=1e-6, msg="cfg_euler")
+    z = torch.randn(1000)
+    close(ops.to_bf16(z.to(DEV)), z.to(torch.bfloat16), rtol=0, atol=0, msg="to_bf16 RNE")
+
+
+def test_patchify_embed_and_unpatchify(ops):
+    cfg = O.DiTConfig(**O.TINY)
+    sd = O.make_state_dict(cfg)
+    B, T, H, W = 2, 3, 8, 12
+    x, ref, pose = rnd(B, T, 16, H, W, seed=1), rnd(1, 1, 16, H, W, seed=2), rnd(1, T, 16, H // 2, W // 2, seed=3)
+    x20 = torch.cat([x, torch.zeros(B, T, 4, H, W)], 2)
+    r20 = torch.cat([ref.expand(B, -1, -1, -1, -1), torch.ones(B, 1, 4, H, W)], 2)
+    p20 = torch.cat([pose.expand(B, -1, -1, -1, -1), torch.ones(B, T, 4, H // 2, W // 2)], 2)
+    want = O.patch_embed(cfg, sd, x20, r20, p20)
+    tok = ops.patchify(x.to(DEV), gpu_bf16(ref), gpu_bf16(pose))
+    D = cfg.hidden_size
+    Lrn = (1 + T) * (H // 2) * (W // 2)
+    h = torch.empty(B, tok.shape[1], D, device=DEV, dtype=torch.bfloat16)
+    for name, sl in (("proj", slice(0, Lrn)), ("proj_pose", slice(Lrn, None))):
+        wp = torch.zeros(D, 128)
+        wp[:, :80] = sd[f"mixins.patch_embed.{name}.weight"].reshape(D, 80)
+        for b in range(B):
+            ops.gemm(tok[b, sl], gpu_bf16(wp), sd[f"mixins.patch_embed.{name}.bias"].to(DEV), out=h[b, sl])
+    close(h, want, msg="patchify + patch-embed GEMM")
+    # unpatchify against the oracle's rearrangement (final_layer with identity weights is overkill:
+    # test the index map directly)
+    tokout = rnd(B, T * (H // 2) * (W // 2), 64, seed=9)
+    wantu = tokout.reshape(B, T, H // 2, W // 2, 1, 2, 2, 16).permute(0, 1, 4, 7, 2, 5, 3, 6).reshape(B, T, 16, H, W)
+    close(ops.unpatchify(gpu_bf16(tokout), T, H, W), wantu, rtol=0, atol=0, msg="unpatchify")

@@ -13,15 +13,20 @@ def _load(golden_dir, name):
 
 
 def test_state_dict_spec_matches_survey_count():
-    cfg = O.DiTConfig(**O.TINY)
+    cfg = O.DiTConfig(hidden_size=128, num_layers=2, num_attention_heads=4, inner_hidden_size=256, text_dim=64,
+                      time_freq_dim=256, time_embed_dim=128)
     assert len(O.state_dict_spec(cfg)) == 73           # SURVEY.md Appendix B [probe]
     n = sum(int(np.prod(s)) for s in O.state_dict_spec(cfg).values())
-    assert n == 2474432                                 # reference parameter count for this config
+    assert n == 2474432                                 # reference parameter count for the survey's probe config
 
 
-def test_dit_forward_matches_reference(golden_dir):
-    g = _load(golden_dir, "dit_tiny.npz")
-    cfg = O.DiTConfig(**O.TINY)
+import pytest
+
+
+@pytest.mark.parametrize("name,cfgd", [("dit_tiny.npz", O.TINY), ("dit_config1.npz", O.CONFIG1)])
+def test_dit_forward_matches_reference(golden_dir, name, cfgd):
+    g = _load(golden_dir, name)
+    cfg = O.DiTConfig(**cfgd)
     sd = O.make_state_dict(cfg, seed=int(g["seed"]))
     out, hidden = O.dit_forward(cfg, sd, g["x"], g["t"], g["ctx"], g["ref"], g["pose"], g["clip"], return_hidden=True)
     for i in range(cfg.num_layers):
