@@ -150,6 +150,11 @@ int scail_unpatchify(const scail_bf16* tok, float* out, int64_t n_batch, int64_t
  * (guiders.py:41-45 + sampling_utils.py:7-10 + Euler update sampling.py:960-963), all fp32. */
 int scail_cfg_euler(float* x, const float* v, int64_t n, float cfg_scale, float dsigma, void* stream);
 
+/* Tuning / A-B knob for kernel variants (same results, different schedules); used by tools/microbench.py.
+ * knobs: "attn_variant" (bit 0: s_setprio around MFMA clusters, bit 1: skip no-op O rescales [default],
+ *        bit 3: software-pipelined kernel). */
+int scail_tune_set(const char* knob, int value);
+
 /* fp32 -> bf16 (round to nearest even) and back; plumbing for boundary tensors. */
 int scail_f32_to_bf16(const float* x, scail_bf16* y, int64_t n, void* stream);
 int scail_bf16_to_f32(const scail_bf16* x, float* y, int64_t n, void* stream);

@@ -30,6 +30,7 @@
 #define K_LD (HD + 8)      // elements per K row in LDS (272 B)
 #define V_LD (KVBLK + 8)   // elements per V^T row in LDS (144 B)
 #define ATT_LDS_BYTES (2 * (KVBLK * K_LD + HD * V_LD) * 2)
+#define ATT_PP_LDS_BYTES (ATT_LDS_BYTES + QBLK * K_LD * 2)
 
 struct AttnParams {
     const u16* q; int64_t q_bs, q_rs;
@@ -41,6 +42,9 @@ struct AttnParams {
     int accumulate;
 };
 
+// VARIANT bit 0: s_setprio(1) around the MFMA clusters; bit 1: skip the O rescale when no row's running
+// max moved in this tile (exact: alpha == 1 for every lane).
+template <int VARIANT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* Ks = smem;                       // [2][KVBLK][K_LD]
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[f][e] = 0.f;
         const u16* ks_ = Ks + (cur * KVBLK + ql) * K_LD + g * 8;
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
 #pragma unroll
@@ -122,6 +127,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
                 s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[f], 0, 0, 0);
             }
         }
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
         // ---- mask the padded keys of a segment's last tile ----
         if (tail < KVBLK) {
             const int t = tt % tps;
@@ -155,11 +161,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
                 rs += pv;
             }
         l_run = l_run * alpha + rs;
+        if (!(VARIANT & 2) || !__all(m_new == m_run)) {
+#pragma unroll
+            for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        }
         m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < HD / 32; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
         // ---- P^T fragments: k-slot group ks <-> score registers s[ks>>1][8 (ks&1) .. +7] ----
         bf16x8 pf[4];
 #pragma unroll
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
         }
         // ---- O^T += V^T P^T ----
         const u16* vs_ = Vs + (cur * HD + ql) * V_LD + g * 8;
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -182,6 +191,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[d], 0, 0, 0);
             }
         }
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
         if (tt + 1 < ntiles) { S_STORE(cur ^ 1) }
         __syncthreads();
     }
@@ -214,6 +224,258 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
     }
 }
 
+
+// ================================================================================================
+// Building blocks shared with the software-pipelined kernel below (Q fragments are read from LDS there).
+// A "ping-pong" variant (the two wave groups half a tile apart: one on the matrix pipe while its SIMD
+// partner runs the softmax, two barriers per tile) was measured at 584 TFLOP/s against 1035-1078 for the
+// lock-step kernel above -- its control flow made hipcc drain vmcnt at every half-step -- and removed.
+// ================================================================================================
+#define PP_QK(S_, slot_)                                                                          \
+    {                                                                                             \
+        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                             \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) S_[f][e] = 0.f;                        \
+        const u16* ks_ = Ks + ((slot_) * KVBLK + ql) * K_LD + g * 8;                              \
+        _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks) {                                  \
+            const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(qs_ + ks * 16);                   \
+            _Pragma("unroll") for (int f = 0; f < 2; ++f) {                                       \
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + f * 32 * K_LD + ks * 16); \
+                S_[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfr, S_[f], 0, 0, 0);         \
+            }                                                                                     \
+        }                                                                                         \
+    }
+#define PP_PV(slot_)                                                                              \
+    {                                                                                             \
+        const u16* vs_ = Vs + ((slot_) * HD + ql) * V_LD + g * 8;                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                        \
+            _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) {                                 \
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * V_LD + ks * 16); \
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[d], 0, 0, 0);        \
+            }                                                                                     \
+        }                                                                                         \
+    }
+#define PP_LOAD_K(tt_)                                                                                    \
+    {                                                                                                     \
+        const int seg_ = (tt_) / tps, key0_ = ((tt_) - seg_ * tps) * KVBLK;                               \
+        const u16* kp_ = kbase + (int64_t)seg_ * p.k_ss;                                                  \
+        kr0 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow, p.Lk - 1) * p.k_rs);       \
+        kr1 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + 32, p.Lk - 1) * p.k_rs);  \
+    }
+#define PP_LOAD_V(tt_)                                                                                    \
+    {                                                                                                     \
+        const int seg_ = (tt_) / tps, key0_ = ((tt_) - seg_ * tps) * KVBLK;                               \
+        const u16* vp_ = vbase + (int64_t)seg_ * p.vt_ss + key0_;                                         \
+        vr0 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)vrow * p.Lkp);                               \
+        vr1 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + 64) * p.Lkp);                        \
+    }
+#define PP_STORE_K(slot_)                                                                          \
+    {                                                                                              \
+        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow) * K_LD + kcc * 8) = kr0;           \
+        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + 32) * K_LD + kcc * 8) = kr1;      \
+    }
+#define PP_STORE_V(slot_)                                                                          \
+    {                                                                                              \
+        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow) * V_LD + vcc * 8) = vr0;              \
+        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + 64) * V_LD + vcc * 8) = vr1;         \
+    }
+
+
+// ================================================================================================
+// Software-pipelined structure.  One code path for all 8 waves; inside a wave the QK^T MFMAs of tile
+// t+1 are issued interleaved (sched_group_barrier) with the softmax VALU work of tile t, which is
+// independent of them -- the matrix pipe runs asynchronously, so the VALU instructions placed in the
+// gaps between MFMA issues are free.  Then P(t).V(t).  Straight-line loop body (tile indices past the
+// end are clamped instead of branched around, so hipcc's s_waitcnt placement stays exact).
+//   LDS: K ring 2 slots (K(t+1) read in iteration t, K(t+2) written at its end), V ring 2 slots,
+//   Q rows of the block (re-read per tile; frees 32 VGPRs for the second score tile).
+// ================================================================================================
+// row max of a 64-key score tile held as S_[2][16] per lane, combined across the row's two lanes
+// (lane, lane^32) with v_permlane32_swap: r[0] = {lo, lo}, r[1] = {hi, hi} -> max(r[0], r[1])
+#define SWP_ROWMAX(S_, OUT_)                                                                      \
+    {                                                                                             \
+        float mx_ = S_[0][0];                                                                     \
+        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) mx_ = fmaxf(mx_, S_[f][r]);            \
+        const unsigned mi_ = __float_as_uint(mx_);                                                \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(mi_, mi_, false, false);                \
+        OUT_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                           \
+    }
+
+// exp / sum / pack part of the online softmax, row max MX_ already known
+#define SWP_SOFTMAX(S_, MX_)                                                                      \
+    const float m_new_ = fmaxf(m_run, MX_);                                                       \
+    const float alpha_ = __builtin_amdgcn_exp2f((m_run - m_new_) * sl2);                          \
+    const float msc_ = m_new_ * sl2;                                                              \
+    float rs_ = 0.f;                                                                              \
+    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
+            const float pv_ = __builtin_amdgcn_exp2f(S_[f][r] * sl2 - msc_);                      \
+            S_[f][r] = pv_;                                                                       \
+            rs_ += pv_;                                                                           \
+        }                                                                                         \
+    l_run = l_run * alpha_ + rs_;                                                                 \
+    const bool moved_ = !__all(m_new_ == m_run);                                                  \
+    m_run = m_new_;                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
+        uint4 u_;                                                                                 \
+        const int f = ks >> 1, r0 = (ks & 1) * 8;                                                 \
+        u_.x = pack_bf16x2(S_[f][r0 + 0], S_[f][r0 + 1]);                                         \
+        u_.y = pack_bf16x2(S_[f][r0 + 2], S_[f][r0 + 3]);                                         \
+        u_.z = pack_bf16x2(S_[f][r0 + 4], S_[f][r0 + 5]);                                         \
+        u_.w = pack_bf16x2(S_[f][r0 + 6], S_[f][r0 + 7]);                                         \
+        pf[ks] = __builtin_bit_cast(bf16x8, u_);                                                  \
+    }
+
+#define SWP_MASK(S_, T_)                                                                          \
+    if (tail < KVBLK && ((T_) % tps) == tps - 1) {                                                \
+        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
+                const int key = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;                          \
+                if (key >= tail) S_[f][r] = -INFINITY;                                            \
+            }                                                                                     \
+    }
+
+// MFMA / VALU(+TRANS) interleave groups: one MFMA, then n VALU instructions
+#define SWP_GA __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);
+#define SWP_GB __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 3, 0);
+#define SWP_X16(G_) G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_
+
+// keeps a value computed BEFORE this point (machine sinking would otherwise move the exp2 chain below
+// the rescale branch, out of the block that holds the QK^T MFMAs it is meant to hide under)
+#define SWP_PIN(x_) { const uint4 pin_ = __builtin_bit_cast(uint4, x_); asm volatile("" :: "v"(pin_.x), "v"(pin_.y), "v"(pin_.z), "v"(pin_.w)); }
+
+// One pipelined iteration.  In: SC_ = scores of tile T_ (masked), MXC_ = their row max.
+//   block A:  SN_ = QK^T(T_+1)          ||  exp / sum / pack of SC_ -> P fragments
+//   (rare)    O *= alpha when some row max moved;  mask SN_ when T_+1 is a segment's ragged tile
+//   block B:  O += V^T(T_) P^T(T_)      ||  MXN_ = row max of SN_
+#define SWP_ITER(SC_, SN_, MXC_, MXN_, T_, HAS_NEXT_)                                              \
+    {                                                                                              \
+        const int cur_ = (T_) & 1;                                                                 \
+        PP_LOAD_K(min((T_) + 2, ntiles - 1))                                                       \
+        PP_LOAD_V(min((T_) + 1, ntiles - 1))                                                       \
+        if (HAS_NEXT_) PP_QK(SN_, cur_ ^ 1)                                                        \
+        SWP_SOFTMAX(SC_, MXC_)                                                                     \
+        if (HAS_NEXT_) { SWP_X16(SWP_GA) }                                                         \
+        SWP_PIN(pf[0]) SWP_PIN(pf[1]) SWP_PIN(pf[2]) SWP_PIN(pf[3])                                \
+        if (moved_) {                                                                              \
+            _Pragma("unroll") for (int d = 0; d < HD / 32; ++d)                                    \
+                _Pragma("unroll") for (int e = 0; e < 16; ++e) o[d][e] *= alpha_;                  \
+        }                                                                                          \
+        if (HAS_NEXT_) SWP_MASK(SN_, (T_) + 1)                                                     \
+        PP_PV(cur_)                                                                                \
+        if (HAS_NEXT_) {                                                                           \
+            SWP_ROWMAX(SN_, MXN_)                                                                  \
+            SWP_X16(SWP_GB)                                                                        \
+        }                                                                                          \
+        PP_STORE_K(cur_)                                                                           \
+        PP_STORE_V(cur_ ^ 1)                                                                       \
+        __syncthreads();                                                                           \
+    }
+
+__global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Ks = smem;                              // [2][KVBLK][K_LD]
+    u16* Vs = smem + 2 * KVBLK * K_LD;           // [2][HD][V_LD]
+    u16* Qs = Vs + 2 * HD * V_LD;                // [8 waves][32][K_LD]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, g = lane >> 5;
+    const int h = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int q0 = blockIdx.x * QBLK + wave * 32;
+
+    const u16* qs_ = Qs + (wave * 32 + ql) * K_LD + g * 8;
+    {
+        const int qrow = min(q0 + ql, p.Lq - 1);
+        const u16* qp = p.q + b * p.q_bs + (int64_t)qrow * p.q_rs + (int64_t)h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks)
+            *reinterpret_cast<uint4*>(const_cast<u16*>(qs_) + ks * 16) = *reinterpret_cast<const uint4*>(qp + ks * 16);
+    }
+    const int krow = tid >> 4, kcc = tid & 15;
+    const int vrow = tid >> 3, vcc = tid & 7;
+    const u16* kbase = p.k + b * p.k_bs + (int64_t)h * HD + kcc * 8;
+    const u16* vbase = p.vt + b * p.vt_bs + (int64_t)h * HD * p.Lkp + vcc * 8;
+    const int tps = p.Lkp / KVBLK;
+    const int ntiles = tps * p.n_seg;
+    const int tail = p.Lk - (tps - 1) * KVBLK;
+    const float sl2 = p.sl2;
+    uint4 kr0, kr1, vr0, vr1;
+
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 sa[2], sb[2];
+    bf16x8 pf[4];
+
+    // prologue: K(0) -> slot 0, K(1) -> slot 1, V(0) -> slot 0; scores of tile 0
+    PP_LOAD_K(0)
+    PP_LOAD_V(0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    PP_STORE_K(0)
+    PP_STORE_V(0)
+    PP_LOAD_K(min(1, ntiles - 1))
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    PP_STORE_K(1)
+    __syncthreads();
+    float mxa, mxb = 0.f;
+    PP_QK(sa, 0)
+    SWP_MASK(sa, 0)
+    SWP_ROWMAX(sa, mxa)
+    __syncthreads();   // slot 0 is rewritten with K(2) at the end of iteration 0
+
+    int t = 0;
+    for (; t + 2 < ntiles; t += 2) {
+        SWP_ITER(sa, sb, mxa, mxb, t, true)
+        SWP_ITER(sb, sa, mxb, mxa, t + 1, true)
+    }
+    if (ntiles - t == 2) {
+        SWP_ITER(sa, sb, mxa, mxb, t, true)
+        SWP_ITER(sb, sa, mxb, mxa, t + 1, false)
+    } else {
+        SWP_ITER(sa, sb, mxa, mxb, t, false)
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + ql;
+    if (qrow < p.Lq) {
+        u16* op = p.o + b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * HD + 4 * g;
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = o[d][4 * rr + e] * inv;
+                uint2* dst = reinterpret_cast<uint2*>(op + d * 32 + rr * 8);
+                if (p.accumulate) {
+                    const uint2 old = *dst;
+                    v[0] += bf_lo(old.x); v[1] += bf_hi(old.x);
+                    v[2] += bf_lo(old.y); v[3] += bf_hi(old.y);
+                }
+                uint2 w;
+                w.x = pack_bf16x2(v[0], v[1]);
+                w.y = pack_bf16x2(v[2], v[3]);
+                *dst = w;
+            }
+        }
+    }
+}
+
+// bit 3: software-pipelined kernel (measured 990 vs 1035 TFLOP/s: not the default); else the lock-step
+// kernel with bit 0 = s_setprio around MFMA clusters (-3 %), bit 1 = skip no-op O rescales (+4 %, default)
+static int g_attn_variant = 2;
+extern "C" int scail_tune_set(const char* knob, int value) {
+    if (std::string(knob) == "attn_variant") { g_attn_variant = value; return 0; }
+    scail_set_error(std::string("scail_tune_set: unknown knob ") + knob);
+    return 1;
+}
+
 extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t q_rs,
                                      const scail_bf16* k, int64_t k_ss, int64_t k_bs, int64_t k_rs,
                                      const scail_bf16* vt, int64_t vt_ss, int64_t vt_bs,
@@ -233,11 +495,15 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     if (Lq == 0 || n_batch == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-        if (e != hipSuccess) {
-            scail_set_error(std::string("flash_attn: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
-            return 2;
+        const void* fns[5] = {reinterpret_cast<const void*>(&flash_attn_kernel<0>), reinterpret_cast<const void*>(&flash_attn_kernel<1>),
+                              reinterpret_cast<const void*>(&flash_attn_kernel<2>), reinterpret_cast<const void*>(&flash_attn_kernel<3>),
+                              reinterpret_cast<const void*>(&flash_attn_swp_kernel)};
+        for (int i = 0; i < 5; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i >= 4 ? ATT_PP_LDS_BYTES : ATT_LDS_BYTES);
+            if (e != hipSuccess) {
+                scail_set_error(std::string("flash_attn: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
+                return 2;
+            }
         }
         attr_set = true;
     }
@@ -250,6 +516,15 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     p.sl2 = scale * 1.4426950408889634f;
     p.accumulate = accumulate;
     dim3 grid((unsigned)((Lq + QBLK - 1) / QBLK), (unsigned)heads, (unsigned)n_batch);
-    hipLaunchKernelGGL(flash_attn_kernel, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p);
+    if (g_attn_variant & 8) {
+        hipLaunchKernelGGL(flash_attn_swp_kernel, grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+        return scail_check_launch("flash_attn");
+    }
+    switch (g_attn_variant & 3) {
+        case 0: hipLaunchKernelGGL(flash_attn_kernel<0>, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+        case 1: hipLaunchKernelGGL(flash_attn_kernel<1>, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+        case 2: hipLaunchKernelGGL(flash_attn_kernel<2>, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL(flash_attn_kernel<3>, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+    }
     return scail_check_launch("flash_attn");
 }

@@ -29,6 +29,7 @@ SIGNATURES = {
     "scail_patchify": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "scail_unpatchify": [_p, _p, _i64, _i64, _i64, _i64, _p],
     "scail_cfg_euler": [_p, _p, _i64, _f, _f, _p],
+    "scail_tune_set": [C.c_char_p, _i],
     "scail_f32_to_bf16": [_p, _p, _i64, _p],
     "scail_bf16_to_f32": [_p, _p, _i64, _p],
 }
@@ -73,3 +74,7 @@ def call(name: str, *args) -> None:
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise ScailHipError(f"{name} failed ({rc}): {lib.scail_last_error().decode()}")
+
+
+def tune_set(knob: str, value: int) -> None:
+    call("scail_tune_set", knob.encode(), int(value))

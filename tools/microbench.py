@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--K", type=int, default=5120)
     ap.add_argument("--epi", type=int, default=0)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--variants", type=str, default="0")
     a = ap.parse_args()
     lib.load()
     dev = "cuda"
@@ -53,9 +54,17 @@ def main():
             k, v = rn(a.B, Lk, D), rn(a.B, Lk, D)
         vt = ops.transpose_v(v, a.heads)
         out = torch.empty(a.B, a.L, D, device=dev, dtype=torch.bfloat16)
-        med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), a.iters)
         fl = 4.0 * a.L * Lk * 128 * a.heads * a.B
-        print(json.dumps(dict(case="attn", B=a.B, heads=a.heads, Lq=a.L, Lk=Lk, ms=med, ms_min=best, tflops=fl / med / 1e9)))
+        ref = None
+        for rnd_ in range(2):                       # interleaved rounds: within-probe A/B
+            for var in [int(x) for x in a.variants.split(",")]:
+                lib.tune_set("attn_variant", var)
+                med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), a.iters)
+                if ref is None:
+                    ref = out.clone()
+                diff = float((out.float() - ref.float()).abs().max())
+                print(json.dumps(dict(case="attn", variant=var, B=a.B, heads=a.heads, Lq=a.L, Lk=Lk, ms=med, ms_min=best,
+                                      tflops=fl / med / 1e9, maxdiff_vs_first=diff)))
     elif a.what == "gemm":
         x, w = rn(a.M, a.K), rn(a.N, a.K) * 0.02
         b = torch.randn(a.N, device=dev)
