@@ -152,7 +152,7 @@ int scail_cfg_euler(float* x, const float* v, int64_t n, float cfg_scale, float 
 
 /* Tuning / A-B knob for kernel variants (same results, different schedules); used by tools/microbench.py.
  * knobs: "attn_variant" (bit 0: s_setprio around MFMA clusters, bit 1: skip no-op O rescales [default],
- *        bit 3: software-pipelined kernel). */
+ *        bit 3: software-pipelined kernel); "gemm_tile" (0 auto, 128, 256). */
 int scail_tune_set(const char* knob, int value);
 
 /* fp32 -> bf16 (round to nearest even) and back; plumbing for boundary tensors. */

@@ -469,9 +469,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
 
 // bit 3: software-pipelined kernel (measured 990 vs 1035 TFLOP/s: not the default); else the lock-step
 // kernel with bit 0 = s_setprio around MFMA clusters (-3 %), bit 1 = skip no-op O rescales (+4 %, default)
+int scail_gemm_tune(int v);
 static int g_attn_variant = 2;
 extern "C" int scail_tune_set(const char* knob, int value) {
     if (std::string(knob) == "attn_variant") { g_attn_variant = value; return 0; }
+    if (std::string(knob) == "gemm_tile") return scail_gemm_tune(value);
     scail_set_error(std::string("scail_tune_set: unknown knob ") + knob);
     return 1;
 }

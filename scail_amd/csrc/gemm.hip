@@ -16,12 +16,8 @@
 // per group, m fastest) so the 64 co-resident tiles of an XCD touch 8 + 8 operand panels.
 #include "common.h"
 
-#define BM 128
-#define BN 128
 #define BK 64
 #define LDT 72  // padded LDS row, elements (144 B)
-#define GEMM_THREADS 256
-#define GEMM_LDS_BYTES (2 * (BM + BN) * LDT * 2)
 #define GROUP_M 8
 
 struct GemmParams {
@@ -34,8 +30,17 @@ struct GemmParams {
     const float* gate; int64_t gate_stride; int64_t rows_per_batch;
 };
 
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
+// Two instantiations share this body:
+//   128 x 128 tile, 4 waves (2 x 2), wave tile 64 x 64,  74 KB LDS, 2 workgroups per CU  (small / ragged N)
+//   256 x 256 tile, 8 waves (2 x 4), wave tile 128 x 64, 147 KB LDS, 1 workgroup per CU  (the big per-token
+//   GEMMs: half the L2->LDS bytes per FLOP, 6 LDS fragment reads per 8 MFMAs instead of 4 per 4)
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
+    constexpr int NT = 64 * WM * WN;      // threads
+    constexpr int RS = NT / 8;            // tile rows covered by one staging pass (8 x 16 B chunks per row)
+    static_assert(BM / RS == 4 && BN / RS == 4, "staging code below is written for 4 passes per operand");
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MI = WTM / 32, NI = WTN / 32;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* Xs = smem;                  // [2][BM][LDT]
     u16* Ws = smem + 2 * BM * LDT;   // [2][BN][LDT]
@@ -58,15 +63,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     const int m0 = pid_m * BM, n0 = pid_n * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, g = lane >> 5;
 
-    // ---- staging coordinates: chunk = tid + 256 i  -> row = (tid >> 3) + 32 i, kc = tid & 7 ----
+    // ---- staging: chunk = tid + NT i  -> row = (tid >> 3) + RS i, kc = tid & 7 ----
     const int srow = tid >> 3, kc = tid & 7;
     // (named scalars, not arrays: hipcc sends register arrays written under a branch to scratch)
 #define ROWPTR(i_)                                                                              \
-    const u16* xptr##i_ = p.x + (int64_t)min(m0 + srow + 32 * i_, p.M - 1) * p.lda + kc * 8;    \
-    const u16* wptr##i_ = p.w + (int64_t)min(n0 + srow + 32 * i_, p.N - 1) * p.K + kc * 8;      \
+    const u16* xptr##i_ = p.x + (int64_t)min(m0 + srow + RS * i_, p.M - 1) * p.lda + kc * 8;    \
+    const u16* wptr##i_ = p.w + (int64_t)min(n0 + srow + RS * i_, p.N - 1) * p.K + kc * 8;      \
     uint4 xr##i_, wr##i_;
     ROWPTR(0) ROWPTR(1) ROWPTR(2) ROWPTR(3)
 #define G_LOAD1(i_, k0_)                                              \
@@ -74,15 +79,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     wr##i_ = *reinterpret_cast<const uint4*>(wptr##i_ + (k0_));
 #define G_LOAD(k0_) G_LOAD1(0, k0_) G_LOAD1(1, k0_) G_LOAD1(2, k0_) G_LOAD1(3, k0_)
 #define S_STORE1(i_, buf_)                                                                        \
-    *reinterpret_cast<uint4*>(Xs + ((buf_) * BM + srow + 32 * i_) * LDT + kc * 8) = xr##i_;       \
-    *reinterpret_cast<uint4*>(Ws + ((buf_) * BN + srow + 32 * i_) * LDT + kc * 8) = wr##i_;
+    *reinterpret_cast<uint4*>(Xs + ((buf_) * BM + srow + RS * i_) * LDT + kc * 8) = xr##i_;       \
+    *reinterpret_cast<uint4*>(Ws + ((buf_) * BN + srow + RS * i_) * LDT + kc * 8) = wr##i_;
 #define S_STORE(buf_) S_STORE1(0, buf_) S_STORE1(1, buf_) S_STORE1(2, buf_) S_STORE1(3, buf_)
 
-    f32x16 acc[2][2];  // [ni][mi]
+    f32x16 acc[NI][MI];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < MI; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
@@ -93,20 +98,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) { G_LOAD((t + 1) * BK) }
-        const u16* xs = Xs + (cur * BM + wm * 64 + l31) * LDT + g * 8;
-        const u16* ws = Ws + (cur * BN + wn * 64 + l31) * LDT + g * 8;
+        const u16* xs = Xs + (cur * BM + wm * WTM + l31) * LDT + g * 8;
+        const u16* ws = Ws + (cur * BN + wn * WTN + l31) * LDT + g * 8;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 wf[2], xf[2];
+            bf16x8 wf[NI], xf[MI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * LDT + ks * 16);
-                xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * LDT + ks * 16);
-            }
+            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * LDT + ks * 16);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * LDT + ks * 16);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
         if (t + 1 < nk) { S_STORE(cur ^ 1) }
@@ -115,16 +119,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
 
     // ---- epilogue: lane holds column m, rows n = nbase + 8 rr + 4 g + e ----
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = m0 + wm * 64 + mi * 32 + l31;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * WTM + mi * 32 + l31;
         if (m >= p.M) continue;
         int64_t bidx = 0;
         if (EPI == SCAIL_EPI_RESID && p.gate != nullptr) bidx = (int64_t)m / p.rows_per_batch;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int n = n0 + wn * 64 + ni * 32 + 8 * rr + 4 * g;
+                const int n = n0 + wn * WTN + ni * 32 + 8 * rr + 4 * g;
                 if (n >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -160,12 +164,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
-template <int EPI>
-static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force (tools/microbench.py A/B)
+int scail_gemm_tune(int v) { g_gemm_tile = v; return 0; }
+
+template <int BM, int BN, int WM, int WN, int EPI>
+static int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds = 2 * (BM + BN) * LDT * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WM, WN, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             scail_set_error(std::string("gemm: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
             return 2;
@@ -173,8 +181,15 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((unsigned)tiles), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, EPI>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, stream, p);
     return scail_check_launch("gemm_bf16");
+}
+
+template <int EPI>
+static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+    const bool big = g_gemm_tile == 256 || (g_gemm_tile == 0 && p.M >= 2048 && p.N >= 1024);
+    if (big) return launch_gemm_t<256, 256, 2, 4, EPI>(p, stream);
+    return launch_gemm_t<128, 128, 2, 2, EPI>(p, stream);
 }
 
 extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf16* w, const float* bias,

@@ -46,9 +46,18 @@ def close(a, b, rtol=2e-2, atol=2e-2, msg=""):
 
 
 # ------------------------------------------------------------------------------------------------
+@pytest.fixture(params=[128, 256])
+def gemm_tile(request):
+    """Force each GEMM tile instantiation in turn (the library picks by shape otherwise)."""
+    from scail_amd import lib as L
+    L.tune_set("gemm_tile", request.param)
+    yield request.param
+    L.tune_set("gemm_tile", 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 128), (1000, 384, 256), (77, 64, 320), (256, 512, 5120)])
 @pytest.mark.parametrize("epi", ["bias", "gelu_tanh", "gelu_erf"])
-def test_gemm(ops, M, N, K, epi):
+def test_gemm(ops, gemm_tile, M, N, K, epi):
     from scail_amd import lib as L
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
     ref = x @ w.t() + b
@@ -61,7 +70,7 @@ def test_gemm(ops, M, N, K, epi):
     close(y, ref, rtol=1e-2, atol=1e-2, msg=f"gemm {M}x{N}x{K} {epi}")
 
 
-def test_gemm_transpose_detecting(ops):
+def test_gemm_transpose_detecting(ops, gemm_tile):
     """A = I with an asymmetric W catches an output written transposed (guide rule 16)."""
     K = N = 128
     x = torch.eye(K)
@@ -70,7 +79,7 @@ def test_gemm_transpose_detecting(ops):
     close(y, w.t(), rtol=1e-2, atol=1e-3, msg="gemm identity")
 
 
-def test_gemm_strided_and_residual(ops):
+def test_gemm_strided_and_residual(ops, gemm_tile):
     from scail_amd import lib as L
     B, Lr, K, N = 2, 150, 128, 256
     xbig = rnd(B, Lr, 3 * K, seed=4)

@@ -72,9 +72,12 @@ def main():
         kw = {}
         if a.epi == 3:
             kw = dict(resid=y, gate=torch.randn(2, a.N, device=dev), rows_per_batch=a.M // 2)
-        med, best = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=a.epi, **kw), a.iters)
         fl = 2.0 * a.M * a.N * a.K
-        print(json.dumps(dict(case="gemm", M=a.M, N=a.N, K=a.K, epi=a.epi, ms=med, ms_min=best, tflops=fl / med / 1e9)))
+        for rnd_ in range(2):
+            for var in [int(z) for z in a.variants.split(",")]:
+                lib.tune_set("gemm_tile", var)
+                med, best = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=a.epi, **kw), a.iters)
+                print(json.dumps(dict(case="gemm", tile=var, M=a.M, N=a.N, K=a.K, epi=a.epi, ms=med, ms_min=best, tflops=fl / med / 1e9)))
     else:
         D = 5120
         x = rn(2, a.L, D)
