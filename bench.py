@@ -192,6 +192,13 @@ def main():
     attn_flops = 4.0 * (L // world) * L * 128 * nh * 2
     ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms else None
     fl = step_flops(p, L, Lt, Lc)
+    traffic = None                      # measured offline with rocprofv3 --pmc (cannot run inside the bench)
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))["flash_attn_self"]
+        if tr["shape"] == {"B": 2, "heads": nh, "Lq": L // world, "Lk": L}:
+            traffic = tr["traffic_bytes"]
+    except Exception:
+        pass
     out = {
         "metric": "denoising-step latent tokens/sec", "value": Lnoise / t_step, "unit": "latent tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3,
@@ -204,7 +211,7 @@ def main():
                    "finite": finite},
         "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel (self-attention)", "achieved": ach,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
-                     "traffic": None, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,
+                     "traffic": traffic, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,
                      "launches_timed": len(timer.events.get("self_attn", []))},
     }
     if args.layers is not None:
