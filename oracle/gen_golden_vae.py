@@ -1,0 +1,42 @@
+"""Generate tests/golden/vae_tiny.npz by running the REAL reference WanVAE_ (chunked, feature caches)
+on CPU in fp32.  Build-container only.  Usage: python oracle/gen_golden_vae.py"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.join("/root/reference", "sgm", "models"))
+
+from oracle import wan_vae_oracle as V  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def main():
+    import wan_vae as ref                      # sgm/models/wan_vae.py imports standalone (torch + einops)
+    cfg = V.VAEConfig(dim=32, z_dim=16)
+    sd = V.make_state_dict(cfg, seed=4321)
+    model = ref.WanVAE_(dim=cfg.dim, z_dim=cfg.z_dim, dim_mult=list(cfg.dim_mult), num_res_blocks=2, attn_scales=[],
+                        temperal_downsample=list(cfg.temperal_downsample), dropout=0.0).eval()
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    scale = [torch.tensor(V.LATENT_MEAN), 1.0 / torch.tensor(V.LATENT_STD)]
+    g = torch.Generator().manual_seed(5)
+    video = (torch.rand(1, 3, 9, 32, 48, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    z_in = torch.randn(1, 16, 3, 4, 6, generator=g).to(torch.bfloat16).float()
+    with torch.no_grad():
+        mu = model.encode(video, scale)
+        rec = model.decode(z_in, scale).clamp(-1, 1)
+        mu1 = model.encode(video[:, :, :1], scale)          # single image (the ref-frame encode of the CLI)
+    np.savez_compressed(os.path.join(OUT, "vae_tiny.npz"), seed=4321, dim=32, video=video.numpy(), mu=mu.numpy(),
+                        z_in=z_in.numpy(), rec=rec.numpy(), mu1=mu1.numpy())
+    print("vae_tiny: mu", tuple(mu.shape), float(mu.abs().mean()), "rec", tuple(rec.shape), float(rec.abs().mean()))
+
+
+if __name__ == "__main__":
+    main()

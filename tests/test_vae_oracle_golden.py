@@ -1,0 +1,38 @@
+"""Pin the whole-sequence VAE oracle (oracle/wan_vae_oracle.py) to outputs of the REAL chunked
+reference WanVAE_ (tests/golden/vae_tiny.npz, oracle/gen_golden_vae.py)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import wan_vae_oracle as V
+
+
+def _load(golden_dir):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, "vae_tiny.npz")).items()}
+
+
+def test_vae_state_dict_param_count():
+    cfg = V.VAEConfig(dim=96, z_dim=16)
+    n = sum(int(np.prod(s)) for s in V.state_dict_spec(cfg).values())
+    assert abs(n - 126.9e6) < 0.2e6           # 126.9 M parameters
+
+
+def test_encode_matches_reference(golden_dir):
+    g = _load(golden_dir)
+    cfg = V.VAEConfig(dim=int(g["dim"]), z_dim=16)
+    sd = V.make_state_dict(cfg, seed=int(g["seed"]))
+    with torch.no_grad():
+        mu = V.encode(cfg, sd, g["video"])
+        mu1 = V.encode(cfg, sd, g["video"][:, :, :1])
+    torch.testing.assert_close(mu, g["mu"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(mu1, g["mu1"], rtol=1e-4, atol=1e-4)
+
+
+def test_decode_matches_reference(golden_dir):
+    g = _load(golden_dir)
+    cfg = V.VAEConfig(dim=int(g["dim"]), z_dim=16)
+    sd = V.make_state_dict(cfg, seed=int(g["seed"]))
+    with torch.no_grad():
+        rec = V.decode(cfg, sd, g["z_in"])
+    torch.testing.assert_close(rec, g["rec"], rtol=1e-4, atol=1e-4)
