@@ -150,6 +150,43 @@ int scail_unpatchify(const scail_bf16* tok, float* out, int64_t n_batch, int64_t
  * (guiders.py:41-45 + sampling_utils.py:7-10 + Euler update sampling.py:960-963), all fp32. */
 int scail_cfg_euler(float* x, const float* v, int64_t n, float cfg_scale, float dsigma, void* stream);
 
+
+/* ---- Wan2.1 causal 3D VAE (sgm/models/wan_vae.py), channels-last (T,H,W,C) bf16 activations ------------- */
+
+/*
+ * Implicit-GEMM convolution, whole sequence in one pass:
+ *   y[voxel(to,ho,wo), n] = bias[n] + sum_{dt,dh,dw,c} x[ti, hi, wi, c] * w[n, ((dt*kh+dh)*kw+dw)*Cin + c] (+ resid)
+ *   ti = to*st + dt - pt,  hi = ho*sh + dh - ph,  wi = wo*sw + dw - pw   (out-of-range -> 0);
+ *   ups != 0: the input is virtually nearest-exact upsampled 2x in H and W first (hi, wi index the
+ *   upsampled grid, source pixel = index >> 1)                                  (Upsample + Conv2d, :76-85)
+ * Covers CausalConv3d (:17-36: pt = 2*p front padding only), the stride-2 downsampling convs with
+ * ZeroPad2d((0,1,0,1)) (:87-96: ph = pw = 0) and the temporal convs of Resample (:84-96).
+ *   x (Ti,Hi,Wi,Cin) with Cin % 8 == 0;  w (>= N rows, Kpad) bf16, K zero-padded to a multiple of 64;
+ *   output voxel index = ((to*ot_mul + ot_off)*Ho + ho)*Wo + wo, row stride ldc (resid likewise, ldr);
+ *   geom = {Ti,Hi,Wi,Cin, To,Ho,Wo, kt,kh,kw, st,sh,sw, pt,ph,pw, ups, ot_mul,ot_off, N,Kpad} (21 int32, host).
+ */
+int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
+                    const scail_bf16* resid, int64_t ldr, const int32_t* geom, void* stream);
+
+/* RMS_norm over channels (F.normalize * sqrt(C) * gamma, :39-54) + optional SiLU; x,y (nvox, C), gamma fp32. */
+int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* gamma, int64_t nvox, int64_t C, int silu,
+                   void* stream);
+
+/* In-place row softmax of scale * s (AttentionBlock, :252); n % 8 == 0, n <= 8192. */
+int scail_softmax_rows(scail_bf16* s, int64_t ld, int64_t rows, int64_t n, float scale, void* stream);
+
+/* Batched 2-D transpose (R x C, row stride ldi) -> (C x R, row stride ldo). */
+int scail_transpose2d(const scail_bf16* in, int64_t ldi, int64_t in_bs, scail_bf16* out, int64_t ldo,
+                      int64_t out_bs, int64_t R, int64_t C, int64_t batch, void* stream);
+
+/* planar fp32 (C, N) -> channels-last bf16 (N, Cpad): y = x*a[c] + b[c] (a, b may be NULL), pad channels zero. */
+int scail_to_channels_last(const float* x, scail_bf16* y, const float* a, const float* b, int64_t C,
+                           int64_t Cpad, int64_t N, void* stream);
+
+/* channels-last bf16 (N, ldx) -> planar fp32 (C, N): y = clamp((x + b[c]) * a[c], lo, hi). */
+int scail_from_channels_last(const scail_bf16* x, int64_t ldx, float* y, const float* a, const float* b,
+                             int64_t C, int64_t N, float lo, float hi, void* stream);
+
 /* Tuning / A-B knob for kernel variants (same results, different schedules); used by tools/microbench.py.
  * knobs: "attn_variant" (bit 0: s_setprio around MFMA clusters, bit 1: skip no-op O rescales [default],
  *        bit 3: software-pipelined kernel); "gemm_tile" (0 auto, 128, 256). */

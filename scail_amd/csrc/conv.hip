@@ -1,0 +1,380 @@
+// Wan2.1 causal 3D VAE kernels (reference sgm/models/wan_vae.py) for gfx950.
+//
+// Layout: channels-last activations (T, H, W, C) bf16 -- a voxel's channels are contiguous, so every
+// convolution is an implicit GEMM  y[voxel, cout] = sum_k A[voxel, k] . W[cout, k],  k = (tap, cin) with
+// cin fastest, whose A rows are gathered 16 bytes (8 channels) at a time straight from the input tensor
+// (zero for causal / spatial padding) into the same padded, double-buffered LDS tiles and MFMA 32x32x16
+// main loop as scail_gemm_bf16.  One kernel covers CausalConv3d 3x3x3 / 1x1x1 / 3x1x1 (front-only time
+// padding, wan_vae.py:17-36), the stride-2 temporal and spatial downsampling convs (:87-96) and the 3x3
+// conv behind the nearest-exact 2x upsampling (:76-85; the upsample is folded into the gather: source
+// pixel = (dst + tap - 1) >> 1).  The whole video is processed in one pass -- with 288 GB of HBM the
+// reference's 1/4/4-frame chunking and its per-conv feature caches are unnecessary (the equivalence is
+// pinned by oracle/wan_vae_oracle.py against the chunked reference).
+#include "common.h"
+
+#define CBM 128
+#define CBN 128
+#define CBK 64
+#define CLDT 72
+#define CONV_THREADS 256
+#define CONV_LDS_BYTES (2 * (CBM + CBN) * CLDT * 2)
+
+struct ConvParams {
+    const u16* x;      // (Ti, Hi, Wi, Cin)
+    const u16* w;      // (Cout_rows, Kpad), k = tap * Cin + c
+    const float* bias; // (N) or null
+    u16* y; int64_t ldc;          // output voxel v -> y + v * ldc
+    const u16* resid; int64_t ldr;
+    int Ti, Hi, Wi, Cin;
+    int To, Ho, Wo;               // output extents covered by this launch (M = To*Ho*Wo)
+    int kt, kh, kw, st, sh, sw, pt, ph, pw, ups;
+    int ot_mul, ot_off;           // output frame = to * ot_mul + ot_off
+    int N, Kpad, Ktrue;
+    int64_t M;
+};
+
+template <int EPI>  // 0: bias, 3: bias + residual
+__global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Xs = smem;
+    u16* Ws = smem + 2 * CBM * CLDT;
+
+    const int tiles_n = (p.N + CBN - 1) / CBN;
+    const int64_t pid_m = blockIdx.x / tiles_n;     // n fastest: the (few) n-tiles of one voxel block
+    const int pid_n = blockIdx.x % tiles_n;         // run back to back and share the gathered input in L2
+    const int64_t m0 = pid_m * CBM;
+    const int n0 = pid_n * CBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, g = lane >> 5;
+    const int srow = tid >> 3, kc = tid & 7;
+    const int HWo = p.Ho * p.Wo;
+
+    // ---- per-thread output rows (voxels) of the A tile: decode once ----
+#define CROW(i_)                                                                         \
+    int tb##i_, hb##i_, wb##i_;                                                          \
+    {                                                                                    \
+        const int64_t m_ = m0 + srow + 32 * i_;                                          \
+        const bool ok_ = m_ < p.M;                                                       \
+        const int64_t mm_ = ok_ ? m_ : 0;                                                \
+        const int to_ = (int)(mm_ / HWo);                                                \
+        const int r_ = (int)(mm_ - (int64_t)to_ * HWo);                                  \
+        const int ho_ = r_ / p.Wo, wo_ = r_ - ho_ * p.Wo;                                \
+        tb##i_ = ok_ ? to_ * p.st - p.pt : -(1 << 28);   /* invalid row -> always OOB */ \
+        hb##i_ = ho_ * p.sh - p.ph;                                                      \
+        wb##i_ = wo_ * p.sw - p.pw;                                                      \
+    }                                                                                    \
+    const u16* wptr##i_ = p.w + (int64_t)min(n0 + srow + 32 * i_, p.N - 1) * p.Kpad + kc * 8; \
+    uint4 xr##i_, wr##i_;
+    CROW(0) CROW(1) CROW(2) CROW(3)
+    const int khw = p.kh * p.kw;
+    const int Hlim = p.ups ? 2 * p.Hi : p.Hi, Wlim = p.ups ? 2 * p.Wi : p.Wi;
+
+#define CLOAD1(i_, k0_)                                                                          \
+    {                                                                                            \
+        const int ti_ = tb##i_ + dt_, hi_ = hb##i_ + dh_, wi_ = wb##i_ + dw_;                     \
+        const bool v_ = kvalid_ && ti_ >= 0 && ti_ < p.Ti && hi_ >= 0 && hi_ < Hlim && wi_ >= 0 && wi_ < Wlim; \
+        const int hs_ = p.ups ? (hi_ >> 1) : hi_, ws_ = p.ups ? (wi_ >> 1) : wi_;                 \
+        const int64_t off_ = (((int64_t)ti_ * p.Hi + hs_) * p.Wi + ws_) * p.Cin + c_;             \
+        xr##i_ = v_ ? *reinterpret_cast<const uint4*>(p.x + off_) : make_uint4(0, 0, 0, 0);       \
+        wr##i_ = *reinterpret_cast<const uint4*>(wptr##i_ + (k0_));                               \
+    }
+#define CLOAD(k0_)                                                         \
+    {                                                                      \
+        const int k_ = (k0_) + kc * 8;                                     \
+        const bool kvalid_ = k_ < p.Ktrue;                                 \
+        const int tap_ = kvalid_ ? k_ / p.Cin : 0;                         \
+        const int c_ = kvalid_ ? k_ - tap_ * p.Cin : 0;                    \
+        const int dt_ = tap_ / khw;                                        \
+        const int r2_ = tap_ - dt_ * khw;                                  \
+        const int dh_ = r2_ / p.kw, dw_ = r2_ - dh_ * p.kw;                \
+        CLOAD1(0, k0_) CLOAD1(1, k0_) CLOAD1(2, k0_) CLOAD1(3, k0_)        \
+    }
+#define CSTORE1(i_, buf_)                                                                         \
+    *reinterpret_cast<uint4*>(Xs + ((buf_) * CBM + srow + 32 * i_) * CLDT + kc * 8) = xr##i_;      \
+    *reinterpret_cast<uint4*>(Ws + ((buf_) * CBN + srow + 32 * i_) * CLDT + kc * 8) = wr##i_;
+#define CSTORE(buf_) CSTORE1(0, buf_) CSTORE1(1, buf_) CSTORE1(2, buf_) CSTORE1(3, buf_)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int nk = p.Kpad / CBK;
+    CLOAD(0)
+    CSTORE(0)
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) CLOAD((t + 1) * CBK)
+        const u16* xs = Xs + (cur * CBM + wm * 64 + l31) * CLDT + g * 8;
+        const u16* ws = Ws + (cur * CBN + wn * 64 + l31) * CLDT + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < CBK / 16; ++ks) {
+            bf16x8 wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * CLDT + ks * 16);
+                xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * CLDT + ks * 16);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (t + 1 < nk) { CSTORE(cur ^ 1) }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int64_t m = m0 + wm * 64 + mi * 32 + l31;
+        if (m >= p.M) continue;
+        const int to = (int)(m / HWo);
+        const int r = (int)(m - (int64_t)to * HWo);
+        const int64_t vox = ((int64_t)(to * p.ot_mul + p.ot_off)) * HWo + r;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int n = n0 + wn * 64 + ni * 32 + 8 * rr + 4 * g;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * rr + e];
+                if (p.bias != nullptr) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (EPI == 3) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(p.resid + vox * p.ldr + n);
+                    v[0] += bf_lo(rv.x); v[1] += bf_hi(rv.x); v[2] += bf_lo(rv.y); v[3] += bf_hi(rv.y);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(p.y + vox * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RMS_norm over channels (F.normalize * sqrt(C) * gamma, wan_vae.py:39-54) + optional SiLU.
+// LPV lanes per voxel (power of two >= C/8), 64/LPV voxels per wave.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rms_silu_kernel(const u16* __restrict__ x, u16* __restrict__ y,
+                                                       const float* __restrict__ gamma, int64_t nvox, int C,
+                                                       int lpv_log2, int silu) {
+    const int lpv = 1 << lpv_log2;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t vox = gtid >> lpv_log2;
+    const int sub = (int)(gtid & (lpv - 1));
+    const int nch = C >> 3;
+    const bool act = vox < nvox && sub < nch;
+    float v[8];
+    float q = 0.f;
+    if (act) {
+        unpack8(*reinterpret_cast<const uint4*>(x + vox * C + sub * 8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q += v[e] * v[e];
+    }
+    for (int o = 1; o < lpv; o <<= 1) q += __shfl_xor(q, o, 64);
+    if (!act) return;
+    const float inv = sqrtf((float)C) / fmaxf(sqrtf(q), 1e-12f);
+    float o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float t = v[e] * inv * gamma[sub * 8 + e];
+        o8[e] = silu ? silu_f(t) : t;
+    }
+    *reinterpret_cast<uint4*>(y + vox * C + sub * 8) = pack8(o8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax over rows in place (mid-block attention, wan_vae.py:252), scale folded in; n <= 8192
+// ------------------------------------------------------------------------------------------------
+#define SM_MAXV 4
+__global__ __launch_bounds__(256) void softmax_rows_kernel(u16* __restrict__ s, int64_t ld, int n, float scale) {
+    __shared__ float red[4];
+    u16* row = s + (int64_t)blockIdx.x * ld;
+    const int nvec = n >> 3;
+    float v[SM_MAXV][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SM_MAXV; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < nvec) {
+            unpack8(*reinterpret_cast<const uint4*>(row + c * 8), v[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[j][e]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sl2 = scale * 1.4426950408889634f;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < SM_MAXV; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[j][e] = __builtin_amdgcn_exp2f((v[j][e] - mx) * sl2);
+                sum += v[j][e];
+            }
+        }
+    }
+    sum = block_sum_256(sum, red);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < SM_MAXV; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] *= inv;
+            *reinterpret_cast<uint4*>(row + c * 8) = pack8(v[j]);
+        }
+    }
+}
+
+// batched 2-D transpose  (R x C, row stride ldi) -> (C x R), 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose2d_kernel(const u16* __restrict__ in, int64_t ldi, int64_t in_bs,
+                                                          u16* __restrict__ out, int64_t ldo, int64_t out_bs, int R, int C) {
+    __shared__ u16 tile[64][66];
+    const u16* src = in + (int64_t)blockIdx.z * in_bs;
+    u16* dst = out + (int64_t)blockIdx.z * out_bs;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < R && c0 + c < C) ? src[(int64_t)(r0 + r) * ldi + c0 + c] : (u16)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < C && r0 + r < R) dst[(int64_t)(c0 + c) * ldo + r0 + r] = tile[r][c];
+    }
+}
+
+// planar fp32 (C, N) -> channels-last bf16 (N, Cpad) with per-channel affine; channels >= C are zero
+__global__ void to_channels_last_kernel(const float* __restrict__ x, u16* __restrict__ y, const float* __restrict__ a,
+                                        const float* __restrict__ b, int C, int Cpad, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Cpad) return;
+    const int c = (int)(i % Cpad);
+    const int64_t n = i / Cpad;
+    float v = 0.f;
+    if (c < C) v = x[(int64_t)c * N + n] * (a ? a[c] : 1.f) + (b ? b[c] : 0.f);
+    y[i] = f2bf(v);
+}
+
+// channels-last bf16 (N, ldx) -> planar fp32 (C, N): y = clamp((x + b) * a, lo, hi)
+__global__ void from_channels_last_kernel(const u16* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                          const float* __restrict__ a, const float* __restrict__ b, int C, int64_t N,
+                                          float lo, float hi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int64_t n = i % N;
+    const int c = (int)(i / N);
+    float v = (bf2f(x[n * ldx + c]) + (b ? b[c] : 0.f)) * (a ? a[c] : 1.f);
+    y[i] = fminf(fmaxf(v, lo), hi);
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
+                               const scail_bf16* resid, int64_t ldr, const int32_t* geom, void* stream) {
+    // geom: Ti Hi Wi Cin | To Ho Wo | kt kh kw | st sh sw | pt ph pw | ups | ot_mul ot_off | N Kpad
+    ConvParams p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc; p.resid = resid; p.ldr = ldr;
+    p.Ti = geom[0]; p.Hi = geom[1]; p.Wi = geom[2]; p.Cin = geom[3];
+    p.To = geom[4]; p.Ho = geom[5]; p.Wo = geom[6];
+    p.kt = geom[7]; p.kh = geom[8]; p.kw = geom[9];
+    p.st = geom[10]; p.sh = geom[11]; p.sw = geom[12];
+    p.pt = geom[13]; p.ph = geom[14]; p.pw = geom[15];
+    p.ups = geom[16]; p.ot_mul = geom[17]; p.ot_off = geom[18];
+    p.N = geom[19]; p.Kpad = geom[20];
+    p.Ktrue = p.kt * p.kh * p.kw * p.Cin;
+    p.M = (int64_t)p.To * p.Ho * p.Wo;
+    SCAIL_REQUIRE(p.Cin % 8 == 0, "Cin must be a multiple of 8 (pad the channels)");
+    SCAIL_REQUIRE(p.N % 8 == 0 && p.Kpad % CBK == 0 && p.Kpad >= p.Ktrue, "N % 8 == 0, Kpad % 64 == 0, Kpad >= taps*Cin");
+    SCAIL_REQUIRE(ldc % 4 == 0 && (resid == nullptr || ldr % 4 == 0), "output / residual row strides must be multiples of 4");
+    SCAIL_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0,
+                  "pointer alignment");
+    if (p.M == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<3>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES);
+        if (e0 != hipSuccess || e1 != hipSuccess) {
+            scail_set_error("conv3d: hipFuncSetAttribute failed");
+            return 2;
+        }
+        attr_set = true;
+    }
+    const int64_t tiles = ((p.M + CBM - 1) / CBM) * ((p.N + CBN - 1) / CBN);
+    SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
+    if (resid != nullptr)
+        hipLaunchKernelGGL(conv_igemm_kernel<3>, dim3((unsigned)tiles), dim3(CONV_THREADS), CONV_LDS_BYTES, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv_igemm_kernel<0>, dim3((unsigned)tiles), dim3(CONV_THREADS), CONV_LDS_BYTES, (hipStream_t)stream, p);
+    return scail_check_launch("conv3d_cl");
+}
+
+extern "C" int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* gamma, int64_t nvox, int64_t C, int silu,
+                              void* stream) {
+    SCAIL_REQUIRE(C % 8 == 0 && C <= 512, "C must be a multiple of 8, <= 512");
+    if (nvox == 0) return 0;
+    int lg = 0;
+    while ((8 << lg) < C) ++lg;
+    const int64_t threads = nvox << lg;
+    hipLaunchKernelGGL(rms_silu_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       gamma, nvox, (int)C, lg, silu);
+    return scail_check_launch("rms_silu");
+}
+
+extern "C" int scail_softmax_rows(scail_bf16* s, int64_t ld, int64_t rows, int64_t n, float scale, void* stream) {
+    SCAIL_REQUIRE(n % 8 == 0 && n <= 256 * 8 * SM_MAXV && ld % 8 == 0, "n must be a multiple of 8, <= 8192");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, ld, (int)n, scale);
+    return scail_check_launch("softmax_rows");
+}
+
+extern "C" int scail_transpose2d(const scail_bf16* in, int64_t ldi, int64_t in_bs, scail_bf16* out, int64_t ldo,
+                                 int64_t out_bs, int64_t R, int64_t Cc, int64_t batch, void* stream) {
+    if (R == 0 || Cc == 0 || batch == 0) return 0;
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)((Cc + 63) / 64), (unsigned)((R + 63) / 64), (unsigned)batch),
+                       dim3(256), 0, (hipStream_t)stream, in, ldi, in_bs, out, ldo, out_bs, (int)R, (int)Cc);
+    return scail_check_launch("transpose2d");
+}
+
+extern "C" int scail_to_channels_last(const float* x, scail_bf16* y, const float* a, const float* b, int64_t C,
+                                      int64_t Cpad, int64_t N, void* stream) {
+    const int64_t total = N * Cpad;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(to_channels_last_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       y, a, b, (int)C, (int)Cpad, N);
+    return scail_check_launch("to_channels_last");
+}
+
+extern "C" int scail_from_channels_last(const scail_bf16* x, int64_t ldx, float* y, const float* a, const float* b,
+                                        int64_t C, int64_t N, float lo, float hi, void* stream) {
+    const int64_t total = N * C;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(from_channels_last_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, y, a, b, (int)C, N, lo, hi);
+    return scail_check_launch("from_channels_last");
+}

@@ -29,6 +29,12 @@ SIGNATURES = {
     "scail_patchify": [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _p],
     "scail_unpatchify": [_p, _p, _i64, _i64, _i64, _i64, _p],
     "scail_cfg_euler": [_p, _p, _i64, _f, _f, _p],
+    "scail_conv3d_cl": [_p, _p, _p, _p, _i64, _p, _i64, _p, _p],
+    "scail_rms_silu": [_p, _p, _p, _i64, _i64, _i, _p],
+    "scail_softmax_rows": [_p, _i64, _i64, _i64, _f, _p],
+    "scail_transpose2d": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "scail_to_channels_last": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
+    "scail_from_channels_last": [_p, _i64, _p, _p, _p, _i64, _i64, _f, _f, _p],
     "scail_tune_set": [C.c_char_p, _i],
     "scail_f32_to_bf16": [_p, _p, _i64, _p],
     "scail_bf16_to_f32": [_p, _p, _i64, _p],

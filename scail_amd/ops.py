@@ -240,3 +240,105 @@ def to_f32(x):
     y = torch.empty(x.shape, device=x.device, dtype=f32)
     L.call("scail_bf16_to_f32", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# Wan2.1 VAE ops (channels-last activations)
+# ------------------------------------------------------------------------------------------------
+def prep_conv_weight(w: torch.Tensor, b: Optional[torch.Tensor], cin_pad: Optional[int] = None):
+    """torch conv weight (Cout, Cin, kt, kh, kw) [or (Cout, Cin, kh, kw)] -> dict for conv3d_cl:
+    w2 (Cout_pad8, Kpad) bf16 with k = ((dt*kh+dh)*kw+dw)*Cin_pad + c, zero padded; bias fp32 (Cout_pad8)."""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    Cout, Cin, kt, kh, kw = w.shape
+    cin_pad = cin_pad or ((Cin + 7) // 8 * 8)
+    n_pad = (Cout + 7) // 8 * 8
+    wt = torch.zeros(n_pad, kt, kh, kw, cin_pad, device=w.device, dtype=torch.float32)
+    wt[:Cout, ..., :Cin] = w.detach().float().permute(0, 2, 3, 4, 1)
+    K = kt * kh * kw * cin_pad
+    Kpad = (K + 63) // 64 * 64
+    w2 = torch.zeros(n_pad, Kpad, device=w.device, dtype=bf16)
+    w2[:, :K] = wt.reshape(n_pad, K).to(bf16)
+    bias = torch.zeros(n_pad, device=w.device, dtype=f32)
+    if b is not None:
+        bias[:Cout] = b.detach().float()
+    return dict(w=w2.contiguous(), b=bias, N=n_pad, Cout=Cout, Cin=cin_pad, Kpad=Kpad, k=(kt, kh, kw))
+
+
+def conv3d_cl(x, wp, out_shape, stride=(1, 1, 1), pad=None, ups=False, out=None, ot_mul=1, ot_off=0, resid=None):
+    """x (Ti,Hi,Wi,Cin) bf16 contiguous; wp from prep_conv_weight; out_shape = (To,Ho,Wo) covered by this call.
+    pad = (pt, ph, pw): front/top/left padding (default: causal 'same': (kt-1, kh//2, kw//2)).
+    Output tensor ``out`` (frames, Ho, Wo, N) -- frame index = to*ot_mul + ot_off."""
+    import ctypes as C
+    _chk(x, bf16, "conv3d_cl.x")
+    assert x.is_contiguous() and x.dim() == 4 and x.shape[3] == wp["Cin"], (x.shape, wp["Cin"])
+    Ti, Hi, Wi, Cin = x.shape
+    To, Ho, Wo = out_shape
+    kt, kh, kw = wp["k"]
+    if pad is None:
+        pad = (kt - 1, kh // 2, kw // 2)
+    if out is None:
+        assert ot_mul == 1 and ot_off == 0
+        out = torch.empty(To, Ho, Wo, wp["N"], device=x.device, dtype=bf16)
+    assert out.is_contiguous() and out.shape[1:3] == (Ho, Wo) and out.shape[3] >= wp["N"]
+    assert (To - 1) * ot_mul + ot_off < out.shape[0]
+    ldr = 0
+    if resid is not None:
+        _chk(resid, bf16, "conv3d_cl.resid")
+        assert resid.is_contiguous() and resid.shape[:3] == out.shape[:3]
+        ldr = resid.shape[3]
+    geom = (C.c_int32 * 21)(Ti, Hi, Wi, Cin, To, Ho, Wo, kt, kh, kw, stride[0], stride[1], stride[2], pad[0], pad[1], pad[2],
+                            1 if ups else 0, ot_mul, ot_off, wp["N"], wp["Kpad"])
+    L.call("scail_conv3d_cl", x.data_ptr(), wp["w"].data_ptr(), wp["b"].data_ptr(), out.data_ptr(), out.shape[3],
+           _ptr(resid), ldr, C.cast(geom, C.c_void_p), _stream())
+    return out
+
+
+def rms_silu(x, gamma, silu=True, out=None):
+    """x (..., C) channels-last bf16 contiguous; gamma fp32 (C)."""
+    _chk(x, bf16, "rms_silu.x"); _chk(gamma, f32, "rms_silu.gamma")
+    assert x.is_contiguous()
+    Cc = x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    L.call("scail_rms_silu", x.data_ptr(), out.data_ptr(), gamma.data_ptr(), x.numel() // Cc, Cc, 1 if silu else 0, _stream())
+    return out
+
+
+def softmax_rows_(s, n, scale):
+    """In place softmax(scale * s[:, :n]) over rows of a 2-D bf16 tensor (row stride s.stride(0))."""
+    _chk(s, bf16, "softmax_rows.s")
+    assert s.dim() == 2 and s.stride(1) == 1
+    L.call("scail_softmax_rows", s.data_ptr(), s.stride(0), s.shape[0], n, float(scale), _stream())
+    return s
+
+
+def transpose2d(x, out):
+    """x (B, R, C) view (last dim contiguous) -> out (B, C, >=R) (writes the first R columns)."""
+    _chk(x, bf16, "transpose2d.x"); _chk(out, bf16, "transpose2d.out")
+    B, R, Cc = x.shape
+    assert x.stride(2) == 1 and out.stride(2) == 1 and out.shape[0] == B and out.shape[1] == Cc and out.shape[2] >= R
+    L.call("scail_transpose2d", x.data_ptr(), x.stride(1), x.stride(0), out.data_ptr(), out.stride(1), out.stride(0), R, Cc, B,
+           _stream())
+    return out
+
+
+def to_channels_last(x, cpad, a=None, b=None):
+    """x fp32 (C, T, H, W) -> (T, H, W, cpad) bf16, y = x*a[c] + b[c]."""
+    _chk(x, f32, "to_channels_last.x")
+    x = x.contiguous()
+    Cc, T, H, W = x.shape
+    y = torch.empty(T, H, W, cpad, device=x.device, dtype=bf16)
+    L.call("scail_to_channels_last", x.data_ptr(), y.data_ptr(), _ptr(a), _ptr(b), Cc, cpad, T * H * W, _stream())
+    return y
+
+
+def from_channels_last(x, Cc, a=None, b=None, lo=-3.0e38, hi=3.0e38):
+    """x bf16 (T, H, W, ld) -> fp32 (Cc, T, H, W): clamp((x + b[c]) * a[c], lo, hi)."""
+    _chk(x, bf16, "from_channels_last.x")
+    assert x.is_contiguous()
+    T, H, W, ld = x.shape
+    y = torch.empty(Cc, T, H, W, device=x.device, dtype=f32)
+    L.call("scail_from_channels_last", x.data_ptr(), ld, y.data_ptr(), _ptr(a), _ptr(b), Cc, T * H * W, float(lo), float(hi),
+           _stream())
+    return y
