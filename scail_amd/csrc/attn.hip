@@ -44,17 +44,29 @@ struct AttnParams {
 
 // VARIANT bit 0: s_setprio(1) around the MFMA clusters; bit 1: skip the O rescale when no row's running
 // max moved in this tile (exact: alpha == 1 for every lane).
-template <int VARIANT>
-__global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p) {
+// ABLATION ONLY (wrong results, tools/microbench.py): bit 4 = no softmax (P = bf16(S)), bit 5 = no K/V
+// staging and no barrier inside the loop (tile 0 reused).
+// NW = waves per workgroup: 8 (256 query rows, one workgroup per CU) or 4 (128 rows, TWO independent
+// workgroups per CU: while one sits in its per-tile barrier / first-LDS-read bubble or in its softmax,
+// the other keeps the SIMDs' matrix pipes busy; costs 2x the L2->LDS K/V traffic).
+template <int VARIANT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(AttnParams p) {
+    constexpr int NTH = 64 * NW;
+    // bit 8: K / V^T tiles arrive by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, written
+    // lane-linearly, so rows cannot be padded); bank conflicts are removed by an XOR swizzle of the 16-byte
+    // chunk index applied to the per-lane SOURCE address and to the fragment reads (same involution).
+    constexpr bool DMA = (VARIANT & 256) != 0;
+    constexpr int KLD = DMA ? HD : K_LD, VLD = DMA ? KVBLK : V_LD;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
-    u16* Ks = smem;                       // [2][KVBLK][K_LD]
-    u16* Vs = smem + 2 * KVBLK * K_LD;    // [2][HD][V_LD]
+    u16* Ks = smem;                     // [2][KVBLK][KLD]
+    u16* Vs = smem + 2 * KVBLK * KLD;   // [2][HD][VLD]
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, g = lane >> 5;
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
-    const int q0 = blockIdx.x * QBLK + wave * 32;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
 
     // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16 ks + 8 g .. +7] ----
     bf16x8 qf[HD / 16];
@@ -65,32 +77,74 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
         for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
     }
 
-    // ---- staging coordinates (2 K chunks + 2 V^T chunks of 16 B per thread per tile) ----
-    const int krow = tid >> 4, kcc = tid & 15;  // K chunk c = tid + 512 i: row = (tid>>4) + 32 i
-    const int vrow = tid >> 3, vcc = tid & 7;   // V chunk c = tid + 512 i: row = (tid>>3) + 64 i
+    // ---- staging coordinates: 1024 K chunks + 1024 V^T chunks of 16 B per tile, 1024 / NTH each per thread ----
+    constexpr int KRS = NTH / 16, VRS = NTH / 8;   // tile rows covered per staging pass
+    const int krow = tid >> 4, kcc = tid & 15;     // K chunk c = tid + NTH i: row = (tid >> 4) + KRS i
+    const int vrow = tid >> 3, vcc = tid & 7;      // V chunk c = tid + NTH i: row = (tid >> 3) + VRS i
     const u16* kbase = p.k + b * p.k_bs + (int64_t)h * HD + kcc * 8;
     const u16* vbase = p.vt + b * p.vt_bs + (int64_t)h * HD * p.Lkp + vcc * 8;
     const int tps = p.Lkp / KVBLK;          // tiles per segment
     const int ntiles = tps * p.n_seg;
-    uint4 kr0, kr1, vr0, vr1;  // named scalars (register arrays written under a branch go to scratch)
+    uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;  // named scalars (register arrays written under a branch go to scratch)
 #define G_LOAD(tt_)                                                                               \
     {                                                                                             \
         const int seg_ = (tt_) / tps, t_ = (tt_) - seg_ * tps;                                    \
         const int key0_ = t_ * KVBLK;                                                             \
         const u16* kp_ = kbase + (int64_t)seg_ * p.k_ss;                                          \
         const u16* vp_ = vbase + (int64_t)seg_ * p.vt_ss + key0_;                                 \
-        kr0 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow, p.Lk - 1) * p.k_rs);       \
-        kr1 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + 32, p.Lk - 1) * p.k_rs);  \
+        kr0 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow, p.Lk - 1) * p.k_rs);            \
+        kr1 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + KRS, p.Lk - 1) * p.k_rs);      \
         vr0 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)vrow * p.Lkp);                       \
-        vr1 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + 64) * p.Lkp);                \
+        vr1 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + VRS) * p.Lkp);               \
+        if (NW == 4) {                                                                            \
+            kr2 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + 2 * KRS, p.Lk - 1) * p.k_rs);  \
+            kr3 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + 3 * KRS, p.Lk - 1) * p.k_rs);  \
+            vr2 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + 2 * VRS) * p.Lkp);       \
+            vr3 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + 3 * VRS) * p.Lkp);       \
+        }                                                                                         \
     }
 #define S_STORE(buf_)                                                                             \
     {                                                                                             \
         *reinterpret_cast<uint4*>(Ks + ((buf_) * KVBLK + krow) * K_LD + kcc * 8) = kr0;           \
-        *reinterpret_cast<uint4*>(Ks + ((buf_) * KVBLK + krow + 32) * K_LD + kcc * 8) = kr1;      \
+        *reinterpret_cast<uint4*>(Ks + ((buf_) * KVBLK + krow + KRS) * K_LD + kcc * 8) = kr1;     \
         *reinterpret_cast<uint4*>(Vs + ((buf_) * HD + vrow) * V_LD + vcc * 8) = vr0;              \
-        *reinterpret_cast<uint4*>(Vs + ((buf_) * HD + vrow + 64) * V_LD + vcc * 8) = vr1;         \
+        *reinterpret_cast<uint4*>(Vs + ((buf_) * HD + vrow + VRS) * V_LD + vcc * 8) = vr1;        \
+        if (NW == 4) {                                                                            \
+            *reinterpret_cast<uint4*>(Ks + ((buf_) * KVBLK + krow + 2 * KRS) * K_LD + kcc * 8) = kr2;  \
+            *reinterpret_cast<uint4*>(Ks + ((buf_) * KVBLK + krow + 3 * KRS) * K_LD + kcc * 8) = kr3;  \
+            *reinterpret_cast<uint4*>(Vs + ((buf_) * HD + vrow + 2 * VRS) * V_LD + vcc * 8) = vr2;     \
+            *reinterpret_cast<uint4*>(Vs + ((buf_) * HD + vrow + 3 * VRS) * V_LD + vcc * 8) = vr3;     \
+        }                                                                                         \
     }
+
+    // LDS-DMA pieces of this wave: K piece j = rows 4j..4j+3 (lane -> row 4j + (l >> 4), chunk l & 15),
+    // V^T piece j = rows 8j..8j+7 (lane -> row 8j + (l >> 3), chunk l & 7); 16 pieces each per tile.
+    constexpr int PPW = 16 / NW;   // pieces per wave and operand
+    const int dk_row = lane >> 4, dk_c = lane & 15, dv_row = lane >> 3, dv_c = lane & 7;
+#define DMA_ISSUE(tt_, buf_)                                                                                \
+    {                                                                                                       \
+        const int seg_ = (tt_) / tps, t_ = (tt_) - seg_ * tps;                                              \
+        const int key0_ = t_ * KVBLK;                                                                       \
+        const u16* kp_ = p.k + b * p.k_bs + (int64_t)h * HD + (int64_t)seg_ * p.k_ss;                       \
+        const u16* vp_ = p.vt + b * p.vt_bs + (int64_t)h * HD * p.Lkp + (int64_t)seg_ * p.vt_ss + key0_;    \
+        _Pragma("unroll") for (int i_ = 0; i_ < PPW; ++i_) {                                                \
+            const int j_ = wave * PPW + i_;                                                                 \
+            const int kr_ = 4 * j_ + dk_row;                                                                \
+            const u16* ks_src = kp_ + (int64_t)min(key0_ + kr_, p.Lk - 1) * p.k_rs + ((dk_c ^ (kr_ & 15)) << 3);  \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks_src,          \
+                (__attribute__((address_space(3))) void*)(Ks + ((buf_) * KVBLK + 4 * j_) * KLD), 16, 0, 0);  \
+            const int vr_ = 8 * j_ + dv_row;                                                                \
+            const u16* vs_src = vp_ + (int64_t)vr_ * p.Lkp + ((dv_c ^ ((vr_ >> 1) & 7)) << 3);              \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs_src,          \
+                (__attribute__((address_space(3))) void*)(Vs + ((buf_) * HD + 8 * j_) * VLD), 16, 0, 0);     \
+        }                                                                                                   \
+    }
+    // swizzled fragment-read offsets (elements): chunk (2 ks + g) of row ql
+    int koff[HD / 16], voff[4];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) koff[ks] = DMA ? (((2 * ks + g) ^ (ql & 15)) << 3) : (ks * 16 + g * 8);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) voff[ks] = DMA ? (((2 * ks + g) ^ ((ql >> 1) & 7)) << 3) : (ks * 16 + g * 8);
 
     f32x16 o[HD / 32];
 #pragma unroll
@@ -101,15 +155,27 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
     const float sl2 = p.sl2;
     const int tail = p.Lk - (tps - 1) * KVBLK;  // valid keys in the last tile of a segment (1..64)
 
-    G_LOAD(0)
+    if (DMA) {
+        DMA_ISSUE(0, 0)
+    } else {
+        G_LOAD(0)
+    }
     // drain the Q-fragment loads here: otherwise hipcc's in-order vmcnt bookkeeping makes the first
     // QK^T MFMAs of EVERY iteration wait for the freshly issued tile t+1 loads (vmcnt(3..0))
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
-    S_STORE(0)
+    if (!DMA) S_STORE(0)
     __syncthreads();
     for (int tt = 0; tt < ntiles; ++tt) {
-        const int cur = tt & 1;
-        if (tt + 1 < ntiles) G_LOAD(tt + 1)
+        const int cur = (VARIANT & 32) ? 0 : (tt & 1);
+        if (!(VARIANT & 32)) {
+            if (tt + 1 < ntiles) {
+                if (DMA) {
+                    DMA_ISSUE(tt + 1, cur ^ 1)
+                } else {
+                    G_LOAD(tt + 1)
+                }
+            }
+        }
 
         // ---- S^T = K Q^T ----
         f32x16 s[2];
@@ -117,13 +183,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[f][e] = 0.f;
-        const u16* ks_ = Ks + (cur * KVBLK + ql) * K_LD + g * 8;
+        const u16* ks_ = Ks + (cur * KVBLK + ql) * KLD;
         if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + f * 32 * K_LD + ks * 16);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + f * 32 * KLD + koff[ks]);
                 s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[f], 0, 0, 0);
             }
         }
@@ -142,6 +208,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
             }
         }
         // ---- online softmax ----
+        if (!(VARIANT & 16)) {
         float mx = s[0][0];
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -168,6 +235,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
                 for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
         }
         m_run = m_new;
+        } else { l_run = 1.f; }
         // ---- P^T fragments: k-slot group ks <-> score registers s[ks>>1][8 (ks&1) .. +7] ----
         bf16x8 pf[4];
 #pragma unroll
@@ -181,19 +249,21 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_kernel(AttnParams p
             pf[ks] = __builtin_bit_cast(bf16x8, u);
         }
         // ---- O^T += V^T P^T ----
-        const u16* vs_ = Vs + (cur * HD + ql) * V_LD + g * 8;
+        const u16* vs_ = Vs + (cur * HD + ql) * VLD;
         if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int d = 0; d < HD / 32; ++d) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * V_LD + ks * 16);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * VLD + voff[ks]);
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[d], 0, 0, 0);
             }
         }
         if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
-        if (tt + 1 < ntiles) { S_STORE(cur ^ 1) }
-        __syncthreads();
+        if (!(VARIANT & 32)) {
+            if (!DMA) { if (tt + 1 < ntiles) { S_STORE(cur ^ 1) } }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: O[q][32 d + 8 rr + 4 g + e] ----
@@ -497,11 +567,12 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     if (Lq == 0 || n_batch == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[5] = {reinterpret_cast<const void*>(&flash_attn_kernel<0>), reinterpret_cast<const void*>(&flash_attn_kernel<1>),
-                              reinterpret_cast<const void*>(&flash_attn_kernel<2>), reinterpret_cast<const void*>(&flash_attn_kernel<3>),
-                              reinterpret_cast<const void*>(&flash_attn_swp_kernel)};
-        for (int i = 0; i < 5; ++i) {
-            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i >= 4 ? ATT_PP_LDS_BYTES : ATT_LDS_BYTES);
+        const void* fns[10] = {reinterpret_cast<const void*>(&flash_attn_kernel<258, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<2, 4>), reinterpret_cast<const void*>(&flash_attn_kernel<0, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<1, 8>),
+                              reinterpret_cast<const void*>(&flash_attn_kernel<2, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<3, 8>),
+                              reinterpret_cast<const void*>(&flash_attn_swp_kernel), reinterpret_cast<const void*>(&flash_attn_kernel<18, 8>),
+                              reinterpret_cast<const void*>(&flash_attn_kernel<34, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<50, 8>)};
+        for (int i = 0; i < 10; ++i) {
+            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i == 6 ? ATT_PP_LDS_BYTES : ATT_LDS_BYTES);
             if (e != hipSuccess) {
                 scail_set_error(std::string("flash_attn: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
                 return 2;
@@ -522,11 +593,23 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         hipLaunchKernelGGL(flash_attn_swp_kernel, grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         return scail_check_launch("flash_attn");
     }
+    if (g_attn_variant & 256) {  // LDS-DMA staging
+        hipLaunchKernelGGL((flash_attn_kernel<258, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p);
+        return scail_check_launch("flash_attn");
+    }
+    if (g_attn_variant & 64) {   // 4-wave workgroups, two per CU
+        dim3 grid4((unsigned)((Lq + 127) / 128), (unsigned)heads, (unsigned)n_batch);
+        hipLaunchKernelGGL((flash_attn_kernel<2, 4>), grid4, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
+        return scail_check_launch("flash_attn");
+    }
+    if (g_attn_variant == 18) { hipLaunchKernelGGL((flash_attn_kernel<18, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
+    if (g_attn_variant == 34) { hipLaunchKernelGGL((flash_attn_kernel<34, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
+    if (g_attn_variant == 50) { hipLaunchKernelGGL((flash_attn_kernel<50, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
     switch (g_attn_variant & 3) {
-        case 0: hipLaunchKernelGGL(flash_attn_kernel<0>, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
-        case 1: hipLaunchKernelGGL(flash_attn_kernel<1>, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
-        case 2: hipLaunchKernelGGL(flash_attn_kernel<2>, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
-        default: hipLaunchKernelGGL(flash_attn_kernel<3>, grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+        case 0: hipLaunchKernelGGL((flash_attn_kernel<0, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+        case 1: hipLaunchKernelGGL((flash_attn_kernel<1, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+        case 2: hipLaunchKernelGGL((flash_attn_kernel<2, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL((flash_attn_kernel<3, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
     }
     return scail_check_launch("flash_attn");
 }

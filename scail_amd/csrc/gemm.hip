@@ -34,16 +34,85 @@ struct GemmParams {
 //   128 x 128 tile, 4 waves (2 x 2), wave tile 64 x 64,  74 KB LDS, 2 workgroups per CU  (small / ragged N)
 //   256 x 256 tile, 8 waves (2 x 4), wave tile 128 x 64, 147 KB LDS, 1 workgroup per CU  (the big per-token
 //   GEMMs: half the L2->LDS bytes per FLOP, 6 LDS fragment reads per 8 MFMAs instead of 4 per 4)
-template <int BM, int BN, int WM, int WN, int EPI>
+// Fused epilogue shared by the kernels below.  A lane holds output column m (= row of x) and, per 32x32
+// accumulator fragment, rows n = nbase + 8 rr + 4 g + e.  All loads of one pass (bias once; residual and
+// gate per output row) are issued before their first use: one memory round trip per pass.
+template <int EPI, int MI, int NI, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmParams& p, int m0, int n0, int wm, int wn,
+                                              int l31, int g) {
+    float4 bb[NI][4];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int n = n0 + wn * WTN + ni * 32 + 8 * rr + 4 * g;
+            bb[ni][rr] = (p.bias != nullptr && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = m0 + wm * WTM + mi * 32 + l31;
+        if (m >= p.M) continue;
+        uint2 rv[NI][4];
+        float4 gt[NI][4];
+        if (EPI == SCAIL_EPI_RESID) {
+            const int64_t bidx = (p.gate != nullptr) ? (int64_t)m / p.rows_per_batch : 0;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int n = n0 + wn * WTN + ni * 32 + 8 * rr + 4 * g;
+                    const bool ok = n < p.N;
+                    rv[ni][rr] = ok ? *reinterpret_cast<const uint2*>(p.resid + (int64_t)m * p.ldr + n) : make_uint2(0, 0);
+                    gt[ni][rr] = (ok && p.gate != nullptr) ? *reinterpret_cast<const float4*>(p.gate + bidx * p.gate_stride + n)
+                                                           : make_float4(1.f, 1.f, 1.f, 1.f);
+                }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int n = n0 + wn * WTN + ni * 32 + 8 * rr + 4 * g;
+                if (n >= p.N) continue;
+                float v[4];
+                v[0] = acc[ni][mi][4 * rr + 0] + bb[ni][rr].x;
+                v[1] = acc[ni][mi][4 * rr + 1] + bb[ni][rr].y;
+                v[2] = acc[ni][mi][4 * rr + 2] + bb[ni][rr].z;
+                v[3] = acc[ni][mi][4 * rr + 3] + bb[ni][rr].w;
+                if (EPI == SCAIL_EPI_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+                } else if (EPI == SCAIL_EPI_GELU_ERF) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                } else if (EPI == SCAIL_EPI_RESID) {
+                    v[0] = bf_lo(rv[ni][rr].x) + gt[ni][rr].x * v[0];
+                    v[1] = bf_hi(rv[ni][rr].x) + gt[ni][rr].y * v[1];
+                    v[2] = bf_lo(rv[ni][rr].y) + gt[ni][rr].z * v[2];
+                    v[3] = bf_hi(rv[ni][rr].y) + gt[ni][rr].w * v[3];
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(p.y + (int64_t)m * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
+// DMA: operand tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave-instruction,
+// lane-linear -> unpadded 128-B rows); bank conflicts are removed by XOR-ing the 16-byte chunk index with
+// (row >> 1) & 7 on the per-lane SOURCE address and on the fragment reads.  No staging VGPRs, no ds_write.
+template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NT = 64 * WM * WN;      // threads
+    constexpr int LDX = DMA ? BK : LDT;   // LDS row length (elements)
     constexpr int RS = NT / 8;            // tile rows covered by one staging pass (8 x 16 B chunks per row)
     static_assert(BM / RS == 4 && BN / RS == 4, "staging code below is written for 4 passes per operand");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
-    u16* Xs = smem;                  // [2][BM][LDT]
-    u16* Ws = smem + 2 * BM * LDT;   // [2][BN][LDT]
+    u16* Xs = smem;                  // [2][BM][LDX]
+    u16* Ws = smem + 2 * BM * LDX;   // [2][BN][LDX]
 
     // ---- tile mapping ----
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -62,7 +131,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
     const int pid_n = (wg % in_group) / gsz;
     const int m0 = pid_m * BM, n0 = pid_n * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, g = lane >> 5;
 
@@ -83,6 +153,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
     *reinterpret_cast<uint4*>(Ws + ((buf_) * BN + srow + RS * i_) * LDT + kc * 8) = wr##i_;
 #define S_STORE(buf_) S_STORE1(0, buf_) S_STORE1(1, buf_) S_STORE1(2, buf_) S_STORE1(3, buf_)
 
+    // LDS-DMA pieces: piece j of an operand = tile rows 8j..8j+7; lane -> row 8j + (l >> 3), chunk l & 7
+    constexpr int PA = BM / 8 / (NT / 64), PB = BN / 8 / (NT / 64);   // pieces per wave
+    const int d_row = lane >> 3, d_c = lane & 7;
+#define DMA_ISSUE(k0_, buf_)                                                                                  \
+    {                                                                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < PA; ++i_) {                                                   \
+            const int r_ = 8 * (wave * PA + i_) + d_row;                                                      \
+            const u16* src_ = p.x + (int64_t)min(m0 + r_, p.M - 1) * p.lda + (k0_) + ((d_c ^ ((r_ >> 1) & 7)) << 3);  \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,              \
+                (__attribute__((address_space(3))) void*)(Xs + ((buf_) * BM + 8 * (wave * PA + i_)) * LDX), 16, 0, 0); \
+        }                                                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < PB; ++i_) {                                                   \
+            const int r_ = 8 * (wave * PB + i_) + d_row;                                                      \
+            const u16* src_ = p.w + (int64_t)min(n0 + r_, p.N - 1) * p.K + (k0_) + ((d_c ^ ((r_ >> 1) & 7)) << 3);    \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,              \
+                (__attribute__((address_space(3))) void*)(Ws + ((buf_) * BN + 8 * (wave * PB + i_)) * LDX), 16, 0, 0); \
+        }                                                                                                     \
+    }
+    int foff[BK / 16];   // fragment-read offset (elements) of chunk (2 ks + g) in this lane's row
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) foff[ks] = DMA ? (((2 * ks + g) ^ ((l31 >> 1) & 7)) << 3) : (ks * 16 + g * 8);
+
     f32x16 acc[NI][MI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -92,87 +184,159 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     const int nk = p.K / BK;
-    G_LOAD(0)
-    S_STORE(0)
+    if (DMA) {
+        DMA_ISSUE(0, 0)
+    } else {
+        G_LOAD(0)
+        S_STORE(0)
+    }
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nk) { G_LOAD((t + 1) * BK) }
-        const u16* xs = Xs + (cur * BM + wm * WTM + l31) * LDT + g * 8;
-        const u16* ws = Ws + (cur * BN + wn * WTN + l31) * LDT + g * 8;
+        if (t + 1 < nk) {
+            if (DMA) {
+                DMA_ISSUE((t + 1) * BK, cur ^ 1)
+            } else {
+                G_LOAD((t + 1) * BK)
+            }
+        }
+        const u16* xs = Xs + (cur * BM + wm * WTM + l31) * LDX;
+        const u16* ws = Ws + (cur * BN + wn * WTN + l31) * LDX;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 wf[NI], xf[MI];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * LDT + ks * 16);
+            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * LDX + foff[ks]);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * LDT + ks * 16);
+            for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * LDX + foff[ks]);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
-        if (t + 1 < nk) { S_STORE(cur ^ 1) }
+        if (!DMA) { if (t + 1 < nk) { S_STORE(cur ^ 1) } }
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds column m, rows n = nbase + 8 rr + 4 g + e ----
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = m0 + wm * WTM + mi * 32 + l31;
-        if (m >= p.M) continue;
-        int64_t bidx = 0;
-        if (EPI == SCAIL_EPI_RESID && p.gate != nullptr) bidx = (int64_t)m / p.rows_per_batch;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int n = n0 + wn * WTN + ni * 32 + 8 * rr + 4 * g;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * rr + e];
-                if (p.bias != nullptr) {
-                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if (EPI == SCAIL_EPI_GELU_TANH) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-                } else if (EPI == SCAIL_EPI_GELU_ERF) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
-                } else if (EPI == SCAIL_EPI_RESID) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(p.resid + (int64_t)m * p.ldr + n);
-                    float gt[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (p.gate != nullptr) {
-                        const float4 gg = *reinterpret_cast<const float4*>(p.gate + bidx * p.gate_stride + n);
-                        gt[0] = gg.x; gt[1] = gg.y; gt[2] = gg.z; gt[3] = gg.w;
-                    }
-                    v[0] = bf_lo(rv.x) + gt[0] * v[0];
-                    v[1] = bf_hi(rv.x) + gt[1] * v[1];
-                    v[2] = bf_lo(rv.y) + gt[2] * v[2];
-                    v[3] = bf_hi(rv.y) + gt[3] * v[3];
-                }
-                uint2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(p.y + (int64_t)m * p.ldc + n) = o;
-            }
-        }
-    }
+    gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
 }
 
-static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force (tools/microbench.py A/B)
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves, LDS-DMA into a 4-deep ring of HALF k-tiles (32 k each, 16 KB per operand),
+// prefetch distance 3: the barrier that ends half-tile h only needs half-tile h+1 (issued two barriers
+// earlier) -> counted s_waitcnt vmcnt(8) leaves the two youngest half-tiles in flight across it, so the
+// matrix pipes never idle behind a fresh load.  Raw s_barrier (a __syncthreads() would drain vmcnt to 0).
+// LDS image per half-tile: [256 rows][32 elements] (64-B rows, 4 x 16-B chunks), chunk index XOR-ed with
+// (row >> 2) & 3 on the DMA source address and on the fragment reads -> conflict-free ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, HK = 32, NS = 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Xs = smem;                     // [NS][BM][HK]
+    u16* Ws = smem + NS * BM * HK;      // [NS][BN][HK]
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nb = tiles_m * tiles_n;
+    int wg;
+    {
+        const int id = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = id & 7, loc = id >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int in_group = GROUP_M * tiles_n;
+    const int gid = wg / in_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int pid_m = first_m + (wg % in_group) % gsz;
+    const int pid_n = (wg % in_group) / gsz;
+    const int m0 = pid_m * BM, n0 = pid_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, g = lane >> 5;
+
+    // DMA pieces: 1 KiB = 16 rows x 64 B; lane -> row 16 j + (l >> 2), chunk l & 3; 16 pieces per operand
+    // per half-tile, 2 per wave.  Row pointers (clamped) are fixed for the whole k loop.
+    const int d_row = lane >> 2, d_c = lane & 3;
+    const int ra0 = 16 * (wave * 2) + d_row, ra1 = ra0 + 16;
+    const int sw0 = ((d_c ^ ((ra0 >> 2) & 3)) << 3), sw1 = ((d_c ^ ((ra1 >> 2) & 3)) << 3);
+    const u16* xa0 = p.x + (int64_t)min(m0 + ra0, p.M - 1) * p.lda + sw0;
+    const u16* xa1 = p.x + (int64_t)min(m0 + ra1, p.M - 1) * p.lda + sw1;
+    const u16* wb0 = p.w + (int64_t)min(n0 + ra0, p.N - 1) * p.K + sw0;
+    const u16* wb1 = p.w + (int64_t)min(n0 + ra1, p.N - 1) * p.K + sw1;
+#define RING_ISSUE(h_)                                                                                         \
+    {                                                                                                          \
+        const int k0_ = (h_) * HK, s_ = (h_) & (NS - 1);                                                       \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xa0 + k0_),           \
+            (__attribute__((address_space(3))) void*)(Xs + (s_ * BM + 16 * (wave * 2)) * HK), 16, 0, 0);       \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xa1 + k0_),           \
+            (__attribute__((address_space(3))) void*)(Xs + (s_ * BM + 16 * (wave * 2 + 1)) * HK), 16, 0, 0);   \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb0 + k0_),           \
+            (__attribute__((address_space(3))) void*)(Ws + (s_ * BN + 16 * (wave * 2)) * HK), 16, 0, 0);       \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb1 + k0_),           \
+            (__attribute__((address_space(3))) void*)(Ws + (s_ * BN + 16 * (wave * 2 + 1)) * HK), 16, 0, 0);   \
+    }
+    const int fo0 = (((0 + g) ^ ((l31 >> 2) & 3)) << 3), fo1 = (((2 + g) ^ ((l31 >> 2) & 3)) << 3);
+
+    f32x16 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int nh = p.K / HK;
+    RING_ISSUE(0)
+    if (nh > 1) RING_ISSUE(1)
+    if (nh > 2) RING_ISSUE(2)
+    // half-tile 0 landed: at most min(nh,3)-1 younger groups of 4 may stay in flight
+    if (nh > 2) __builtin_amdgcn_s_waitcnt(0x0F78);        // vmcnt(8)
+    else if (nh > 1) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    for (int h = 0; h < nh; ++h) {
+        if (h + 3 < nh) RING_ISSUE(h + 3)
+        const int s_ = h & (NS - 1);
+        const u16* xs = Xs + (s_ * BM + wm * WTM + l31) * HK;
+        const u16* ws = Ws + (s_ * BN + wn * WTN + l31) * HK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? fo1 : fo0;
+            bf16x8 wf[NI], xf[MI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * HK + fo);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * HK + fo);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        // half-tile h+1 must have landed (this wave's pieces; the barrier extends it to all waves) and this
+        // wave's LDS reads of slot s_ must be complete before slot s_ is refilled after the barrier
+        if (h + 3 < nh) __builtin_amdgcn_s_waitcnt(0x0078);        // vmcnt(8)  lgkmcnt(0)
+        else if (h + 2 < nh) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4)  lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0)  lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    }
+    gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
+}
+
+static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 tile + LDS-DMA; 258: 256 tile + DMA ring
 int scail_gemm_tune(int v) { g_gemm_tile = v; return 0; }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
 static int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
-    constexpr int lds = 2 * (BM + BN) * LDT * 2;
+    constexpr int lds = 2 * (BM + BN) * (DMA ? BK : LDT) * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WM, WN, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WM, WN, EPI, DMA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             scail_set_error(std::string("gemm: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
@@ -181,15 +345,37 @@ static int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, EPI>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, EPI, DMA>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, stream, p);
+    return scail_check_launch("gemm_bf16");
+}
+
+template <int EPI>
+static int launch_gemm_ring(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds = 4 * (256 + 256) * 32 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("gemm: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI>), dim3((unsigned)tiles), dim3(512), lds, stream, p);
     return scail_check_launch("gemm_bf16");
 }
 
 template <int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
-    const bool big = g_gemm_tile == 256 || (g_gemm_tile == 0 && p.M >= 2048 && p.N >= 1024);
-    if (big) return launch_gemm_t<256, 256, 2, 4, EPI>(p, stream);
-    return launch_gemm_t<128, 128, 2, 2, EPI>(p, stream);
+    // measured at M = 97 664 (profiles/r01_pmc.md): 128 tile 820, 256 tile 1000, 256 + LDS-DMA 1090 (default
+    // for the big per-token GEMMs), 256 + DMA ring of half k-tiles with counted vmcnt 1025 TFLOP/s
+    if (g_gemm_tile == 258) return launch_gemm_ring<EPI>(p, stream);
+    if (g_gemm_tile == 256) return launch_gemm_t<256, 256, 2, 4, EPI, false>(p, stream);
+    const bool big = g_gemm_tile == 257 || (g_gemm_tile == 0 && p.M >= 2048 && p.N >= 1024);
+    if (big) return launch_gemm_t<256, 256, 2, 4, EPI, true>(p, stream);
+    return launch_gemm_t<128, 128, 2, 2, EPI, false>(p, stream);
 }
 
 extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf16* w, const float* bias,

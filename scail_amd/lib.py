@@ -72,6 +72,9 @@ def load() -> C.CDLL:
         fn.argtypes = args
         fn.restype = C.c_int
     _lib = lib
+    for env, knob in (("SCAIL_ATTN_VARIANT", b"attn_variant"), ("SCAIL_GEMM_TILE", b"gemm_tile")):   # A/B overrides for test runs
+        if os.environ.get(env):
+            lib.scail_tune_set(knob, int(os.environ[env]))
     return lib
 
 

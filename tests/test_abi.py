@@ -97,3 +97,25 @@ def test_reference_yaml_targets_resolve():
         guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 4}})})
     sig = s.sigmas()
     assert sig.shape == (51,) and sig[0] == 1 and sig[-1] == 0 and s.guider.scale == 4
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """<load>/latest + <iter>/mp_rank_00_model_states.pt with 'module' keys model.diffusion_model.* (model_io.py)."""
+    from scail_amd import checkpoint
+    from scail_amd.cli import TINY
+    from scail_amd.engine import SATVideoDiffusionEngine
+    mc = dict(TINY["model"]); mc["build_first_stage"] = False
+    a = SATVideoDiffusionEngine(mc, device="cpu")
+    name = checkpoint.save_checkpoint(a, str(tmp_path), 1000)
+    assert name.endswith("1000/mp_rank_00_model_states.pt")
+    keys = list(torch.load(name)["module"].keys())
+    assert all(k.startswith("model.diffusion_model.") for k in keys) and len(keys) == 73
+    mc2 = dict(mc); mc2["network_config"] = dict(mc["network_config"]); mc2["network_config"]["params"] = dict(mc["network_config"]["params"], init_seed=99)
+    b = SATVideoDiffusionEngine(mc2, device="cpu")
+    k0 = "model.diffusion_model.transformer.layers.0.attention.dense.weight"
+    assert not torch.equal(a.state_dict()[k0], b.state_dict()[k0])
+    it, missing, unexpected = checkpoint.load_checkpoint(b, str(tmp_path))
+    assert it == 1000 and not missing and not unexpected
+    assert all(torch.equal(a.state_dict()[k], b.state_dict()[k]) for k in keys)
+    with pytest.raises(ValueError, match="metadata"):
+        checkpoint.load_checkpoint(b, str(tmp_path / "nope"))

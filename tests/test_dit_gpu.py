@@ -175,3 +175,11 @@ def test_sequence_parallel_emulated_equals_single(golden_dir, world):
     assert not errs, errs
     torch.testing.assert_close(outs[0].float().cpu(), g["out"], rtol=2e-2, atol=2e-2)
     assert _cos(outs[0].float().cpu(), g["out"]) >= 0.999
+
+
+def test_cli_tiny_end_to_end():
+    """BASELINE.json configs[0] shape through the CLI driver: VAE encode -> 2-step sampler -> VAE decode."""
+    from scail_amd import cli
+    video, z, dt = cli.run(cli.TINY, steps=2, frames=13)
+    assert z.shape == (1, 16, 4, 8, 8) and video.shape == (1, 3, 13, 64, 64)
+    assert torch.isfinite(video).all() and 0.0 <= float(video.min()) and float(video.max()) <= 1.0
