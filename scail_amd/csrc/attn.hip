@@ -406,8 +406,8 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(AttnParams p) {
     }
 
 // MFMA / VALU(+TRANS) interleave groups: one MFMA, then n VALU instructions
-#define SWP_GA __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);
-#define SWP_GB __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, 3, 0);
+#define SWP_GA __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, GA, 0);
+#define SWP_GB __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, GB, 0);
 #define SWP_X16(G_) G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_
 
 // keeps a value computed BEFORE this point (machine sinking would otherwise move the exp2 chain below
@@ -442,6 +442,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(AttnParams p) {
         __syncthreads();                                                                           \
     }
 
+template <int GA, int GB>   // VALU(+TRANS) instructions scheduled into each MFMA gap of block A / block B
 __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* Ks = smem;                              // [2][KVBLK][K_LD]
@@ -537,10 +538,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
     }
 }
 
-// bit 3: software-pipelined kernel (measured 990 vs 1035 TFLOP/s: not the default); else the lock-step
-// kernel with bit 0 = s_setprio around MFMA clusters (-3 %), bit 1 = skip no-op O rescales (+4 %, default)
+// Kernel selection (A/B measured on one box, B=2 x 8 heads x 48 832 keys, random data; lock-step + rescale
+// skip = 100 %):  bit 0 s_setprio around MFMA clusters -3 %;  bit 1 rescale skip +4 % (in the baseline);
+// bit 6 4-wave workgroups x 2 per CU -7 %;  bit 8 LDS-DMA K/V staging -3 %;  bit 3 software-pipelined kernel
+// with (bits 12+) 9/3 VALU per MFMA gap -3 %, 6/4 -4 %, 5/5 +3 %, **4/4 +4 % (default)**, 3/3 +2.5 %.
+// bits 4/5 are ablations (wrong results): no softmax -14 % time, no staging/barrier -15 %, neither -35 %.
 int scail_gemm_tune(int v);
-static int g_attn_variant = 2;
+static int g_attn_variant = 8 | (2 << 12);
 extern "C" int scail_tune_set(const char* knob, int value) {
     if (std::string(knob) == "attn_variant") { g_attn_variant = value; return 0; }
     if (std::string(knob) == "gemm_tile") return scail_gemm_tune(value);
@@ -569,7 +573,7 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     if (!attr_set) {
         const void* fns[10] = {reinterpret_cast<const void*>(&flash_attn_kernel<258, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<2, 4>), reinterpret_cast<const void*>(&flash_attn_kernel<0, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<1, 8>),
                               reinterpret_cast<const void*>(&flash_attn_kernel<2, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<3, 8>),
-                              reinterpret_cast<const void*>(&flash_attn_swp_kernel), reinterpret_cast<const void*>(&flash_attn_kernel<18, 8>),
+                              reinterpret_cast<const void*>(&flash_attn_swp_kernel<9, 3>), reinterpret_cast<const void*>(&flash_attn_kernel<18, 8>),
                               reinterpret_cast<const void*>(&flash_attn_kernel<34, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<50, 8>)};
         for (int i = 0; i < 10; ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i == 6 ? ATT_PP_LDS_BYTES : ATT_LDS_BYTES);
@@ -590,7 +594,20 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     p.accumulate = accumulate;
     dim3 grid((unsigned)((Lq + QBLK - 1) / QBLK), (unsigned)heads, (unsigned)n_batch);
     if (g_attn_variant & 8) {
-        hipLaunchKernelGGL(flash_attn_swp_kernel, grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+        const int sub = g_attn_variant >> 12;     // A/B of the interleave density
+        static bool swp_attr = false;
+        if (!swp_attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<5, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+            swp_attr = true;
+        }
+        if (sub == 1) hipLaunchKernelGGL((flash_attn_swp_kernel<5, 5>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+        else if (sub == 2) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+        else if (sub == 3) hipLaunchKernelGGL((flash_attn_swp_kernel<6, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+        else if (sub == 4) hipLaunchKernelGGL((flash_attn_swp_kernel<3, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((flash_attn_swp_kernel<9, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         return scail_check_launch("flash_attn");
     }
     if (g_attn_variant & 256) {  // LDS-DMA staging
