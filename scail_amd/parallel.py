@@ -54,6 +54,10 @@ class TorchDistBackend:
         w = self.dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1), group=self.group, async_op=async_op)
         return _Handle(w if async_op else None)
 
+    def all_to_all(self, out, inp):
+        """out[s] <- rank s's inp[my rank]; out, inp: (size, ...) contiguous."""
+        self.dist.all_to_all_single(out.view(-1), inp.reshape(-1), group=self.group)
+
     def gather_cat(self, t, dim):
         """Concatenate along ``dim`` on group rank 0 (reference: dist.gather + concat, :578-585);
         other ranks get their own shard back."""
@@ -99,6 +103,13 @@ class ThreadBackend:
         self._sync()
         return _Handle(None)
 
+    def all_to_all(self, out, inp):
+        self.shared.slots[self.rank] = inp
+        self._sync()
+        for r in range(self.size):
+            out[r].copy_(self.shared.slots[r][self.rank])
+        self._sync()
+
     def gather_cat(self, t, dim):
         self.shared.slots[self.rank] = t
         self._sync()
@@ -110,10 +121,22 @@ class ThreadBackend:
 class SequenceParallel:
     """What the engine and the DiT need from a sequence-parallel group."""
 
-    def __init__(self, backend):
+    def __init__(self, backend, mode: str = "auto"):
+        """mode: 'allgather' (K / V^T all-gather, any head count), 'ulysses' (head <-> sequence all-to-all of
+        q, k, v and o like the reference, 4x less traffic at 8 ranks, needs heads % size == 0) or 'auto'
+        (ulysses when it divides and size >= 4: received bytes per rank and layer at config 2 are
+        2 GB (N-1)/N for the all-gather vs 4 GB (N-1)/N^2 for the all-to-alls)."""
         self.backend = backend
         self.rank, self.size = backend.rank, backend.size
+        self.mode = mode
         self._buf = {}
+
+    def resolve_mode(self, heads: int) -> str:
+        if self.mode != "auto":
+            if self.mode == "ulysses" and heads % self.size:
+                raise ValueError(f"ulysses needs heads ({heads}) divisible by the group size ({self.size})")
+            return self.mode
+        return "ulysses" if (heads % self.size == 0 and self.size >= 4) else "allgather"
 
     # ---- host-side sharding (diffusion_video.py:495-552) ----
     @staticmethod
@@ -141,6 +164,42 @@ class SequenceParallel:
 
     # ---- the one per-layer exchange ----
     def self_attention(self, net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps):
+        if self.resolve_mode(net.num_attention_heads) == "ulysses":
+            return self.self_attention_ulysses(net, lw, xn, qkv, cos, sin, att, Ltok, eps)
+        return self.self_attention_allgather(net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps)
+
+    def self_attention_ulysses(self, net, lw, xn, qkv, cos, sin, att, Ltok, eps):
+        """The reference's exchange (sat/mpu/ulysses_attn_layer.py:65-107): scatter heads / gather sequence for
+        q, k, v in ONE all-to-all, attention over the full sequence for heads/size heads, all-to-all back.
+        Norm + RoPE are applied before the exchange (the q/k RMSNorm spans all heads of a token)."""
+        D, nh, N = net.hidden_size, net.num_attention_heads, self.size
+        B = xn.shape[0]
+        Hn = nh // N
+        Dn = Hn * 128
+        ops.gemm(xn, lw["qkv_w"], lw["qkv_b"], out=qkv)
+        ops.rmsnorm_rope(qkv[..., D:2 * D], lw["kn"], cos, sin, rows_per_batch=Ltok, eps=eps)
+        ops.rmsnorm_rope(qkv[..., :D], lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
+        key = ("u", B, Ltok)
+        if key not in self._buf:
+            dev = xn.device
+            Lp = (Ltok + 63) // 64 * 64
+            e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.bfloat16)
+            self._buf = {key: dict(send=e(N, 3, B, Ltok, Dn), recv=e(N, 3, B, Ltok, Dn), vtg=e(N, B, Hn, 128, Lp),
+                                   oseg=e(N, B, Ltok, Dn), back=e(N, B, Ltok, Dn))}
+        bf = self._buf[key]
+        bf["send"].copy_(qkv.view(B, Ltok, 3, N, Dn).permute(3, 2, 0, 1, 4))       # (dst rank, q|k|v, B, L, Dn)
+        self.backend.all_to_all(bf["recv"], bf["send"])                            # recv[src rank] = its tokens, my heads
+        recv, vtg, oseg = bf["recv"], bf["vtg"], bf["oseg"]
+        for s in range(N):
+            ops.transpose_v(recv[s, 2], Hn, out=vtg[s])
+        for s in range(N):                                                         # queries of source rank s
+            net._timed("self_attn", ops.flash_attn, recv[s, 0], recv[0, 1], vtg[0], out=oseg[s], n_seg=N,
+                       k_seg_stride=recv.stride(0), vt_seg_stride=vtg.stride(0))
+        self.backend.all_to_all(bf["back"], oseg)                                  # back[g] = my tokens, head group g
+        att.view(B, Ltok, N, Dn).copy_(bf["back"].permute(1, 2, 0, 3))
+        return att
+
+    def self_attention_allgather(self, net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps):
         """xn (B, Lloc, D) -> att (B, Lloc, D): K/V projection, K norm+RoPE, V^T staging, all-gather
         of both, (overlapped) Q projection + norm + RoPE, attention over all ranks' keys."""
         D, nh = net.hidden_size, net.num_attention_heads
@@ -186,4 +245,4 @@ def init_from_env(backend: str = "nccl") -> Optional[SequenceParallel]:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    return SequenceParallel(TorchDistBackend(None))
+    return SequenceParallel(TorchDistBackend(None), mode=os.environ.get("SCAIL_SP_MODE", "auto"))

@@ -142,8 +142,8 @@ def test_engine_sample_from_reference_yaml_shapes():
     torch.testing.assert_close(z2.float(), z.float(), rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sequence_parallel_emulated_equals_single(golden_dir, world):
+@pytest.mark.parametrize("world,mode", [(2, "allgather"), (2, "ulysses")])
+def test_sequence_parallel_emulated_equals_single(golden_dir, world, mode):
     """N virtual SP ranks (threads sharing the one GPU, scail_amd.parallel.ThreadBackend) run the real
     multi-rank data path: H-chunked latents, rank-shifted RoPE, K / V^T all-gather, multi-segment
     attention kernel, gather to rank 0.  Must reproduce the reference golden (= SP 1)."""
@@ -157,7 +157,7 @@ def test_sequence_parallel_emulated_equals_single(golden_dir, world):
         try:
             torch.cuda.set_device(0)
             cfg, sd, net = _net(O.TINY, int(g["seed"]))
-            sp = SequenceParallel(ThreadBackend(shared, r))
+            sp = SequenceParallel(ThreadBackend(shared, r), mode=mode)
             net.sp = sp
             sp.check_latent(g["x"].shape[3], g["x"].shape[4], 3)
             ch = lambda t: sp.chunk(t.to(DEV), 3)

@@ -43,6 +43,11 @@ def _worker(rank, world, port, golden, q):
     out = O.dit_forward(cfg, sd, sp.chunk(x, cd), g["t"], g["ctx"], sp.chunk(g["ref"], cd), sp.chunk(g["pose"], cd),
                         g["clip"], H_shift=rank * (Hs // 2), kv_gather=kv_gather)
     full = sp.gather_to_rank0(out, cd)
+    # the ulysses exchange primitive: out[s] <- rank s's inp[my rank]
+    inp = torch.arange(world * 3, dtype=torch.float32).reshape(world, 3) + 100 * rank
+    got = torch.empty_like(inp)
+    sp.backend.all_to_all(got, inp)
+    assert torch.equal(got, torch.stack([torch.arange(3, dtype=torch.float32) + 3 * rank + 100 * s for s in range(world)]))
     if rank == 0:
         q.put((full - g["out"]).abs().max().item())
     dist.barrier()
