@@ -187,6 +187,30 @@ int scail_to_channels_last(const float* x, scail_bf16* y, const float* a, const 
 int scail_from_channels_last(const scail_bf16* x, int64_t ldx, float* y, const float* a, const float* b,
                              int64_t C, int64_t N, float lo, float hi, void* stream);
 
+
+/* ---- conditioning encoders (UMT5-XXL text encoder, CLIP ViT-H/14 visual) ---------------- */
+
+/*
+ * Small-sequence softmax attention, head_dim <= 128, K and V of one (batch, head) resident in LDS.
+ *   o = softmax(scale * q k^T + bias_tab[bucket[i, j], h] + mask) v
+ * strides = {q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs} (elements, host array); head h at column h*head_dim.
+ * bucket int32 [Lq, Lk] + bias_tab fp32 [n_buckets, heads]: T5 relative-position bias (umt5.py:224-268, 101-113);
+ * key_mask int32 [n_batch, key_mask_bs]: 0 -> key excluded (umt5.py:106-110).  CLIP: no bias/mask, scale
+ * 1/sqrt(head_dim) (clip.py:96-103).
+ */
+int scail_attn_small(const scail_bf16* q, const scail_bf16* k, const scail_bf16* v, scail_bf16* o,
+                     const int64_t* strides, int64_t n_batch, int64_t heads, int64_t Lq, int64_t Lk, int64_t head_dim,
+                     float scale, const int32_t* bucket, const float* bias_tab, const int32_t* key_mask,
+                     int64_t key_mask_bs, void* stream);
+
+/* y = a * b elementwise (gated-GELU FFN of T5, umt5.py:141). */
+int scail_mul_bf16(const scail_bf16* a, const scail_bf16* b, scail_bf16* y, int64_t n, void* stream);
+
+/* y[r,:] = x[r,:] * rowscale[r] + addrow[r % add_rows,:]  (zeroing padded text rows umt5.py:522; adding the
+ * ViT position embedding clip.py:317-318).  rowscale fp32 / addrow bf16 may be NULL. */
+int scail_row_affine(const scail_bf16* x, scail_bf16* y, const float* rowscale, const scail_bf16* addrow, int64_t add_rows,
+                     int64_t rows, int64_t D, void* stream);
+
 /* Tuning / A-B knob for kernel variants (same results, different schedules); used by tools/microbench.py.
  * knobs: "attn_variant" (bit 0: s_setprio around MFMA clusters, bit 1: skip no-op O rescales [default],
  *        bit 3: software-pipelined kernel); "gemm_tile" (0 auto, 128, 256). */

@@ -454,3 +454,139 @@ extern "C" int scail_bf16_to_f32(const scail_bf16* x, float* y, int64_t n, void*
                        (hipStream_t)stream, x, y, n);
     return scail_check_launch("bf16_to_f32");
 }
+
+// ================================================================================================
+// Small-sequence attention for the conditioning encoders (UMT5: 64 heads x 64, relative-position bias,
+// key padding mask, no scaling -- umt5.py:72-123; CLIP ViT-H: 16 heads x 80, scale 1/sqrt(80) --
+// clip.py:71-108).  Sequences are <= 512 tokens and the FLOPs are negligible (4 GFLOP per T5 layer), so
+// this is a plain VALU kernel: K and V of one (batch, head) live in LDS, one wave per query row.
+// ================================================================================================
+#define SA_ROWS 32   // query rows per workgroup (8 per wave)
+__global__ __launch_bounds__(256) void attn_small_kernel(
+    const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v, u16* __restrict__ o,
+    int64_t q_bs, int64_t q_rs, int64_t k_bs, int64_t k_rs, int64_t v_bs, int64_t v_rs, int64_t o_bs, int64_t o_rs,
+    int Lq, int Lk, int hd, float scale, const int* __restrict__ bucket, const float* __restrict__ bias_tab, int n_heads_tab,
+    const int* __restrict__ kmask, int64_t kmask_bs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    const int ldk = hd + 8;                                  // padded rows: conflict-free 16-byte reads
+    u16* Ks = reinterpret_cast<u16*>(sm_raw);                // [Lk][ldk]
+    u16* Vs = Ks + (size_t)Lk * ldk;                         // [Lk][hd]
+    float* Ps = reinterpret_cast<float*>(Vs + (size_t)Lk * hd);   // [4 waves][Lk]
+    float* Qs = Ps + 4 * Lk;                                 // [4 waves][hd]
+    const int h = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cpr = hd >> 3;
+    for (int c = tid; c < Lk * cpr; c += 256) {
+        const int j = c / cpr, cc = c - j * cpr;
+        *reinterpret_cast<uint4*>(Ks + j * ldk + cc * 8) = *reinterpret_cast<const uint4*>(k + b * k_bs + (int64_t)j * k_rs + h * hd + cc * 8);
+        *reinterpret_cast<uint4*>(Vs + j * hd + cc * 8) = *reinterpret_cast<const uint4*>(v + b * v_bs + (int64_t)j * v_rs + h * hd + cc * 8);
+    }
+    __syncthreads();
+    float* P = Ps + wave * Lk;
+    float* Q = Qs + wave * hd;
+    const int i0 = blockIdx.x * SA_ROWS;
+    for (int ii = wave; ii < SA_ROWS; ii += 4) {
+        const int i = i0 + ii;
+        if (i >= Lq) break;                                   // wave-uniform
+        for (int d = lane; d < hd; d += 64) Q[d] = bf2f(q[b * q_bs + (int64_t)i * q_rs + h * hd + d]) * scale;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0): Q visible to the whole wave
+        float mx = -INFINITY;
+        for (int j = lane; j < Lk; j += 64) {
+            float s = 0.f;
+            for (int c = 0; c < cpr; ++c) {
+                float kf[8];
+                unpack8(*reinterpret_cast<const uint4*>(Ks + j * ldk + c * 8), kf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += Q[c * 8 + e] * kf[e];
+            }
+            if (bias_tab != nullptr) s += bias_tab[bucket[(int64_t)i * Lk + j] * n_heads_tab + h];
+            if (kmask != nullptr && kmask[b * kmask_bs + j] == 0) s = -INFINITY;
+            P[j] = s;
+            mx = fmaxf(mx, s);
+        }
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) mx = fmaxf(mx, __shfl_xor(mx, of, 64));
+        float sum = 0.f;
+        for (int j = lane; j < Lk; j += 64) {
+            const float pv = __expf(P[j] - mx);
+            P[j] = pv;
+            sum += pv;
+        }
+        sum = wave_sum(sum);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const float inv = 1.0f / sum;
+        for (int d = lane; d < hd; d += 64) {
+            float acc = 0.f;
+            for (int j = 0; j < Lk; ++j) acc += P[j] * bf2f(Vs[j * hd + d]);
+            o[b * o_bs + (int64_t)i * o_rs + h * hd + d] = f2bf(acc * inv);
+        }
+    }
+}
+
+__global__ void mul_bf16_kernel(const u16* __restrict__ a, const u16* __restrict__ b, u16* __restrict__ y, int64_t n8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float fa[8], fb[8], fo[8];
+    unpack8(*reinterpret_cast<const uint4*>(a + i * 8), fa);
+    unpack8(*reinterpret_cast<const uint4*>(b + i * 8), fb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fo[e] = fa[e] * fb[e];
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8(fo);
+}
+
+// y[r, :] = x[r, :] * rowscale[r] + addrow[r % add_rows, :]   (either may be NULL)
+__global__ void row_affine_kernel(const u16* __restrict__ x, u16* __restrict__ y, const float* __restrict__ rowscale,
+                                  const u16* __restrict__ addrow, int64_t add_rows, int64_t rows, int D8) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D8) return;
+    const int64_t r = i / D8;
+    const int c = (int)(i - r * D8);
+    float f[8], a[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + i * 8), f);
+    const float s = rowscale ? rowscale[r] : 1.f;
+    if (addrow) unpack8(*reinterpret_cast<const uint4*>(addrow + ((r % add_rows) * D8 + c) * 8), a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = f[e] * s + (addrow ? a[e] : 0.f);
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8(f);
+}
+
+extern "C" int scail_attn_small(const scail_bf16* q, const scail_bf16* k, const scail_bf16* v, scail_bf16* o,
+                                const int64_t* strides, int64_t n_batch, int64_t heads, int64_t Lq, int64_t Lk, int64_t head_dim,
+                                float scale, const int32_t* bucket, const float* bias_tab, const int32_t* key_mask,
+                                int64_t key_mask_bs, void* stream) {
+    SCAIL_REQUIRE(head_dim % 8 == 0 && head_dim <= 128, "head_dim must be a multiple of 8, <= 128");
+    SCAIL_REQUIRE((bucket == nullptr) == (bias_tab == nullptr), "bucket and bias table go together");
+    for (int i = 0; i < 8; ++i) SCAIL_REQUIRE(strides[i] % 8 == 0, "strides must keep 16-byte alignment");
+    const size_t lds = (size_t)Lk * (head_dim + 8) * 2 + (size_t)Lk * head_dim * 2 + 4 * Lk * 4 + 4 * head_dim * 4;
+    SCAIL_REQUIRE(lds <= 160 * 1024, "K and V of one head must fit in LDS (Lk * head_dim too large for this kernel)");
+    if (Lq == 0 || n_batch == 0) return 0;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { scail_set_error("attn_small: hipFuncSetAttribute failed"); return 2; }
+        lds_set = lds;
+    }
+    dim3 grid((unsigned)((Lq + SA_ROWS - 1) / SA_ROWS), (unsigned)heads, (unsigned)n_batch);
+    hipLaunchKernelGGL(attn_small_kernel, grid, dim3(256), lds, (hipStream_t)stream, q, k, v, o, strides[0], strides[1], strides[2],
+                       strides[3], strides[4], strides[5], strides[6], strides[7], (int)Lq, (int)Lk, (int)head_dim, scale, bucket, bias_tab,
+                       (int)heads, key_mask, key_mask_bs);
+    return scail_check_launch("attn_small");
+}
+
+extern "C" int scail_mul_bf16(const scail_bf16* a, const scail_bf16* b, scail_bf16* y, int64_t n, void* stream) {
+    SCAIL_REQUIRE(n % 8 == 0, "n must be a multiple of 8");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(mul_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, n / 8);
+    return scail_check_launch("mul_bf16");
+}
+
+extern "C" int scail_row_affine(const scail_bf16* x, scail_bf16* y, const float* rowscale, const scail_bf16* addrow, int64_t add_rows,
+                                int64_t rows, int64_t D, void* stream) {
+    SCAIL_REQUIRE(D % 8 == 0, "D must be a multiple of 8");
+    if (rows == 0) return 0;
+    const int64_t total = rows * (D / 8);
+    hipLaunchKernelGGL(row_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, rowscale,
+                       addrow, add_rows > 0 ? add_rows : 1, rows, (int)(D / 8));
+    return scail_check_launch("row_affine");
+}

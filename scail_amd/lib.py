@@ -35,6 +35,9 @@ SIGNATURES = {
     "scail_transpose2d": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "scail_to_channels_last": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "scail_from_channels_last": [_p, _i64, _p, _p, _p, _i64, _i64, _f, _f, _p],
+    "scail_attn_small": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p, _p, _p, _i64, _p],
+    "scail_mul_bf16": [_p, _p, _p, _i64, _p],
+    "scail_row_affine": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "scail_tune_set": [C.c_char_p, _i],
     "scail_f32_to_bf16": [_p, _p, _i64, _p],
     "scail_bf16_to_f32": [_p, _p, _i64, _p],

@@ -342,3 +342,57 @@ def from_channels_last(x, Cc, a=None, b=None, lo=-3.0e38, hi=3.0e38):
     L.call("scail_from_channels_last", x.data_ptr(), ld, y.data_ptr(), _ptr(a), _ptr(b), Cc, T * H * W, float(lo), float(hi),
            _stream())
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# conditioning-encoder ops
+# ------------------------------------------------------------------------------------------------
+def attn_small(q, k, v, heads, scale=1.0, bucket=None, bias_tab=None, key_mask=None, out=None):
+    """q (B, Lq, H*hd), k/v (B, Lk, H*hd) bf16 views (last dim contiguous) -> (B, Lq, H*hd).
+    bucket int32 (Lq, Lk) + bias_tab fp32 (n_buckets, H); key_mask int32 (B, Lk), 0 = excluded."""
+    import ctypes as C
+    _chk(q, bf16, "attn_small.q"); _chk(k, bf16, "attn_small.k"); _chk(v, bf16, "attn_small.v")
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    hd = D // heads
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
+    if out is None:
+        out = torch.empty(B, Lq, D, device=q.device, dtype=bf16)
+    st = (C.c_int64 * 8)(q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1))
+    if bucket is not None:
+        assert bucket.dtype == torch.int32 and bucket.is_contiguous() and bucket.shape == (Lq, Lk)
+        _chk(bias_tab, f32, "attn_small.bias_tab")
+        assert bias_tab.is_contiguous() and bias_tab.shape[1] == heads
+    if key_mask is not None:
+        assert key_mask.dtype == torch.int32 and key_mask.shape == (B, Lk) and key_mask.stride(1) == 1
+    L.call("scail_attn_small", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), C.cast(st, C.c_void_p), B, heads, Lq, Lk,
+           hd, float(scale), _ptr(bucket), _ptr(bias_tab), _ptr(key_mask), key_mask.stride(0) if key_mask is not None else 0,
+           _stream())
+    return out
+
+
+def mul_(a, b, out=None):
+    _chk(a, bf16, "mul.a"); _chk(b, bf16, "mul.b")
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = a if out is None else out
+    L.call("scail_mul_bf16", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+    return out
+
+
+def row_affine(x, rowscale=None, addrow=None, out=None):
+    """x (rows.., D) bf16 contiguous: y[r] = x[r] * rowscale[r] + addrow[r % addrow.rows]."""
+    _chk(x, bf16, "row_affine.x")
+    assert x.is_contiguous()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    out = torch.empty_like(x) if out is None else out
+    ar = 0
+    if addrow is not None:
+        _chk(addrow, bf16, "row_affine.addrow")
+        assert addrow.is_contiguous() and addrow.shape[-1] == D
+        ar = addrow.numel() // D
+    if rowscale is not None:
+        _chk(rowscale, f32, "row_affine.rowscale")
+        assert rowscale.numel() == rows and rowscale.is_contiguous()
+    L.call("scail_row_affine", x.data_ptr(), out.data_ptr(), _ptr(rowscale), _ptr(addrow), ar, rows, D, _stream())
+    return out
