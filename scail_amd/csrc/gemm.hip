@@ -102,7 +102,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NI][MI], const GemmP
 // DMA: operand tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave-instruction,
 // lane-linear -> unpadded 128-B rows); bank conflicts are removed by XOR-ing the 16-byte chunk index with
 // (row >> 1) & 7 on the per-lane SOURCE address and on the fragment reads.  No staging VGPRs, no ds_write.
-template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
+// ABL (ablation, wrong results, tools/microbench.py only): bit 0 = no operand loads inside the k loop,
+// bit 1 = no barrier inside the k loop.
+template <int BM, int BN, int WM, int WN, int EPI, bool DMA, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NT = 64 * WM * WN;      // threads
     constexpr int LDX = DMA ? BK : LDT;   // LDS row length (elements)
@@ -156,19 +158,37 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
     // LDS-DMA pieces: piece j of an operand = tile rows 8j..8j+7; lane -> row 8j + (l >> 3), chunk l & 7
     constexpr int PA = BM / 8 / (NT / 64), PB = BN / 8 / (NT / 64);   // pieces per wave
     const int d_row = lane >> 3, d_c = lane & 7;
+    const int lm0 = (ABL & 8) ? 0 : m0, ln0 = (ABL & 8) ? 0 : n0;   // ablation: every block loads tile (0,0): all L2 hits
 #define DMA_ISSUE(k0_, buf_)                                                                                  \
     {                                                                                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < PA; ++i_) {                                                   \
             const int r_ = 8 * (wave * PA + i_) + d_row;                                                      \
-            const u16* src_ = p.x + (int64_t)min(m0 + r_, p.M - 1) * p.lda + (k0_) + ((d_c ^ ((r_ >> 1) & 7)) << 3);  \
+            const u16* src_ = p.x + (int64_t)min(lm0 + r_, p.M - 1) * p.lda + ((ABL & 16) ? 0 : (k0_)) + ((d_c ^ ((r_ >> 1) & 7)) << 3);  \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,              \
                 (__attribute__((address_space(3))) void*)(Xs + ((buf_) * BM + 8 * (wave * PA + i_)) * LDX), 16, 0, 0); \
         }                                                                                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < PB; ++i_) {                                                   \
             const int r_ = 8 * (wave * PB + i_) + d_row;                                                      \
-            const u16* src_ = p.w + (int64_t)min(n0 + r_, p.N - 1) * p.K + (k0_) + ((d_c ^ ((r_ >> 1) & 7)) << 3);    \
+            const u16* src_ = p.w + (int64_t)min(ln0 + r_, p.N - 1) * p.K + ((ABL & 16) ? 0 : (k0_)) + ((d_c ^ ((r_ >> 1) & 7)) << 3);    \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,              \
                 (__attribute__((address_space(3))) void*)(Ws + ((buf_) * BN + 8 * (wave * PB + i_)) * LDX), 16, 0, 0); \
+        }                                                                                                     \
+    }
+    // one A piece + one B piece (index part_) of this wave: spreading the 2 x PA issues over the k-steps keeps
+    // the wave's MFMA stream from stalling behind 8 back-to-back DMA issues (each costs ~100 issue cycles)
+#define DMA_ISSUE_PART(k0_, buf_, part_)                                                                      \
+    {                                                                                                         \
+        if ((part_) < PA) {                                                                                   \
+            const int r_ = 8 * (wave * PA + (part_)) + d_row;                                                 \
+            const u16* src_ = p.x + (int64_t)min(m0 + r_, p.M - 1) * p.lda + (k0_) + ((d_c ^ ((r_ >> 1) & 7)) << 3);  \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,              \
+                (__attribute__((address_space(3))) void*)(Xs + ((buf_) * BM + 8 * (wave * PA + (part_))) * LDX), 16, 0, 0); \
+        }                                                                                                     \
+        if ((part_) < PB) {                                                                                   \
+            const int r_ = 8 * (wave * PB + (part_)) + d_row;                                                 \
+            const u16* src_ = p.w + (int64_t)min(n0 + r_, p.N - 1) * p.K + (k0_) + ((d_c ^ ((r_ >> 1) & 7)) << 3);    \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,              \
+                (__attribute__((address_space(3))) void*)(Ws + ((buf_) * BN + 8 * (wave * PB + (part_))) * LDX), 16, 0, 0); \
         }                                                                                                     \
     }
     int foff[BK / 16];   // fragment-read offset (elements) of chunk (2 ks + g) in this lane's row
@@ -193,9 +213,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nk) {
+        if (t + 1 < nk && !(ABL & 1)) {
             if (DMA) {
-                DMA_ISSUE((t + 1) * BK, cur ^ 1)
+                if (!(ABL & 4)) DMA_ISSUE((t + 1) * BK, cur ^ 1)
             } else {
                 G_LOAD((t + 1) * BK)
             }
@@ -214,9 +234,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+            if (DMA && (ABL & 4) && t + 1 < nk) DMA_ISSUE_PART((t + 1) * BK, cur ^ 1, ks)
         }
         if (!DMA) { if (t + 1 < nk) { S_STORE(cur ^ 1) } }
-        __syncthreads();
+        if (!(ABL & 2)) __syncthreads();
     }
 
     gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
@@ -328,15 +349,123 @@ __global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(GemmParams p) {
     gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ping-pong variant of the ring kernel.  The two wave rows (waves 0-3 / 4-7; wave w and w+4 share a SIMD)
+// run one barrier interval apart: in every interval one wave of each SIMD issues its 16-MFMA cluster for
+// half k-tile h at raised priority while its partner issues the LDS-DMA for half-tile h+3 and reads the 12
+// fragments of its next half-tile -- the matrix pipe never waits for LDS and the reads never wait for the
+// pipe.  Two raw barriers per half-tile; counted vmcnt(8) keeps two half-tiles in flight across them.
+//   interval 2h   : g0 reads h      | g1 MFMA h-1
+//   interval 2h+1 : g0 MFMA h       | g1 reads h
+// Slot (h+3)&3 was last read (by g1) in interval 2h-1, so it may be refilled from interval 2h on; every
+// wave has its share of half-tile h+1 landed before each barrier it signals, so half-tile h is complete
+// for both groups when they read it.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, HK = 32, NS = 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Xs = smem;
+    u16* Ws = smem + NS * BM * HK;
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nb = tiles_m * tiles_n;
+    int wg;
+    {
+        const int id = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = id & 7, loc = id >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int in_group = GROUP_M * tiles_n;
+    const int gid = wg / in_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int pid_m = first_m + (wg % in_group) % gsz;
+    const int pid_n = (wg % in_group) / gsz;
+    const int m0 = pid_m * BM, n0 = pid_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int grp = wm;
+    const int l31 = lane & 31, g = lane >> 5;
+
+    const int d_row = lane >> 2, d_c = lane & 3;
+    const int ra0 = 16 * (wave * 2) + d_row, ra1 = ra0 + 16;
+    const int sw0 = ((d_c ^ ((ra0 >> 2) & 3)) << 3), sw1 = ((d_c ^ ((ra1 >> 2) & 3)) << 3);
+    const u16* xa0 = p.x + (int64_t)min(m0 + ra0, p.M - 1) * p.lda + sw0;
+    const u16* xa1 = p.x + (int64_t)min(m0 + ra1, p.M - 1) * p.lda + sw1;
+    const u16* wb0 = p.w + (int64_t)min(n0 + ra0, p.N - 1) * p.K + sw0;
+    const u16* wb1 = p.w + (int64_t)min(n0 + ra1, p.N - 1) * p.K + sw1;
+    const int fo0 = (((0 + g) ^ ((l31 >> 2) & 3)) << 3), fo1 = (((2 + g) ^ ((l31 >> 2) & 3)) << 3);
+
+    f32x16 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int nh = p.K / HK;
+    RING_ISSUE(0)
+    RING_ISSUE(min(1, nh - 1))      // clamped re-loads keep the in-flight count uniform (always 4 per issue)
+    RING_ISSUE(min(2, nh - 1))
+    __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(8): half-tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int h = 0; h < nh; ++h) {
+        // ---- read interval ----
+        {
+            const int hn = min(h + 3, nh - 1);    // past the end: harmless re-load of the last half-tile into a dead slot
+            const int k0_ = hn * HK, s2_ = (h + 3) & (NS - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xa0 + k0_),
+                (__attribute__((address_space(3))) void*)(Xs + (s2_ * BM + 16 * (wave * 2)) * HK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xa1 + k0_),
+                (__attribute__((address_space(3))) void*)(Xs + (s2_ * BM + 16 * (wave * 2 + 1)) * HK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb0 + k0_),
+                (__attribute__((address_space(3))) void*)(Ws + (s2_ * BN + 16 * (wave * 2)) * HK), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb1 + k0_),
+                (__attribute__((address_space(3))) void*)(Ws + (s2_ * BN + 16 * (wave * 2 + 1)) * HK), 16, 0, 0);
+        }
+        const int s_ = h & (NS - 1);
+        const u16* xs = Xs + (s_ * BM + wm * WTM + l31) * HK;
+        const u16* ws = Ws + (s_ * BN + wn * WTN + l31) * HK;
+        bf16x8 wf[2][NI], xf[2][MI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { wf[0][i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * HK + fo0); wf[1][i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * HK + fo1); }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { xf[0][i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * HK + fo0); xf[1][i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * HK + fo1); }
+        // own share of half-tile h+1 landed (h+2, h+3 may fly); fragment reads complete before the slot can be refilled
+        __builtin_amdgcn_s_waitcnt(0x0078);     // vmcnt(8) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        // ---- MFMA interval ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // drain the clamped tail loads before the LDS goes away
+    gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
+}
+
 static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 tile + LDS-DMA; 258: 256 tile + DMA ring
 int scail_gemm_tune(int v) { g_gemm_tile = v; return 0; }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool DMA>
+template <int BM, int BN, int WM, int WN, int EPI, bool DMA, int ABL = 0>
 static int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * (DMA ? BK : LDT) * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WM, WN, EPI, DMA>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WM, WN, EPI, DMA, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             scail_set_error(std::string("gemm: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
@@ -345,7 +474,7 @@ static int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, EPI, DMA>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, EPI, DMA, ABL>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, stream, p);
     return scail_check_launch("gemm_bf16");
 }
 
@@ -368,7 +497,32 @@ static int launch_gemm_ring(const GemmParams& p, hipStream_t stream) {
 }
 
 template <int EPI>
+static int launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds = 4 * (256 + 256) * 32 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("gemm: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3((unsigned)tiles), dim3(512), lds, stream, p);
+    return scail_check_launch("gemm_bf16");
+}
+
+template <int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+    if (g_gemm_tile == 259) return launch_gemm_pp<EPI>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1001) return launch_gemm_t<256, 256, 2, 4, 0, true, 1>(p, stream);   // ablations
+    if (EPI == 0 && g_gemm_tile == 1002) return launch_gemm_t<256, 256, 2, 4, 0, true, 2>(p, stream);
+    if (g_gemm_tile == 260) return launch_gemm_t<256, 256, 2, 4, EPI, true, 4>(p, stream);   // DMA issue spread over the k-steps
+    if (EPI == 0 && g_gemm_tile == 1008) return launch_gemm_t<256, 256, 2, 4, EPI, true, 8>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1024) return launch_gemm_t<256, 256, 2, 4, EPI, true, 24>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1003) return launch_gemm_t<256, 256, 2, 4, 0, true, 3>(p, stream);
     // measured at M = 97 664 (profiles/r01_pmc.md): 128 tile 820, 256 tile 1000, 256 + LDS-DMA 1090 (default
     // for the big per-token GEMMs), 256 + DMA ring of half k-tiles with counted vmcnt 1025 TFLOP/s
     if (g_gemm_tile == 258) return launch_gemm_ring<EPI>(p, stream);
