@@ -115,6 +115,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # SCAIL_DIST_BACKEND=gloo: TEST vehicle only -- several ranks share GPU 0 and the exchanges are staged through the
+    # host (RCCL refuses duplicate devices); lets the N > 1 code path of this script run on a 1-GPU box
+    backend = os.environ.get("SCAIL_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -122,7 +127,7 @@ def main():
     from scail_amd.dit import DiffusionTransformer
     from scail_amd.sampler import make_flow_timesteps
     lib.load()
-    sp = parallel.init_from_env("nccl") if world > 1 else None
+    sp = parallel.init_from_env(backend) if world > 1 else None
     import torch.distributed as dist
 
     p, (T, H, W), Lt, Lc = CONFIGS[args.config]
@@ -177,11 +182,13 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
-    elapsed = torch.tensor([t1 - t0], device=dev, dtype=torch.float64)
+    elapsed = torch.tensor([t1 - t0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     finite = bool(torch.isfinite(x).all().item())
+    x_full = sp.gather_to_rank0(x, chunk_dim) if sp is not None else x       # after the timed region: result fingerprint
+    x_abs_mean = float(x_full.abs().mean().item())
 
     hp, wp = H // 2, W // 2
     Lnoise = T * hp * wp
@@ -189,13 +196,16 @@ def main():
     t_step = elapsed / args.steps
     nh = p["num_attention_heads"]
     attn_ms = timer.mean_ms("self_attn")
-    attn_flops = 4.0 * (L // world) * L * 128 * nh * 2
+    # one launch = local queries x all keys; in ulysses mode a launch covers heads/world heads of ONE source rank's queries
+    sp_mode = sp.resolve_mode(nh) if sp is not None else "none"
+    attn_heads = nh // world if sp_mode == "ulysses" else nh
+    attn_flops = 4.0 * (L // world) * L * 128 * attn_heads * 2
     ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms else None
     fl = step_flops(p, L, Lt, Lc)
     traffic = None                      # measured offline with rocprofv3 --pmc (cannot run inside the bench)
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))["flash_attn_self"]
-        if tr["shape"] == {"B": 2, "heads": nh, "Lq": L // world, "Lk": L}:
+        if tr["shape"] == {"B": 2, "heads": attn_heads, "Lq": L // world, "Lk": L}:
             traffic = tr["traffic_bytes"]
     except Exception:
         pass
@@ -206,9 +216,9 @@ def main():
         "config": {"workload": f"SCAIL-{args.config} DiT sampler step (batch-2 CFG forward + Euler), 512x896x81f latent "
                                f"({T},16,{H},{W}), L={L} tokens (ref+noise+pose), text {Lt}, clip {Lc}, "
                                f"{p['num_layers']} layers, random-init bf16 weights",
-                   "parallelism": f"sp{world}", "cond_cache": False, "noise_tokens": Lnoise, "all_tokens_x_batch": 2 * L,
+                   "parallelism": f"sp{world}" + (f"-{sp_mode}" if sp is not None else ""), "cond_cache": False, "noise_tokens": Lnoise, "all_tokens_x_batch": 2 * L,
                    "step_tflop": fl / 1e12, "step_mfma_frac": fl / t_step / (world * PEAK_BF16_TFLOPS * 1e12),
-                   "finite": finite},
+                   "finite": finite, "x_abs_mean": x_abs_mean},
         "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel (self-attention)", "achieved": ach,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
                      "traffic": traffic, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,

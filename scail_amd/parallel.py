@@ -45,22 +45,56 @@ class TorchDistBackend:
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self._src = dist.get_global_rank(group, 0) if group is not None else 0
+        # gloo moves host memory only: device tensors are staged through the host.  That is a TEST vehicle (several
+        # ranks sharing one GPU, where RCCL refuses duplicate devices), never the production path (nccl == RCCL).
+        self.host_staged = dist.get_backend(group) == "gloo"
+
+    def _staged(self, t):
+        return self.host_staged and t.is_cuda
 
     def broadcast(self, t):
+        if self._staged(t):
+            h = t.cpu()
+            self.dist.broadcast(h, src=self._src, group=self.group)
+            t.copy_(h)
+            return
         self.dist.broadcast(t, src=self._src, group=self.group)
 
     def all_gather_into(self, out, inp, async_op=True):
         """out: (size, *inp.shape) contiguous."""
+        if self._staged(inp):
+            hi = inp.reshape(-1).cpu()
+            ho = [torch.empty_like(hi) for _ in range(self.size)]     # gloo has no all_gather_into_tensor
+            self.dist.all_gather(ho, hi, group=self.group)
+            out.view(self.size, -1).copy_(torch.stack(ho))
+            return _Handle(None)
         w = self.dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1), group=self.group, async_op=async_op)
         return _Handle(w if async_op else None)
 
     def all_to_all(self, out, inp):
         """out[s] <- rank s's inp[my rank]; out, inp: (size, ...) contiguous."""
+        if self.host_staged:                                          # gloo has no all_to_all_single: N gathers
+            hi = inp.reshape(self.size, -1).cpu() if inp.is_cuda else inp.reshape(self.size, -1)
+            rows = []
+            for dst in range(self.size):
+                lst = [torch.empty_like(hi[dst]) for _ in range(self.size)] if self.rank == dst else None
+                self.dist.gather(hi[dst].contiguous(), gather_list=lst,
+                                 dst=self.dist.get_global_rank(self.group, dst) if self.group is not None else dst,
+                                 group=self.group)
+                if self.rank == dst:
+                    rows = lst
+            out.view(self.size, -1).copy_(torch.stack(rows))
+            return
         self.dist.all_to_all_single(out.view(-1), inp.reshape(-1), group=self.group)
 
     def gather_cat(self, t, dim):
         """Concatenate along ``dim`` on group rank 0 (reference: dist.gather + concat, :578-585);
         other ranks get their own shard back."""
+        if self._staged(t):
+            h = t.cpu()
+            lst = [torch.zeros_like(h) for _ in range(self.size)] if self.rank == 0 else None
+            self.dist.gather(h, gather_list=lst, dst=self._src, group=self.group)
+            return torch.cat(lst, dim=dim).to(t.device) if self.rank == 0 else t
         if self.rank == 0:
             lst = [torch.zeros_like(t) for _ in range(self.size)]
         else:

@@ -1,0 +1,46 @@
+"""bench.py contract on the GPU box: one JSON line at N=1, and the N=2 launch line the driver uses
+(python -m torch.distributed.run ...) -- here with both ranks on GPU 0 and the exchanges staged through
+the host (SCAIL_DIST_BACKEND=gloo; RCCL refuses two ranks on one device), so that the multi-rank code
+path of the script itself (sharding, both exchange modes, barrier/max timing, rank-0 print) is executed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(cmd, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_single_tiny():
+    o = _run([sys.executable, "bench.py", "--config", "tiny", "--steps", "2", "--warmup", "1"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in o, k
+    assert o["n_gpus"] == 1 and o["config"]["finite"] and o["value"] > 0
+    assert o["roofline"]["achieved"] > 0 and o["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.parametrize("mode", ["allgather", "ulysses"])
+def test_bench_two_ranks_one_gpu(mode):
+    one = _run([sys.executable, "bench.py", "--config", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", "29641", "bench.py", "--gpus", "2", "--config", "tiny",
+                "--steps", "2", "--warmup", "1"],
+               {"SCAIL_DIST_BACKEND": "gloo", "SCAIL_SP_MODE": mode})
+    assert two["n_gpus"] == 2 and two["config"]["finite"]
+    assert two["config"]["parallelism"] == f"sp2-{mode}"
+    assert "cpu_baseline" not in two
+    # same seeds, same steps: the sharded run reproduces the single-rank latent (bf16 re-association only)
+    assert abs(two["config"]["x_abs_mean"] - one["config"]["x_abs_mean"]) < 2e-3 * one["config"]["x_abs_mean"]
