@@ -460,6 +460,171 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmParams p) {
 static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 tile + LDS-DMA; 258: 256 tile + DMA ring
 int scail_gemm_tune(int v) { g_gemm_tile = v; return 0; }
 
+
+// ------------------------------------------------------------------------------------------------
+// Quadrant-phase kernel ("q8", gemm_tile 261).  256 x 256 x 64 tile, 8 waves (2 x 4), wave tile 128(m) x 64(n)
+// worked as FOUR 64 x 32 quadrants per k-tile, each = 8 MFMA 32x32x16 (256 matrix-pipe cycles):
+//     phase 0: read a0 block 1 (4 x b128) + b0 (4)       MFMA a0.b0     a0/a1 = rows 0-63 / 64-127 of the wave's 128
+//     phase 1: read b1 (4)                               MFMA a0.b1     b0/b1 = cols 0-31 / 32-63 of the wave's 64
+//     phase 2: read a1 (8)                               MFMA a1.b1     (block = 32 rows)
+//     phase 3: read a0 block 0 of the NEXT k-tile (4)    MFMA a1.b0
+// The two wave rows (waves 0-3 / 4-7; wave w and w+4 share a SIMD) run one barrier interval apart, so in every
+// interval one wave per SIMD is in its MFMA section while its partner reads fragments and issues LDS-DMA.
+// Operands are staged as four 16 KB "streams" per k-tile, each the rows one phase reads
+//     Af = a0 rows of both wave rows, As = a1 rows, Bf = b0 rows of the four wave columns, Bs = b1 rows
+// (2 DMA pieces per wave per stream: buffer_load_dwordx4 ... lds, tile origin in the descriptor, 32-bit lane
+// offsets), double-buffered per stream.  One stream is issued per phase:
+//     phase 0 of tile T: Bs(T+1)   phase 1: As(T+1)   phase 2: Af(T+2)   phase 3: Bf(T+2)
+// WAR: each is issued >= 2 phases after the last read of the slot it overwrites (the reads were retired by an
+// lgkmcnt(0) and a barrier lies between).  RAW: every phase ends its read section with s_waitcnt vmcnt(8) (4
+// streams in flight), so the stream issued in phase g-4 is retired by every wave in phase g and first read in
+// phase g+1 or later -- at least one barrier after the slowest wave's wait.  A load has ~4 phases to land.
+// Measured (M = 97 664, N = 15 360, K = 5120): 1.21 PFLOP/s vs 1.09 for the lock-step DMA kernel; ablations:
+// no DMA 1.50, no fragment reads 1.30, neither 1.64 (barrier-paced MFMA only), all-L2-hit operands 1.27,
+// no vmcnt waits +1 %, 4-byte instead of 16-byte DMA pieces +-0 (the DMA cost is per instruction, ~80 issue
+// cycles, not per byte).  global_load_lds instead of the buffer form: -5 %; DMA issued inside the MFMA section:
+// -4 %; DMA before the fragment reads: -1.5 %.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int ABL = 0>   // ABL (microbench only, wrong results): 1 no DMA in the loop, 2 no fragment reads
+                                  // in the loop, 4 no vmcnt waits, 8 every block loads tile (0,0)
+__global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256, WN = 4;
+    constexpr int WTM = 128, WTN = 64, MI = 4, NI = 2;
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Xs = smem;                    // [2][BM][BK]
+    u16* Ws = smem + 2 * BM * BK;      // [2][BN][BK]
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nb = tiles_m * tiles_n;
+    int wg;
+    {
+        const int id = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = id & 7, loc = id >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int in_group = GROUP_M * tiles_n;
+    const int gid = wg / in_group;
+    const int first_m = gid * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int pid_m = first_m + (wg % in_group) % gsz;
+    const int pid_n = (wg % in_group) / gsz;
+    const int m0 = pid_m * BM, n0 = pid_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, g = lane >> 5;
+
+    // DMA: piece j = 2 wave + i of a stream = its rows r' = 8j .. 8j+7 (lane -> row 8j + (l >> 3), chunk l & 7);
+    // stream row r' -> tile row:  A streams (r' >> 6) * 128 + (r' & 63) [+ 64 for As],  B (r' >> 5) * 64 + (r' & 31) [+ 32]
+    // lane byte offsets from the tile origin (rows past M / N clamp to the last row; their outputs are not stored)
+    const int d_row = lane >> 3, d_c = lane & 7;
+    const u16* xt = p.x + (int64_t)((ABL & 8) ? 0 : m0) * p.lda;     // tile origins (uniform)
+    const u16* wt = p.w + (int64_t)((ABL & 8) ? 0 : n0) * p.K;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(xt), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16*>(wt), 0, 0x7FFFFFFF, 0x00020000);
+#define Q8_ROWS(i_)                                                                                         \
+    const int ja##i_ = 8 * (2 * wave + i_);                                                                 \
+    const int rbAf##i_ = (ja##i_ >> 6) * 128 + (ja##i_ & 63), rbBf##i_ = (ja##i_ >> 5) * 64 + (ja##i_ & 31);  \
+    const int oAf##i_ = 2 * ((min(m0 + rbAf##i_ + d_row, p.M - 1) - m0) * (int)p.lda + ((d_c ^ (((rbAf##i_ + d_row) >> 1) & 7)) << 3));            \
+    const int oAs##i_ = 2 * ((min(m0 + rbAf##i_ + 64 + d_row, p.M - 1) - m0) * (int)p.lda + ((d_c ^ (((rbAf##i_ + 64 + d_row) >> 1) & 7)) << 3));  \
+    const int oBf##i_ = 2 * ((min(n0 + rbBf##i_ + d_row, p.N - 1) - n0) * p.K + ((d_c ^ (((rbBf##i_ + d_row) >> 1) & 7)) << 3));                   \
+    const int oBs##i_ = 2 * ((min(n0 + rbBf##i_ + 32 + d_row, p.N - 1) - n0) * p.K + ((d_c ^ (((rbBf##i_ + 32 + d_row) >> 1) & 7)) << 3));
+    Q8_ROWS(0) Q8_ROWS(1)
+#define Q8_DMA(rs_, voff_, soff_, dst_)                                                             \
+    if (ABL & 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(dst_), 4, voff_, soff_, 0, 0);  \
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(dst_), 16, voff_, soff_, 0, 0);
+#define Q8_ISSUE_A(tile_, radd_, o0_, o1_)                                                          \
+    {                                                                                               \
+        u16* d_ = Xs + ((tile_) & 1) * BM * BK;                                                     \
+        Q8_DMA(rsA, o0_, (tile_) * (BK * 2), d_ + (rbAf0 + radd_) * BK)                             \
+        Q8_DMA(rsA, o1_, (tile_) * (BK * 2), d_ + (rbAf1 + radd_) * BK)                             \
+    }
+#define Q8_ISSUE_B(tile_, radd_, o0_, o1_)                                                          \
+    {                                                                                               \
+        u16* d_ = Ws + ((tile_) & 1) * BN * BK;                                                     \
+        Q8_DMA(rsB, o0_, (tile_) * (BK * 2), d_ + (rbBf0 + radd_) * BK)                             \
+        Q8_DMA(rsB, o1_, (tile_) * (BK * 2), d_ + (rbBf1 + radd_) * BK)                             \
+    }
+#define Q8_VM8 __builtin_amdgcn_s_waitcnt(0x0F78);    // vmcnt(8)
+#define Q8_VM0 __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0)
+#define Q8_LGKM0 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#define Q8_SB __builtin_amdgcn_sched_barrier(0);
+
+    // fragment reads: lane -> row l31 of a 32-row block, 16-byte chunk (2 ks + g) ^ ((row >> 1) & 7)
+    const int e0 = ((g ^ ((l31 >> 1) & 7)) << 3);
+    const u16* xs0 = Xs + (wm * WTM + l31) * BK;
+    const u16* ws0 = Ws + (wn * WTN + l31) * BK;
+
+    f32x16 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    bf16x8 fa[2][4], fn[4], fb0[4], fb1[4];     // fn = block 0 of a0, read one phase ahead of its tile
+#define Q8_READ_BLK(dst_, buf_, blk_)                                                               \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                             \
+        dst_[ks_] = *reinterpret_cast<const bf16x8*>(xs0 + ((buf_) * BM + (blk_) * 32) * BK + (e0 ^ (ks_ << 4)));
+#define Q8_READ_B(dst_, buf_, half_)                                                                \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                             \
+        dst_[ks_] = *reinterpret_cast<const bf16x8*>(ws0 + ((buf_) * BN + (half_) * 32) * BK + (e0 ^ (ks_ << 4)));
+    // Issue priority goes to the wave in its read/DMA section (s_setprio 1 outside the MFMA section): the MFMA wave
+    // needs one issue slot per 32 cycles, the loader is issue-bound (+2 % measured; ABL bit 32 = the other way round).
+    // MFMAs are pure register ops: nothing orders them against s_barrier / s_setprio for the compiler, and hipcc does
+    // sink them into the next phase's read section.  The empty volatile asms tie the operands (after the barrier)
+    // and the accumulators (before the next barrier) to the instruction stream.
+#define Q8_PIN4(f_) asm volatile("" : "+v"(f_[0]), "+v"(f_[1]), "+v"(f_[2]), "+v"(f_[3]));
+#define Q8_MFMA(ni_, mi0_, fa0_, fa1_, fb_)                                                         \
+    Q8_PIN4(fa0_) Q8_PIN4(fa1_) Q8_PIN4(fb_)                                                        \
+    __builtin_amdgcn_s_setprio((ABL & 32) ? 1 : 0);                                                 \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                           \
+        acc[ni_][mi0_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[ks_], fa0_[ks_], acc[ni_][mi0_], 0, 0, 0);             \
+        acc[ni_][mi0_ + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb_[ks_], fa1_[ks_], acc[ni_][mi0_ + 1], 0, 0, 0);     \
+    }                                                                                               \
+    __builtin_amdgcn_s_setprio((ABL & 32) ? 0 : 1);                                                 \
+    asm volatile("" : "+v"(acc[ni_][mi0_]), "+v"(acc[ni_][mi0_ + 1]));
+    // one phase: fragment reads, this phase's stream issue + counted wait, barrier, MFMA quadrant, barrier
+#define Q8_PHASE(READS_, COND_, ISSUE_, ni_, mi0_, fa0_, fa1_, fb_)                                 \
+    if (!(ABL & 2) || t == 0) { READS_ }                                                            \
+    if (!(ABL & 1) && (COND_)) { ISSUE_ if (!(ABL & 4)) { Q8_VM8 } } else { Q8_VM0 }                \
+    Q8_SB __builtin_amdgcn_s_barrier(); Q8_LGKM0 Q8_SB                                              \
+    Q8_MFMA(ni_, mi0_, fa0_, fa1_, fb_)                                                             \
+    Q8_SB __builtin_amdgcn_s_barrier(); Q8_SB
+#define Q8_TILE(C1_, C2_)                                                                           \
+    {                                                                                               \
+        const int buf = t & 1;                                                                      \
+        Q8_PHASE(Q8_READ_BLK(fa[1], buf, 1) Q8_READ_B(fb0, buf, 0), C1_, Q8_ISSUE_B(t + 1, 32, oBs0, oBs1), 0, 0, fn, fa[1], fb0)  \
+        Q8_PHASE(Q8_READ_B(fb1, buf, 1), C1_, Q8_ISSUE_A(t + 1, 64, oAs0, oAs1), 1, 0, fn, fa[1], fb1)                            \
+        Q8_PHASE(Q8_READ_BLK(fa[0], buf, 2) Q8_READ_BLK(fa[1], buf, 3), C2_, Q8_ISSUE_A(t + 2, 0, oAf0, oAf1), 1, 2, fa[0], fa[1], fb1) \
+        Q8_PHASE(Q8_READ_BLK(fn, buf ^ 1, 0), C2_, Q8_ISSUE_B(t + 2, 0, oBf0, oBf1), 0, 2, fa[0], fa[1], fb0)                      \
+    }
+
+    const int nk = p.K / BK;
+    // prologue: all four streams of tile 0, Af and Bf of tile 1
+    Q8_ISSUE_A(0, 0, oAf0, oAf1)
+    Q8_ISSUE_B(0, 0, oBf0, oBf1)
+    Q8_ISSUE_B(0, 32, oBs0, oBs1)
+    Q8_ISSUE_A(0, 64, oAs0, oAs1)
+    if (nk > 1) {
+        Q8_ISSUE_A(1, 0, oAf0, oAf1)
+        Q8_ISSUE_B(1, 0, oBf0, oBf1)
+        Q8_VM8                      // Af(0), Bf(0) landed (this wave's pieces)
+    } else {
+        Q8_VM0
+    }
+    __builtin_amdgcn_s_barrier();
+    Q8_READ_BLK(fn, 0, 0)
+    if (wm == 1) __builtin_amdgcn_s_barrier();      // wave row 1 runs one interval behind row 0
+
+    int t = 0;
+    for (; t + 2 < nk; ++t) Q8_TILE(true, true)
+    for (; t < nk; ++t) Q8_TILE(t + 1 < nk, false)
+    if (wm == 0) __builtin_amdgcn_s_barrier();      // re-align the two wave rows
+    gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, bool DMA, int ABL = 0>
 static int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * (DMA ? BK : LDT) * 2;
@@ -514,8 +679,36 @@ static int launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
     return scail_check_launch("gemm_bf16");
 }
 
+template <int EPI, int ABL = 0>
+static int launch_gemm_q8(const GemmParams& p, hipStream_t stream) {
+    constexpr int lds = 2 * (256 + 256) * BK * 2;   // 128 KB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_q8_kernel<EPI, ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("scail_gemm_bf16: hipFuncSetAttribute: ") + hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    hipLaunchKernelGGL((gemm_bf16_q8_kernel<EPI, ABL>), dim3((unsigned)tiles), dim3(512), lds, stream, p);
+    return scail_check_launch("gemm_bf16");
+}
+
 template <int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+    if (g_gemm_tile == 261) return launch_gemm_q8<EPI>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1101) return launch_gemm_q8<0, 1>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1102) return launch_gemm_q8<0, 2>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1103) return launch_gemm_q8<0, 3>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1104) return launch_gemm_q8<0, 4>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1108) return launch_gemm_q8<0, 8>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1112) return launch_gemm_q8<0, 12>(p, stream);
+    if (g_gemm_tile == 262) return launch_gemm_q8<EPI, 32>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1116) return launch_gemm_q8<0, 16>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1124) return launch_gemm_q8<0, 24>(p, stream);
     if (g_gemm_tile == 259) return launch_gemm_pp<EPI>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1001) return launch_gemm_t<256, 256, 2, 4, 0, true, 1>(p, stream);   // ablations
     if (EPI == 0 && g_gemm_tile == 1002) return launch_gemm_t<256, 256, 2, 4, 0, true, 2>(p, stream);
@@ -523,12 +716,15 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (EPI == 0 && g_gemm_tile == 1008) return launch_gemm_t<256, 256, 2, 4, EPI, true, 8>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1024) return launch_gemm_t<256, 256, 2, 4, EPI, true, 24>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1003) return launch_gemm_t<256, 256, 2, 4, 0, true, 3>(p, stream);
-    // measured at M = 97 664 (profiles/r01_pmc.md): 128 tile 820, 256 tile 1000, 256 + LDS-DMA 1090 (default
-    // for the big per-token GEMMs), 256 + DMA ring of half k-tiles with counted vmcnt 1025 TFLOP/s
+    // measured at M = 97 664 (profiles/r01_pmc.md): 128 tile 820, 256 tile 1000, 256 + LDS-DMA 1090, 256 + DMA ring
+    // of half k-tiles with counted vmcnt 1025, ping-pong 1000, quadrant-phase q8 1240-1290 TFLOP/s (default for the
+    // big per-token GEMMs; the vendor library's assembly kernel reaches 1500 on the same shapes)
     if (g_gemm_tile == 258) return launch_gemm_ring<EPI>(p, stream);
     if (g_gemm_tile == 256) return launch_gemm_t<256, 256, 2, 4, EPI, false>(p, stream);
-    const bool big = g_gemm_tile == 257 || (g_gemm_tile == 0 && p.M >= 2048 && p.N >= 1024);
-    if (big) return launch_gemm_t<256, 256, 2, 4, EPI, true>(p, stream);
+    const bool big = g_gemm_tile == 0 && p.M >= 2048 && p.N >= 1024;
+    // q8 addresses a tile through a 2 GB buffer descriptor with 32-bit lane offsets
+    if (big && 512 * p.lda + 2 * (int64_t)p.K < (1ll << 31) && 514 * (int64_t)p.K < (1ll << 31)) return launch_gemm_q8<EPI>(p, stream);
+    if (big || g_gemm_tile == 257) return launch_gemm_t<256, 256, 2, 4, EPI, true>(p, stream);
     return launch_gemm_t<128, 128, 2, 2, EPI, false>(p, stream);
 }
 

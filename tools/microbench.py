@@ -28,6 +28,7 @@ def timeit(fn, iters, warmup=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["attn", "gemm", "rows"])
+    ap.add_argument("--vendor", action="store_true", help="also time torch's library GEMM (yardstick)")
     ap.add_argument("--L", type=int, default=48832)
     ap.add_argument("--Lk", type=int, default=None)
     ap.add_argument("--heads", type=int, default=8)
@@ -73,6 +74,10 @@ def main():
         if a.epi == 3:
             kw = dict(resid=y, gate=torch.randn(2, a.N, device=dev), rows_per_batch=a.M // 2)
         fl = 2.0 * a.M * a.N * a.K
+        if a.vendor:      # yardstick only (never on the product path): the vendor library through torch
+            bb = b.to(torch.bfloat16)
+            med, best = timeit(lambda: torch.nn.functional.linear(x, w, bb), a.iters)
+            print(json.dumps(dict(case="gemm", tile="vendor(torch F.linear)", M=a.M, N=a.N, K=a.K, ms=med, ms_min=best, tflops=fl / med / 1e9)))
         for rnd_ in range(2):
             for var in [int(z) for z in a.variants.split(",")]:
                 lib.tune_set("gemm_tile", var)
