@@ -216,6 +216,11 @@ int scail_row_affine(const scail_bf16* x, scail_bf16* y, const float* rowscale, 
  *        bit 3: software-pipelined kernel); "gemm_tile" (0 auto, 128, 256). */
 int scail_tune_set(const char* knob, int value);
 
+/* Measurement aid: out2[0] = summed workgroup lifetimes in s_memtime ticks (shader cycles), out2[1] = workgroup count
+ * of the launches made with the clock-stamped microbench variants (gemm_tile 1300-1364, attn_variant bit 20) since the
+ * last reset. */
+int scail_debug_cycles(unsigned long long* out2, int reset);
+
 /* fp32 -> bf16 (round to nearest even) and back; plumbing for boundary tensors. */
 int scail_f32_to_bf16(const float* x, scail_bf16* y, int64_t n, void* stream);
 int scail_bf16_to_f32(const scail_bf16* x, float* y, int64_t n, void* stream);

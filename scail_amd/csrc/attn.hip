@@ -40,7 +40,22 @@ struct AttnParams {
     int heads, Lq, Lk, Lkp, n_seg;
     float sl2;  // scale * log2(e)
     int accumulate;
+    int probe;  // measurement aid: add this workgroup's lifetime (s_memtime ticks) to g_attn_clk
 };
+
+__device__ unsigned long long g_attn_clk[2] = {0ull, 0ull};
+int scail_attn_clk(unsigned long long* out2, int reset) {
+    if (out2 != nullptr) {
+        unsigned long long v[2];
+        if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_attn_clk), 16) != hipSuccess) return 2;
+        out2[0] += v[0]; out2[1] += v[1];
+    }
+    if (reset) {
+        const unsigned long long z[2] = {0ull, 0ull};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_clk), z, 16) != hipSuccess) return 2;
+    }
+    return 0;
+}
 
 // VARIANT bit 0: s_setprio(1) around the MFMA clusters; bit 1: skip the O rescale when no row's running
 // max moved in this tile (exact: alpha == 1 for every lane).
@@ -67,6 +82,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(AttnParams p) {
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
     const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+    const unsigned long long clk0 = p.probe ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16 ks + 8 g .. +7] ----
     bf16x8 qf[HD / 16];
@@ -292,6 +308,10 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(AttnParams p) {
             }
         }
     }
+    if (p.probe && tid == 0) {
+        atomicAdd(&g_attn_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);
+        atomicAdd(&g_attn_clk[1], 1ull);
+    }
 }
 
 
@@ -455,6 +475,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
     const int q0 = blockIdx.x * QBLK + wave * 32;
+    const unsigned long long clk0 = p.probe ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const u16* qs_ = Qs + (wave * 32 + ql) * K_LD + g * 8;
     {
@@ -536,6 +557,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
             }
         }
     }
+    if (p.probe && tid == 0) {
+        atomicAdd(&g_attn_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);
+        atomicAdd(&g_attn_clk[1], 1ull);
+    }
 }
 
 // Kernel selection (A/B measured on one box, B=2 x 8 heads x 48 832 keys, random data; lock-step + rescale
@@ -592,9 +617,10 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     p.heads = (int)heads; p.Lq = (int)Lq; p.Lk = (int)Lk; p.Lkp = (int)Lkp; p.n_seg = (int)n_seg;
     p.sl2 = scale * 1.4426950408889634f;
     p.accumulate = accumulate;
+    p.probe = (g_attn_variant >> 20) & 1;
     dim3 grid((unsigned)((Lq + QBLK - 1) / QBLK), (unsigned)heads, (unsigned)n_batch);
     if (g_attn_variant & 8) {
-        const int sub = g_attn_variant >> 12;     // A/B of the interleave density
+        const int sub = (g_attn_variant >> 12) & 15;     // A/B of the interleave density
         static bool swp_attr = false;
         if (!swp_attr) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<5, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
@@ -619,9 +645,9 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         hipLaunchKernelGGL((flash_attn_kernel<2, 4>), grid4, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
         return scail_check_launch("flash_attn");
     }
-    if (g_attn_variant == 18) { hipLaunchKernelGGL((flash_attn_kernel<18, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
-    if (g_attn_variant == 34) { hipLaunchKernelGGL((flash_attn_kernel<34, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
-    if (g_attn_variant == 50) { hipLaunchKernelGGL((flash_attn_kernel<50, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
+    if ((g_attn_variant & 0xFFFFF) == 18) { hipLaunchKernelGGL((flash_attn_kernel<18, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
+    if ((g_attn_variant & 0xFFFFF) == 34) { hipLaunchKernelGGL((flash_attn_kernel<34, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
+    if ((g_attn_variant & 0xFFFFF) == 50) { hipLaunchKernelGGL((flash_attn_kernel<50, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
     switch (g_attn_variant & 3) {
         case 0: hipLaunchKernelGGL((flash_attn_kernel<0, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
         case 1: hipLaunchKernelGGL((flash_attn_kernel<1, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
     constexpr int NT = 64 * WM * WN;      // threads
     constexpr int LDX = DMA ? BK : LDT;   // LDS row length (elements)
     constexpr int RS = NT / 8;            // tile rows covered by one staging pass (8 x 16 B chunks per row)
-    static_assert(BM / RS == 4 && BN / RS == 4, "staging code below is written for 4 passes per operand");
+    static_assert(DMA || (BM / RS == 4 && BN / RS == 4), "the register staging code below is written for 4 passes per operand");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -461,6 +461,31 @@ static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 t
 int scail_gemm_tune(int v) { g_gemm_tile = v; return 0; }
 
 
+// Measurement aid (tools/microbench.py): summed lifetime of the q8 workgroups in s_memtime ticks (= shader clock
+// cycles; the counters of the 8 XCDs are not synchronised, so only per-workgroup differences are meaningful) and
+// their count: sum / 256 CUs / wall time = the clock the chip sustains under a given variant.  Only kernels
+// instantiated with ABL bit 128 write it.
+__device__ unsigned long long g_q8_clk[2] = {0ull, 0ull};
+int scail_attn_clk(unsigned long long* out2, int reset);   // attn.hip: same counters for the attention kernel
+extern "C" int scail_debug_cycles(unsigned long long* out2, int reset) {
+    if (out2 != nullptr && hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_q8_clk), 16) != hipSuccess) {
+        scail_set_error("scail_debug_cycles: hipMemcpyFromSymbol failed");
+        return 2;
+    }
+    if (scail_attn_clk(out2, reset) != 0) {
+        scail_set_error("scail_debug_cycles: attention counters");
+        return 2;
+    }
+    if (reset) {
+        const unsigned long long init[2] = {0ull, 0ull};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_q8_clk), init, 16) != hipSuccess) {
+            scail_set_error("scail_debug_cycles: hipMemcpyToSymbol failed");
+            return 2;
+        }
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Quadrant-phase kernel ("q8", gemm_tile 261).  256 x 256 x 64 tile, 8 waves (2 x 4), wave tile 128(m) x 64(n)
 // worked as FOUR 64 x 32 quadrants per k-tile, each = 8 MFMA 32x32x16 (256 matrix-pipe cycles):
@@ -514,6 +539,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, g = lane >> 5;
+    const unsigned long long clk0 = (ABL & 128) ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // DMA: piece j = 2 wave + i of a stream = its rows r' = 8j .. 8j+7 (lane -> row 8j + (l >> 3), chunk l & 7);
     // stream row r' -> tile row:  A streams (r' >> 6) * 128 + (r' & 63) [+ 64 for As],  B (r' >> 5) * 64 + (r' & 31) [+ 32]
@@ -531,8 +557,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmParams p) {
     const int oBf##i_ = 2 * ((min(n0 + rbBf##i_ + d_row, p.N - 1) - n0) * p.K + ((d_c ^ (((rbBf##i_ + d_row) >> 1) & 7)) << 3));                   \
     const int oBs##i_ = 2 * ((min(n0 + rbBf##i_ + 32 + d_row, p.N - 1) - n0) * p.K + ((d_c ^ (((rbBf##i_ + 32 + d_row) >> 1) & 7)) << 3));
     Q8_ROWS(0) Q8_ROWS(1)
+    // ABL 256 (timing only): every DMA piece reads 1 KB of CONTIGUOUS memory (as if the operands were stored
+    // tile-major) instead of 8 rows x 128 B, 512: only the W pieces do
+#define Q8_CONTIG(o_, j_, str_) ((ABL & (str_)) ? (int)(lane * 16 + (j_) * 1024) : (o_))
+    const int cAf0 = Q8_CONTIG(oAf0, 2 * wave, 256), cAf1 = Q8_CONTIG(oAf1, 2 * wave + 1, 256);
+    const int cAs0 = Q8_CONTIG(oAs0, 16 + 2 * wave, 256), cAs1 = Q8_CONTIG(oAs1, 17 + 2 * wave, 256);
+    const int cBf0 = Q8_CONTIG(oBf0, 2 * wave, 256 | 512), cBf1 = Q8_CONTIG(oBf1, 2 * wave + 1, 256 | 512);
+    const int cBs0 = Q8_CONTIG(oBs0, 16 + 2 * wave, 256 | 512), cBs1 = Q8_CONTIG(oBs1, 17 + 2 * wave, 256 | 512);
+    typedef unsigned int q8_u32x4 __attribute__((ext_vector_type(4)));
+    q8_u32x4 dmy0 = {0u, 0u, 0u, 0u};      // ABL 64: loads to (dead) VGPRs instead of LDS-DMA, to price the DMA issue itself
 #define Q8_DMA(rs_, voff_, soff_, dst_)                                                             \
-    if (ABL & 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(dst_), 4, voff_, soff_, 0, 0);  \
+    if (ABL & 64) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dmy0) : "v"(voff_), "s"(rs_), "s"(soff_));  \
+    else if (ABL & 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(dst_), 4, voff_, soff_, 0, 0);  \
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (__attribute__((address_space(3))) void*)(dst_), 16, voff_, soff_, 0, 0);
 #define Q8_ISSUE_A(tile_, radd_, o0_, o1_)                                                          \
     {                                                                                               \
@@ -595,21 +631,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmParams p) {
 #define Q8_TILE(C1_, C2_)                                                                           \
     {                                                                                               \
         const int buf = t & 1;                                                                      \
-        Q8_PHASE(Q8_READ_BLK(fa[1], buf, 1) Q8_READ_B(fb0, buf, 0), C1_, Q8_ISSUE_B(t + 1, 32, oBs0, oBs1), 0, 0, fn, fa[1], fb0)  \
-        Q8_PHASE(Q8_READ_B(fb1, buf, 1), C1_, Q8_ISSUE_A(t + 1, 64, oAs0, oAs1), 1, 0, fn, fa[1], fb1)                            \
-        Q8_PHASE(Q8_READ_BLK(fa[0], buf, 2) Q8_READ_BLK(fa[1], buf, 3), C2_, Q8_ISSUE_A(t + 2, 0, oAf0, oAf1), 1, 2, fa[0], fa[1], fb1) \
-        Q8_PHASE(Q8_READ_BLK(fn, buf ^ 1, 0), C2_, Q8_ISSUE_B(t + 2, 0, oBf0, oBf1), 0, 2, fa[0], fa[1], fb0)                      \
+        Q8_PHASE(Q8_READ_BLK(fa[1], buf, 1) Q8_READ_B(fb0, buf, 0), C1_, Q8_ISSUE_B(t + 1, 32, cBs0, cBs1), 0, 0, fn, fa[1], fb0)  \
+        Q8_PHASE(Q8_READ_B(fb1, buf, 1), C1_, Q8_ISSUE_A(t + 1, 64, cAs0, cAs1), 1, 0, fn, fa[1], fb1)                            \
+        Q8_PHASE(Q8_READ_BLK(fa[0], buf, 2) Q8_READ_BLK(fa[1], buf, 3), C2_, Q8_ISSUE_A(t + 2, 0, cAf0, cAf1), 1, 2, fa[0], fa[1], fb1) \
+        Q8_PHASE(Q8_READ_BLK(fn, buf ^ 1, 0), C2_, Q8_ISSUE_B(t + 2, 0, cBf0, cBf1), 0, 2, fa[0], fa[1], fb0)                      \
     }
 
     const int nk = p.K / BK;
     // prologue: all four streams of tile 0, Af and Bf of tile 1
-    Q8_ISSUE_A(0, 0, oAf0, oAf1)
-    Q8_ISSUE_B(0, 0, oBf0, oBf1)
-    Q8_ISSUE_B(0, 32, oBs0, oBs1)
-    Q8_ISSUE_A(0, 64, oAs0, oAs1)
+    Q8_ISSUE_A(0, 0, cAf0, cAf1)
+    Q8_ISSUE_B(0, 0, cBf0, cBf1)
+    Q8_ISSUE_B(0, 32, cBs0, cBs1)
+    Q8_ISSUE_A(0, 64, cAs0, cAs1)
     if (nk > 1) {
-        Q8_ISSUE_A(1, 0, oAf0, oAf1)
-        Q8_ISSUE_B(1, 0, oBf0, oBf1)
+        Q8_ISSUE_A(1, 0, cAf0, cAf1)
+        Q8_ISSUE_B(1, 0, cBf0, cBf1)
         Q8_VM8                      // Af(0), Bf(0) landed (this wave's pieces)
     } else {
         Q8_VM0
@@ -622,6 +658,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmParams p) {
     for (; t + 2 < nk; ++t) Q8_TILE(true, true)
     for (; t < nk; ++t) Q8_TILE(t + 1 < nk, false)
     if (wm == 0) __builtin_amdgcn_s_barrier();      // re-align the two wave rows
+    if (ABL & 64) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" :: "v"(dmy0)); }
+    if ((ABL & 128) && tid == 0) {
+        atomicAdd(&g_q8_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);
+        atomicAdd(&g_q8_clk[1], 1ull);
+    }
     gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
 }
 
@@ -700,6 +741,7 @@ static int launch_gemm_q8(const GemmParams& p, hipStream_t stream) {
 template <int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (g_gemm_tile == 261) return launch_gemm_q8<EPI>(p, stream);
+    if (g_gemm_tile == 266) return launch_gemm_t<256, 256, 2, 2, EPI, true>(p, stream);   // 4 waves, 128 x 128 per wave (AGPR accumulators)
     if (EPI == 0 && g_gemm_tile == 1101) return launch_gemm_q8<0, 1>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1102) return launch_gemm_q8<0, 2>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1103) return launch_gemm_q8<0, 3>(p, stream);
@@ -707,6 +749,14 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (EPI == 0 && g_gemm_tile == 1108) return launch_gemm_q8<0, 8>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1112) return launch_gemm_q8<0, 12>(p, stream);
     if (g_gemm_tile == 262) return launch_gemm_q8<EPI, 32>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1300) return launch_gemm_q8<0, 128>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1301) return launch_gemm_q8<0, 129>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1302) return launch_gemm_q8<0, 130>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1303) return launch_gemm_q8<0, 131>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1364) return launch_gemm_q8<0, 192>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1256) return launch_gemm_q8<0, 256>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1512) return launch_gemm_q8<0, 512>(p, stream);
+    if (EPI == 0 && g_gemm_tile == 1164) return launch_gemm_q8<0, 64>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1116) return launch_gemm_q8<0, 16>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1124) return launch_gemm_q8<0, 24>(p, stream);
     if (g_gemm_tile == 259) return launch_gemm_pp<EPI>(p, stream);

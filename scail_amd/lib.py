@@ -39,6 +39,7 @@ SIGNATURES = {
     "scail_mul_bf16": [_p, _p, _p, _i64, _p],
     "scail_row_affine": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "scail_tune_set": [C.c_char_p, _i],
+    "scail_debug_cycles": [C.c_void_p, _i],
     "scail_f32_to_bf16": [_p, _p, _i64, _p],
     "scail_bf16_to_f32": [_p, _p, _i64, _p],
 }

@@ -64,8 +64,19 @@ def main():
                 if ref is None:
                     ref = out.clone()
                 diff = float((out.float() - ref.float()).abs().max())
-                print(json.dumps(dict(case="attn", variant=var, B=a.B, heads=a.heads, Lq=a.L, Lk=Lk, ms=med, ms_min=best,
-                                      tflops=fl / med / 1e9, maxdiff_vs_first=diff)))
+                rec = dict(case="attn", variant=var, B=a.B, heads=a.heads, Lq=a.L, Lk=Lk, ms=med, ms_min=best,
+                           tflops=fl / med / 1e9, maxdiff_vs_first=diff)
+                if var & (1 << 20):         # clock-stamped: one more launch, workgroup lifetimes in shader cycles
+                    import ctypes
+                    buf = (ctypes.c_ulonglong * 2)()
+                    lib.call("scail_debug_cycles", None, 1)
+                    ops.flash_attn(q, k, vt, out=out)
+                    torch.cuda.synchronize()
+                    lib.call("scail_debug_cycles", ctypes.cast(buf, ctypes.c_void_p), 0)
+                    ntile = (Lk + 63) // 64
+                    rec.update(wg=int(buf[1]), cycles_per_wg=buf[0] / max(buf[1], 1), cycles_per_tile=buf[0] / max(buf[1], 1) / ntile,
+                               ghz=buf[0] / 256.0 / (med * 1e6))
+                print(json.dumps(rec))
     elif a.what == "gemm":
         x, w = rn(a.M, a.K), rn(a.N, a.K) * 0.02
         b = torch.randn(a.N, device=dev)
@@ -82,7 +93,17 @@ def main():
             for var in [int(z) for z in a.variants.split(",")]:
                 lib.tune_set("gemm_tile", var)
                 med, best = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=a.epi, **kw), a.iters)
-                print(json.dumps(dict(case="gemm", tile=var, M=a.M, N=a.N, K=a.K, epi=a.epi, ms=med, ms_min=best, tflops=fl / med / 1e9)))
+                rec = dict(case="gemm", tile=var, M=a.M, N=a.N, K=a.K, epi=a.epi, ms=med, ms_min=best, tflops=fl / med / 1e9)
+                if 1300 <= var < 1400:      # clock-stamped variants: one more launch, span in shader cycles vs wall time
+                    import ctypes
+                    buf = (ctypes.c_ulonglong * 2)()
+                    lib.call("scail_debug_cycles", None, 1)
+                    ops.gemm(x, w, b, out=y, epilogue=a.epi, **kw)
+                    torch.cuda.synchronize()
+                    lib.call("scail_debug_cycles", ctypes.cast(buf, ctypes.c_void_p), 0)
+                    cyc = buf[0] / 256.0            # busy cycles per CU (1 workgroup per CU at a time)
+                    rec.update(wg=int(buf[1]), cycles_per_wg=buf[0] / max(buf[1], 1), ghz=cyc / (med * 1e6))
+                print(json.dumps(rec))
     else:
         D = 5120
         x = rn(2, a.L, D)
