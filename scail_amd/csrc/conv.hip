@@ -13,11 +13,9 @@
 #include "common.h"
 
 #define CBM 128
-#define CBN 128
 #define CBK 64
 #define CLDT 72
 #define CONV_THREADS 256
-#define CONV_LDS_BYTES (2 * (CBM + CBN) * CLDT * 2)
 
 struct ConvParams {
     const u16* x;      // (Ti, Hi, Wi, Cin)
@@ -33,20 +31,24 @@ struct ConvParams {
     int64_t M;
 };
 
-template <int EPI>  // 0: bias, 3: bias + residual
+// BN_ / WM_ x WN_: 128 / 2 x 2 (wave tile 64 x 64) for wide layers, 96 / 4 x 1 (wave tile 32 x 96) for the
+// 96-channel decoder / encoder stages, 64 / 4 x 1 (32 x 64) for narrow outputs -- no MFMA work on padding columns.
+template <int EPI, int BN_, int WM_, int WN_>  // EPI 0: bias, 3: bias + residual
 __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) {
+    constexpr int WTM = CBM / WM_, WTN = BN_ / WN_, MI = WTM / 32, NI = WTN / 32, NWP = BN_ / 32;   // NWP: W staging passes
+    static_assert(WM_ * WN_ == 4 && MI >= 1 && NI >= 1 && BN_ % 32 == 0 && NWP <= 4, "tile shape");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* Xs = smem;
     u16* Ws = smem + 2 * CBM * CLDT;
 
-    const int tiles_n = (p.N + CBN - 1) / CBN;
+    const int tiles_n = (p.N + BN_ - 1) / BN_;
     const int64_t pid_m = blockIdx.x / tiles_n;     // n fastest: the (few) n-tiles of one voxel block
     const int pid_n = blockIdx.x % tiles_n;         // run back to back and share the gathered input in L2
     const int64_t m0 = pid_m * CBM;
-    const int n0 = pid_n * CBN;
+    const int n0 = pid_n * BN_;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN_, wn = wave % WN_;
     const int l31 = lane & 31, g = lane >> 5;
     const int srow = tid >> 3, kc = tid & 7;
     const int HWo = p.Ho * p.Wo;
@@ -66,41 +68,56 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
         wb##i_ = wo_ * p.sw - p.pw;                                                      \
     }                                                                                    \
     const u16* wptr##i_ = p.w + (int64_t)min(n0 + srow + 32 * i_, p.N - 1) * p.Kpad + kc * 8; \
-    uint4 xr##i_, wr##i_;
+    uint4 xr##i_, wr##i_ = make_uint4(0, 0, 0, 0);
     CROW(0) CROW(1) CROW(2) CROW(3)
-    const int khw = p.kh * p.kw;
     const int Hlim = p.ups ? 2 * p.Hi : p.Hi, Wlim = p.ups ? 2 * p.Wi : p.Wi;
 
+    // this thread's k chunk (k = k0 + 8 kc) as (tap = (dt, dh, dw), channel c): advanced by 64 per k-tile
+    // with carries instead of three integer divisions per tile
+    int c_cur, dt_cur, dh_cur, dw_cur;
+    {
+        const int k_ = kc * 8;
+        const int tap_ = k_ / p.Cin;
+        c_cur = k_ - tap_ * p.Cin;
+        const int khw = p.kh * p.kw;
+        dt_cur = tap_ / khw;
+        const int r2_ = tap_ - dt_cur * khw;
+        dh_cur = r2_ / p.kw;
+        dw_cur = r2_ - dh_cur * p.kw;
+    }
 #define CLOAD1(i_, k0_)                                                                          \
     {                                                                                            \
-        const int ti_ = tb##i_ + dt_, hi_ = hb##i_ + dh_, wi_ = wb##i_ + dw_;                     \
+        const int ti_ = tb##i_ + dt_cur, hi_ = hb##i_ + dh_cur, wi_ = wb##i_ + dw_cur;            \
         const bool v_ = kvalid_ && ti_ >= 0 && ti_ < p.Ti && hi_ >= 0 && hi_ < Hlim && wi_ >= 0 && wi_ < Wlim; \
         const int hs_ = p.ups ? (hi_ >> 1) : hi_, ws_ = p.ups ? (wi_ >> 1) : wi_;                 \
-        const int64_t off_ = (((int64_t)ti_ * p.Hi + hs_) * p.Wi + ws_) * p.Cin + c_;             \
+        const int64_t off_ = (((int64_t)ti_ * p.Hi + hs_) * p.Wi + ws_) * p.Cin + c_cur;          \
         xr##i_ = v_ ? *reinterpret_cast<const uint4*>(p.x + off_) : make_uint4(0, 0, 0, 0);       \
-        wr##i_ = *reinterpret_cast<const uint4*>(wptr##i_ + (k0_));                               \
+        if (i_ < NWP) wr##i_ = *reinterpret_cast<const uint4*>(wptr##i_ + (k0_));                 \
     }
+    // loads the chunk at the CURRENT tap state, then advances the state to the next k-tile
 #define CLOAD(k0_)                                                         \
     {                                                                      \
-        const int k_ = (k0_) + kc * 8;                                     \
-        const bool kvalid_ = k_ < p.Ktrue;                                 \
-        const int tap_ = kvalid_ ? k_ / p.Cin : 0;                         \
-        const int c_ = kvalid_ ? k_ - tap_ * p.Cin : 0;                    \
-        const int dt_ = tap_ / khw;                                        \
-        const int r2_ = tap_ - dt_ * khw;                                  \
-        const int dh_ = r2_ / p.kw, dw_ = r2_ - dh_ * p.kw;                \
+        const bool kvalid_ = (k0_) + kc * 8 < p.Ktrue;                     \
         CLOAD1(0, k0_) CLOAD1(1, k0_) CLOAD1(2, k0_) CLOAD1(3, k0_)        \
+        c_cur += CBK;                                                      \
+        while (c_cur >= p.Cin) {                                           \
+            c_cur -= p.Cin;                                                \
+            if (++dw_cur == p.kw) {                                        \
+                dw_cur = 0;                                                \
+                if (++dh_cur == p.kh) { dh_cur = 0; ++dt_cur; }            \
+            }                                                              \
+        }                                                                  \
     }
 #define CSTORE1(i_, buf_)                                                                         \
     *reinterpret_cast<uint4*>(Xs + ((buf_) * CBM + srow + 32 * i_) * CLDT + kc * 8) = xr##i_;      \
-    *reinterpret_cast<uint4*>(Ws + ((buf_) * CBN + srow + 32 * i_) * CLDT + kc * 8) = wr##i_;
+    if (i_ < NWP) *reinterpret_cast<uint4*>(Ws + ((buf_) * BN_ + srow + 32 * i_) * CLDT + kc * 8) = wr##i_;
 #define CSTORE(buf_) CSTORE1(0, buf_) CSTORE1(1, buf_) CSTORE1(2, buf_) CSTORE1(3, buf_)
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][MI];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < MI; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
@@ -111,20 +128,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) CLOAD((t + 1) * CBK)
-        const u16* xs = Xs + (cur * CBM + wm * 64 + l31) * CLDT + g * 8;
-        const u16* ws = Ws + (cur * CBN + wn * 64 + l31) * CLDT + g * 8;
+        const u16* xs = Xs + (cur * CBM + wm * WTM + l31) * CLDT + g * 8;
+        const u16* ws = Ws + (cur * BN_ + wn * WTN + l31) * CLDT + g * 8;
 #pragma unroll
         for (int ks = 0; ks < CBK / 16; ++ks) {
-            bf16x8 wf[2], xf[2];
+            bf16x8 wf[NI], xf[MI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * CLDT + ks * 16);
-                xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * CLDT + ks * 16);
-            }
+            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * CLDT + ks * 16);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * CLDT + ks * 16);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
         if (t + 1 < nk) { CSTORE(cur ^ 1) }
@@ -132,17 +148,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
     }
 
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int64_t m = m0 + wm * 64 + mi * 32 + l31;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int64_t m = m0 + wm * WTM + mi * 32 + l31;
         if (m >= p.M) continue;
         const int to = (int)(m / HWo);
         const int r = (int)(m - (int64_t)to * HWo);
         const int64_t vox = ((int64_t)(to * p.ot_mul + p.ot_off)) * HWo + r;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int n = n0 + wn * 64 + ni * 32 + 8 * rr + 4 * g;
+                const int n = n0 + wn * WTN + ni * 32 + 8 * rr + 4 * g;
                 if (n >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -313,24 +329,36 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
                       (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0,
                   "pointer alignment");
     if (p.M == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES);
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<3>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES);
-        if (e0 != hipSuccess || e1 != hipSuccess) {
-            scail_set_error("conv3d: hipFuncSetAttribute failed");
-            return 2;
-        }
-        attr_set = true;
+    // N tile: of 128 / 96 / 64 the one with the fewest padding columns (ties -> the wider tile)
+    int bn = 128;
+    {
+        int64_t best = (p.N + 127) / 128 * 128;
+        const int64_t c96 = (p.N + 95) / 96 * 96, c64 = (p.N + 63) / 64 * 64;
+        if (c96 < best) { best = c96; bn = 96; }
+        if (c64 < best) { best = c64; bn = 64; }
     }
-    const int64_t tiles = ((p.M + CBM - 1) / CBM) * ((p.N + CBN - 1) / CBN);
-    SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
-    if (resid != nullptr)
-        hipLaunchKernelGGL(conv_igemm_kernel<3>, dim3((unsigned)tiles), dim3(CONV_THREADS), CONV_LDS_BYTES, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv_igemm_kernel<0>, dim3((unsigned)tiles), dim3(CONV_THREADS), CONV_LDS_BYTES, (hipStream_t)stream, p);
+#define CONV_LAUNCH(EPI_, BN_, WM_, WN_)                                                                           \
+    {                                                                                                              \
+        constexpr int lds_ = 2 * (CBM + BN_) * CLDT * 2;                                                           \
+        static bool attr_ = false;                                                                                 \
+        if (!attr_) {                                                                                              \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<EPI_, BN_, WM_, WN_>),        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) {             \
+                scail_set_error("conv3d: hipFuncSetAttribute failed");                                             \
+                return 2;                                                                                          \
+            }                                                                                                      \
+            attr_ = true;                                                                                          \
+        }                                                                                                          \
+        const int64_t tiles = ((p.M + CBM - 1) / CBM) * ((p.N + BN_ - 1) / BN_);                                   \
+        SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");                                                      \
+        hipLaunchKernelGGL((conv_igemm_kernel<EPI_, BN_, WM_, WN_>), dim3((unsigned)tiles), dim3(CONV_THREADS), lds_, \
+                           (hipStream_t)stream, p);                                                                \
+    }
+    if (resid != nullptr) {
+        if (bn == 64) CONV_LAUNCH(3, 64, 4, 1) else if (bn == 96) CONV_LAUNCH(3, 96, 4, 1) else CONV_LAUNCH(3, 128, 2, 2)
+    } else {
+        if (bn == 64) CONV_LAUNCH(0, 64, 4, 1) else if (bn == 96) CONV_LAUNCH(0, 96, 4, 1) else CONV_LAUNCH(0, 128, 2, 2)
+    }
     return scail_check_launch("conv3d_cl");
 }
 
