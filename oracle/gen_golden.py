@@ -13,6 +13,7 @@ parity tests use are outputs of the reference's own classes on seeded inputs:
   rope_tiny.npz     Rotary3DPositionEmbeddingMixin.rotary/_ref/_pose on a random tensor
   sampler_tiny.npz  RFSampler + Denoiser(RFScaling) + VanillaCFG + OpenAIWrapper, 2 steps
   sigmas50.npz      50-step schedule (sampling.py:888-903)
+  sampler_long_tiny.npz  RFSamplerLong (sampling.py:986-1085): 6-frame latent, three overlapping 4-frame tiles, 2 steps
 """
 from __future__ import annotations
 
@@ -156,6 +157,48 @@ def gen_sampler(cfg, sd, net, inp):
     print("sampler_tiny: xT abs-mean", float(xT.abs().mean()), "sigmas", sig.tolist())
 
 
+def gen_sampler_long(cfg, sd, net, inp):
+    """RFSamplerLong (sampling.py:986-1085) on a 6-frame latent, two overlapping 4-frame tiles, 2 steps."""
+    ref = ref_shims.load_reference()
+    sampling, denoiser_mod, wrappers = ref["sampling"], ref["denoiser"], ref["wrappers"]
+    from sgm.modules.diffusionmodules.denoiser_scaling import RFScaling
+    from sgm.modules.diffusionmodules.denoiser_weighting import EpsWeighting
+
+    class _Den(denoiser_mod.Denoiser):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.weighting = EpsWeighting()
+            self.scaling = RFScaling()
+
+    den = _Den()
+    wrapped = wrappers.OpenAIWrapper(net, compile_model=False, dtype=torch.float32)
+    sampler = sampling.RFSamplerLong(
+        schedule_shift=False, hunyuan_schedule=True, shift_scale=5, mode="normal", num_steps=2, verbose=False,
+        device="cpu",
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.RFDiscretization",
+                               "params": {"reverse": False}},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 4}})
+    g = torch.Generator().manual_seed(33)
+    T, Tt = 6, 4
+    tiles = [[0, 1, 2, 3], [1, 2, 3, 4], [2, 3, 4, 5]]
+    H, W = inp["x"].shape[-2:]
+    x0 = torch.randn(1, T, 16, H, W, generator=g)
+    smpl_tiled = bf16r(torch.randn(1, len(tiles), Tt, 16, H // 2, W // 2, generator=g))
+    uc_ctx = torch.zeros_like(inp["ctx"][:1])
+    uc_ctx[:, :1] = bf16r(torch.randn(1, 1, inp["ctx"].shape[-1], generator=g))
+    c_ctx = inp["ctx"][1:2]
+    shared = dict(concat_images=torch.zeros(1, Tt, 16, H, W), ref_concat=inp["ref"], smpl_tiled=smpl_tiled,
+                  image_clip_features=inp["clip"])
+    c = dict(crossattn=c_ctx.clone(), **{k: v.clone() for k, v in shared.items()})
+    uc = dict(crossattn=uc_ctx.clone(), **{k: v.clone() for k, v in shared.items()})
+    fn = lambda inp_, sigma, cc, **kw: den(wrapped, inp_, sigma, cc, concat_images=None, chunk_dim=None, **kw)
+    with torch.no_grad():
+        xT = sampler(fn, x0.clone(), c, uc=uc, tile_indices=tiles)
+    np.savez_compressed(os.path.join(OUT, "sampler_long_tiny.npz"), x0=x0.numpy(), uc_ctx=uc_ctx.numpy(),
+                        c_ctx=c_ctx.numpy(), smpl_tiled=smpl_tiled.numpy(), tiles=np.array(tiles), xT=xT.numpy())
+    print("sampler_long_tiny: xT abs-mean", float(xT.abs().mean()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -163,6 +206,7 @@ def main():
     cfg, sd, net, inp = gen_dit_tiny()
     gen_rope(cfg, net)
     gen_sampler(cfg, sd, net, inp)
+    gen_sampler_long(cfg, sd, net, inp)
 
 
 if __name__ == "__main__":

@@ -496,3 +496,48 @@ def sample(cfg: DiTConfig, sd, x0, cond_ctx, uncond_ctx, ref_concat, concat_smpl
         x = x + (sig[i + 1] - sig[i]) * cfg_combine(v_u, v_c, cfg_scale)
         traj.append(x.clone())
     return x, traj
+
+
+def tile_weight(segment_length: int) -> torch.Tensor:
+    """Triangular blending weight of a temporal tile, sampling.py:1038-1040."""
+    w = (torch.arange(segment_length, dtype=torch.float32) + 0.5) * 2.0 / segment_length
+    return torch.minimum(w, 2.0 - w)
+
+
+def sample_long(cfg: DiTConfig, sd, x0, cond_ctx, uncond_ctx, ref_concat, smpl_tiled, image_clip_features,
+                tile_indices, num_steps=50, cfg_scale=4.0, shift_scale=5.0, network=None):
+    """RFSamplerLong.__call__ / sampler_step, sampling.py:1036-1085: every step denoises overlapping temporal
+    tiles of the latent (frame index lists ``tile_indices``) against the matching pose tile ``smpl_tiled[:, k]``
+    and blends the CFG-combined predictions with triangular weights before ONE Euler update of the whole latent.
+    The reference walks the PAIRS (k, k+1), so interior tiles enter the weighted sum twice (and are denoised twice);
+    the restatement keeps that multiplicity in the sums and evaluates each tile once.
+
+    x0 (1,T,16,H,W) fp32; smpl_tiled (1, n_tiles, Ttile, 16, H/2, W/2).  Needs >= 2 tiles like the reference
+    (one tile leaves weight_sum = 0 there)."""
+    n = len(tile_indices)
+    if n < 2:
+        raise ValueError("RFSamplerLong needs at least two temporal tiles")
+    sig = flow_sigmas(num_steps, shift_scale)
+    x = x0.clone().float()
+    ctx = torch.cat([uncond_ctx, cond_ctx], dim=0)
+    w = tile_weight(len(tile_indices[0]))
+    for i in range(num_steps):
+        den = torch.zeros_like(x)
+        wsum = torch.zeros(x.shape[1])
+        t = torch.stack([sig[i], sig[i]]) * 1000.0
+        for k in range(n):
+            idx = list(tile_indices[k])
+            mult = (1 if k == 0 else 2) if k < n - 1 else 1          # pairs (k-1,k) and (k,k+1)
+            xin = torch.cat([x[:, idx], x[:, idx]], dim=0)
+            pose = smpl_tiled[:, k]
+            if network is None:
+                v = dit_forward(cfg, sd, xin, t, ctx, ref_concat, pose, image_clip_features)
+            else:
+                v = network(xin, t, ctx, pose)
+            v_u, v_c = v.float().chunk(2)
+            d = cfg_combine(v_u, v_c, cfg_scale)
+            den[:, idx] += mult * d * w[:, None, None, None]
+            wsum[idx] += mult * w
+        den = den / wsum[:, None, None, None]
+        x = x + (sig[i + 1] - sig[i]) * den
+    return x

@@ -16,6 +16,7 @@ TARGET_MAP = {
     "sgm.modules.diffusionmodules.denoiser_weighting.EpsWeighting": "scail_amd.sampler.EpsWeighting",
     "sgm.modules.diffusionmodules.denoiser_scaling.RFScaling": "scail_amd.sampler.RFScaling",
     "sgm.modules.diffusionmodules.sampling.RFSampler": "scail_amd.sampler.RFSampler",
+    "sgm.modules.diffusionmodules.sampling.RFSamplerLong": "scail_amd.sampler.RFSamplerLong",
     "sgm.modules.diffusionmodules.discretizer.RFDiscretization": "scail_amd.sampler.RFDiscretization",
     "sgm.modules.diffusionmodules.guiders.VanillaCFG": "scail_amd.sampler.VanillaCFG",
     "sgm.modules.diffusionmodules.wrappers.OpenAIWrapper": "scail_amd.sampler.OpenAIWrapper",

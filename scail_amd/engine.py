@@ -48,8 +48,8 @@ class SATVideoDiffusionEngine(nn.Module):
 
     @torch.no_grad()
     def sample(self, cond: Dict, uc: Optional[Dict] = None, batch_size: int = 1, shape: Union[None, Tuple, List] = None,
-               prefix=None, concat_images=None, ofs=None, fps=None, generator: Optional[torch.Generator] = None,
-               num_steps: Optional[int] = None, fused: bool = True, **kwargs):
+               prefix=None, concat_images=None, ofs=None, fps=None, tile_indices=None,
+               generator: Optional[torch.Generator] = None, num_steps: Optional[int] = None, fused: bool = True, **kwargs):
         """diffusion_video.py:456-587.  shape = (T, C, H, W).  Noise is drawn in fp32 on the host RNG
         stream of ``generator`` like ``torch.randn(batch, *shape)`` (:470), broadcast inside the
         sequence-parallel group (:486-493) and H/W-chunked (:495-552); result gathered to SP rank 0 (:571-585)."""
@@ -69,12 +69,18 @@ class SATVideoDiffusionEngine(nn.Module):
                 if k in cond:
                     cond[k] = sp.chunk(cond[k], chunk_dim)
                     uc[k] = sp.chunk(uc[k], chunk_dim)
+            if "smpl_tiled" in cond:                                       # one more leading (tile) axis, :518-524
+                cond["smpl_tiled"] = sp.chunk(cond["smpl_tiled"], chunk_dim + 1)
+                uc["smpl_tiled"] = sp.chunk(uc["smpl_tiled"], chunk_dim + 1)
+        extra = {} if tile_indices is None else {"tile_indices": tile_indices}     # RFSamplerLong, :564-569
+        if tile_indices is not None and not isinstance(self.sampler, S.RFSamplerLong):
+            raise TypeError("tile_indices needs sampler_config.target = RFSamplerLong")
         if fused and isinstance(self.network, DiffusionTransformer):
-            samples = self.sampler.sample_hip(self.network, randn, cond, uc, num_steps=num_steps, chunk_dim=chunk_dim)
+            samples = self.sampler.sample_hip(self.network, randn, cond, uc, num_steps=num_steps, chunk_dim=chunk_dim, **extra)
         else:
             denoiser = lambda inp, sigma, c, **kw: self.denoiser(self.model, inp, sigma, c, concat_images=concat_images,
                                                                   chunk_dim=chunk_dim, **kw)
-            samples = self.sampler(denoiser, randn, dict(cond), uc=dict(uc), num_steps=num_steps)
+            samples = self.sampler(denoiser, randn, dict(cond), uc=dict(uc), num_steps=num_steps, **extra)
         samples = samples.to(self.dtype)
         if sp is not None:
             samples = sp.gather_to_rank0(samples, chunk_dim)

@@ -2,6 +2,7 @@
 ``target:`` strings can be pointed here (seam between L5 engine and L3 DiT).
 
   RFSampler          sgm/modules/diffusionmodules/sampling.py:920-982 (+ make_flow_timesteps :888-903)
+  RFSamplerLong      sampling.py:986-1085 (temporal tiling for videos longer than the trained window)
   Denoiser/RFScaling sgm/modules/diffusionmodules/denoiser.py:9-43, denoiser_scaling.py:71-78
   VanillaCFG         sgm/modules/diffusionmodules/guiders.py:23-57 (+ sampling_utils.py:7-10)
   OpenAIWrapper      sgm/modules/diffusionmodules/wrappers.py:24-45
@@ -179,6 +180,97 @@ class RFSampler:
             t = (sig[i] * 1000.0).repeat(2).to(x.device)                 # c_noise = 1000 sigma (RFScaling)
             v = network.forward_f32(xin, t, ctx, None, cond_key=("sample_hip", id(cond)), chunk_dim=chunk_dim, **shared)
             ops.cfg_euler_(x, v, cfg, float(sig[i + 1] - sig[i]))
+            if step_callback is not None:
+                step_callback(i, x)
+        return x
+
+
+class RFSamplerLong(RFSampler):
+    """sampling.py:986-1085: every step denoises overlapping temporal tiles of the latent (``tile_indices``: lists of
+    frame indices, equal length) against the matching pose tile ``cond['smpl_tiled'][:, k]`` and blends the
+    CFG-combined predictions with triangular weights before one Euler update of the whole latent.
+
+    The reference walks the pairs (k, k+1) and therefore denoises every interior tile twice with identical inputs;
+    here each tile is evaluated once and enters the weighted sums with the same multiplicity (x2 is exact in
+    floating point), which halves the network evaluations for long videos.  Needs >= 2 tiles like the reference
+    (a single tile leaves its weight_sum at zero)."""
+
+    @staticmethod
+    def tile_weight(n: int, device=None) -> torch.Tensor:
+        w = (torch.arange(n, device=device, dtype=torch.float32) + 0.5) * 2.0 / n
+        return torch.minimum(w, 2.0 - w)
+
+    @staticmethod
+    def _mult(k: int, n: int) -> int:
+        return 1 if (k == 0 or k == n - 1) else 2
+
+    @staticmethod
+    def _check(tile_indices):
+        if tile_indices is None or len(tile_indices) < 2:
+            raise ValueError("RFSamplerLong needs tile_indices with at least two temporal tiles")
+        n0 = len(tile_indices[0])
+        if any(len(t) != n0 for t in tile_indices):
+            raise ValueError("all temporal tiles must have the same length")
+
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc=None, scale=None, fps=None, tile_indices=None,
+                     smpl_tiled=None):
+        """sampling.py:1036-1068 (generic protocol: any denoiser / network)."""
+        self._check(tile_indices)
+        n = len(tile_indices)
+        denoised = torch.zeros_like(x)
+        weight_sum = torch.zeros((x.shape[1],), device=x.device)
+        weight = self.tile_weight(len(tile_indices[0]), x.device)
+        for k in range(n):
+            idx = list(tile_indices[k])
+            c_k, uc_k = dict(cond), dict(uc)
+            c_k["concat_smpl_render"] = smpl_tiled[:, k]
+            uc_k["concat_smpl_render"] = smpl_tiled[:, k]
+            d = self.denoise(x[:, idx], denoiser, sigma, c_k, uc_k, scale=scale, fps=fps).to(torch.float32)
+            m = self._mult(k, n)
+            denoised[:, idx] += m * d * weight[:, None, None, None]
+            weight_sum[idx] += m * weight
+        denoised.div_(weight_sum[:, None, None, None])
+        return x + append_dims(next_sigma - sigma, x.ndim) * denoised
+
+    def __call__(self, denoiser, x, cond, uc=None, num_steps=None, scale=None, ofs=None, fps=None, tile_indices=None):
+        sigmas = self.sigmas(num_steps).to(x.device)
+        uc = cond if uc is None else uc
+        s_in = x.new_ones([x.shape[0]])
+        smpl_tiled = cond["smpl_tiled"]
+        for i in range(len(sigmas) - 1):
+            x = self.sampler_step(s_in * sigmas[i], s_in * sigmas[i + 1], denoiser, x, cond, uc, scale=scale, fps=fps,
+                                  tile_indices=tile_indices, smpl_tiled=smpl_tiled)
+        return x
+
+    def sample_hip(self, network, x, cond: Dict, uc: Dict, num_steps=None, scale=None, chunk_dim=None,
+                   step_callback=None, tile_indices=None):
+        """Fused path for the HIP network: per step and tile one batch-2 DiT forward (fp32 out); the text / CLIP
+        conditioning (step- AND tile-invariant) is computed once per request."""
+        self._check(tile_indices)
+        n = len(tile_indices)
+        sig = self.sigmas(num_steps)
+        cfg = float(self.guider.scale if scale is None else scale)
+        ctx = torch.cat((uc["crossattn"], cond["crossattn"]), 0)
+        shared = {k: v for k, v in cond.items() if k not in ("crossattn", "smpl_tiled", "concat_smpl_render")}
+        smpl_tiled = cond["smpl_tiled"]
+        x = x.float().contiguous().clone()
+        dev = x.device
+        weight = self.tile_weight(len(tile_indices[0]), dev)[:, None, None, None]
+        idxs = [torch.as_tensor(list(t), device=dev, dtype=torch.long) for t in tile_indices]
+        wsum = torch.zeros(x.shape[1], device=dev)
+        for k in range(n):
+            wsum[idxs[k]] += self._mult(k, n) * weight[:, 0, 0, 0]
+        inv = (1.0 / wsum)[:, None, None, None]
+        for i in range(len(sig) - 1):
+            t = (sig[i] * 1000.0).repeat(2).to(dev)
+            den = torch.zeros_like(x)
+            for k in range(n):
+                xt = x[:, idxs[k]]
+                v = network.forward_f32(torch.cat([xt, xt], 0), t, ctx, None, cond_key=("sample_hip", id(cond)),
+                                        chunk_dim=chunk_dim, concat_smpl_render=smpl_tiled[:, k], **shared)
+                d = v[0:1] + cfg * (v[1:2] - v[0:1])                     # VanillaCFG, guiders.py:41-45
+                den[:, idxs[k]] += (self._mult(k, n) * weight) * d
+            x = x + float(sig[i + 1] - sig[i]) * (den * inv)
             if step_callback is not None:
                 step_callback(i, x)
         return x

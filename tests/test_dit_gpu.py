@@ -105,6 +105,33 @@ def test_sampler_two_steps_vs_reference_golden(golden_dir):
     torch.testing.assert_close(xT2.cpu(), xT.cpu(), rtol=1e-2, atol=1e-2)
 
 
+def test_sampler_long_vs_reference_golden(golden_dir):
+    """RFSamplerLong (temporal tiling, sampling.py:986-1085): fused HIP path and the generic protocol against the
+    reference's own 2-step run on a 6-frame latent with three overlapping 4-frame tiles."""
+    from scail_amd import sampler as S
+    g = _load(golden_dir, "sampler_long_tiny.npz")
+    d = _load(golden_dir, "dit_tiny.npz")
+    cfg, sd, net = _net(O.TINY, int(d["seed"]))
+    smp = S.RFSamplerLong(hunyuan_schedule=True, shift_scale=5, num_steps=2,
+                          guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 4}})
+    tiles = [list(map(int, r)) for r in g["tiles"]]
+    shared = dict(concat_images=torch.zeros(1, 4, 16, 8, 8, device=DEV), ref_concat=d["ref"].to(DEV),
+                  smpl_tiled=g["smpl_tiled"].to(DEV), image_clip_features=d["clip"].to(DEV))
+    c = dict(crossattn=g["c_ctx"].to(DEV), **shared)
+    uc = dict(crossattn=g["uc_ctx"].to(DEV), **shared)
+    xT = smp.sample_hip(net, g["x0"].to(DEV), c, uc, tile_indices=tiles)
+    torch.testing.assert_close(xT.cpu(), g["xT"], rtol=3e-2, atol=0.14)       # same bound as the plain sampler test
+    assert _cos(xT.cpu(), g["xT"]) >= 0.999
+    assert float((xT.cpu() - g["xT"]).abs().mean()) < 1.5e-2
+    den = S.Denoiser()
+    wrapped = S.OpenAIWrapper(net, dtype=torch.bfloat16)
+    fn = lambda inp, sigma, cc, **kw: den(wrapped, inp, sigma, cc, concat_images=None, chunk_dim=None, **kw)
+    xT2 = smp(fn, g["x0"].to(DEV).clone(), dict(c), uc=dict(uc), tile_indices=tiles)
+    torch.testing.assert_close(xT2.cpu(), xT.cpu(), rtol=1e-2, atol=1e-2)
+    with pytest.raises(ValueError):
+        smp.sample_hip(net, g["x0"].to(DEV)[:, :4], c, uc, tile_indices=tiles[:1])
+
+
 def test_engine_sample_from_reference_yaml_shapes():
     """SATVideoDiffusionEngine.sample through the reference-style model config (targets are the
     reference's class paths, mapped by scail_amd.config)."""

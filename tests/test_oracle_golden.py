@@ -61,6 +61,22 @@ def test_sampler_matches_reference(golden_dir):
     torch.testing.assert_close(xT, g["xT"], rtol=5e-5, atol=5e-5)
 
 
+def test_sampler_long_matches_reference(golden_dir):
+    """RFSamplerLong (temporal tiling, sampling.py:986-1085) on the real reference vs the restatement."""
+    g = _load(golden_dir, "sampler_long_tiny.npz")
+    d = _load(golden_dir, "dit_tiny.npz")
+    cfg = O.DiTConfig(**O.TINY)
+    sd = O.make_state_dict(cfg, seed=int(d["seed"]))
+    tiles = [list(map(int, r)) for r in g["tiles"]]
+    xT = O.sample_long(cfg, sd, g["x0"], g["c_ctx"], g["uc_ctx"], d["ref"], g["smpl_tiled"], d["clip"], tiles, num_steps=2)
+    torch.testing.assert_close(xT, g["xT"], rtol=5e-5, atol=5e-5)
+    w = O.tile_weight(4)
+    assert torch.allclose(w, torch.tensor([0.25, 0.75, 0.75, 0.25]))
+    with pytest.raises(ValueError):
+        O.sample_long(cfg, sd, g["x0"][:, :4], g["c_ctx"], g["uc_ctx"], d["ref"], g["smpl_tiled"][:, :1], d["clip"],
+                      tiles[:1], num_steps=1)
+
+
 def test_sigmas50(golden_dir):
     g = _load(golden_dir, "sigmas50.npz")
     s = O.flow_sigmas(50)
