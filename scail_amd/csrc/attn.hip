@@ -330,6 +330,10 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(AttnParams p) {
             const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(qs_ + ks * 16);                   \
             _Pragma("unroll") for (int f = 0; f < 2; ++f) {                                       \
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + f * 32 * K_LD + ks * 16); \
+                if (SWP_ABL & 1) { /* timing ablation: every K fragment read twice */             \
+                    const bf16x8 kd_ = *reinterpret_cast<const bf16x8*>(ks_ + (f ^ 1) * 32 * K_LD + ks * 16 + 8 * K_LD); \
+                    asm volatile("" :: "v"(kd_));                                                 \
+                }                                                                                 \
                 S_[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfr, S_[f], 0, 0, 0);         \
             }                                                                                     \
         }                                                                                         \
@@ -340,6 +344,10 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(AttnParams p) {
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                        \
             _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) {                                 \
                 const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * V_LD + ks * 16); \
+                if (SWP_ABL & 1) { /* timing ablation: every V fragment read twice */             \
+                    const bf16x8 vd_ = *reinterpret_cast<const bf16x8*>(vs_ + (d ^ 1) * 32 * V_LD + ks * 16 + 8 * V_LD); \
+                    asm volatile("" :: "v"(vd_));                                                 \
+                }                                                                                 \
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[d], 0, 0, 0);        \
             }                                                                                     \
         }                                                                                         \
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(AttnParams p) {
         __syncthreads();                                                                           \
     }
 
-template <int GA, int GB>   // VALU(+TRANS) instructions scheduled into each MFMA gap of block A / block B
+template <int GA, int GB, int SWP_ABL = 0>   // VALU(+TRANS) instructions scheduled into each MFMA gap of block A / block B
 __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* Ks = smem;                              // [2][KVBLK][K_LD]
@@ -568,6 +576,261 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
 // bit 6 4-wave workgroups x 2 per CU -7 %;  bit 8 LDS-DMA K/V staging -3 %;  bit 3 software-pipelined kernel
 // with (bits 12+) 9/3 VALU per MFMA gap -3 %, 6/4 -4 %, 5/5 +3 %, **4/4 +4 % (default)**, 3/3 +2.5 %.
 // bits 4/5 are ablations (wrong results): no softmax -14 % time, no staging/barrier -15 %, neither -35 %.
+
+// ================================================================================================
+// 4 waves x 64 query rows ("w4").  The chip is power-limited under this kernel (profiles/r01_power.md), and
+// doubling the K / V^T fragment reads of the 8-wave kernel costs +18 % time: LDS traffic per FLOP is what to cut.
+// Here a wave owns TWO 32-row query blocks, so every K / V^T fragment read from LDS feeds two MFMAs, and Q (64 rows
+// x 128 = 64 VGPRs) stays in registers: 128 KB of LDS reads per 64-key tile and CU instead of 320 KB.  One wave
+// per SIMD with the 512-register budget (O accumulators 128 -> AGPRs, Q 64, two score buffers 2 x 32, P 16).
+// The software pipeline runs on HALF tiles (32 keys; a full second 64-key score tile does not fit): unit
+// u = (tile, half):  QK^T(u+1) MFMAs || exp / sum / pack of unit u;  P(u).V(u) MFMAs || row max of unit u+1.
+// LDS staging, slots and the barrier stay per 64-key tile.
+// ================================================================================================
+// scores of half F_ (keys 32 F_ .. +31) of the tile in K slot slot_, both query blocks
+#define W4_QK(S_, slot_, F_)                                                                      \
+    {                                                                                             \
+        _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                          \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) S_[qb][e] = 0.f;                       \
+        const u16* ks_ = Ks + ((slot_) * KVBLK + 32 * (F_) + ql) * K_LD + g * 8;                  \
+        _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks) {                                  \
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + ks * 16);                    \
+            _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                    \
+                S_[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], S_[qb], 0, 0, 0); \
+        }                                                                                         \
+    }
+// O += V^T[:, keys of half F_] . P^T
+#define W4_PV(slot_, F_)                                                                          \
+    {                                                                                             \
+        const u16* vs_ = Vs + ((slot_) * HD + ql) * V_LD + 32 * (F_) + g * 8;                     \
+        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                                        \
+            _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) {                                 \
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * V_LD + k2 * 16); \
+                _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                \
+                    o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][k2], o[qb][d], 0, 0, 0); \
+            }                                                                                     \
+        }                                                                                         \
+    }
+// 1024 K chunks + 1024 V^T chunks of 16 B per tile, 4 + 4 per thread
+#define W4_LOAD_K(tt_)                                                                                    \
+    {                                                                                                     \
+        const int seg_ = (tt_) / tps, key0_ = ((tt_) - seg_ * tps) * KVBLK;                               \
+        const u16* kp_ = kbase + (int64_t)seg_ * p.k_ss;                                                  \
+        kr0 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow, p.Lk - 1) * p.k_rs);       \
+        kr1 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + KR, p.Lk - 1) * p.k_rs);  \
+        if (NQB == 2) {                                                                                   \
+            kr2 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + 2 * KR, p.Lk - 1) * p.k_rs);  \
+            kr3 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + 3 * KR, p.Lk - 1) * p.k_rs);  \
+        }                                                                                                 \
+    }
+#define W4_LOAD_V(tt_)                                                                                    \
+    {                                                                                                     \
+        const int seg_ = (tt_) / tps, key0_ = ((tt_) - seg_ * tps) * KVBLK;                               \
+        const u16* vp_ = vbase + (int64_t)seg_ * p.vt_ss + key0_;                                         \
+        vr0 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)vrow * p.Lkp);                               \
+        vr1 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + VR) * p.Lkp);                        \
+        if (NQB == 2) {                                                                                   \
+            vr2 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + 2 * VR) * p.Lkp);                \
+            vr3 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + 3 * VR) * p.Lkp);                \
+        }                                                                                                 \
+    }
+#define W4_STORE_K(slot_)                                                                          \
+    {                                                                                              \
+        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow) * K_LD + kcc * 8) = kr0;           \
+        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + KR) * K_LD + kcc * 8) = kr1;      \
+        if (NQB == 2) {                                                                            \
+            *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + 2 * KR) * K_LD + kcc * 8) = kr2;  \
+            *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + 3 * KR) * K_LD + kcc * 8) = kr3;  \
+        }                                                                                          \
+    }
+#define W4_STORE_V(slot_)                                                                          \
+    {                                                                                              \
+        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow) * V_LD + vcc * 8) = vr0;              \
+        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + VR) * V_LD + vcc * 8) = vr1;         \
+        if (NQB == 2) {                                                                            \
+            *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + 2 * VR) * V_LD + vcc * 8) = vr2; \
+            *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + 3 * VR) * V_LD + vcc * 8) = vr3; \
+        }                                                                                          \
+    }
+#define W4_ROWMAX(S_, OUT_)                                                                       \
+    _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) {                                            \
+        float mx_ = S_[qb][0];                                                                    \
+        _Pragma("unroll") for (int r = 1; r < 16; ++r) mx_ = fmaxf(mx_, S_[qb][r]);               \
+        const unsigned mi_ = __float_as_uint(mx_);                                                \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(mi_, mi_, false, false);                \
+        OUT_[qb] = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                       \
+    }
+#define W4_SOFTMAX(S_, MX_)                                                                       \
+    bool moved_ = false;                                                                          \
+    float alpha_[NQB];                                                                              \
+    _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) {                                            \
+        const float m_new_ = fmaxf(m_run[qb], MX_[qb]);                                           \
+        alpha_[qb] = __builtin_amdgcn_exp2f((m_run[qb] - m_new_) * sl2);                          \
+        const float msc_ = m_new_ * sl2;                                                          \
+        float rs_ = 0.f;                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
+            const float pv_ = __builtin_amdgcn_exp2f(S_[qb][r] * sl2 - msc_);                     \
+            S_[qb][r] = pv_;                                                                      \
+            rs_ += pv_;                                                                           \
+        }                                                                                         \
+        l_run[qb] = l_run[qb] * alpha_[qb] + rs_;                                                 \
+        moved_ = moved_ || !__all(m_new_ == m_run[qb]);                                           \
+        m_run[qb] = m_new_;                                                                       \
+        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                                        \
+            uint4 u_;                                                                             \
+            const int r0 = k2 * 8;                                                                \
+            u_.x = pack_bf16x2(S_[qb][r0 + 0], S_[qb][r0 + 1]);                                   \
+            u_.y = pack_bf16x2(S_[qb][r0 + 2], S_[qb][r0 + 3]);                                   \
+            u_.z = pack_bf16x2(S_[qb][r0 + 4], S_[qb][r0 + 5]);                                   \
+            u_.w = pack_bf16x2(S_[qb][r0 + 6], S_[qb][r0 + 7]);                                   \
+            pf[qb][k2] = __builtin_bit_cast(bf16x8, u_);                                          \
+        }                                                                                         \
+    }
+// keys of half F_ of tile T_ past the segment's ragged end -> -inf
+#define W4_MASK(S_, T_, F_)                                                                       \
+    if (tail < KVBLK && ((T_) % tps) == tps - 1) {                                                \
+        _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                          \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
+                const int key = 32 * (F_) + (r & 3) + 8 * (r >> 2) + 4 * g;                       \
+                if (key >= tail) S_[qb][r] = -INFINITY;                                           \
+            }                                                                                     \
+    }
+#define W4_GA __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, GA, 0);
+#define W4_GB __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, GB, 0);
+#define W4_X16(G_) G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_
+// one unit: SC_ = masked scores of (T_, F_) with row max MXC_; SN_/MXN_ = the NEXT unit (NT_, NF_) in K slot NSLOT_
+#define W4_UNIT(SC_, SN_, MXC_, MXN_, T_, F_, NT_, NF_, NSLOT_, HAS_NEXT_)                         \
+    {                                                                                              \
+        if (HAS_NEXT_) W4_QK(SN_, NSLOT_, NF_)                                                     \
+        W4_SOFTMAX(SC_, MXC_)                                                                      \
+        if (HAS_NEXT_) { W4_X16(W4_GA) }                                                           \
+        _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) { SWP_PIN(pf[qb][0]) SWP_PIN(pf[qb][1]) } \
+        if (moved_) {                                                                              \
+            _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                       \
+                _Pragma("unroll") for (int d = 0; d < HD / 32; ++d)                                \
+                    _Pragma("unroll") for (int e = 0; e < 16; ++e) o[qb][d][e] *= alpha_[qb];      \
+        }                                                                                          \
+        if (HAS_NEXT_) W4_MASK(SN_, NT_, NF_)                                                      \
+        W4_PV((T_) & 1, F_)                                                                        \
+        if (HAS_NEXT_) {                                                                           \
+            W4_ROWMAX(SN_, MXN_)                                                                   \
+            W4_X16(W4_GB)                                                                          \
+        }                                                                                          \
+    }
+// one 64-key tile = two units + the staging of K(T+2) / V(T+1) and the barrier
+#define W4_TILE(T_, HAS_NEXT_)                                                                     \
+    {                                                                                              \
+        const int cur_ = (T_) & 1;                                                                 \
+        W4_LOAD_K(min((T_) + 2, ntiles - 1))                                                       \
+        W4_LOAD_V(min((T_) + 1, ntiles - 1))                                                       \
+        W4_UNIT(sa, sb, mxa, mxb, T_, 0, T_, 1, cur_, true)                                        \
+        W4_UNIT(sb, sa, mxb, mxa, T_, 1, (T_) + 1, 0, cur_ ^ 1, HAS_NEXT_)                         \
+        W4_STORE_K(cur_)                                                                           \
+        W4_STORE_V(cur_ ^ 1)                                                                       \
+        __syncthreads();                                                                           \
+    }
+
+template <int NQB, int GA, int GB>   // NQB query blocks of 32 rows per wave: 2 -> 4 waves (one per SIMD), 1 -> 8 waves
+__global__ __launch_bounds__(512 / NQB) void flash_attn_w4_kernel(AttnParams p) {
+    constexpr int NTH = 512 / NQB, KR = NTH / 16, VR = NTH / 8;   // threads, tile rows per staging pass
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Ks = smem;                              // [2][KVBLK][K_LD]
+    u16* Vs = smem + 2 * KVBLK * K_LD;           // [2][HD][V_LD]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, g = lane >> 5;
+    const int h = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int q0 = blockIdx.x * QBLK + wave * 32 * NQB;
+    const unsigned long long clk0 = p.probe ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    bf16x8 qf[NQB][HD / 16];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int qrow = min(q0 + 32 * qb + ql, p.Lq - 1);
+        const u16* qp = p.q + b * p.q_bs + (int64_t)qrow * p.q_rs + (int64_t)h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    }
+    const int krow = tid >> 4, kcc = tid & 15;     // K chunk: row = (tid >> 4) + KR i
+    const int vrow = tid >> 3, vcc = tid & 7;      // V chunk: row = (tid >> 3) + VR i
+    const u16* kbase = p.k + b * p.k_bs + (int64_t)h * HD + kcc * 8;
+    const u16* vbase = p.vt + b * p.vt_bs + (int64_t)h * HD * p.Lkp + vcc * 8;
+    const int tps = p.Lkp / KVBLK;
+    const int ntiles = tps * p.n_seg;
+    const int tail = p.Lk - (tps - 1) * KVBLK;
+    const float sl2 = p.sl2;
+    uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
+
+    f32x16 o[NQB][HD / 32];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[qb][d][e] = 0.f;
+    float m_run[NQB], l_run[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
+    f32x16 sa[NQB], sb[NQB];
+    bf16x8 pf[NQB][2];
+
+    // prologue: K(0) -> slot 0, K(1) -> slot 1, V(0) -> slot 0; scores of unit (0, 0)
+    W4_LOAD_K(0)
+    W4_LOAD_V(0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    W4_STORE_K(0)
+    W4_STORE_V(0)
+    W4_LOAD_K(min(1, ntiles - 1))
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    W4_STORE_K(1)
+    __syncthreads();
+    float mxa[NQB], mxb[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) mxb[qb] = 0.f;
+    W4_QK(sa, 0, 0)
+    W4_MASK(sa, 0, 0)
+    W4_ROWMAX(sa, mxa)
+
+    int t = 0;
+    for (; t + 1 < ntiles; ++t) W4_TILE(t, true)
+    W4_TILE(t, false)
+
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qrow = q0 + 32 * qb + ql;
+        if (qrow < p.Lq) {
+            u16* op = p.o + b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * HD + 4 * g;
+#pragma unroll
+            for (int d = 0; d < HD / 32; ++d) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = o[qb][d][4 * rr + e] * inv;
+                    uint2* dst = reinterpret_cast<uint2*>(op + d * 32 + rr * 8);
+                    if (p.accumulate) {
+                        const uint2 old = *dst;
+                        v[0] += bf_lo(old.x); v[1] += bf_hi(old.x);
+                        v[2] += bf_lo(old.y); v[3] += bf_hi(old.y);
+                    }
+                    uint2 w;
+                    w.x = pack_bf16x2(v[0], v[1]);
+                    w.y = pack_bf16x2(v[2], v[3]);
+                    *dst = w;
+                }
+            }
+        }
+    }
+    if (p.probe && tid == 0) {
+        atomicAdd(&g_attn_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);
+        atomicAdd(&g_attn_clk[1], 1ull);
+    }
+}
+
 int scail_gemm_tune(int v);
 static int g_attn_variant = 8 | (2 << 12);
 extern "C" int scail_tune_set(const char* knob, int value) {
@@ -619,6 +882,24 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     p.accumulate = accumulate;
     p.probe = (g_attn_variant >> 20) & 1;
     dim3 grid((unsigned)((Lq + QBLK - 1) / QBLK), (unsigned)heads, (unsigned)n_batch);
+    if (g_attn_variant & (512 | 1024)) {   // half-tile pipeline, Q in registers: 512 = 4 waves x 64 rows, 1024 = 8 waves x 32 rows
+        const int sub = (g_attn_variant >> 12) & 15;
+        static bool w4_attr = false;
+        if (!w4_attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<1, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<1, 5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<1, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<1, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+            w4_attr = true;
+        }
+        if (g_attn_variant & 512) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2>), grid, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
+        else if (sub == 1) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 5, 2>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
+        else if (sub == 2) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 3, 2>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
+        else if (sub == 3) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 4, 3>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((flash_attn_w4_kernel<1, 4, 2>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
+        return scail_check_launch("flash_attn");
+    }
     if (g_attn_variant & 8) {
         const int sub = (g_attn_variant >> 12) & 15;     // A/B of the interleave density
         static bool swp_attr = false;
@@ -627,12 +908,14 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
             swp_attr = true;
         }
         if (sub == 1) hipLaunchKernelGGL((flash_attn_swp_kernel<5, 5>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 2) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 3) hipLaunchKernelGGL((flash_attn_swp_kernel<6, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 4) hipLaunchKernelGGL((flash_attn_swp_kernel<3, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+        else if (sub == 5) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4, 1>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((flash_attn_swp_kernel<9, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         return scail_check_launch("flash_attn");
     }

@@ -157,12 +157,26 @@ def test_rope_tables_match_oracle():
 
 
 # ------------------------------------------------------------------------------------------------
+# every schedule of the attention kernel that can be selected (default = software-pipelined 4/4) must give the
+# same results: lock-step (2), lock-step + LDS-DMA staging (258), 4-wave x 2 workgroups (66), software-pipelined
+# 5/5 (8 | 1<<12), half-tile pipeline with Q in registers on 8 waves (1024) and on 4 waves x 64 rows (512)
+ATTN_VARIANTS = [8 | (2 << 12), 2, 258, 66, 8 | (1 << 12), 1024, 512]
+
+
+@pytest.fixture(params=ATTN_VARIANTS)
+def attn_variant(request):
+    from scail_amd import lib as L
+    L.tune_set("attn_variant", request.param)
+    yield request.param
+    L.tune_set("attn_variant", ATTN_VARIANTS[0])
+
+
 def _attn_ref(q, k, v, heads):
     return O._merge(O.sdpa(O._heads(q, heads), O._heads(k, heads), O._heads(v, heads)))
 
 
 @pytest.mark.parametrize("Lq,Lk", [(64, 64), (300, 300), (257, 512), (1000, 257), (96, 96), (40, 1)])
-def test_flash_attn(ops, Lq, Lk):
+def test_flash_attn(ops, attn_variant, Lq, Lk):
     B, H = 2, 2
     D = H * 128
     q, k, v = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3)
@@ -172,7 +186,7 @@ def test_flash_attn(ops, Lq, Lk):
     close(o, ref, rtol=2e-2, atol=1e-2, msg=f"flash_attn Lq={Lq} Lk={Lk}")
 
 
-def test_flash_attn_strided_qkv_and_accumulate(ops):
+def test_flash_attn_strided_qkv_and_accumulate(ops, attn_variant):
     B, H, Lt = 2, 2, 200
     D = H * 128
     qkv = rnd(B, Lt, 3 * D, seed=1)
@@ -189,7 +203,7 @@ def test_flash_attn_strided_qkv_and_accumulate(ops):
     close(o, ref2, atol=2e-2, msg="accumulate + broadcast K/V")
 
 
-def test_flash_attn_segments(ops):
+def test_flash_attn_segments(ops, attn_variant):
     """n_seg > 1: keys of 3 equally sized segments (sequence-parallel all-gather layout)."""
     B, H, Lq, Ls, S = 1, 2, 130, 100, 3
     D = H * 128
@@ -202,7 +216,7 @@ def test_flash_attn_segments(ops):
     close(o, ref, atol=1e-2, msg="segmented keys")
 
 
-def test_flash_attn_rescale_branch(ops):
+def test_flash_attn_rescale_branch(ops, attn_variant):
     """A key that dominates late in the sequence forces the online-softmax running max to jump
     (guide rule 26): the result must still match the fp32 oracle."""
     B, H, Lq, Lk = 1, 1, 64, 320
