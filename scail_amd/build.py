@@ -12,6 +12,10 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libscail_hip.so")
 SOURCES = ["errors.hip", "rowops.hip", "gemm.hip", "attn.hip", "conv.hip"]
 ARCH = "gfx950"
+# per-file extra flags.  attn.hip: keep MFMA results in arch VGPRs even in the 256-thread kernels (hipcc otherwise puts every
+# accumulator of a kernel that may use > 256 registers into AGPRs, and the softmax then reads its scores back one
+# v_accvgpr_read at a time); kernels with <= 256 registers per wave are unaffected.
+EXTRA_FLAGS = {}
 
 
 def _hipcc() -> str:
@@ -29,7 +33,8 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "scail_hip.h")]
+    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "scail_hip.h"),
+                        os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -43,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -590,24 +590,29 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
 // scores of half F_ (keys 32 F_ .. +31) of the tile in K slot slot_, both query blocks
 #define W4_QK(S_, slot_, F_)                                                                      \
     {                                                                                             \
-        _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                          \
+        _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                        \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) S_[qb][e] = 0.f;                       \
-        const u16* ks_ = Ks + ((slot_) * KVBLK + 32 * (F_) + ql) * K_LD + g * 8;                  \
+        const u16* ks_ = Ks + ((slot_) * KVBLK + 32 * (F_) + ql) * KLD;                           \
+        bf16x8 kfr_[HD / 16];   /* all 8 fragments requested before the first MFMA */             \
+        _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks)                                    \
+            kfr_[ks] = *reinterpret_cast<const bf16x8*>(ks_ + koff[ks]);                          \
         _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks) {                                  \
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + ks * 16);                    \
             _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                    \
-                S_[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], S_[qb], 0, 0, 0); \
+                S_[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr_[ks], qf[qb][ks], S_[qb], 0, 0, 0); \
         }                                                                                         \
     }
 // O += V^T[:, keys of half F_] . P^T
 #define W4_PV(slot_, F_)                                                                          \
     {                                                                                             \
-        const u16* vs_ = Vs + ((slot_) * HD + ql) * V_LD + 32 * (F_) + g * 8;                     \
+        const u16* vs_ = Vs + ((slot_) * HD + ql) * VLD;                                          \
+        bf16x8 vfr_[2][HD / 32];                                                                  \
+        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                          \
+            _Pragma("unroll") for (int d = 0; d < HD / 32; ++d)                                   \
+                vfr_[k2][d] = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * VLD + voff[2 * (F_) + k2]); \
         _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                                        \
             _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) {                                 \
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * V_LD + k2 * 16); \
                 _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                \
-                    o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][k2], o[qb][d], 0, 0, 0); \
+                    o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr_[k2][d], pf[qb][k2], o[qb][d], 0, 0, 0); \
             }                                                                                     \
         }                                                                                         \
     }
@@ -636,20 +641,20 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
     }
 #define W4_STORE_K(slot_)                                                                          \
     {                                                                                              \
-        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow) * K_LD + kcc * 8) = kr0;           \
-        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + KR) * K_LD + kcc * 8) = kr1;      \
+        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow) * KLD + kcc * 8) = kr0;           \
+        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + KR) * KLD + kcc * 8) = kr1;      \
         if (NQB == 2) {                                                                            \
-            *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + 2 * KR) * K_LD + kcc * 8) = kr2;  \
-            *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + 3 * KR) * K_LD + kcc * 8) = kr3;  \
+            *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + 2 * KR) * KLD + kcc * 8) = kr2;  \
+            *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + 3 * KR) * KLD + kcc * 8) = kr3;  \
         }                                                                                          \
     }
 #define W4_STORE_V(slot_)                                                                          \
     {                                                                                              \
-        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow) * V_LD + vcc * 8) = vr0;              \
-        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + VR) * V_LD + vcc * 8) = vr1;         \
+        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow) * VLD + vcc * 8) = vr0;              \
+        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + VR) * VLD + vcc * 8) = vr1;         \
         if (NQB == 2) {                                                                            \
-            *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + 2 * VR) * V_LD + vcc * 8) = vr2; \
-            *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + 3 * VR) * V_LD + vcc * 8) = vr3; \
+            *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + 2 * VR) * VLD + vcc * 8) = vr2; \
+            *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + 3 * VR) * VLD + vcc * 8) = vr3; \
         }                                                                                          \
     }
 #define W4_ROWMAX(S_, OUT_)                                                                       \
@@ -695,47 +700,98 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
                 if (key >= tail) S_[qb][r] = -INFINITY;                                           \
             }                                                                                     \
     }
-#define W4_GA __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, GA, 0);
-#define W4_GB __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, GB, 0);
-#define W4_X16(G_) G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_ G_
+// Issue order of a 16-MFMA block (8 fragment reads, each feeding the two query blocks): three reads up front, then
+// per fragment  MFMA | read of the fragment three pairs ahead | n VALU | MFMA | n VALU  -- with one wave per SIMD
+// nothing else covers the LDS latency, so the reads have to run ~6 MFMAs (190 cycles) ahead of their use.
+#define W4_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
+#define W4_PAIR(N_) W4_SGB(0x008, 1) W4_SGB(0x100, 1) W4_SGB(0x402, N_) W4_SGB(0x008, 1) W4_SGB(0x402, N_)
+#define W4_PIPE(N_) W4_SGB(0x100, 3) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_)
+// O *= alpha (rare: only when a row max moved).  In the 4-wave kernel O lives in AGPRs; written as one
+// read-multiply-write per register so that this cold block needs ONE temporary instead of pulling all 128 accumulators
+// into VGPRs at once (which made hipcc spill loop invariants of the hot path to scratch).
+#define W4_RESCALE(acc_, a_)                                                                      \
+    if (NQB == 2) {                                                                               \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                          \
+            float t_, c_ = acc_[e];                                                               \
+            asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_mul_f32 %0, %0, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %1, %0\n\ts_nop 1" \
+                         : "=&v"(t_), "+a"(c_) : "v"(a_));                                          \
+            acc_[e] = c_;                                                                         \
+        }                                                                                         \
+    } else {                                                                                      \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) acc_[e] *= a_;                             \
+    }
 // one unit: SC_ = masked scores of (T_, F_) with row max MXC_; SN_/MXN_ = the NEXT unit (NT_, NF_) in K slot NSLOT_
 #define W4_UNIT(SC_, SN_, MXC_, MXN_, T_, F_, NT_, NF_, NSLOT_, HAS_NEXT_)                         \
     {                                                                                              \
         if (HAS_NEXT_) W4_QK(SN_, NSLOT_, NF_)                                                     \
         W4_SOFTMAX(SC_, MXC_)                                                                      \
-        if (HAS_NEXT_) { W4_X16(W4_GA) }                                                           \
+        if (HAS_NEXT_) { W4_PIPE(GA) }                                                             \
         _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) { SWP_PIN(pf[qb][0]) SWP_PIN(pf[qb][1]) } \
         if (moved_) {                                                                              \
             _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                       \
-                _Pragma("unroll") for (int d = 0; d < HD / 32; ++d)                                \
-                    _Pragma("unroll") for (int e = 0; e < 16; ++e) o[qb][d][e] *= alpha_[qb];      \
+                _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) W4_RESCALE(o[qb][d], alpha_[qb]) \
         }                                                                                          \
         if (HAS_NEXT_) W4_MASK(SN_, NT_, NF_)                                                      \
         W4_PV((T_) & 1, F_)                                                                        \
         if (HAS_NEXT_) {                                                                           \
             W4_ROWMAX(SN_, MXN_)                                                                   \
-            W4_X16(W4_GB)                                                                          \
+            W4_PIPE(GB)                                                                            \
         }                                                                                          \
+    }
+// LDS-DMA staging (DMA = true): K piece j = rows 4j..4j+3 (lane -> row 4j + (l >> 4), chunk l & 15), V^T piece j = rows
+// 8j..8j+7 (lane -> row 8j + (l >> 3), chunk l & 7), 16 pieces each per tile; unpadded rows, XOR swizzle on the source
+// address and on the fragment reads.  K ring of THREE slots (K(T+2) lands while K(T) and K(T+1) are still read).
+#define W4_DMA(tt_, kslot_, vslot_, DO_K_, DO_V_)                                                           \
+    {                                                                                                       \
+        const int seg_ = (tt_) / tps, key0_ = ((tt_) - seg_ * tps) * KVBLK;                                 \
+        const u16* kp_ = p.k + b * p.k_bs + (int64_t)h * HD + (int64_t)seg_ * p.k_ss;                       \
+        const u16* vp_ = p.vt + b * p.vt_bs + (int64_t)h * HD * p.Lkp + (int64_t)seg_ * p.vt_ss + key0_;    \
+        _Pragma("unroll") for (int i_ = 0; i_ < PPW; ++i_) {                                                \
+            const int j_ = wave * PPW + i_;                                                                 \
+            if (DO_K_) {                                                                                    \
+                const int kr_ = 4 * j_ + dk_row;                                                            \
+                const u16* src_ = kp_ + (int64_t)min(key0_ + kr_, p.Lk - 1) * p.k_rs + ((dk_c ^ (kr_ & 15)) << 3);  \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,       \
+                    (__attribute__((address_space(3))) void*)(Ks + ((kslot_) * KVBLK + 4 * j_) * KLD), 16, 0, 0);    \
+            }                                                                                               \
+            if (DO_V_) {                                                                                    \
+                const int vr_ = 8 * j_ + dv_row;                                                            \
+                const u16* src_ = vp_ + (int64_t)vr_ * p.Lkp + ((dv_c ^ ((vr_ >> 1) & 7)) << 3);            \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,       \
+                    (__attribute__((address_space(3))) void*)(Vs + ((vslot_) * HD + 8 * j_) * VLD), 16, 0, 0);       \
+            }                                                                                               \
+        }                                                                                                   \
     }
 // one 64-key tile = two units + the staging of K(T+2) / V(T+1) and the barrier
 #define W4_TILE(T_, HAS_NEXT_)                                                                     \
     {                                                                                              \
         const int cur_ = (T_) & 1;                                                                 \
-        W4_LOAD_K(min((T_) + 2, ntiles - 1))                                                       \
-        W4_LOAD_V(min((T_) + 1, ntiles - 1))                                                       \
-        W4_UNIT(sa, sb, mxa, mxb, T_, 0, T_, 1, cur_, true)                                        \
-        W4_UNIT(sb, sa, mxb, mxa, T_, 1, (T_) + 1, 0, cur_ ^ 1, HAS_NEXT_)                         \
-        W4_STORE_K(cur_)                                                                           \
-        W4_STORE_V(cur_ ^ 1)                                                                       \
+        const int kc_ = DMA ? (T_) % 3 : cur_, kn_ = DMA ? ((T_) + 1) % 3 : (cur_ ^ 1);            \
+        if (DMA) {                                                                                 \
+            W4_DMA(min((T_) + 2, ntiles - 1), ((T_) + 2) % 3, 0, true, false)                      \
+            W4_DMA(min((T_) + 1, ntiles - 1), 0, cur_ ^ 1, false, true)                            \
+        } else {                                                                                   \
+            W4_LOAD_K(min((T_) + 2, ntiles - 1))                                                   \
+            W4_LOAD_V(min((T_) + 1, ntiles - 1))                                                   \
+        }                                                                                          \
+        W4_UNIT(sa, sb, mxa, mxb, T_, 0, T_, 1, kc_, true)                                         \
+        W4_UNIT(sb, sa, mxb, mxa, T_, 1, (T_) + 1, 0, kn_, HAS_NEXT_)                              \
+        if (DMA) {                                                                                 \
+            __builtin_amdgcn_s_waitcnt(0x0F70);                                                    \
+        } else {                                                                                   \
+            W4_STORE_K(cur_)                                                                       \
+            W4_STORE_V(cur_ ^ 1)                                                                   \
+        }                                                                                          \
         __syncthreads();                                                                           \
     }
 
-template <int NQB, int GA, int GB>   // NQB query blocks of 32 rows per wave: 2 -> 4 waves (one per SIMD), 1 -> 8 waves
+template <int NQB, int GA, int GB, bool DMA = false>   // NQB query blocks of 32 rows per wave: 2 -> 4 waves (one per SIMD), 1 -> 8 waves
 __global__ __launch_bounds__(512 / NQB) void flash_attn_w4_kernel(AttnParams p) {
     constexpr int NTH = 512 / NQB, KR = NTH / 16, VR = NTH / 8;   // threads, tile rows per staging pass
+    constexpr int KLD = DMA ? HD : K_LD, VLD = DMA ? KVBLK : V_LD, NKS = DMA ? 3 : 2, PPW = 2 * NQB;
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* Ks = smem;                              // [2][KVBLK][K_LD]
-    u16* Vs = smem + 2 * KVBLK * K_LD;           // [2][HD][V_LD]
+    u16* Vs = smem + NKS * KVBLK * KLD;          // [2][HD][VLD]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -743,6 +799,12 @@ __global__ __launch_bounds__(512 / NQB) void flash_attn_w4_kernel(AttnParams p) 
     const int h = blockIdx.y;
     const int64_t b = blockIdx.z;
     const int q0 = blockIdx.x * QBLK + wave * 32 * NQB;
+    const int dk_row = lane >> 4, dk_c = lane & 15, dv_row = lane >> 3, dv_c = lane & 7;
+    int koff[HD / 16], voff[4];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) koff[ks] = DMA ? (((2 * ks + g) ^ (ql & 15)) << 3) : (ks * 16 + g * 8);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) voff[ks] = DMA ? (((2 * ks + g) ^ ((ql >> 1) & 7)) << 3) : (ks * 16 + g * 8);
     const unsigned long long clk0 = p.probe ? __builtin_amdgcn_s_memtime() : 0ull;
 
     bf16x8 qf[NQB][HD / 16];
@@ -777,14 +839,20 @@ __global__ __launch_bounds__(512 / NQB) void flash_attn_w4_kernel(AttnParams p) 
     bf16x8 pf[NQB][2];
 
     // prologue: K(0) -> slot 0, K(1) -> slot 1, V(0) -> slot 0; scores of unit (0, 0)
-    W4_LOAD_K(0)
-    W4_LOAD_V(0)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    W4_STORE_K(0)
-    W4_STORE_V(0)
-    W4_LOAD_K(min(1, ntiles - 1))
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    W4_STORE_K(1)
+    if (DMA) {
+        W4_DMA(0, 0, 0, true, true)
+        W4_DMA(min(1, ntiles - 1), 1, 0, true, false)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    } else {
+        W4_LOAD_K(0)
+        W4_LOAD_V(0)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        W4_STORE_K(0)
+        W4_STORE_V(0)
+        W4_LOAD_K(min(1, ntiles - 1))
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        W4_STORE_K(1)
+    }
     __syncthreads();
     float mxa[NQB], mxb[NQB];
 #pragma unroll
@@ -893,7 +961,16 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<1, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
             w4_attr = true;
         }
-        if (g_attn_variant & 512) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2>), grid, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
+        constexpr int w4dma_lds = (3 * KVBLK * HD + 2 * HD * KVBLK) * 2;
+        static bool w4d_attr = false;
+        if (!w4d_attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 6, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
+            w4d_attr = true;
+        }
+        if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 1) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 6, 2, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
+        else if ((g_attn_variant & 512) && (g_attn_variant & 2048)) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
+        else if (g_attn_variant & 512) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2>), grid, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 1) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 5, 2>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 2) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 3, 2>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 3) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 4, 3>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
