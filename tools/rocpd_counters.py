@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""Per-kernel mean of the PMC counters in a rocprofv3 (ROCm 7.2, rocpd sqlite) --pmc run.
+usage: python tools/rocpd_counters.py <results.db> [name-substring]   -> one line per (kernel, counter)"""
+import sqlite3
+import sys
+
+
+def main():
+    c = sqlite3.connect(sys.argv[1])
+    sub = sys.argv[2] if len(sys.argv) > 2 else ""
+    cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else ("name" if "name" in cols else None)
+    cnt_col = "counter_name" if "counter_name" in cols else "counter"
+    val_col = "value" if "value" in cols else "counter_value"
+    disp = "dispatch_id" if "dispatch_id" in cols else None
+    if name_col is None:
+        print("columns:", cols)
+        return
+    # a counter is reported per dimension instance (XCD / SE ...): sum them per dispatch, then average the dispatches
+    q = (f"select {name_col}, {cnt_col}, avg(v), count(*) from (select {name_col}, {cnt_col}, {disp}, sum({val_col}) as v "
+         f"from counters_collection where {name_col} like ? group by {name_col}, {cnt_col}, {disp}) group by {name_col}, {cnt_col}")
+    for name, cn, v, n in c.execute(q, (f"%{sub}%",)):
+        print(f"{name[:70]:70s} {cn:28s} mean/launch {v:.6g}  launches {n}")
+
+
+if __name__ == "__main__":
+    main()
