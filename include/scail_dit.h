@@ -1,0 +1,91 @@
+/*
+ * scail_dit.h -- network-level entry points of libscail_hip.so (seam B1: what
+ * `OpenAIWrapper.forward -> DiffusionTransformer.forward` (wrappers.py:40-45, dit_video_crossattn_sc_xc.py:1452-1587)
+ * amounts to for one sampler step), composed in C++ from the operator entry points of scail_hip.h.  No torch, no
+ * Python: a C program holding device pointers can run the denoising loop with this header alone.
+ *
+ * Ownership: the caller owns every buffer (weights, inputs, outputs, workspace, conditioning cache); the handle
+ * only keeps the configuration and COPIES OF THE POINTER TABLES (not of the weights).  All work is enqueued on the
+ * hipStream_t passed last; there is no host synchronisation, so a step can be stream-captured into a hipGraph after
+ * one warm-up call.  Return 0 / non-zero + scail_last_error().  Single sequence-parallel rank only: the per-layer
+ * exchange of the multi-GPU path lives in the host (scail_amd/parallel.py, RCCL through torch.distributed).
+ */
+#ifndef SCAIL_DIT_H
+#define SCAIL_DIT_H
+
+#include "scail_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct scail_dit_config {
+    int32_t hidden_size;       /* D, multiple of 128 */
+    int32_t num_heads;         /* D / 128 */
+    int32_t inner_hidden_size; /* FF */
+    int32_t num_layers;
+    int32_t text_dim;          /* 4096 for UMT5-XXL */
+    int32_t clip_dim;          /* 1280 */
+    int32_t time_freq_dim;     /* 256 */
+    int32_t time_embed_dim;
+    float layernorm_epsilon;   /* 1e-6 */
+} scail_dit_config;
+
+/* One transformer layer (reference state_dict keys in comments; W = bf16 [out,in], b / norm weights = fp32). */
+typedef struct scail_dit_layer {
+    const scail_bf16* qkv_w; const float* qkv_b;     /* transformer.layers.i.attention.query_key_value */
+    const scail_bf16* o_w; const float* o_b;         /* ...attention.dense */
+    const float* qn; const float* kn;                /* mixins.adaln_layer.query/key_layernorm_list.i.weight */
+    const scail_bf16* cq_w; const float* cq_b;       /* ...cross_attention.query */
+    const scail_bf16* co_w; const float* co_b;       /* ...cross_attention.dense */
+    const float* cqn;                                /* mixins.adaln_layer.cross_query_layernorm_list.i.weight */
+    const float* ln_w; const float* ln_b;            /* ...post_cross_attention_layernorm */
+    const scail_bf16* w1; const float* b1;           /* ...mlp.dense_h_to_4h */
+    const scail_bf16* w2; const float* b2;           /* ...mlp.dense_4h_to_h */
+} scail_dit_layer;
+
+typedef struct scail_dit_weights {
+    const scail_bf16* patch_w; const float* patch_b; /* mixins.patch_embed.proj, [D,128] (80 real columns, zero padded) */
+    const scail_bf16* pose_w; const float* pose_b;   /* mixins.patch_embed.proj_pose, same layout */
+    const scail_bf16* time0_w; const float* time0_b; /* time_embed.0 [Dt, freq] */
+    const scail_bf16* time2_w; const float* time2_b; /* time_embed.2 [Dt, Dt] */
+    const scail_bf16* adaln_w; const float* adaln_b; /* adaln_projection.1 [6D, Dt] */
+    const float* adaln_tables;                       /* mixins.adaln_layer.adaLN_modulations, [layers, 6D] */
+    const float* final_table;                        /* mixins.final_layer.adaLN_modulation, [2D] */
+    const scail_bf16* final_w; const float* final_b; /* mixins.final_layer.linear [64, D] */
+    const scail_dit_layer* layers;                   /* [num_layers] */
+} scail_dit_weights;
+
+/* Step-invariant conditioning (text / CLIP keys and transposed values of every layer), produced by the host once per
+ * request (scail_amd.dit.DiffusionTransformer._conditioning; dit...:1505-1515, 1116-1142). */
+typedef struct scail_dit_cond {
+    const scail_bf16* k_text;   /* [layers, B, Lt, D] */
+    const scail_bf16* vt_text;  /* [layers, B, heads, 128, ceil64(Lt)] */
+    const scail_bf16* k_clip;   /* [layers, Bc, Lc, D], Bc in {1, B} */
+    const scail_bf16* vt_clip;  /* [layers, Bc, heads, 128, ceil64(Lc)] */
+    int64_t Lt, Lc, Bc;
+} scail_dit_cond;
+
+typedef struct scail_dit scail_dit;
+
+int scail_dit_create(const scail_dit_config* cfg, const scail_dit_weights* w, scail_dit** out);
+void scail_dit_destroy(scail_dit* h);
+
+/* Bytes of caller-provided device workspace one step needs for a (B, T, H, W) latent batch. */
+int64_t scail_dit_workspace_bytes(const scail_dit* h, int64_t B, int64_t T, int64_t H, int64_t W);
+
+/*
+ * One network evaluation: out[B,T,16,H,W] fp32 = DiT(x[B,T,16,H,W] fp32, timesteps[B] fp32 (= 1000 sigma), cond, ref, pose).
+ *   ref bf16 [n_ref,1,16,H,W], pose bf16 [n_pose,T,16,H/2,W/2] (n_* in {1, B}: CFG repeat, dit...:1479-1495);
+ *   rope_cos / rope_sin fp32 [L, 64] per-token pair tables for L = (1+T)(H/2)(W/2) + T(H/4)(W/4) tokens
+ *   (scail_amd/rope.py; Rotary3DPositionEmbeddingMixin dit...:382-757);  workspace: scail_dit_workspace_bytes().
+ */
+int scail_dit_step(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
+                   const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
+                   const float* rope_cos, const float* rope_sin, float* out,
+                   int64_t B, int64_t T, int64_t H, int64_t W, void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCAIL_DIT_H */

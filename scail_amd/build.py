@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libscail_hip.so")
-SOURCES = ["errors.hip", "rowops.hip", "gemm.hip", "attn.hip", "conv.hip"]
+SOURCES = ["errors.hip", "rowops.hip", "gemm.hip", "attn.hip", "conv.hip", "dit_step.hip"]
 ARCH = "gfx950"
 # per-file extra flags.  attn.hip: keep MFMA results in arch VGPRs even in the 256-thread kernels (hipcc otherwise puts every
 # accumulator of a kernel that may use > 256 registers into AGPRs, and the softmax then reads its scores back one
@@ -34,6 +34,7 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "scail_hip.h"),
+                        os.path.join(os.path.dirname(PKG), "include", "scail_dit.h"),
                         os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 

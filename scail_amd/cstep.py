@@ -1,0 +1,94 @@
+"""Binding of the C-level step executor (include/scail_dit.h, csrc/dit_step.hip): the whole network evaluation of one
+sampler step is ONE call into libscail_hip.so -- the host only hands over device pointers.  Used by
+``DiffusionTransformer`` when ``use_c_step`` is set (single sequence-parallel rank); the Python orchestration in
+``dit._run`` stays as the multi-rank / instrumented path and as the cross-check (both enqueue the same kernels in the same
+order, so their results are bit-identical)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict
+
+import torch
+
+from . import lib as L
+
+_p, _i64 = C.c_void_p, C.c_int64
+
+
+class DitConfig(C.Structure):
+    _fields_ = [("hidden_size", C.c_int32), ("num_heads", C.c_int32), ("inner_hidden_size", C.c_int32),
+                ("num_layers", C.c_int32), ("text_dim", C.c_int32), ("clip_dim", C.c_int32),
+                ("time_freq_dim", C.c_int32), ("time_embed_dim", C.c_int32), ("layernorm_epsilon", C.c_float)]
+
+
+_LAYER_FIELDS = ["qkv_w", "qkv_b", "o_w", "o_b", "qn", "kn", "cq_w", "cq_b", "co_w", "co_b", "cqn", "ln_w", "ln_b",
+                 "w1", "b1", "w2", "b2"]
+
+
+class DitLayer(C.Structure):
+    _fields_ = [(n, _p) for n in _LAYER_FIELDS]
+
+
+class DitWeights(C.Structure):
+    _fields_ = [(n, _p) for n in ("patch_w", "patch_b", "pose_w", "pose_b", "time0_w", "time0_b", "time2_w", "time2_b",
+                                  "adaln_w", "adaln_b", "adaln_tables", "final_table", "final_w", "final_b")] + \
+               [("layers", C.POINTER(DitLayer))]
+
+
+class DitCond(C.Structure):
+    _fields_ = [("k_text", _p), ("vt_text", _p), ("k_clip", _p), ("vt_clip", _p), ("Lt", _i64), ("Lc", _i64), ("Bc", _i64)]
+
+
+class CStep:
+    """Handle around scail_dit_create / scail_dit_step for one prepared network (``net.prepare()`` dict)."""
+
+    def __init__(self, net, W: Dict):
+        L.load()
+        self._keep = W                                   # the pointer tables reference these tensors
+        cfg = DitConfig(net.hidden_size, net.num_attention_heads, net.inner_hidden_size, net.num_layers, net.text_dim,
+                        1280, net.time_freq_dim, net.time_embed_dim, float(net.layernorm_epsilon))
+        layers = (DitLayer * net.num_layers)()
+        for i, lw in enumerate(W["layers"]):
+            for n in _LAYER_FIELDS:
+                setattr(layers[i], n, lw[n].data_ptr())
+        w = DitWeights(W["patch_w"].data_ptr(), W["patch_b"].data_ptr(), W["pose_w"].data_ptr(), W["pose_b"].data_ptr(),
+                       W["time_embed.0.w"].data_ptr(), W["time_embed.0.b"].data_ptr(),
+                       W["time_embed.2.w"].data_ptr(), W["time_embed.2.b"].data_ptr(),
+                       W["adaln_projection.1.w"].data_ptr(), W["adaln_projection.1.b"].data_ptr(),
+                       W["adaln_tables"].data_ptr(), W["final_table"].data_ptr(), W["final_w"].data_ptr(),
+                       W["final_b"].data_ptr(), layers)
+        h = _p()
+        L.call("scail_dit_create", C.byref(cfg), C.byref(w), C.byref(h))
+        self._h = h
+        self._ws = None
+
+    def close(self):
+        if self._h is not None:
+            L.load().scail_dit_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workspace_bytes(self, B, T, H, W) -> int:
+        n = L.load().scail_dit_workspace_bytes(self._h, B, T, H, W)
+        if n < 0:
+            raise L.ScailHipError("scail_dit_workspace_bytes: bad shape")
+        return n
+
+    def step(self, x32, t32, cond: Dict, ref, pose, cos, sin) -> torch.Tensor:
+        B, T, _, H, W = x32.shape
+        need = self.workspace_bytes(B, T, H, W)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x32.device:
+            self._ws = torch.empty(need, device=x32.device, dtype=torch.uint8)
+        k_text, k_clip = cond["k_text"], cond["k_clip"]
+        cc = DitCond(k_text.data_ptr(), cond["vt_text"].data_ptr(), k_clip.data_ptr(), cond["vt_clip"].data_ptr(),
+                     k_text.shape[2], k_clip.shape[2], k_clip.shape[1])
+        out = torch.empty(B, T, 16, H, W, device=x32.device, dtype=torch.float32)
+        L.call("scail_dit_step", self._h, x32.data_ptr(), t32.data_ptr(), C.byref(cc), ref.data_ptr(), ref.shape[0],
+               pose.data_ptr(), pose.shape[0], cos.data_ptr(), sin.data_ptr(), out.data_ptr(), B, T, H, W,
+               self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
+        return out

@@ -19,6 +19,8 @@ inefficiencies"):
 """
 from __future__ import annotations
 
+import os
+
 import math
 from functools import reduce
 from operator import mul
@@ -126,6 +128,9 @@ class DiffusionTransformer(nn.Module):
         self.sp = None                     # scail_amd.parallel.SequenceParallel or None
         self._tap = None                   # debug/test hook: called as _tap(layer_index, hidden_states)
         self.kernel_timer = None           # bench hook: object with .run(tag, fn, *a, **k) bracketing fn with HIP events
+        # one C call per network evaluation (include/scail_dit.h) instead of ~25 ctypes calls per layer; env override
+        self.use_c_step = os.environ.get("SCAIL_C_STEP", "1") != "0"
+        self._cstep = None
 
     # ------------------------------------------------------------------------------------------
     # parameters (reference names / shapes)
@@ -276,6 +281,7 @@ class DiffusionTransformer(nn.Module):
             layers.append(lw)
         W["layers"] = layers
         self._prepared = W
+        self._cstep = None                 # pointer tables of a previous prepare() are stale
         return W
 
     # ------------------------------------------------------------------------------------------
@@ -410,6 +416,12 @@ class DiffusionTransformer(nn.Module):
             raise L.ScailHipError("context batch must equal the (CFG-doubled) input batch")
         cond = self._conditioning(ctx, clip, cond_key)
         cos, sin = self._rope(T, hp, wp, H_shift, W_shift, dev)
+        if self.use_c_step and self._tap is None and self.kernel_timer is None and not (self.sp is not None and self.sp.size > 1):
+            # the whole evaluation as ONE call into the library (include/scail_dit.h); same kernels, same order
+            if self._cstep is None:
+                from .cstep import CStep
+                self._cstep = CStep(self, W)
+            return self._cstep.step(x32, t32, cond, ref.contiguous(), pose.contiguous(), cos, sin)
         ws = self._workspace(B, Ltok, Lnoise, dev)
 
         # ---- time / AdaLN tables (reference :1521-1555, :1025-1028, :823) ----

@@ -1,4 +1,4 @@
-"""ctypes binding of libscail_hip.so (include/scail_hip.h).  Fails loudly when the library is
+"""ctypes binding of libscail_hip.so (include/scail_hip.h, include/scail_dit.h).  Fails loudly when the library is
 missing -- there is deliberately no fallback path."""
 from __future__ import annotations
 
@@ -42,7 +42,14 @@ SIGNATURES = {
     "scail_debug_cycles": [C.c_void_p, _i],
     "scail_f32_to_bf16": [_p, _p, _i64, _p],
     "scail_bf16_to_f32": [_p, _p, _i64, _p],
+    # include/scail_dit.h (structs are passed by pointer; scail_amd/cstep.py builds them)
+    "scail_dit_create": [_p, _p, _p],
+    "scail_dit_destroy": [_p],
+    "scail_dit_workspace_bytes": [_p, _i64, _i64, _i64, _i64],
+    "scail_dit_step": [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p],
 }
+# return types other than the int status
+RESTYPES = {"scail_dit_destroy": None, "scail_dit_workspace_bytes": _i64}
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2
@@ -74,7 +81,7 @@ def load() -> C.CDLL:
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args
-        fn.restype = C.c_int
+        fn.restype = RESTYPES.get(name, C.c_int)
     _lib = lib
     for env, knob in (("SCAIL_ATTN_VARIANT", b"attn_variant"), ("SCAIL_GEMM_TILE", b"gemm_tile")):   # A/B overrides for test runs
         if os.environ.get(env):

@@ -1,5 +1,5 @@
 """CPU-only checks of the drop-in boundary: the C-ABI library builds, loads without a GPU and exports
-every symbol include/scail_hip.h declares; the ctypes table covers the same set; the product path
+every symbol include/*.h declares; the ctypes table covers the same set; the product path
 refuses to run without a GPU instead of silently falling back."""
 import ctypes
 import os
@@ -11,10 +11,16 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+HEADERS = ["scail_hip.h", "scail_dit.h"]
+
+
+def _header_source():
+    src = "\n".join(open(os.path.join(ROOT, "include", h)).read() for h in HEADERS)
+    return re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+
 def _header_symbols():
-    src = open(os.path.join(ROOT, "include", "scail_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(scail_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(scail_[a-z0-9_]+)\s*\(", _header_source())))
 
 
 @pytest.fixture(scope="module")
@@ -35,9 +41,9 @@ def test_ctypes_table_matches_header(libpath):
     from scail_amd import lib as L
     declared = set(_header_symbols()) - {"scail_last_error", "scail_abi_version"}
     assert set(L.SIGNATURES) == declared
-    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "scail_hip.h")).read(), flags=re.S)
+    src = _header_source()
     for name, args in L.SIGNATURES.items():
-        m = re.search(r"int\s+" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        m = re.search(r"(?:int|void|int64_t)\s+" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
         assert m, name
         assert len([a for a in m.group(1).split(",") if a.strip()]) == len(args), name
     lib = L.load()
@@ -52,6 +58,9 @@ def test_argument_validation_without_gpu(libpath):
         L.call("scail_gemm_bf16", None, 72, None, None, None, 16, 8, 16, 72, 0, None, 0, None, 0, 0, None)
     with pytest.raises(L.ScailHipError, match="M must be <= 8"):
         L.call("scail_small_linear", None, None, None, None, 9, 8, 8, 0, 0, None)
+    with pytest.raises(L.ScailHipError, match="null argument"):
+        L.call("scail_dit_create", None, None, None)
+    assert L.load().scail_dit_workspace_bytes(None, 2, 4, 8, 8) == -1
     with pytest.raises(L.ScailHipError, match="unknown epilogue"):
         L.call("scail_gemm_bf16", None, 64, None, None, None, 16, 8, 16, 64, 99, None, 0, None, 0, 0, None)
 

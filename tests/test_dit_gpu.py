@@ -61,6 +61,38 @@ def test_dit_forward_vs_reference_golden(golden_dir, name, cfgd):
     assert _cos(out.float().cpu(), g["out"]) >= 0.999
 
 
+@pytest.mark.parametrize("name,cfgd", [("dit_tiny.npz", O.TINY), ("dit_config1.npz", O.CONFIG1)])
+def test_c_step_executor_equals_host_orchestration_and_golden(golden_dir, name, cfgd):
+    """include/scail_dit.h: the whole evaluation as one C call.  It enqueues the same kernels in the same order as the
+    Python orchestration, so the two must agree BIT FOR BIT; and it must match the reference golden like the other path.
+    A captured hipGraph of the step must replay to the same result (no host sync inside the call)."""
+    g = _load(golden_dir, name)
+    cfg, sd, net = _net(cfgd, int(g["seed"]))
+    kw = dict(concat_images=torch.zeros(1, *g["x"].shape[1:], device=DEV), ref_concat=g["ref"].to(DEV),
+              concat_smpl_render=g["pose"].to(DEV), image_clip_features=g["clip"].to(DEV))
+    x, t, ctx = g["x"].to(DEV), g["t"].to(DEV), g["ctx"].to(DEV)
+    net.use_c_step = False
+    o_py = net.forward_f32(x, t, ctx, None, **kw)
+    net.use_c_step = True
+    o_c = net.forward_f32(x, t, ctx, None, **kw)
+    assert net._cstep is not None, "the C executor was not used"
+    assert torch.equal(o_c, o_py)
+    torch.testing.assert_close(o_c.cpu(), g["out"], rtol=2e-2, atol=2e-2)
+    # stream capture -> graph replay
+    # (cond_key: the conditioning cache is then matched by key, not by a device-side tensor comparison that would sync)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        net.forward_f32(x, t, ctx, None, cond_key="graph", **kw)   # warm-up on the capture stream (lazy attribute setup)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        o_g = net.forward_f32(x, t, ctx, None, cond_key="graph", **kw)
+    o_g.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o_g, o_py)
+
+
 def test_dit_conditioning_cache_and_batch_of_one(golden_dir):
     """Same inputs twice (cache hit) and a changed prompt (cache miss) must both be right."""
     g = _load(golden_dir, "dit_tiny.npz")
