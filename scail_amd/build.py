@@ -12,9 +12,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libscail_hip.so")
 SOURCES = ["errors.hip", "rowops.hip", "gemm.hip", "attn.hip", "conv.hip", "dit_step.hip"]
 ARCH = "gfx950"
-# per-file extra flags.  attn.hip: keep MFMA results in arch VGPRs even in the 256-thread kernels (hipcc otherwise puts every
-# accumulator of a kernel that may use > 256 registers into AGPRs, and the softmax then reads its scores back one
-# v_accvgpr_read at a time); kernels with <= 256 registers per wave are unaffected.
+# per-file extra flags (e.g. {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]} keeps MFMA results of the 256-thread
+# attention variants in arch VGPRs; measured, not needed by any default kernel)
 EXTRA_FLAGS = {}
 
 

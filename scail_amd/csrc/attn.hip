@@ -588,34 +588,50 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
 // LDS staging, slots and the barrier stay per 64-key tile.
 // ================================================================================================
 // scores of half F_ (keys 32 F_ .. +31) of the tile in K slot slot_, both query blocks
-#define W4_QK(S_, slot_, F_)                                                                      \
+#define W4_K_ISSUE(slot_, F_)                                                                     \
+    {                                                                                             \
+        const u16* ks_ = Ks + ((slot_) * KVBLK + 32 * (F_) + ql) * KLD;                           \
+        _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks)                                    \
+            kfr[ks] = *reinterpret_cast<const bf16x8*>(ks_ + koff[ks]);                           \
+    }
+#define W4_QK_MFMA(S_)                                                                            \
     {                                                                                             \
         _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                        \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) S_[qb][e] = 0.f;                       \
-        const u16* ks_ = Ks + ((slot_) * KVBLK + 32 * (F_) + ql) * KLD;                           \
-        bf16x8 kfr_[HD / 16];   /* all 8 fragments requested before the first MFMA */             \
-        _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks)                                    \
-            kfr_[ks] = *reinterpret_cast<const bf16x8*>(ks_ + koff[ks]);                          \
         _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks) {                                  \
             _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                    \
-                S_[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr_[ks], qf[qb][ks], S_[qb], 0, 0, 0); \
+                S_[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[qb][ks], S_[qb], 0, 0, 0); \
         }                                                                                         \
     }
+#define W4_QK(S_, slot_, F_) W4_K_ISSUE(slot_, F_) W4_QK_MFMA(S_)
 // O += V^T[:, keys of half F_] . P^T
-#define W4_PV(slot_, F_)                                                                          \
+#define W4_V_ISSUE(slot_, F_)                                                                     \
     {                                                                                             \
         const u16* vs_ = Vs + ((slot_) * HD + ql) * VLD;                                          \
-        bf16x8 vfr_[2][HD / 32];                                                                  \
         _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                          \
             _Pragma("unroll") for (int d = 0; d < HD / 32; ++d)                                   \
-                vfr_[k2][d] = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * VLD + voff[2 * (F_) + k2]); \
+                vfr[k2][d] = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * VLD + voff[2 * (F_) + k2]); \
+    }
+// AO (4-wave kernel): the P.V MFMAs are written as inline asm with the accumulators constrained to AGPRs, the QK^T MFMAs
+// stay builtins compiled in VGPR form (-mllvm -amdgpu-mfma-vgpr-form, scail_amd/build.py): O (128 registers, touched only
+// by these MFMAs and the rare rescale) lives in AGPRs, the scores the softmax VALU works on in arch VGPRs.  hipcc alone
+// puts either everything (default for > 256-register kernels: every softmax operand then goes through v_accvgpr_read,
+// which interlocks with the matrix pipe) or nothing into AGPRs.  Hazards: back-to-back accumulation into the same
+// vDst needs no software wait; the epilogue's reads of O are preceded by explicit s_nops (W4_AO_DRAIN).
+#define W4_PV_MFMA()                                                                              \
+    {                                                                                             \
         _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                                        \
             _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) {                                 \
-                _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                \
-                    o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr_[k2][d], pf[qb][k2], o[qb][d], 0, 0, 0); \
+                _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) {                              \
+                    if (AO) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"                \
+                                         : "+a"(o[qb][d]) : "v"(vfr[k2][d]), "v"(pf[qb][k2]));    \
+                    else o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[k2][d], pf[qb][k2], o[qb][d], 0, 0, 0); \
+                }                                                                                 \
             }                                                                                     \
         }                                                                                         \
     }
+#define W4_AO_DRAIN asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+#define W4_PV(slot_, F_) W4_V_ISSUE(slot_, F_) W4_PV_MFMA()
 // 1024 K chunks + 1024 V^T chunks of 16 B per tile, 4 + 4 per thread
 #define W4_LOAD_K(tt_)                                                                                    \
     {                                                                                                     \
@@ -710,7 +726,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
 // read-multiply-write per register so that this cold block needs ONE temporary instead of pulling all 128 accumulators
 // into VGPRs at once (which made hipcc spill loop invariants of the hot path to scratch).
 #define W4_RESCALE(acc_, a_)                                                                      \
-    if (NQB == 2) {                                                                               \
+    if (AO) {                                                                               \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                          \
             float t_, c_ = acc_[e];                                                               \
             asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_mul_f32 %0, %0, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %1, %0\n\ts_nop 1" \
@@ -721,21 +737,38 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
         _Pragma("unroll") for (int e = 0; e < 16; ++e) acc_[e] *= a_;                             \
     }
 // one unit: SC_ = masked scores of (T_, F_) with row max MXC_; SN_/MXN_ = the NEXT unit (NT_, NF_) in K slot NSLOT_
-#define W4_UNIT(SC_, SN_, MXC_, MXN_, T_, F_, NT_, NF_, NSLOT_, HAS_NEXT_)                         \
+#define W4_UNIT(SC_, SN_, MXC_, MXN_, T_, F_, NT_, NF_, NSLOT_, HAS_NEXT_, N2SLOT_, N2F_, HAS_N2_)   \
     {                                                                                              \
-        if (HAS_NEXT_) W4_QK(SN_, NSLOT_, NF_)                                                     \
+        if (XPF) {   /* operands of a block are requested one block earlier (see W4 header comment) */ \
+            W4_V_ISSUE((T_) & 1, F_)                                                               \
+            if (HAS_NEXT_) W4_QK_MFMA(SN_)                                                         \
+        } else {                                                                                   \
+            if (HAS_NEXT_) W4_QK(SN_, NSLOT_, NF_)                                                 \
+        }                                                                                          \
         W4_SOFTMAX(SC_, MXC_)                                                                      \
         if (HAS_NEXT_) { W4_PIPE(GA) }                                                             \
         _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) { SWP_PIN(pf[qb][0]) SWP_PIN(pf[qb][1]) } \
+        if (XPF) {                                                                                 \
+            _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                       \
+                _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) SWP_PIN(vfr[k2][d])            \
+        }                                                                                          \
         if (moved_) {                                                                              \
             _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                       \
                 _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) W4_RESCALE(o[qb][d], alpha_[qb]) \
         }                                                                                          \
         if (HAS_NEXT_) W4_MASK(SN_, NT_, NF_)                                                      \
-        W4_PV((T_) & 1, F_)                                                                        \
+        if (XPF) {                                                                                 \
+            if (HAS_N2_) W4_K_ISSUE(N2SLOT_, N2F_)                                                 \
+            W4_PV_MFMA()                                                                           \
+        } else {                                                                                   \
+            W4_PV((T_) & 1, F_)                                                                    \
+        }                                                                                          \
         if (HAS_NEXT_) {                                                                           \
             W4_ROWMAX(SN_, MXN_)                                                                   \
             W4_PIPE(GB)                                                                            \
+        }                                                                                          \
+        if (XPF && (HAS_N2_)) {                                                                    \
+            _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks) SWP_PIN(kfr[ks])                \
         }                                                                                          \
     }
 // LDS-DMA staging (DMA = true): K piece j = rows 4j..4j+3 (lane -> row 4j + (l >> 4), chunk l & 15), V^T piece j = rows
@@ -774,8 +807,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
             W4_LOAD_K(min((T_) + 2, ntiles - 1))                                                   \
             W4_LOAD_V(min((T_) + 1, ntiles - 1))                                                   \
         }                                                                                          \
-        W4_UNIT(sa, sb, mxa, mxb, T_, 0, T_, 1, kc_, true)                                         \
-        W4_UNIT(sb, sa, mxb, mxa, T_, 1, (T_) + 1, 0, kn_, HAS_NEXT_)                              \
+        W4_UNIT(sa, sb, mxa, mxb, T_, 0, T_, 1, kc_, true, kn_, 0, HAS_NEXT_)                      \
+        W4_UNIT(sb, sa, mxb, mxa, T_, 1, (T_) + 1, 0, kn_, HAS_NEXT_, kn_, 1, HAS_NEXT_)           \
         if (DMA) {                                                                                 \
             __builtin_amdgcn_s_waitcnt(0x0F70);                                                    \
         } else {                                                                                   \
@@ -785,7 +818,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
         __syncthreads();                                                                           \
     }
 
-template <int NQB, int GA, int GB, bool DMA = false>   // NQB query blocks of 32 rows per wave: 2 -> 4 waves (one per SIMD), 1 -> 8 waves
+template <int NQB, int GA, int GB, bool DMA = false, bool XPF = false, bool AO = false>   // NQB query blocks of 32 rows per wave: 2 -> 4 waves (one per SIMD), 1 -> 8 waves;
+                                                                         // XPF: the K / V^T fragments of a block are read from LDS during the PREVIOUS block
 __global__ __launch_bounds__(512 / NQB) void flash_attn_w4_kernel(AttnParams p) {
     constexpr int NTH = 512 / NQB, KR = NTH / 16, VR = NTH / 8;   // threads, tile rows per staging pass
     constexpr int KLD = DMA ? HD : K_LD, VLD = DMA ? KVBLK : V_LD, NKS = DMA ? 3 : 2, PPW = 2 * NQB;
@@ -837,6 +871,7 @@ __global__ __launch_bounds__(512 / NQB) void flash_attn_w4_kernel(AttnParams p) 
     for (int qb = 0; qb < NQB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
     f32x16 sa[NQB], sb[NQB];
     bf16x8 pf[NQB][2];
+    bf16x8 kfr[HD / 16], vfr[2][HD / 32];     // K fragments of one 32-key half, V^T fragments of one half
 
     // prologue: K(0) -> slot 0, K(1) -> slot 1, V(0) -> slot 0; scores of unit (0, 0)
     if (DMA) {
@@ -860,10 +895,12 @@ __global__ __launch_bounds__(512 / NQB) void flash_attn_w4_kernel(AttnParams p) 
     W4_QK(sa, 0, 0)
     W4_MASK(sa, 0, 0)
     W4_ROWMAX(sa, mxa)
+    if (XPF) W4_K_ISSUE(0, 1)      // fragments of unit (0, 1), consumed by the first block of the loop
 
     int t = 0;
     for (; t + 1 < ntiles; ++t) W4_TILE(t, true)
     W4_TILE(t, false)
+    if (AO) { W4_AO_DRAIN }
 
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
@@ -966,9 +1003,17 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         if (!w4d_attr) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 6, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
             w4d_attr = true;
         }
-        if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 1) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 6, 2, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
+        if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 4) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, true, true, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
+        else if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 5) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, true, false, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
+        else if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 2) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, true, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
+        else if ((g_attn_variant & 512) && sub == 3) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, false, true>), grid, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
+        else if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 1) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 6, 2, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
         else if ((g_attn_variant & 512) && (g_attn_variant & 2048)) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
         else if (g_attn_variant & 512) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2>), grid, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 1) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 5, 2>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
