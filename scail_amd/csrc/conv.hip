@@ -181,6 +181,159 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Halo-tile kernel for the 3x3x3 stride-1 causal convolutions (all ResidualBlock convs: 26 of the 33 decoder convs).
+// The gather kernel above fetches every input voxel once per tap (27x) and restages it through registers; here a
+// workgroup owns an 8 x 16 block of ONE output frame, keeps the 3-frame (8+2) x (16+2) input patch of a CS-channel
+// slice resident in LDS and reads the A fragments of every tap straight from it at the tap's offset: the patch is
+// loaded once per slice (3.4x the block's own voxels instead of 27x) and never restaged.  Only the weights stream:
+// per (dt, dh) "tap row" a [96 x (3 taps x CS k)] tile, register-staged.  4 waves, wave = 32 voxels (2 rows of the
+// block) x 96 output channels.  Patch voxels and W rows are padded by 16 B: 16 consecutive voxels / rows start in 16
+// distinct 16-byte bank groups.
+//   CS = 48, two W buffers (one barrier per tap row, 27 MFMAs per wave between barriers): 118.8 KB LDS, 1 workgroup / CU
+//   CS = 32, one W buffer (two barriers per tap row, 18 MFMAs):                             63.2 KB LDS, 2 workgroups / CU
+// ------------------------------------------------------------------------------------------------
+#define HT_TH 8
+#define HT_TW 16
+#define HT_BN 96
+#define HT_PVOX (3 * (HT_TH + 2) * (HT_TW + 2))
+template <int CS, int NWB> struct HaloCfg {
+    static constexpr int PS = CS + 8, WS = 3 * CS + 8;                     // strides in elements
+    static constexpr int PCH = HT_PVOX * (CS / 8), WCH = HT_BN * 3 * (CS / 8);
+    static constexpr int NP = (PCH + 255) / 256, NWL = (WCH + 255) / 256;  // chunks per thread
+    static constexpr int LDS = (HT_PVOX * PS + NWB * HT_BN * WS) * 2;
+};
+
+template <int EPI, int CS, int NWB>
+__global__ __launch_bounds__(256, (NWB == 1 ? 2 : 1)) void conv_halo_kernel(ConvParams p) {
+    using Cfg = HaloCfg<CS, NWB>;
+    constexpr int PS = Cfg::PS, WS = Cfg::WS, PCH = Cfg::PCH, WCH = Cfg::WCH, NP = Cfg::NP, NWL = Cfg::NWL, CPV = CS / 8;
+    static_assert(NP <= 13 && NWL <= 7, "staging register sets below");
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Ps = smem;                          // [3][TH+2][TW+2][PS]
+    u16* Ws = smem + HT_PVOX * PS;           // [NWB][BN][WS]
+
+    const int tiles_n = (p.N + HT_BN - 1) / HT_BN;
+    const int tiles_w = (p.Wo + HT_TW - 1) / HT_TW, tiles_h = (p.Ho + HT_TH - 1) / HT_TH;
+    int bid = blockIdx.x;
+    const int tn = bid % tiles_n; bid /= tiles_n;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h;
+    const int to = bid / tiles_h;
+    const int n0 = tn * HT_BN, h0 = th * HT_TH, w0 = tw * HT_TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, g = lane >> 5;
+
+    // ---- patch chunk c = tid + 256 i: voxel = c / CPV, 16-byte channel chunk = c % CPV ----
+#define HT_PDECL(i_)                                                                                   \
+    const int pc##i_ = tid + 256 * i_;                                                                 \
+    int64_t psrc##i_ = -1; int pdst##i_ = 0;                                                           \
+    if (i_ < NP && pc##i_ < PCH) {                                                                     \
+        const int vox_ = pc##i_ / CPV, ch_ = pc##i_ - vox_ * CPV;                                      \
+        const int dt_ = vox_ / ((HT_TH + 2) * (HT_TW + 2)), rem_ = vox_ - dt_ * ((HT_TH + 2) * (HT_TW + 2)); \
+        const int rr_ = rem_ / (HT_TW + 2), cc_ = rem_ - rr_ * (HT_TW + 2);                            \
+        const int ti_ = to + dt_ - p.pt, hi_ = h0 + rr_ - p.ph, wi_ = w0 + cc_ - p.pw;                 \
+        if (ti_ >= 0 && ti_ < p.Ti && hi_ >= 0 && hi_ < p.Hi && wi_ >= 0 && wi_ < p.Wi)                \
+            psrc##i_ = (((int64_t)ti_ * p.Hi + hi_) * p.Wi + wi_) * p.Cin + ch_ * 8;                   \
+        pdst##i_ = vox_ * PS + ch_ * 8;                                                                \
+    }                                                                                                  \
+    uint4 pr##i_ = make_uint4(0, 0, 0, 0);
+    HT_PDECL(0) HT_PDECL(1) HT_PDECL(2) HT_PDECL(3) HT_PDECL(4) HT_PDECL(5) HT_PDECL(6)
+    HT_PDECL(7) HT_PDECL(8) HT_PDECL(9) HT_PDECL(10) HT_PDECL(11) HT_PDECL(12)
+#define HT_PLOAD(i_, c0_) if (i_ < NP) pr##i_ = (psrc##i_ >= 0) ? *reinterpret_cast<const uint4*>(p.x + psrc##i_ + (c0_)) : make_uint4(0, 0, 0, 0);
+#define HT_PSTORE(i_) if (i_ < NP && pc##i_ < PCH) *reinterpret_cast<uint4*>(Ps + pdst##i_) = pr##i_;
+#define HT_P13(M_, ...) M_(0, ##__VA_ARGS__) M_(1, ##__VA_ARGS__) M_(2, ##__VA_ARGS__) M_(3, ##__VA_ARGS__) M_(4, ##__VA_ARGS__) \
+    M_(5, ##__VA_ARGS__) M_(6, ##__VA_ARGS__) M_(7, ##__VA_ARGS__) M_(8, ##__VA_ARGS__) M_(9, ##__VA_ARGS__)                    \
+    M_(10, ##__VA_ARGS__) M_(11, ##__VA_ARGS__) M_(12, ##__VA_ARGS__)
+
+    // ---- W chunk c = tid + 256 i of a tap row: n = c / (3 CPV), dw = (c % (3 CPV)) / CPV, 16-byte chunk = c % CPV ----
+#define HT_WDECL(i_)                                                                                   \
+    const int wc##i_ = tid + 256 * i_;                                                                 \
+    const int wn##i_ = wc##i_ / (3 * CPV), wrem##i_ = wc##i_ - wn##i_ * (3 * CPV), wdw##i_ = wrem##i_ / CPV, wch##i_ = wrem##i_ - wdw##i_ * CPV; \
+    const u16* wsrc##i_ = p.w + (int64_t)min(n0 + wn##i_, p.N - 1) * p.Kpad + wdw##i_ * p.Cin + wch##i_ * 8; \
+    const int wdst##i_ = wn##i_ * WS + wdw##i_ * CS + wch##i_ * 8;                                     \
+    uint4 wr##i_ = make_uint4(0, 0, 0, 0);
+    HT_WDECL(0) HT_WDECL(1) HT_WDECL(2) HT_WDECL(3) HT_WDECL(4) HT_WDECL(5) HT_WDECL(6)
+#define HT_WLOAD(i_, k0_) if (i_ < NWL && wc##i_ < WCH) wr##i_ = *reinterpret_cast<const uint4*>(wsrc##i_ + (k0_));
+#define HT_WSTORE(i_, buf_) if (i_ < NWL && wc##i_ < WCH) *reinterpret_cast<uint4*>(Ws + (buf_) * HT_BN * WS + wdst##i_) = wr##i_;
+#define HT_W7(M_, ...) M_(0, ##__VA_ARGS__) M_(1, ##__VA_ARGS__) M_(2, ##__VA_ARGS__) M_(3, ##__VA_ARGS__) M_(4, ##__VA_ARGS__) \
+    M_(5, ##__VA_ARGS__) M_(6, ##__VA_ARGS__)
+
+    // ---- fragment bases ----
+    const int vloc = wave * 32 + l31;                                // voxel of the block: row vloc >> 4, col vloc & 15
+    const u16* pa = Ps + ((vloc >> 4) * (HT_TW + 2) + (vloc & 15)) * PS + g * 8;
+    const u16* wb = Ws + l31 * WS + g * 8;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+
+    const int nslice = p.Cin / CS;
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int c0 = sl * CS;
+        HT_P13(HT_PLOAD, c0)
+        HT_W7(HT_WLOAD, c0)                          // tap row 0 of this slice
+        __syncthreads();                             // every wave is done with the previous slice's patch and W tile
+        HT_P13(HT_PSTORE)
+        HT_W7(HT_WSTORE, 0)
+        __syncthreads();
+#pragma unroll 1
+        for (int row = 0; row < 9; ++row) {          // row = dt * 3 + dh
+            const int cur = (NWB == 2) ? (row & 1) : 0;
+            if (row + 1 < 9) { HT_W7(HT_WLOAD, (row + 1) * 3 * p.Cin + c0) }
+            const int dt = row / 3, dh = row - dt * 3;
+            const u16* pr_ = pa + ((dt * (HT_TH + 2) + dh) * (HT_TW + 2)) * PS;
+            const u16* wr_ = wb + cur * HT_BN * WS;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+                for (int ks = 0; ks < CS / 16; ++ks) {
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(pr_ + dw * PS + ks * 16);
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr_ + nb * 32 * WS + dw * CS + ks * 16);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nb], 0, 0, 0);
+                    }
+                }
+            if (NWB == 1) __syncthreads();           // single buffer: every wave has read this row's tile
+            if (row + 1 < 9) { HT_W7(HT_WSTORE, (NWB == 2) ? (cur ^ 1) : 0) }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane = voxel vloc, rows n = n0 + nb * 32 + 8 rr + 4 g + e ----
+    const int ho = h0 + (vloc >> 4), wo = w0 + (vloc & 15);
+    if (ho < p.Ho && wo < p.Wo) {
+        const int64_t vox = ((int64_t)(to * p.ot_mul + p.ot_off) * p.Ho + ho) * p.Wo + wo;
+#pragma unroll
+        for (int nb = 0; nb < 3; ++nb) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int n = n0 + nb * 32 + 8 * rr + 4 * g;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[nb][4 * rr + e];
+                if (p.bias != nullptr) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (EPI == 3) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(p.resid + vox * p.ldr + n);
+                    v[0] += bf_lo(rv.x); v[1] += bf_hi(rv.x); v[2] += bf_lo(rv.y); v[3] += bf_hi(rv.y);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(p.y + vox * p.ldc + n) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // RMS_norm over channels (F.normalize * sqrt(C) * gamma, wan_vae.py:39-54) + optional SiLU.
 // LPV lanes per voxel (power of two >= C/8), 64/LPV voxels per wave.
 // ------------------------------------------------------------------------------------------------
@@ -308,6 +461,9 @@ __global__ void from_channels_last_kernel(const u16* __restrict__ x, int64_t ldx
 // ================================================================================================
 // C ABI
 // ================================================================================================
+static int g_conv_halo = 2;
+int scail_conv_tune(int v) { g_conv_halo = v; return 0; }
+
 extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
                                const scail_bf16* resid, int64_t ldr, const int32_t* geom, void* stream) {
     // geom: Ti Hi Wi Cin | To Ho Wo | kt kh kw | st sh sw | pt ph pw | ups | ot_mul ot_off | N Kpad
@@ -329,6 +485,34 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
                       (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0,
                   "pointer alignment");
     if (p.M == 0) return 0;
+    // 3x3x3 stride-1 causal convolutions: halo-tile kernel.  Knob conv_halo: 0 off, 1 = 48-channel slices / 1 workgroup
+    // per CU, 2 = 32-channel slices / 2 workgroups per CU (default)
+    if (g_conv_halo && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups &&
+        p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi && p.N >= 48 &&
+        p.Cin % ((g_conv_halo == 1) ? 48 : 32) == 0) {
+#define HALO_LAUNCH(EPI_, CS_, NWB_)                                                                               \
+    {                                                                                                              \
+        constexpr int lds_ = HaloCfg<CS_, NWB_>::LDS;                                                              \
+        static bool attr_ = false;                                                                                 \
+        if (!attr_) {                                                                                              \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<EPI_, CS_, NWB_>),             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) {             \
+                scail_set_error("conv3d: hipFuncSetAttribute failed");                                             \
+                return 2;                                                                                          \
+            }                                                                                                      \
+            attr_ = true;                                                                                          \
+        }                                                                                                          \
+        hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
+    }
+        const int64_t tiles = (int64_t)p.To * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW) * ((p.N + HT_BN - 1) / HT_BN);
+        SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
+        if (g_conv_halo == 1) {
+            if (resid != nullptr) HALO_LAUNCH(3, 48, 2) else HALO_LAUNCH(0, 48, 2)
+        } else {
+            if (resid != nullptr) HALO_LAUNCH(3, 32, 1) else HALO_LAUNCH(0, 32, 1)
+        }
+        return scail_check_launch("conv3d_cl");
+    }
     // N tile: of 128 / 96 / 64 the one with the fewest padding columns (ties -> the wider tile)
     int bn = 128;
     {

@@ -32,11 +32,23 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm()))
 
 
-@pytest.mark.parametrize("cin,cout,k", [(16, 32, (3, 3, 3)), (96, 96, (3, 3, 3)), (96, 192, (1, 1, 1)), (32, 64, (3, 1, 1)), (8, 96, (3, 3, 3))])
-def test_causal_conv3d(cin, cout, k):
+@pytest.fixture(params=[2, 1, 0])
+def conv_halo(request):
+    """every path of the 3x3x3 convolution: halo-tile kernel with 32-channel slices (default), 48-channel slices, gather kernel"""
+    from scail_amd import lib as L
+    L.tune_set("conv_halo", request.param)
+    yield request.param
+    L.tune_set("conv_halo", 2)
+
+
+@pytest.mark.parametrize("cin,cout,k,thw", [(16, 32, (3, 3, 3), (5, 10, 12)), (96, 96, (3, 3, 3), (5, 10, 12)),
+                                           (96, 192, (1, 1, 1), (5, 10, 12)), (32, 64, (3, 1, 1), (5, 10, 12)),
+                                           (8, 96, (3, 3, 3), (5, 10, 12)), (192, 96, (3, 3, 3), (3, 17, 35)),
+                                           (96, 200, (3, 3, 3), (2, 8, 16)), (64, 48, (3, 3, 3), (4, 9, 33))])
+def test_causal_conv3d(cin, cout, k, thw, conv_halo):
     from scail_amd import ops
     g = torch.Generator().manual_seed(0)
-    T, H, W = 5, 10, 12
+    T, H, W = thw
     x = bfr(torch.randn(cin, T, H, W, generator=g))
     w = bfr(torch.randn(cout, cin, *k, generator=g) / (cin * k[0] * k[1] * k[2]) ** 0.5)
     b = torch.randn(cout, generator=g)
