@@ -337,32 +337,59 @@ __global__ __launch_bounds__(256, (NWB == 1 ? 2 : 1)) void conv_halo_kernel(Conv
 // RMS_norm over channels (F.normalize * sqrt(C) * gamma, wan_vae.py:39-54) + optional SiLU.
 // LPV lanes per voxel (power of two >= C/8), 64/LPV voxels per wave.
 // ------------------------------------------------------------------------------------------------
+// LPV lanes per voxel (power of two), CPL 16-byte chunks per lane (lane j owns chunks j, j + LPV, ...: C = 96 -> 4 lanes
+// x 3 chunks, all lanes busy), VPT voxels per lane group with every load issued before the first use.
+template <int CPL, int VPT>
 __global__ __launch_bounds__(256) void rms_silu_kernel(const u16* __restrict__ x, u16* __restrict__ y,
                                                        const float* __restrict__ gamma, int64_t nvox, int C,
                                                        int lpv_log2, int silu) {
     const int lpv = 1 << lpv_log2;
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t vox = gtid >> lpv_log2;
+    const int64_t vox0 = (gtid >> lpv_log2) * VPT;
     const int sub = (int)(gtid & (lpv - 1));
     const int nch = C >> 3;
-    const bool act = vox < nvox && sub < nch;
-    float v[8];
-    float q = 0.f;
-    if (act) {
-        unpack8(*reinterpret_cast<const uint4*>(x + vox * C + sub * 8), v);
+    uint4 raw[VPT][CPL];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q += v[e] * v[e];
-    }
-    for (int o = 1; o < lpv; o <<= 1) q += __shfl_xor(q, o, 64);
-    if (!act) return;
-    const float inv = sqrtf((float)C) / fmaxf(sqrtf(q), 1e-12f);
-    float o8[8];
+    for (int j = 0; j < VPT; ++j)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float t = v[e] * inv * gamma[sub * 8 + e];
-        o8[e] = silu ? silu_f(t) : t;
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = sub + c * lpv;
+            raw[j][c] = (vox0 + j < nvox && ch < nch) ? *reinterpret_cast<const uint4*>(x + (vox0 + j) * C + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    float gm[CPL][8];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = min(sub + c * lpv, nch - 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gm[c][e] = gamma[ch * 8 + e];
     }
-    *reinterpret_cast<uint4*>(y + vox * C + sub * 8) = pack8(o8);
+    const float sC = sqrtf((float)C);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        float v[CPL][8];
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            unpack8(raw[j][c], v[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q += v[c][e] * v[c][e];
+        }
+        for (int o = 1; o < lpv; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float inv = sC / fmaxf(sqrtf(q), 1e-12f);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = sub + c * lpv;
+            if (vox0 + j < nvox && ch < nch) {
+                float o8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = v[c][e] * inv * gm[c][e];
+                    o8[e] = silu ? silu_f(t) : t;
+                }
+                *reinterpret_cast<uint4*>(y + (vox0 + j) * C + ch * 8) = pack8(o8);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -550,11 +577,19 @@ extern "C" int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* g
                               void* stream) {
     SCAIL_REQUIRE(C % 8 == 0 && C <= 512, "C must be a multiple of 8, <= 512");
     if (nvox == 0) return 0;
+    // lanes per voxel: 3 chunks per lane when the chunk count is 3 x 2^k (96, 192, 384 channels), else 1 chunk per lane
+    const int nch = (int)(C / 8);
+    const bool three = nch % 3 == 0 && ((nch / 3) & (nch / 3 - 1)) == 0;
+    const int lanes = three ? nch / 3 : nch;
     int lg = 0;
-    while ((8 << lg) < C) ++lg;
-    const int64_t threads = nvox << lg;
-    hipLaunchKernelGGL(rms_silu_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y,
-                       gamma, nvox, (int)C, lg, silu);
+    while ((1 << lg) < lanes) ++lg;
+    constexpr int VPT = 2;
+    const int64_t threads = ((nvox + VPT - 1) / VPT) << lg;
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (three)
+        hipLaunchKernelGGL((rms_silu_kernel<3, VPT>), grid, dim3(256), 0, (hipStream_t)stream, x, y, gamma, nvox, (int)C, lg, silu);
+    else
+        hipLaunchKernelGGL((rms_silu_kernel<1, VPT>), grid, dim3(256), 0, (hipStream_t)stream, x, y, gamma, nvox, (int)C, lg, silu);
     return scail_check_launch("rms_silu");
 }
 
