@@ -128,3 +128,41 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     assert all(torch.equal(a.state_dict()[k], b.state_dict()[k]) for k in keys)
     with pytest.raises(ValueError, match="metadata"):
         checkpoint.load_checkpoint(b, str(tmp_path / "nope"))
+
+
+def test_more_argument_validation_without_gpu(libpath):
+    """Every entry point validates shapes / strides / alignment on the host before touching the device."""
+    import ctypes as C
+    from scail_amd import lib as L
+    L.load()
+    A = 0x1000       # a fake, suitably aligned device address: validation fails before it is ever dereferenced
+    cases = [
+        ("keep 16-byte", "scail_flash_attn_bf16", (A, 0, 132, A, 0, 0, 128, A, 0, 0, A, 0, 128, 1, 1, 8, 8, 1, 0.1, 0, None)),
+        ("at least one key", "scail_flash_attn_bf16", (A, 0, 128, A, 0, 0, 128, A, 0, 0, A, 0, 128, 1, 1, 8, 0, 1, 0.1, 0, None)),
+        ("vt batch stride", "scail_flash_attn_bf16", (A, 0, 128, A, 0, 0, 128, A, 0, 8, A, 0, 128, 2, 1, 8, 8, 1, 0.1, 0, None)),
+        ("multiple of 8 and <= 6144", "scail_ln_modulate", (A, 8200, A, 8200, A, A, 8200, 1, 1, 1, 0, 8200, 1e-6, None)),
+        ("16-byte aligned", "scail_layernorm_affine", (A + 2, 64, A, 64, A, A, 1, 64, 1e-6, None)),
+        ("cos and sin tables go together", "scail_rmsnorm_rope", (A, 128, A, 128, A, A, None, 1, 1, 128, 128, 1e-6, None)),
+        ("head_dim must be a multiple of 8 dividing D", "scail_rmsnorm_rope", (A, 128, A, 128, A, None, None, 1, 1, 128, 48, 1e-6, None)),
+        ("16-byte alignment", "scail_transpose_v", (A, 12, 0, A, 1, 1, 128, 8, None)),
+        ("K must be a multiple of 8", "scail_small_linear", (A, A, None, A, 2, 8, 12, 0, 0, None)),
+        ("multiples of 4", "scail_patchify", (A, A, A, A, 2, 1, 1, 1, 6, 8, 128, None)),
+        ("kpad must be", "scail_patchify", (A, A, A, A, 2, 1, 1, 1, 8, 8, 72, None)),
+        ("cond batch must be 1 or n_batch", "scail_patchify", (A, A, A, A, 4, 2, 1, 1, 8, 8, 128, None)),
+        ("C must be a multiple of 8", "scail_rms_silu", (A, A, A, 4, 20, 1, None)),
+        ("n must be a multiple of 8, <= 8192", "scail_softmax_rows", (A, 16384, 1, 16384, 1.0, None)),
+        ("RESID epilogue needs resid", "scail_gemm_bf16", (A, 64, A, None, A, 16, 8, 16, 64, 3, None, 0, None, 0, 0, None)),
+        ("gate needs rows_per_batch", "scail_gemm_bf16", (A, 64, A, None, A, 16, 8, 16, 64, 3, A, 16, A, 16, 0, None)),
+        ("pointer alignment", "scail_gemm_bf16", (A + 4, 64, A, None, A, 16, 8, 16, 64, 0, None, 0, None, 0, 0, None)),
+        ("unknown knob", "scail_tune_set", (b"no_such_knob", 1)),
+    ]
+    for needle, fn, args in cases:
+        with pytest.raises(L.ScailHipError, match=needle):
+            L.call(fn, *args)
+    geom = (C.c_int32 * 21)(4, 8, 8, 12, 4, 8, 8, 3, 3, 3, 1, 1, 1, 2, 1, 1, 0, 1, 0, 16, 384)
+    with pytest.raises(L.ScailHipError, match="Cin must be a multiple of 8"):
+        L.call("scail_conv3d_cl", A, A, None, A, 16, None, 0, C.cast(geom, C.c_void_p), None)
+    # empty problems are accepted and do nothing (no launch, so no device needed)
+    L.call("scail_gemm_bf16", A, 64, A, None, A, 16, 0, 16, 64, 0, None, 0, None, 0, 0, None)
+    L.call("scail_flash_attn_bf16", A, 0, 128, A, 0, 0, 128, A, 0, 0, A, 0, 128, 1, 1, 0, 8, 1, 0.1, 0, None)
+    L.call("scail_rms_silu", A, A, A, 0, 32, 1, None)
