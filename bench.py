@@ -199,13 +199,14 @@ def main():
     # one launch = local queries x all keys; in ulysses mode a launch covers heads/world heads of ONE source rank's queries
     sp_mode = sp.resolve_mode(nh) if sp is not None else "none"
     attn_heads = nh // world if sp_mode == "ulysses" else nh
-    attn_flops = 4.0 * (L // world) * L * 128 * attn_heads * 2
+    attn_B = 2 if sp is None else 1          # the sequence-parallel path launches per CFG batch element (comm / compute overlap)
+    attn_flops = 4.0 * (L // world) * L * 128 * attn_heads * attn_B
     ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms else None
     fl = step_flops(p, L, Lt, Lc)
     traffic = None                      # measured offline with rocprofv3 --pmc (cannot run inside the bench)
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))["flash_attn_self"]
-        if tr["shape"] == {"B": 2, "heads": attn_heads, "Lq": L // world, "Lk": L}:
+        if tr["shape"] == {"B": attn_B, "heads": attn_heads, "Lq": L // world, "Lk": L}:
             traffic = tr["traffic_bytes"]
     except Exception:
         pass

@@ -13,7 +13,8 @@ peer links, no ring dependence), after which every rank runs full attention of i
 against the n_seg gathered key segments (``scail_flash_attn_bf16`` n_seg > 1).  Softmax is
 permutation invariant over keys, so rank-major key order is harmless.  Everything else in the
 block is per-token and needs no communication; weights are replicated (32 GB << 288 GB HBM).
-The K/V projection is issued first so the all-gather overlaps the Q projection + Q norm/RoPE.
+The K/V projection is issued first so the all-gather overlaps the Q projection + Q norm/RoPE; the two CFG batch
+elements are independent sequences, so the exchange of one runs under the attention of the other (both modes).
 """
 from __future__ import annotations
 
@@ -71,8 +72,9 @@ class TorchDistBackend:
         w = self.dist.all_gather_into_tensor(out.view(-1), inp.reshape(-1), group=self.group, async_op=async_op)
         return _Handle(w if async_op else None)
 
-    def all_to_all(self, out, inp):
-        """out[s] <- rank s's inp[my rank]; out, inp: (size, ...) contiguous."""
+    def all_to_all(self, out, inp, async_op=False):
+        """out[s] <- rank s's inp[my rank]; out, inp: (size, ...) contiguous.  async_op: returns a handle whose wait()
+        makes the current stream wait (RCCL runs the exchange on its own stream meanwhile)."""
         if self.host_staged:                                          # gloo has no all_to_all_single: N gathers
             hi = inp.reshape(self.size, -1).cpu() if inp.is_cuda else inp.reshape(self.size, -1)
             rows = []
@@ -84,8 +86,9 @@ class TorchDistBackend:
                 if self.rank == dst:
                     rows = lst
             out.view(self.size, -1).copy_(torch.stack(rows))
-            return
-        self.dist.all_to_all_single(out.view(-1), inp.reshape(-1), group=self.group)
+            return _Handle(None)
+        w = self.dist.all_to_all_single(out.view(-1), inp.reshape(-1), group=self.group, async_op=async_op)
+        return _Handle(w if async_op else None)
 
     def gather_cat(self, t, dim):
         """Concatenate along ``dim`` on group rank 0 (reference: dist.gather + concat, :578-585);
@@ -137,12 +140,13 @@ class ThreadBackend:
         self._sync()
         return _Handle(None)
 
-    def all_to_all(self, out, inp):
+    def all_to_all(self, out, inp, async_op=False):
         self.shared.slots[self.rank] = inp
         self._sync()
         for r in range(self.size):
             out[r].copy_(self.shared.slots[r][self.rank])
         self._sync()
+        return _Handle(None)
 
     def gather_cat(self, t, dim):
         self.shared.slots[self.rank] = t
@@ -205,7 +209,9 @@ class SequenceParallel:
     def self_attention_ulysses(self, net, lw, xn, qkv, cos, sin, att, Ltok, eps):
         """The reference's exchange (sat/mpu/ulysses_attn_layer.py:65-107): scatter heads / gather sequence for
         q, k, v in ONE all-to-all, attention over the full sequence for heads/size heads, all-to-all back.
-        Norm + RoPE are applied before the exchange (the q/k RMSNorm spans all heads of a token)."""
+        Norm + RoPE are applied before the exchange (the q/k RMSNorm spans all heads of a token).
+        The CFG batch elements are independent sequences, so they are pipelined: the exchange of element b+1
+        runs (on RCCL's stream) under the attention of element b, and the way back of b under the attention of b+1."""
         D, nh, N = net.hidden_size, net.num_attention_heads, self.size
         B = xn.shape[0]
         Hn = nh // N
@@ -218,24 +224,32 @@ class SequenceParallel:
             dev = xn.device
             Lp = (Ltok + 63) // 64 * 64
             e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.bfloat16)
-            self._buf = {key: dict(send=e(N, 3, B, Ltok, Dn), recv=e(N, 3, B, Ltok, Dn), vtg=e(N, B, Hn, 128, Lp),
-                                   oseg=e(N, B, Ltok, Dn), back=e(N, B, Ltok, Dn))}
+            self._buf = {key: dict(send=e(B, N, 3, Ltok, Dn), recv=e(B, N, 3, Ltok, Dn), vtg=e(B, N, 1, Hn, 128, Lp),
+                                   oseg=e(B, N, Ltok, Dn), back=e(B, N, Ltok, Dn))}
         bf = self._buf[key]
-        bf["send"].copy_(qkv.view(B, Ltok, 3, N, Dn).permute(3, 2, 0, 1, 4))       # (dst rank, q|k|v, B, L, Dn)
-        self.backend.all_to_all(bf["recv"], bf["send"])                            # recv[src rank] = its tokens, my heads
-        recv, vtg, oseg = bf["recv"], bf["vtg"], bf["oseg"]
-        for s in range(N):
-            ops.transpose_v(recv[s, 2], Hn, out=vtg[s])
-        for s in range(N):                                                         # queries of source rank s
-            net._timed("self_attn", ops.flash_attn, recv[s, 0], recv[0, 1], vtg[0], out=oseg[s], n_seg=N,
-                       k_seg_stride=recv.stride(0), vt_seg_stride=vtg.stride(0))
-        self.backend.all_to_all(bf["back"], oseg)                                  # back[g] = my tokens, head group g
-        att.view(B, Ltok, N, Dn).copy_(bf["back"].permute(1, 2, 0, 3))
+        send, recv, vtg, oseg, back = bf["send"], bf["recv"], bf["vtg"], bf["oseg"], bf["back"]
+        fwd = []
+        for b in range(B):                                                  # (dst rank, q|k|v, L, Dn) per batch element
+            send[b].copy_(qkv[b].view(Ltok, 3, N, Dn).permute(2, 1, 0, 3))
+            fwd.append(self.backend.all_to_all(recv[b], send[b], async_op=True))   # recv[b][src] = its tokens, my heads
+        bwd = []
+        for b in range(B):
+            fwd[b].wait()
+            for s_ in range(N):
+                ops.transpose_v(recv[b, s_, 2:3], Hn, out=vtg[b, s_])
+            for s_ in range(N):                                             # queries of source rank s_
+                net._timed("self_attn", ops.flash_attn, recv[b, s_, 0:1], recv[b, 0, 1:2], vtg[b, 0], out=oseg[b, s_:s_ + 1],
+                           n_seg=N, k_seg_stride=recv.stride(1), vt_seg_stride=vtg.stride(1))
+            bwd.append(self.backend.all_to_all(back[b], oseg[b], async_op=True))    # back[b][g] = my tokens, head group g
+        for b in range(B):
+            bwd[b].wait()
+            att[b].view(Ltok, N, Dn).copy_(back[b].permute(1, 0, 2))
         return att
 
     def self_attention_allgather(self, net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps):
-        """xn (B, Lloc, D) -> att (B, Lloc, D): K/V projection, K norm+RoPE, V^T staging, all-gather
-        of both, (overlapped) Q projection + norm + RoPE, attention over all ranks' keys."""
+        """xn (B, Lloc, D) -> att (B, Lloc, D): K/V projection, K norm+RoPE, V^T staging, all-gather of both per CFG
+        batch element, Q projection + norm + RoPE under the first gather, then attention over all ranks' keys element
+        by element -- the gather of element b+1 runs (on RCCL's stream) under the attention of element b."""
         D, nh = net.hidden_size, net.num_attention_heads
         B = xn.shape[0]
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
@@ -245,21 +259,23 @@ class SequenceParallel:
             dev = xn.device
             self._buf = {key: dict(
                 kloc=torch.empty(B, Ltok, D, device=dev, dtype=torch.bfloat16),
-                kg=torch.empty(self.size, B, Ltok, D, device=dev, dtype=torch.bfloat16),
-                vtg=torch.empty(self.size, B, nh, 128, Lp, device=dev, dtype=torch.bfloat16))}
+                kg=torch.empty(B, self.size, 1, Ltok, D, device=dev, dtype=torch.bfloat16),
+                vtg=torch.empty(B, self.size, 1, nh, 128, Lp, device=dev, dtype=torch.bfloat16))}
         bufs = self._buf[key]
+        kloc, kg, vtg = bufs["kloc"], bufs["kg"], bufs["vtg"]
         ops.gemm(xn, lw["qkv_w"][D:], lw["qkv_b"][D:], out=qkv[..., D:])           # K and V columns
-        ops.rmsnorm_rope(k, lw["kn"], cos, sin, out=bufs["kloc"], rows_per_batch=Ltok, eps=eps)
+        ops.rmsnorm_rope(k, lw["kn"], cos, sin, out=kloc, rows_per_batch=Ltok, eps=eps)
         ops.transpose_v(v, nh, out=vt_loc)
-        h1 = self.backend.all_gather_into(bufs["kg"], bufs["kloc"])
-        h2 = self.backend.all_gather_into(bufs["vtg"], vt_loc)
+        hs = []
+        for b in range(B):
+            hs.append((self.backend.all_gather_into(kg[b], kloc[b:b + 1]), self.backend.all_gather_into(vtg[b], vt_loc[b:b + 1])))
         ops.gemm(xn, lw["qkv_w"][:D], lw["qkv_b"][:D], out=q)                       # overlaps the exchange
         ops.rmsnorm_rope(q, lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
-        h1.wait()
-        h2.wait()
-        kg, vtg = bufs["kg"], bufs["vtg"]
-        net._timed("self_attn", ops.flash_attn, q, kg[0], vtg[0], out=att, n_seg=self.size,
-                   k_seg_stride=kg.stride(0), vt_seg_stride=vtg.stride(0))
+        for b in range(B):
+            hs[b][0].wait()
+            hs[b][1].wait()
+            net._timed("self_attn", ops.flash_attn, q[b:b + 1], kg[b, 0], vtg[b, 0], out=att[b:b + 1], n_seg=self.size,
+                       k_seg_stride=kg.stride(1), vt_seg_stride=vtg.stride(1))
         return att
 
 
