@@ -200,13 +200,14 @@ def main():
     sp_mode = sp.resolve_mode(nh) if sp is not None else "none"
     attn_heads = nh // world if sp_mode == "ulysses" else nh
     attn_B = 2 if sp is None else 1          # the sequence-parallel path launches per CFG batch element (comm / compute overlap)
-    attn_flops = 4.0 * (L // world) * L * 128 * attn_heads * attn_B
+    attn_Lq = L if sp_mode == "ulysses" else L // world      # ulysses: all ranks' query rows of this rank's heads
+    attn_flops = 4.0 * attn_Lq * L * 128 * attn_heads * attn_B
     ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms else None
     fl = step_flops(p, L, Lt, Lc)
     traffic = None                      # measured offline with rocprofv3 --pmc (cannot run inside the bench)
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))["flash_attn_self"]
-        if tr["shape"] == {"B": attn_B, "heads": attn_heads, "Lq": L // world, "Lk": L}:
+        if tr["shape"] == {"B": attn_B, "heads": attn_heads, "Lq": attn_Lq, "Lk": L}:
             traffic = tr["traffic_bytes"]
     except Exception:
         pass

@@ -235,11 +235,12 @@ class SequenceParallel:
         bwd = []
         for b in range(B):
             fwd[b].wait()
-            for s_ in range(N):
-                ops.transpose_v(recv[b, s_, 2:3], Hn, out=vtg[b, s_])
-            for s_ in range(N):                                             # queries of source rank s_
-                net._timed("self_attn", ops.flash_attn, recv[b, s_, 0:1], recv[b, 0, 1:2], vtg[b, 0], out=oseg[b, s_:s_ + 1],
-                           n_seg=N, k_seg_stride=recv.stride(1), vt_seg_stride=vtg.stride(1))
+            ops.transpose_v(recv[b, :, 2], Hn, out=vtg[b].view(N, Hn, 128, -1))   # all source ranks' V in one launch
+            # ONE launch: the source rank is the kernel's batch index for q / o (N x Ltok query rows), K / V^T are the N
+            # gathered segments broadcast over it -- N * Ltok / 256 x heads/N workgroups instead of N launches that
+            # each fill less than the chip
+            net._timed("self_attn", ops.flash_attn, recv[b, :, 0], recv[b, 0:1, 1], vtg[b, 0], out=oseg[b],
+                       n_seg=N, k_seg_stride=recv.stride(1), vt_seg_stride=vtg.stride(1))
             bwd.append(self.backend.all_to_all(back[b], oseg[b], async_op=True))    # back[b][g] = my tokens, head group g
         for b in range(B):
             bwd[b].wait()
