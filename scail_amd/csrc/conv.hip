@@ -196,16 +196,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 #define HT_TW 16
 #define HT_BN 96
 #define HT_PVOX (3 * (HT_TH + 2) * (HT_TW + 2))
-template <int CS, int NWB> struct HaloCfg {
-    static constexpr int PS = CS + 8, WS = 3 * CS + 8;                     // strides in elements
+// SWZ: no padding; instead the 16-byte chunk index inside a voxel / W tap is XOR-ed with (index >> 2) & 3 of the voxel /
+// row (needs CS == 32: 4 chunks): the two W buffers then fit next to the patch in half the LDS of a CU.
+template <int CS, int NWB, bool SWZ = false> struct HaloCfg {
+    static constexpr int PS = SWZ ? CS : CS + 8, WS = SWZ ? 3 * CS : 3 * CS + 8;   // strides in elements
     static constexpr int PCH = HT_PVOX * (CS / 8), WCH = HT_BN * 3 * (CS / 8);
     static constexpr int NP = (PCH + 255) / 256, NWL = (WCH + 255) / 256;  // chunks per thread
     static constexpr int LDS = (HT_PVOX * PS + NWB * HT_BN * WS) * 2;
 };
 
-template <int EPI, int CS, int NWB>
-__global__ __launch_bounds__(256, (NWB == 1 ? 2 : 1)) void conv_halo_kernel(ConvParams p) {
-    using Cfg = HaloCfg<CS, NWB>;
+template <int EPI, int CS, int NWB, bool SWZ = false>
+__global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_kernel(ConvParams p) {
+    using Cfg = HaloCfg<CS, NWB, SWZ>;
+    static_assert(!SWZ || CS == 32, "the swizzle works on 4 chunks per voxel");
     constexpr int PS = Cfg::PS, WS = Cfg::WS, PCH = Cfg::PCH, WCH = Cfg::WCH, NP = Cfg::NP, NWL = Cfg::NWL, CPV = CS / 8;
     static_assert(NP <= 13 && NWL <= 7, "staging register sets below");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256, (NWB == 1 ? 2 : 1)) void conv_halo_kernel(Conv
         const int ti_ = to + dt_ - p.pt, hi_ = h0 + rr_ - p.ph, wi_ = w0 + cc_ - p.pw;                 \
         if (ti_ >= 0 && ti_ < p.Ti && hi_ >= 0 && hi_ < p.Hi && wi_ >= 0 && wi_ < p.Wi)                \
             psrc##i_ = (((int64_t)ti_ * p.Hi + hi_) * p.Wi + wi_) * p.Cin + ch_ * 8;                   \
-        pdst##i_ = vox_ * PS + ch_ * 8;                                                                \
+        pdst##i_ = vox_ * PS + (SWZ ? ((ch_ ^ ((vox_ >> 2) & 3)) << 3) : ch_ * 8);                     \
     }                                                                                                  \
     uint4 pr##i_ = make_uint4(0, 0, 0, 0);
     HT_PDECL(0) HT_PDECL(1) HT_PDECL(2) HT_PDECL(3) HT_PDECL(4) HT_PDECL(5) HT_PDECL(6)
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256, (NWB == 1 ? 2 : 1)) void conv_halo_kernel(Conv
     const int wc##i_ = tid + 256 * i_;                                                                 \
     const int wn##i_ = wc##i_ / (3 * CPV), wrem##i_ = wc##i_ - wn##i_ * (3 * CPV), wdw##i_ = wrem##i_ / CPV, wch##i_ = wrem##i_ - wdw##i_ * CPV; \
     const u16* wsrc##i_ = p.w + (int64_t)min(n0 + wn##i_, p.N - 1) * p.Kpad + wdw##i_ * p.Cin + wch##i_ * 8; \
-    const int wdst##i_ = wn##i_ * WS + wdw##i_ * CS + wch##i_ * 8;                                     \
+    const int wdst##i_ = wn##i_ * WS + wdw##i_ * CS + (SWZ ? ((wch##i_ ^ ((wn##i_ >> 2) & 3)) << 3) : wch##i_ * 8); \
     uint4 wr##i_ = make_uint4(0, 0, 0, 0);
     HT_WDECL(0) HT_WDECL(1) HT_WDECL(2) HT_WDECL(3) HT_WDECL(4) HT_WDECL(5) HT_WDECL(6)
 #define HT_WLOAD(i_, k0_) if (i_ < NWL && wc##i_ < WCH) wr##i_ = *reinterpret_cast<const uint4*>(wsrc##i_ + (k0_));
@@ -261,8 +264,12 @@ __global__ __launch_bounds__(256, (NWB == 1 ? 2 : 1)) void conv_halo_kernel(Conv
 
     // ---- fragment bases ----
     const int vloc = wave * 32 + l31;                                // voxel of the block: row vloc >> 4, col vloc & 15
-    const u16* pa = Ps + ((vloc >> 4) * (HT_TW + 2) + (vloc & 15)) * PS + g * 8;
-    const u16* wb = Ws + l31 * WS + g * 8;
+    const int pv0 = (vloc >> 4) * (HT_TW + 2) + (vloc & 15);         // its patch voxel at tap (0, 0, 0)
+    const u16* pa = Ps + pv0 * PS + (SWZ ? 0 : g * 8);
+    const u16* wb = Ws + l31 * WS + (SWZ ? 0 : g * 8);
+    int wsw[CS / 16];                                                // swizzled W chunk offset per k-step (row bits are lane constants)
+#pragma unroll
+    for (int ks = 0; ks < CS / 16; ++ks) wsw[ks] = SWZ ? (((ks * 2 + g) ^ ((l31 >> 2) & 3)) << 3) : ks * 16;
 
     f32x16 acc[3];
 #pragma unroll
@@ -284,19 +291,22 @@ __global__ __launch_bounds__(256, (NWB == 1 ? 2 : 1)) void conv_halo_kernel(Conv
             const int cur = (NWB == 2) ? (row & 1) : 0;
             if (row + 1 < 9) { HT_W7(HT_WLOAD, (row + 1) * 3 * p.Cin + c0) }
             const int dt = row / 3, dh = row - dt * 3;
-            const u16* pr_ = pa + ((dt * (HT_TH + 2) + dh) * (HT_TW + 2)) * PS;
+            const int toff = (dt * (HT_TH + 2) + dh) * (HT_TW + 2);
+            const u16* pr_ = pa + toff * PS;
             const u16* wr_ = wb + cur * HT_BN * WS;
 #pragma unroll
-            for (int dw = 0; dw < 3; ++dw)
+            for (int dw = 0; dw < 3; ++dw) {
+                const int psw = SWZ ? (((pv0 + toff + dw) >> 2) & 3) : 0;       // this tap's voxel: its swizzle bits
 #pragma unroll
                 for (int ks = 0; ks < CS / 16; ++ks) {
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(pr_ + dw * PS + ks * 16);
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(pr_ + dw * PS + (SWZ ? (((ks * 2 + g) ^ psw) << 3) : ks * 16));
 #pragma unroll
                     for (int nb = 0; nb < 3; ++nb) {
-                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr_ + nb * 32 * WS + dw * CS + ks * 16);
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr_ + nb * 32 * WS + dw * CS + wsw[ks]);
                         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nb], 0, 0, 0);
                     }
                 }
+            }
             if (NWB == 1) __syncthreads();           // single buffer: every wave has read this row's tile
             if (row + 1 < 9) { HT_W7(HT_WSTORE, (NWB == 2) ? (cur ^ 1) : 0) }
             __syncthreads();
@@ -488,7 +498,7 @@ __global__ void from_channels_last_kernel(const u16* __restrict__ x, int64_t ldx
 // ================================================================================================
 // C ABI
 // ================================================================================================
-static int g_conv_halo = 2;
+static int g_conv_halo = 3;
 int scail_conv_tune(int v) { g_conv_halo = v; return 0; }
 
 extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
@@ -513,30 +523,34 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
                   "pointer alignment");
     if (p.M == 0) return 0;
     // 3x3x3 stride-1 causal convolutions: halo-tile kernel.  Knob conv_halo: 0 off, 1 = 48-channel slices / 1 workgroup
-    // per CU, 2 = 32-channel slices / 2 workgroups per CU (default)
+    // per CU, 3 (default) = 32-channel slices, one padded W buffer (two barriers per tap row), 2 workgroups per CU,
+    // 2 = 32-channel slices, swizzled unpadded layout with two W buffers (one barrier per tap row), 2 workgroups per CU --
+    // measured equal (283 / 490 ms vs 281 / 487 ms encode / decode): the barrier is not what bounds the kernel
     if (g_conv_halo && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups &&
         p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi && p.N >= 48 &&
         p.Cin % ((g_conv_halo == 1) ? 48 : 32) == 0) {
-#define HALO_LAUNCH(EPI_, CS_, NWB_)                                                                               \
+#define HALO_LAUNCH(EPI_, CS_, NWB_, SWZ_)                                                                             \
     {                                                                                                              \
-        constexpr int lds_ = HaloCfg<CS_, NWB_>::LDS;                                                              \
+        constexpr int lds_ = HaloCfg<CS_, NWB_, SWZ_>::LDS;                                                            \
         static bool attr_ = false;                                                                                 \
         if (!attr_) {                                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<EPI_, CS_, NWB_>),             \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<EPI_, CS_, NWB_, SWZ_>),           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) {             \
                 scail_set_error("conv3d: hipFuncSetAttribute failed");                                             \
                 return 2;                                                                                          \
             }                                                                                                      \
             attr_ = true;                                                                                          \
         }                                                                                                          \
-        hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
+        hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_, SWZ_>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
     }
         const int64_t tiles = (int64_t)p.To * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW) * ((p.N + HT_BN - 1) / HT_BN);
         SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
         if (g_conv_halo == 1) {
-            if (resid != nullptr) HALO_LAUNCH(3, 48, 2) else HALO_LAUNCH(0, 48, 2)
+            if (resid != nullptr) HALO_LAUNCH(3, 48, 2, false) else HALO_LAUNCH(0, 48, 2, false)
+        } else if (g_conv_halo == 2) {
+            if (resid != nullptr) HALO_LAUNCH(3, 32, 2, true) else HALO_LAUNCH(0, 32, 2, true)
         } else {
-            if (resid != nullptr) HALO_LAUNCH(3, 32, 1) else HALO_LAUNCH(0, 32, 1)
+            if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false) else HALO_LAUNCH(0, 32, 1, false)
         }
         return scail_check_launch("conv3d_cl");
     }

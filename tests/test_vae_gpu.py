@@ -32,13 +32,14 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm()))
 
 
-@pytest.fixture(params=[2, 1, 0])
+@pytest.fixture(params=[3, 2, 1, 0])
 def conv_halo(request):
-    """every path of the 3x3x3 convolution: halo-tile kernel with 32-channel slices (default), 48-channel slices, gather kernel"""
+    """every path of the 3x3x3 convolution: halo-tile kernel with 32-channel slices padded / one W buffer (default),
+    32-channel slices swizzled / two W buffers, 48-channel slices, and the gather kernel"""
     from scail_amd import lib as L
     L.tune_set("conv_halo", request.param)
     yield request.param
-    L.tune_set("conv_halo", 2)
+    L.tune_set("conv_halo", 3)
 
 
 @pytest.mark.parametrize("cin,cout,k,thw", [(16, 32, (3, 3, 3), (5, 10, 12)), (96, 96, (3, 3, 3), (5, 10, 12)),
