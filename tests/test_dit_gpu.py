@@ -93,6 +93,29 @@ def test_c_step_executor_equals_host_orchestration_and_golden(golden_dir, name, 
     assert torch.equal(o_g, o_py)
 
 
+def test_full_width_layer_vs_oracle():
+    """BASELINE config-2 WIDTH (D = 5120, 40 heads of 128, FF = 13824, text 4096) on a short sequence: one transformer layer
+    + embeddings + final layer against the fp32 oracle.  Exercises the shapes the 14B step uses (40-head attention, the
+    256-wide GEMM tiles on N = 15360 / 13824 / 5120, 5120-wide norms) where the goldens use 256-wide toy networks."""
+    cfgd = dict(hidden_size=5120, num_layers=1, num_attention_heads=40, inner_hidden_size=13824, text_dim=4096,
+                time_freq_dim=256, time_embed_dim=5120, latent_height=64, latent_width=64, num_frames=13)
+    cfg, sd, net = _net(cfgd, 4321)
+    g = torch.Generator().manual_seed(5)
+    r = lambda *sh: torch.randn(*sh, generator=g).to(torch.bfloat16).float()
+    T, H, W = 3, 16, 24                                           # L = 96 + 288 + 72 = 456 tokens
+    x, ctx = r(2, T, 16, H, W), r(2, 20, 4096)
+    ctx[:, 10:] = 0
+    ref, pose, clip = r(1, 1, 16, H, W), r(1, T, 16, H // 2, W // 2), r(1, 9, 1280)
+    t = torch.tensor([640.0, 640.0])
+    want = O.dit_forward(cfg, sd, x, t, ctx, ref, pose, clip)
+    for use_c in (False, True):
+        net.use_c_step = use_c
+        got = net.forward_f32(x.to(DEV), t.to(DEV), ctx.to(DEV), None, concat_images=torch.zeros(1, device=DEV),
+                              ref_concat=ref.to(DEV), concat_smpl_render=pose.to(DEV), image_clip_features=clip.to(DEV))
+        torch.testing.assert_close(got.cpu(), want, rtol=3e-2, atol=3e-2)
+        assert _cos(got.cpu(), want) >= 0.999
+
+
 def test_dit_conditioning_cache_and_batch_of_one(golden_dir):
     """Same inputs twice (cache hit) and a changed prompt (cache miss) must both be right."""
     g = _load(golden_dir, "dit_tiny.npz")

@@ -156,6 +156,35 @@ def test_rope_tables_match_oracle():
         assert torch.equal(cos, oc[:, 0::2]) and torch.equal(sin, os_[:, 0::2])
 
 
+def test_gemm_config2_size_sampled_rows(ops):
+    """The 14B step's own GEMM shapes (M = 2 x 48 832 rows; the default kernel choice): 192 sampled output rows -- including
+    the ragged last m-tile -- against an fp32 matmul of the same bf16 operands, for the bias, GELU and gate + residual epilogues."""
+    from scail_amd import lib as L
+    M = 97664
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    rows = torch.cat([torch.randint(0, M, (184,), device=DEV, generator=gen), torch.arange(M - 8, M, device=DEV)])
+    for N, K, epi in ((15360, 5120, L.EPI_BIAS), (13824, 5120, L.EPI_GELU_TANH), (5120, 13824, L.EPI_RESID)):
+        x = torch.randn(M, K, device=DEV, generator=gen).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=DEV, generator=gen) * 0.02).to(torch.bfloat16)
+        b = torch.randn(N, device=DEV, generator=gen)
+        kw = {}
+        if epi == L.EPI_RESID:
+            resid = torch.randn(M, N, device=DEV, generator=gen).to(torch.bfloat16)
+            gate = torch.randn(2, N, device=DEV, generator=gen)
+            y = resid.clone()
+            kw = dict(resid=y, gate=gate, rows_per_batch=M // 2)
+        else:
+            y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(x, w, b, out=y, epilogue=epi, **kw)
+        ref = x[rows].float() @ w.float().t() + b
+        if epi == L.EPI_GELU_TANH:
+            ref = torch.nn.functional.gelu(ref, approximate="tanh")
+        elif epi == L.EPI_RESID:
+            ref = resid[rows].float() + gate[(rows >= M // 2).long()] * ref
+        torch.testing.assert_close(y[rows].float(), ref, rtol=2e-2, atol=2e-2)
+        del x, w, y
+
+
 # ------------------------------------------------------------------------------------------------
 # every schedule of the attention kernel that can be selected (default = software-pipelined 4/4) must give the
 # same results: lock-step (2), lock-step + LDS-DMA staging (258), 4-wave x 2 workgroups (66), software-pipelined
