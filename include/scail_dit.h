@@ -85,6 +85,19 @@ int scail_dit_step(scail_dit* h, const float* x, const float* timesteps, const s
                    const float* rope_cos, const float* rope_sin, float* out,
                    int64_t B, int64_t T, int64_t H, int64_t W, void* workspace, int64_t workspace_bytes, void* stream);
 
+/*
+ * The whole Euler sampling loop of RFSampler (sampling.py:920-982) with VanillaCFG (guiders.py:41-57) for one request:
+ *   for i < n_steps:  v = DiT([x; x], timesteps[i], cond [uncond | cond], ref, pose);  x += dsigma[i] (v_u + cfg (v_c - v_u))
+ * x fp32 [1,T,16,H,W] in / out (device); timesteps DEVICE fp32 [n_steps][2] (= 1000 sigma_i, twice); dsigma HOST fp32
+ * [n_steps] (= sigma_{i+1} - sigma_i); cond holds the batch-2 conditioning (index 0 = uncond, 1 = cond).
+ * workspace >= scail_dit_sample_workspace_bytes(h, T, H, W).  Nothing synchronises; the call returns once all steps are enqueued.
+ */
+int64_t scail_dit_sample_workspace_bytes(const scail_dit* h, int64_t T, int64_t H, int64_t W);
+int scail_dit_sample(scail_dit* h, float* x, const float* timesteps, const float* dsigma, int64_t n_steps, float cfg_scale,
+                     const scail_dit_cond* cond, const scail_bf16* ref, const scail_bf16* pose,
+                     const float* rope_cos, const float* rope_sin, int64_t T, int64_t H, int64_t W,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

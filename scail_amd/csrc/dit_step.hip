@@ -187,3 +187,38 @@ extern "C" int scail_dit_step(scail_dit* h, const float* x, const float* timeste
     DIT_TRY(scail_unpatchify(tokout, out, B, T, H, W, stream));
     return 0;
 }
+
+// ---- the sampler loop (RFSampler.__call__ + VanillaCFG, sampling.py:920-982, guiders.py:41-57) ----
+extern "C" int64_t scail_dit_sample_workspace_bytes(const scail_dit* h, int64_t T, int64_t H, int64_t W) {
+    const int64_t step = scail_dit_workspace_bytes(h, 2, T, H, W);
+    if (step < 0) return -1;
+    const int64_t n = T * 16 * H * W;
+    return step + 2 * align256(2 * n * 4);     // + [x; x] and [v_u; v_c], fp32
+}
+
+extern "C" int scail_dit_sample(scail_dit* h, float* x, const float* timesteps, const float* dsigma, int64_t n_steps,
+                                float cfg_scale, const scail_dit_cond* cond, const scail_bf16* ref, const scail_bf16* pose,
+                                const float* rope_cos, const float* rope_sin, int64_t T, int64_t H, int64_t W,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+    SCAIL_REQUIRE(h != nullptr && x != nullptr && timesteps != nullptr && dsigma != nullptr && n_steps >= 0, "null argument");
+    const int64_t step_bytes = scail_dit_workspace_bytes(h, 2, T, H, W);
+    SCAIL_REQUIRE(step_bytes >= 0, "bad latent shape");
+    const int64_t n = T * 16 * H * W, pair = align256(2 * n * 4);
+    SCAIL_REQUIRE(workspace != nullptr && workspace_bytes >= step_bytes + 2 * pair, "workspace too small (scail_dit_sample_workspace_bytes)");
+    char* base = static_cast<char*>(workspace);
+    float* xin = reinterpret_cast<float*>(base + step_bytes);
+    float* v = reinterpret_cast<float*>(base + step_bytes + pair);
+    hipStream_t s = (hipStream_t)stream;
+    for (int64_t i = 0; i < n_steps; ++i) {
+        // torch.cat([x] * 2) of VanillaCFG.prepare_inputs (guiders.py:56)
+        if (hipMemcpyAsync(xin, x, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(xin + n, x, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            scail_set_error("scail_dit_sample: hipMemcpyAsync failed");
+            return 2;
+        }
+        DIT_TRY(scail_dit_step(h, xin, timesteps + 2 * i, cond, ref, 1, pose, 1, rope_cos, rope_sin, v, 2, T, H, W, workspace,
+                               step_bytes, stream));
+        DIT_TRY(scail_cfg_euler(x, v, n, cfg_scale, dsigma[i], stream));
+    }
+    return 0;
+}

@@ -92,3 +92,28 @@ class CStep:
                pose.data_ptr(), pose.shape[0], cos.data_ptr(), sin.data_ptr(), out.data_ptr(), B, T, H, W,
                self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
         return out
+
+    def sample(self, x32, sigmas, cfg_scale, cond: Dict, ref, pose, cos, sin) -> torch.Tensor:
+        """The whole Euler loop in one C call (scail_dit_sample).  x32 (1,T,16,H,W) fp32 is updated in place and returned;
+        ``sigmas`` is the host schedule (n_steps + 1 values); ``cond`` the batch-2 conditioning (uncond, cond)."""
+        import ctypes as C2
+        _, T, _, H, W = x32.shape
+        lib = L.load()
+        need = lib.scail_dit_sample_workspace_bytes(self._h, T, H, W)
+        if need < 0:
+            raise L.ScailHipError("scail_dit_sample_workspace_bytes: bad shape")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x32.device:
+            self._ws = torch.empty(need, device=x32.device, dtype=torch.uint8)
+        sig = sigmas.float().cpu()
+        n = sig.numel() - 1
+        ts = (sig[:-1] * 1000.0).repeat_interleave(2).to(x32.device).contiguous()       # (n, 2) device fp32
+        ds = (sig[1:] - sig[:-1]).contiguous()
+        dsa = (C2.c_float * n)(*[float(v) for v in ds])
+        k_text, k_clip = cond["k_text"], cond["k_clip"]
+        cc = DitCond(k_text.data_ptr(), cond["vt_text"].data_ptr(), k_clip.data_ptr(), cond["vt_clip"].data_ptr(),
+                     k_text.shape[2], k_clip.shape[2], k_clip.shape[1])
+        assert x32.is_contiguous() and x32.dtype == torch.float32 and ref.shape[0] == 1 and pose.shape[0] == 1
+        L.call("scail_dit_sample", self._h, x32.data_ptr(), ts.data_ptr(), C2.cast(dsa, C2.c_void_p), n, float(cfg_scale),
+               C2.byref(cc), ref.data_ptr(), pose.data_ptr(), cos.data_ptr(), sin.data_ptr(), T, H, W,
+               self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
+        return x32

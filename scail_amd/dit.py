@@ -404,6 +404,25 @@ class DiffusionTransformer(nn.Module):
                 raise NotImplementedError
         return self._run(x32, t32, ctx, ref, pose, clip, H_shift, W_shift, cond_key)
 
+    def sample_c(self, x32, sigmas, cfg_scale, ctx, ref, pose, clip, cond_key=None):
+        """The whole RFSampler Euler loop as ONE C call (scail_dit_sample, include/scail_dit.h): x32 (1,T,16,H,W) fp32,
+        ctx (2, Lt, text_dim) = [uncond; cond], ref (1,1,16,H,W), pose (1,T,16,H/2,W/2), clip (1,Lc,1280).  Single rank."""
+        from .cstep import CStep
+        W = self.prepare()
+        dev = x32.device
+
+        def as_bf16(t):
+            t = t.to(dev)
+            return ops.to_bf16(t.contiguous()) if t.dtype == torch.float32 else t.to(torch.bfloat16).contiguous()
+
+        _, T, _, H, Wd = x32.shape
+        cond = self._conditioning(as_bf16(ctx), as_bf16(clip), cond_key)
+        cos, sin = self._rope(T, H // 2, Wd // 2, 0, 0, dev)
+        if self._cstep is None:
+            self._cstep = CStep(self, W)
+        x = x32.float().contiguous().clone()
+        return self._cstep.sample(x, sigmas, cfg_scale, cond, as_bf16(ref), as_bf16(pose), cos, sin)
+
     def _run(self, x32, t32, ctx, ref, pose, clip, H_shift=0, W_shift=0, cond_key=None):
         W = self.prepare()
         dev = x32.device

@@ -146,7 +146,11 @@ def test_sampler_two_steps_vs_reference_golden(golden_dir):
                   concat_smpl_render=d["pose"].to(DEV), image_clip_features=d["clip"].to(DEV))
     c = dict(crossattn=g["c_ctx"].to(DEV), **shared)
     uc = dict(crossattn=g["uc_ctx"].to(DEV), **shared)
-    xT = smp.sample_hip(net, g["x0"].to(DEV), c, uc)
+    xT = smp.sample_hip(net, g["x0"].to(DEV), c, uc)               # one C call for the whole loop (scail_dit_sample)
+    net.use_c_step = False
+    xT_py = smp.sample_hip(net, g["x0"].to(DEV), c, uc)            # per-step host loop over the per-op path
+    net.use_c_step = True
+    assert torch.equal(xT, xT_py)
     # per-forward tolerance 2e-2 (bf16) is amplified by CFG: v = v_u + 4 (v_c - v_u) carries up to
     # (2*4 - 1) = 7x the forward error, times sum |dsigma| = 1 over the run -> atol 0.14; the primary
     # criteria are the cosine and the mean error.
