@@ -194,20 +194,20 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 // ------------------------------------------------------------------------------------------------
 #define HT_TH 8
 #define HT_TW 16
-#define HT_BN 96
 #define HT_PVOX (3 * (HT_TH + 2) * (HT_TW + 2))
 // SWZ: no padding; instead the 16-byte chunk index inside a voxel / W tap is XOR-ed with (index >> 2) & 3 of the voxel /
 // row (needs CS == 32: 4 chunks): the two W buffers then fit next to the patch in half the LDS of a CU.
-template <int CS, int NWB, bool SWZ = false> struct HaloCfg {
+template <int CS, int NWB, bool SWZ = false, int BN = 96> struct HaloCfg {
     static constexpr int PS = SWZ ? CS : CS + 8, WS = SWZ ? 3 * CS : 3 * CS + 8;   // strides in elements
-    static constexpr int PCH = HT_PVOX * (CS / 8), WCH = HT_BN * 3 * (CS / 8);
+    static constexpr int PCH = HT_PVOX * (CS / 8), WCH = BN * 3 * (CS / 8);
     static constexpr int NP = (PCH + 255) / 256, NWL = (WCH + 255) / 256;  // chunks per thread
-    static constexpr int LDS = (HT_PVOX * PS + NWB * HT_BN * WS) * 2;
+    static constexpr int LDS = (HT_PVOX * PS + NWB * BN * WS) * 2;
 };
 
-template <int EPI, int CS, int NWB, bool SWZ = false>
+template <int EPI, int CS, int NWB, bool SWZ = false, int BN = 96>   // BN = 96 (three 32-channel blocks) or 32 (narrow outputs: the RGB head)
 __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_kernel(ConvParams p) {
-    using Cfg = HaloCfg<CS, NWB, SWZ>;
+    using Cfg = HaloCfg<CS, NWB, SWZ, BN>;
+    constexpr int NBLK = BN / 32;
     static_assert(!SWZ || CS == 32, "the swizzle works on 4 chunks per voxel");
     constexpr int PS = Cfg::PS, WS = Cfg::WS, PCH = Cfg::PCH, WCH = Cfg::WCH, NP = Cfg::NP, NWL = Cfg::NWL, CPV = CS / 8;
     static_assert(NP <= 13 && NWL <= 7, "staging register sets below");
@@ -215,14 +215,14 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
     u16* Ps = smem;                          // [3][TH+2][TW+2][PS]
     u16* Ws = smem + HT_PVOX * PS;           // [NWB][BN][WS]
 
-    const int tiles_n = (p.N + HT_BN - 1) / HT_BN;
+    const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_w = (p.Wo + HT_TW - 1) / HT_TW, tiles_h = (p.Ho + HT_TH - 1) / HT_TH;
     int bid = blockIdx.x;
     const int tn = bid % tiles_n; bid /= tiles_n;
     const int tw = bid % tiles_w; bid /= tiles_w;
     const int th = bid % tiles_h;
     const int to = bid / tiles_h;
-    const int n0 = tn * HT_BN, h0 = th * HT_TH, w0 = tw * HT_TW;
+    const int n0 = tn * BN, h0 = th * HT_TH, w0 = tw * HT_TW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, g = lane >> 5;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
     uint4 wr##i_ = make_uint4(0, 0, 0, 0);
     HT_WDECL(0) HT_WDECL(1) HT_WDECL(2) HT_WDECL(3) HT_WDECL(4) HT_WDECL(5) HT_WDECL(6)
 #define HT_WLOAD(i_, k0_) if (i_ < NWL && wc##i_ < WCH) wr##i_ = *reinterpret_cast<const uint4*>(wsrc##i_ + (k0_));
-#define HT_WSTORE(i_, buf_) if (i_ < NWL && wc##i_ < WCH) *reinterpret_cast<uint4*>(Ws + (buf_) * HT_BN * WS + wdst##i_) = wr##i_;
+#define HT_WSTORE(i_, buf_) if (i_ < NWL && wc##i_ < WCH) *reinterpret_cast<uint4*>(Ws + (buf_) * BN * WS + wdst##i_) = wr##i_;
 #define HT_W7(M_, ...) M_(0, ##__VA_ARGS__) M_(1, ##__VA_ARGS__) M_(2, ##__VA_ARGS__) M_(3, ##__VA_ARGS__) M_(4, ##__VA_ARGS__) \
     M_(5, ##__VA_ARGS__) M_(6, ##__VA_ARGS__)
 
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
 #pragma unroll
     for (int ks = 0; ks < CS / 16; ++ks) wsw[ks] = SWZ ? (((ks * 2 + g) ^ ((l31 >> 2) & 3)) << 3) : ks * 16;
 
-    f32x16 acc[3];
+    f32x16 acc[NBLK];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < NBLK; ++a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
 
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
             const int dt = row / 3, dh = row - dt * 3;
             const int toff = (dt * (HT_TH + 2) + dh) * (HT_TW + 2);
             const u16* pr_ = pa + toff * PS;
-            const u16* wr_ = wb + cur * HT_BN * WS;
+            const u16* wr_ = wb + cur * BN * WS;
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
                 const int psw = SWZ ? (((pv0 + toff + dw) >> 2) & 3) : 0;       // this tap's voxel: its swizzle bits
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
                 for (int ks = 0; ks < CS / 16; ++ks) {
                     const bf16x8 xf = *reinterpret_cast<const bf16x8*>(pr_ + dw * PS + (SWZ ? (((ks * 2 + g) ^ psw) << 3) : ks * 16));
 #pragma unroll
-                    for (int nb = 0; nb < 3; ++nb) {
+                    for (int nb = 0; nb < NBLK; ++nb) {
                         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr_ + nb * 32 * WS + dw * CS + wsw[ks]);
                         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nb], 0, 0, 0);
                     }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
     if (ho < p.Ho && wo < p.Wo) {
         const int64_t vox = ((int64_t)(to * p.ot_mul + p.ot_off) * p.Ho + ho) * p.Wo + wo;
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb) {
+        for (int nb = 0; nb < NBLK; ++nb) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int n = n0 + nb * 32 + 8 * rr + 4 * g;
@@ -527,30 +527,33 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
     // 2 = 32-channel slices, swizzled unpadded layout with two W buffers (one barrier per tap row), 2 workgroups per CU --
     // measured equal (283 / 490 ms vs 281 / 487 ms encode / decode): the barrier is not what bounds the kernel
     if (g_conv_halo && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups &&
-        p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi && p.N >= 48 &&
-        p.Cin % ((g_conv_halo == 1) ? 48 : 32) == 0) {
-#define HALO_LAUNCH(EPI_, CS_, NWB_, SWZ_)                                                                             \
+        p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
+        p.Cin % ((g_conv_halo == 1 && p.N > 32) ? 48 : 32) == 0 && (p.N <= 32 || p.N >= 48)) {
+#define HALO_LAUNCH(EPI_, CS_, NWB_, SWZ_, BN_)                                                                             \
     {                                                                                                              \
-        constexpr int lds_ = HaloCfg<CS_, NWB_, SWZ_>::LDS;                                                            \
+        constexpr int lds_ = HaloCfg<CS_, NWB_, SWZ_, BN_>::LDS;                                                            \
         static bool attr_ = false;                                                                                 \
         if (!attr_) {                                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<EPI_, CS_, NWB_, SWZ_>),           \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_>),           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) {             \
                 scail_set_error("conv3d: hipFuncSetAttribute failed");                                             \
                 return 2;                                                                                          \
             }                                                                                                      \
             attr_ = true;                                                                                          \
         }                                                                                                          \
-        hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_, SWZ_>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
+        hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
     }
-        const int64_t tiles = (int64_t)p.To * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW) * ((p.N + HT_BN - 1) / HT_BN);
+        const int hbn = p.N <= 32 ? 32 : 96;
+        const int64_t tiles = (int64_t)p.To * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW) * ((p.N + hbn - 1) / hbn);
         SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
-        if (g_conv_halo == 1) {
-            if (resid != nullptr) HALO_LAUNCH(3, 48, 2, false) else HALO_LAUNCH(0, 48, 2, false)
+        if (hbn == 32) {
+            if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 32) else HALO_LAUNCH(0, 32, 1, false, 32)
+        } else if (g_conv_halo == 1) {
+            if (resid != nullptr) HALO_LAUNCH(3, 48, 2, false, 96) else HALO_LAUNCH(0, 48, 2, false, 96)
         } else if (g_conv_halo == 2) {
-            if (resid != nullptr) HALO_LAUNCH(3, 32, 2, true) else HALO_LAUNCH(0, 32, 2, true)
+            if (resid != nullptr) HALO_LAUNCH(3, 32, 2, true, 96) else HALO_LAUNCH(0, 32, 2, true, 96)
         } else {
-            if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false) else HALO_LAUNCH(0, 32, 1, false)
+            if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96) else HALO_LAUNCH(0, 32, 1, false, 96)
         }
         return scail_check_launch("conv3d_cl");
     }

@@ -45,7 +45,8 @@ def conv_halo(request):
 @pytest.mark.parametrize("cin,cout,k,thw", [(16, 32, (3, 3, 3), (5, 10, 12)), (96, 96, (3, 3, 3), (5, 10, 12)),
                                            (96, 192, (1, 1, 1), (5, 10, 12)), (32, 64, (3, 1, 1), (5, 10, 12)),
                                            (8, 96, (3, 3, 3), (5, 10, 12)), (192, 96, (3, 3, 3), (3, 17, 35)),
-                                           (96, 200, (3, 3, 3), (2, 8, 16)), (64, 48, (3, 3, 3), (4, 9, 33))])
+                                           (96, 200, (3, 3, 3), (2, 8, 16)), (64, 48, (3, 3, 3), (4, 9, 33)), (96, 3, (3, 3, 3), (3, 11, 21)),
+                                           (32, 24, (3, 3, 3), (2, 8, 16))])
 def test_causal_conv3d(cin, cout, k, thw, conv_halo):
     from scail_amd import ops
     g = torch.Generator().manual_seed(0)
@@ -57,6 +58,8 @@ def test_causal_conv3d(cin, cout, k, thw, conv_halo):
     wp = ops.prep_conv_weight(w.to(DEV), b.to(DEV))
     y = ops.conv3d_cl(_cl(x), wp, (T, H, W))
     torch.testing.assert_close(_pl(y)[:cout], ref, rtol=2e-2, atol=2e-2)
+    if cout % 8:                                                   # residual tensors are channel-padded like the outputs
+        return
     r = bfr(torch.randn(cout, T, H, W, generator=g))
     y2 = ops.conv3d_cl(_cl(x), wp, (T, H, W), resid=_cl(r))
     torch.testing.assert_close(_pl(y2)[:cout], ref + r, rtol=2e-2, atol=2e-2)
