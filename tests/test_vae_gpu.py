@@ -65,17 +65,17 @@ def test_causal_conv3d(cin, cout, k, thw, conv_halo):
     torch.testing.assert_close(_pl(y2)[:cout], ref + r, rtol=2e-2, atol=2e-2)
 
 
-def test_resample_convs():
+@pytest.mark.parametrize("C,T,H,W", [(32, 5, 8, 12), (192, 2, 9, 21)])
+def test_resample_convs(C, T, H, W, conv_halo):
     from scail_amd import ops
     g = torch.Generator().manual_seed(1)
-    C, T, H, W = 32, 5, 8, 12
     x = bfr(torch.randn(C, T, H, W, generator=g))
     w2 = bfr(torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5)
     b2 = torch.randn(C, generator=g)
     xf = x.permute(1, 0, 2, 3)                                           # (T,C,H,W)
     # downsample2d: ZeroPad2d((0,1,0,1)) + stride-2 conv (wan_vae.py:87-90)
     ref = F.conv2d(F.pad(xf, (0, 1, 0, 1)), w2, b2, stride=2).permute(1, 0, 2, 3)
-    y = ops.conv3d_cl(_cl(x), ops.prep_conv_weight(w2.to(DEV), b2.to(DEV)), (T, H // 2, W // 2), stride=(1, 2, 2), pad=(0, 0, 0))
+    y = ops.conv3d_cl(_cl(x), ops.prep_conv_weight(w2.to(DEV), b2.to(DEV)), (T, ref.shape[2], ref.shape[3]), stride=(1, 2, 2), pad=(0, 0, 0))
     torch.testing.assert_close(_pl(y), ref, rtol=2e-2, atol=2e-2)
     # upsample2d: nearest-exact x2 + conv pad 1 (wan_vae.py:76-79)
     wu = bfr(torch.randn(C // 2, C, 3, 3, generator=g) / (9 * C) ** 0.5)
