@@ -86,6 +86,16 @@ int scail_dit_step(scail_dit* h, const float* x, const float* timesteps, const s
                    int64_t B, int64_t T, int64_t H, int64_t W, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * Seam B2 (the SAT hook `layer_forward`, dit...:1009-1051): ONE transformer block, in place on caller-owned hidden states
+ * hidden bf16 [B, Ltok, D].  mod fp32 [B, 6D] = adaLN embedding + this layer's table (shift_a|scale_a|gate_a|shift_m|scale_m|gate_m);
+ * cond / rope tables as for scail_dit_step (cond is indexed by `layer`).
+ */
+int64_t scail_dit_block_workspace_bytes(const scail_dit* h, int64_t B, int64_t Ltok);
+int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, const float* mod, const scail_dit_cond* cond,
+                    const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * The whole Euler sampling loop of RFSampler (sampling.py:920-982) with VanillaCFG (guiders.py:41-57) for one request:
  *   for i < n_steps:  v = DiT([x; x], timesteps[i], cond [uncond | cond], ref, pose);  x += dsigma[i] (v_u + cfg (v_c - v_u))
  * x fp32 [1,T,16,H,W] in / out (device); timesteps DEVICE fp32 [n_steps][2] (= 1000 sigma_i, twice); dsigma HOST fp32

@@ -71,6 +71,76 @@ __global__ void dup_rows_kernel(const float* __restrict__ in, float* __restrict_
         if (rc_ != 0) return rc_;       \
     }
 
+// One transformer block in place on hid (B, Ltok, D): AdaLNMixin.layer_forward, dit...:1009-1051.
+//   m (B, 6D) fp32 = shift_a | scale_a | gate_a | shift_m | scale_m | gate_m of THIS layer (adaLN emb + table)
+static int dit_block(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, const scail_dit_cond* cond,
+                     const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok,
+                     scail_bf16* xn, scail_bf16* qkv, scail_bf16* att, scail_bf16* ff, scail_bf16* vt, void* stream) {
+    const scail_dit_config& c = h->cfg;
+    const int64_t D = c.hidden_size, FF = c.inner_hidden_size, nh = c.num_heads;
+    const float eps = c.layernorm_epsilon;
+    const int64_t Lp = (Ltok + 63) / 64 * 64;
+    const int64_t Ltp = (cond->Lt + 63) / 64 * 64, Lcp = (cond->Lc + 63) / 64 * 64;
+    const float scale = 0.08838834764831845f;   // 1 / sqrt(128)
+    const int64_t M = B * Ltok;
+    scail_bf16 *q = qkv, *k = qkv + D, *v = qkv + 2 * D;   // column thirds of the fused projection, row stride 3D
+    const scail_dit_layer& lw = h->layers[i];
+    // -- self attention (dit...:1031-1036, :1058-1105) --
+    DIT_TRY(scail_ln_modulate(hid, D, xn, D, m, m + D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
+    DIT_TRY(scail_gemm_bf16(xn, D, lw.qkv_w, lw.qkv_b, qkv, 3 * D, M, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+    DIT_TRY(scail_rmsnorm_rope(k, 3 * D, k, 3 * D, lw.kn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
+    DIT_TRY(scail_transpose_v(v, 3 * D, Ltok * 3 * D, vt, B, nh, 128, Ltok, stream));
+    DIT_TRY(scail_rmsnorm_rope(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
+    DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, k, 0, Ltok * 3 * D, 3 * D, vt, 0, nh * 128 * Lp, att, Ltok * D, D,
+                                  B, nh, Ltok, Ltok, 1, scale, 0, stream));
+    DIT_TRY(scail_gemm_bf16(att, D, lw.o_w, lw.o_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, m + 2 * D, 6 * D, Ltok, stream));
+    // -- cross attention: text + CLIP, ungated residual (dit...:1039-1042, :1107-1203) --
+    DIT_TRY(scail_layernorm_affine(hid, D, xn, D, lw.ln_w, lw.ln_b, M, D, eps, stream));
+    DIT_TRY(scail_gemm_bf16(xn, D, lw.cq_w, lw.cq_b, q, 3 * D, M, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+    DIT_TRY(scail_rmsnorm_rope(q, 3 * D, q, 3 * D, lw.cqn, nullptr, nullptr, M, M, D, 128, eps, stream));
+    const scail_bf16* kt = cond->k_text + i * B * cond->Lt * D;
+    const scail_bf16* vtt = cond->vt_text + i * B * nh * 128 * Ltp;
+    DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, kt, 0, cond->Lt * D, D, vtt, 0, nh * 128 * Ltp, att, Ltok * D, D,
+                                  B, nh, Ltok, cond->Lt, 1, scale, 0, stream));
+    const scail_bf16* kc = cond->k_clip + i * cond->Bc * cond->Lc * D;
+    const scail_bf16* vtc = cond->vt_clip + i * cond->Bc * nh * 128 * Lcp;
+    DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, kc, 0, cond->Bc == 1 ? 0 : cond->Lc * D, D, vtc, 0,
+                                  cond->Bc == 1 ? 0 : nh * 128 * Lcp, att, Ltok * D, D, B, nh, Ltok, cond->Lc, 1, scale, 1, stream));
+    DIT_TRY(scail_gemm_bf16(att, D, lw.co_w, lw.co_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, nullptr, 0, 0, stream));
+    // -- MLP (dit...:1045-1050; sat/transformer_defaults.py:163-176) --
+    DIT_TRY(scail_ln_modulate(hid, D, xn, D, m + 3 * D, m + 4 * D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
+    DIT_TRY(scail_gemm_bf16(xn, D, lw.w1, lw.b1, ff, FF, M, FF, D, SCAIL_EPI_GELU_TANH, nullptr, 0, nullptr, 0, 0, stream));
+    DIT_TRY(scail_gemm_bf16(ff, FF, lw.w2, lw.b2, hid, D, M, D, FF, SCAIL_EPI_RESID, hid, D, m + 5 * D, 6 * D, Ltok, stream));
+    return 0;
+}
+
+// Seam B2 (SAT hook layer_forward): one block on caller-owned hidden states.  Workspace: scail_dit_block_workspace_bytes.
+static int64_t block_ws(const scail_dit_config& c, int64_t B, int64_t Ltok, int64_t* off) {
+    const int64_t D = c.hidden_size, FF = c.inner_hidden_size, nh = c.num_heads, Lp = (Ltok + 63) / 64 * 64;
+    int64_t o = 0;
+    const int64_t sizes[5] = {B * Ltok * D * 2, B * Ltok * 3 * D * 2, B * Ltok * D * 2, B * Ltok * FF * 2, B * nh * 128 * Lp * 2};
+    for (int j = 0; j < 5; ++j) { off[j] = o; o += align256(sizes[j]); }
+    return o;
+}
+extern "C" int64_t scail_dit_block_workspace_bytes(const scail_dit* h, int64_t B, int64_t Ltok) {
+    if (h == nullptr || B <= 0 || Ltok <= 0) return -1;
+    int64_t off[5];
+    return block_ws(h->cfg, B, Ltok, off);
+}
+extern "C" int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, const float* mod, const scail_dit_cond* cond,
+                               const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    SCAIL_REQUIRE(h != nullptr && hidden != nullptr && mod != nullptr && cond != nullptr, "null argument");
+    SCAIL_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && B > 0 && Ltok > 0, "bad layer / shape");
+    int64_t off[5];
+    const int64_t need = block_ws(h->cfg, B, Ltok, off);
+    SCAIL_REQUIRE(workspace != nullptr && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+                  "workspace too small or not 256-byte aligned (scail_dit_block_workspace_bytes)");
+    char* base = static_cast<char*>(workspace);
+    auto P = [&](int j) { return reinterpret_cast<scail_bf16*>(base + off[j]); };
+    return dit_block(h, layer, hidden, mod, cond, rope_cos, rope_sin, B, Ltok, P(0), P(1), P(2), P(3), P(4), stream);
+}
+
 extern "C" int scail_dit_create(const scail_dit_config* cfg, const scail_dit_weights* w, scail_dit** out) {
     SCAIL_REQUIRE(cfg != nullptr && w != nullptr && out != nullptr, "null argument");
     SCAIL_REQUIRE(cfg->hidden_size > 0 && cfg->hidden_size % 128 == 0 && cfg->num_heads * 128 == cfg->hidden_size,
@@ -148,38 +218,8 @@ extern "C" int scail_dit_step(scail_dit* h, const float* x, const float* timeste
                                 KPAD, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
     }
 
-    const int64_t M = B * Ltok;
-    scail_bf16 *q = qkv, *k = qkv + D, *v = qkv + 2 * D;   // column thirds of the fused projection, row stride 3D
-    for (int64_t i = 0; i < nl; ++i) {
-        const scail_dit_layer& lw = h->layers[i];
-        const float* m = mod + i * B * 6 * D;                // (B, 6D): shift_a, scale_a, gate_a, shift_m, scale_m, gate_m
-        // -- self attention (dit...:1031-1036, :1058-1105) --
-        DIT_TRY(scail_ln_modulate(hid, D, xn, D, m, m + D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
-        DIT_TRY(scail_gemm_bf16(xn, D, lw.qkv_w, lw.qkv_b, qkv, 3 * D, M, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
-        DIT_TRY(scail_rmsnorm_rope(k, 3 * D, k, 3 * D, lw.kn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
-        DIT_TRY(scail_transpose_v(v, 3 * D, Ltok * 3 * D, vt, B, nh, 128, Ltok, stream));
-        DIT_TRY(scail_rmsnorm_rope(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
-        DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, k, 0, Ltok * 3 * D, 3 * D, vt, 0, nh * 128 * Lp, att, Ltok * D, D,
-                                      B, nh, Ltok, Ltok, 1, scale, 0, stream));
-        DIT_TRY(scail_gemm_bf16(att, D, lw.o_w, lw.o_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, m + 2 * D, 6 * D, Ltok, stream));
-        // -- cross attention: text + CLIP, ungated residual (dit...:1039-1042, :1107-1203) --
-        DIT_TRY(scail_layernorm_affine(hid, D, xn, D, lw.ln_w, lw.ln_b, M, D, eps, stream));
-        DIT_TRY(scail_gemm_bf16(xn, D, lw.cq_w, lw.cq_b, q, 3 * D, M, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
-        DIT_TRY(scail_rmsnorm_rope(q, 3 * D, q, 3 * D, lw.cqn, nullptr, nullptr, M, M, D, 128, eps, stream));
-        const scail_bf16* kt = cond->k_text + i * B * cond->Lt * D;
-        const scail_bf16* vtt = cond->vt_text + i * B * nh * 128 * Ltp;
-        DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, kt, 0, cond->Lt * D, D, vtt, 0, nh * 128 * Ltp, att, Ltok * D, D,
-                                      B, nh, Ltok, cond->Lt, 1, scale, 0, stream));
-        const scail_bf16* kc = cond->k_clip + i * cond->Bc * cond->Lc * D;
-        const scail_bf16* vtc = cond->vt_clip + i * cond->Bc * nh * 128 * Lcp;
-        DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, kc, 0, cond->Bc == 1 ? 0 : cond->Lc * D, D, vtc, 0,
-                                      cond->Bc == 1 ? 0 : nh * 128 * Lcp, att, Ltok * D, D, B, nh, Ltok, cond->Lc, 1, scale, 1, stream));
-        DIT_TRY(scail_gemm_bf16(att, D, lw.co_w, lw.co_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, nullptr, 0, 0, stream));
-        // -- MLP (dit...:1045-1050; sat/transformer_defaults.py:163-176) --
-        DIT_TRY(scail_ln_modulate(hid, D, xn, D, m + 3 * D, m + 4 * D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
-        DIT_TRY(scail_gemm_bf16(xn, D, lw.w1, lw.b1, ff, FF, M, FF, D, SCAIL_EPI_GELU_TANH, nullptr, 0, nullptr, 0, 0, stream));
-        DIT_TRY(scail_gemm_bf16(ff, FF, lw.w2, lw.b2, hid, D, M, D, FF, SCAIL_EPI_RESID, hid, D, m + 5 * D, 6 * D, Ltok, stream));
-    }
+    for (int64_t i = 0; i < nl; ++i)
+        DIT_TRY(dit_block(h, i, hid, mod + i * B * 6 * D, cond, rope_cos, rope_sin, B, Ltok, xn, qkv, att, ff, vt, stream));
 
     // ---- final layer on the noise tokens only + unpatchify (dit...:818-835, :764-784) ----
     DIT_TRY(scail_ln_modulate(hid, D, xf, D, fin, fin + D, 2 * D, B, Lnoise, Ltok, Lref, D, eps, stream));

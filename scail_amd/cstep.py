@@ -117,3 +117,19 @@ class CStep:
                C2.byref(cc), ref.data_ptr(), pose.data_ptr(), cos.data_ptr(), sin.data_ptr(), T, H, W,
                self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
         return x32
+
+    def block(self, layer: int, hidden: torch.Tensor, mod: torch.Tensor, cond: Dict, cos, sin) -> torch.Tensor:
+        """Seam B2: one transformer block in place on ``hidden`` (B, Ltok, D) bf16; ``mod`` (B, 6D) fp32 = adaLN embedding +
+        this layer's table.  Returns ``hidden``."""
+        B, Ltok, _ = hidden.shape
+        lib = L.load()
+        need = lib.scail_dit_block_workspace_bytes(self._h, B, Ltok)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != hidden.device:
+            self._ws = torch.empty(need, device=hidden.device, dtype=torch.uint8)
+        k_text, k_clip = cond["k_text"], cond["k_clip"]
+        cc = DitCond(k_text.data_ptr(), cond["vt_text"].data_ptr(), k_clip.data_ptr(), cond["vt_clip"].data_ptr(),
+                     k_text.shape[2], k_clip.shape[2], k_clip.shape[1])
+        assert hidden.is_contiguous() and mod.is_contiguous() and mod.dtype == torch.float32
+        L.call("scail_dit_block", self._h, layer, hidden.data_ptr(), mod.data_ptr(), C.byref(cc), cos.data_ptr(), sin.data_ptr(),
+               B, Ltok, self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
+        return hidden

@@ -47,11 +47,14 @@ SIGNATURES = {
     "scail_dit_destroy": [_p],
     "scail_dit_workspace_bytes": [_p, _i64, _i64, _i64, _i64],
     "scail_dit_step": [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p],
+    "scail_dit_block_workspace_bytes": [_p, _i64, _i64],
+    "scail_dit_block": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _i64, _p],
     "scail_dit_sample_workspace_bytes": [_p, _i64, _i64, _i64],
     "scail_dit_sample": [_p, _p, _p, _p, _i64, _f, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _i64, _p],
 }
 # return types other than the int status
-RESTYPES = {"scail_dit_destroy": None, "scail_dit_workspace_bytes": _i64, "scail_dit_sample_workspace_bytes": _i64}
+RESTYPES = {"scail_dit_destroy": None, "scail_dit_workspace_bytes": _i64, "scail_dit_sample_workspace_bytes": _i64,
+            "scail_dit_block_workspace_bytes": _i64}
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2

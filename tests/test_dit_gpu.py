@@ -93,6 +93,40 @@ def test_c_step_executor_equals_host_orchestration_and_golden(golden_dir, name, 
     assert torch.equal(o_g, o_py)
 
 
+def test_c_block_entry_point(golden_dir):
+    """Seam B2 (scail_dit_block): feeding the per-op path's hidden states after the embedding through the C block entry
+    point layer by layer reproduces the per-op path's hidden states bit for bit (and therefore the reference's, which
+    test_dit_forward_vs_reference_golden pins)."""
+    from scail_amd import ops
+    from scail_amd.cstep import CStep
+    g = _load(golden_dir, "dit_tiny.npz")
+    cfg, sd, net = _net(O.TINY, int(g["seed"]))
+    hidden = {}
+    net._tap = lambda i, h: hidden.__setitem__(i, h.clone())
+    kw = dict(concat_images=torch.zeros(1, *g["x"].shape[1:], device=DEV), ref_concat=g["ref"].to(DEV),
+              concat_smpl_render=g["pose"].to(DEV), image_clip_features=g["clip"].to(DEV))
+    net.forward_f32(g["x"].to(DEV), g["t"].to(DEV), g["ctx"].to(DEV), None, **kw)
+    net._tap = None
+    W = net.prepare()
+    cs = CStep(net, W)
+    D = net.hidden_size
+    # the layer's modulation rows, exactly as the host path builds them (time embedding -> adaLN projection + table)
+    t32 = g["t"].to(DEV).float()
+    temb = ops.timestep_embedding(t32, net.time_freq_dim)
+    from scail_amd import lib as L
+    e1 = ops.small_linear(temb, W["time_embed.0.w"], W["time_embed.0.b"], act_out=L.ACT_SILU)
+    emb = ops.small_linear(e1, W["time_embed.2.w"], W["time_embed.2.b"])
+    adaln = ops.small_linear(emb, W["adaln_projection.1.w"], W["adaln_projection.1.b"], act_in=L.ACT_SILU)
+    mod = ops.adaln_table(adaln, W["adaln_tables"])
+    cond = net._cond_cache
+    T, H, Wd = g["x"].shape[1], g["x"].shape[3], g["x"].shape[4]
+    cos, sin = net._rope(T, H // 2, Wd // 2, 0, 0, torch.device(DEV))
+    h = hidden[-1].clone()
+    for i in range(cfg.num_layers):
+        cs.block(i, h, mod[i].contiguous(), cond, cos, sin)
+        assert torch.equal(h, hidden[i]), f"block {i}"
+
+
 def test_full_width_layer_vs_oracle():
     """BASELINE config-2 WIDTH (D = 5120, 40 heads of 128, FF = 13824, text 4096) on a short sequence: one transformer layer
     + embeddings + final layer against the fp32 oracle.  Exercises the shapes the 14B step uses (40-head attention, the
