@@ -297,6 +297,52 @@ def test_sequence_parallel_emulated_equals_single(golden_dir, world, mode):
     assert _cos(outs[0].float().cpu(), g["out"]) >= 0.999
 
 
+@pytest.mark.parametrize("mode,chunk_dim", [("ulysses", 3), ("allgather", 3), ("ulysses", 4), ("auto", 3)])
+def test_sequence_parallel_four_ranks_vs_single_and_oracle(mode, chunk_dim):
+    """Four virtual ranks on a 4-head network (ulysses needs heads % ranks == 0): split along H (chunk_dim 3) and along W
+    (chunk_dim 4, RoPE W shift); the gathered result must equal the single-rank run of the same network and the oracle."""
+    import threading
+    from scail_amd.parallel import SequenceParallel, ThreadBackend
+    world = 4
+    cfgd = dict(hidden_size=512, num_layers=2, num_attention_heads=4, inner_hidden_size=1024, text_dim=64,
+                time_freq_dim=256, time_embed_dim=512, latent_height=64, latent_width=64, num_frames=13)
+    gen = torch.Generator().manual_seed(11)
+    r = lambda *sh: torch.randn(*sh, generator=gen).to(torch.bfloat16).float()
+    T, H, W = (2, 16, 32) if chunk_dim == 3 else (2, 32, 16)
+    x, ctx, t = r(2, T, 16, H, W), r(2, 12, 64), torch.tensor([500.0, 500.0])
+    ref, pose, clip = r(1, 1, 16, H, W), r(1, T, 16, H // 2, W // 2), r(1, 5, 1280)
+    cfg, sd, net1 = _net(cfgd, 77)
+    kw = dict(concat_images=torch.zeros(1, device=DEV), image_clip_features=clip.to(DEV))
+    single = net1(x.to(DEV), timesteps=t.to(DEV), context=ctx.to(DEV), ref_concat=ref.to(DEV), concat_smpl_render=pose.to(DEV), **kw)
+    want = O.dit_forward(cfg, sd, x, t, ctx, ref, pose, clip)
+    torch.testing.assert_close(single.float().cpu(), want, rtol=2e-2, atol=2e-2)
+    shared = ThreadBackend.Shared(world)
+    outs, errs = [None] * world, []
+
+    def run(rk):
+        try:
+            torch.cuda.set_device(0)
+            _, _, net = _net(cfgd, 77)
+            sp = SequenceParallel(ThreadBackend(shared, rk), mode=mode)
+            net.sp = sp
+            assert sp.resolve_mode(4) == ("ulysses" if mode == "auto" else mode)
+            sp.check_latent(H, W, chunk_dim)
+            ch = lambda tt: sp.chunk(tt.to(DEV), chunk_dim)
+            o = net(ch(x), timesteps=t.to(DEV), context=ctx.to(DEV), ref_concat=ch(ref), concat_smpl_render=ch(pose),
+                    chunk_dim=chunk_dim, **kw)
+            outs[rk] = sp.gather_to_rank0(o, chunk_dim)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(rk,)) for rk in range(world)]
+    [tt.start() for tt in th]
+    [tt.join() for tt in th]
+    assert not errs, errs
+    torch.testing.assert_close(outs[0].float().cpu(), single.float().cpu(), rtol=2e-2, atol=2e-2)
+    assert _cos(outs[0].float().cpu(), want) >= 0.999
+
+
 def test_cli_tiny_end_to_end():
     """BASELINE.json configs[0] shape through the CLI driver: VAE encode -> 2-step sampler -> VAE decode."""
     from scail_amd import cli
