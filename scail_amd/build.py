@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libscail_hip.so")
-SOURCES = ["errors.hip", "rowops.hip", "gemm.hip", "attn.hip", "conv.hip", "dit_step.hip"]
+SOURCES = ["errors.hip", "rowops.hip", "gemm.hip", "attn.hip", "conv.hip", "dit_step.hip", "vae_exec.hip"]
 ARCH = "gfx950"
 # per-file extra flags (e.g. {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]} keeps MFMA results of the 256-thread
 # attention variants in arch VGPRs; measured, not needed by any default kernel)
@@ -34,6 +34,7 @@ def needs_build() -> bool:
     t = os.path.getmtime(LIB)
     deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(PKG), "include", "scail_hip.h"),
                         os.path.join(os.path.dirname(PKG), "include", "scail_dit.h"),
+                        os.path.join(os.path.dirname(PKG), "include", "scail_vae.h"),
                         os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -1,4 +1,4 @@
-"""ctypes binding of libscail_hip.so (include/scail_hip.h, include/scail_dit.h).  Fails loudly when the library is
+"""ctypes binding of libscail_hip.so (include/scail_hip.h, include/scail_dit.h, include/scail_vae.h).  Fails loudly when the library is
 missing -- there is deliberately no fallback path."""
 from __future__ import annotations
 
@@ -51,9 +51,15 @@ SIGNATURES = {
     "scail_dit_block": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _i64, _p],
     "scail_dit_sample_workspace_bytes": [_p, _i64, _i64, _i64],
     "scail_dit_sample": [_p, _p, _p, _p, _i64, _f, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _i64, _p],
+    # include/scail_vae.h (scail_amd/cvae.py builds the structs)
+    "scail_vae_create": [_p, _p],
+    "scail_vae_destroy": [_p],
+    "scail_vae_workspace_bytes": [_p, _i64, _i64, _i64],
+    "scail_vae_encode": [_p, _p, _p, _i64, _i64, _i64, _p, _i64, _p],
+    "scail_vae_decode": [_p, _p, _p, _i64, _i64, _i64, _p, _i64, _p],
 }
 # return types other than the int status
-RESTYPES = {"scail_dit_destroy": None, "scail_dit_workspace_bytes": _i64, "scail_dit_sample_workspace_bytes": _i64,
+RESTYPES = {"scail_dit_destroy": None, "scail_vae_destroy": None, "scail_vae_workspace_bytes": _i64, "scail_dit_workspace_bytes": _i64, "scail_dit_sample_workspace_bytes": _i64,
             "scail_dit_block_workspace_bytes": _i64}
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID = 0, 1, 2, 3

@@ -61,6 +61,9 @@ class WanVAE_(nn.Module):
                 w = torch.randn(shape, device=dev, generator=g) / math.sqrt(fan_in)
             _register(self, n, nn.Parameter(w.to(torch.bfloat16), requires_grad=False))
         self._prepared = None
+        # one C call per encode / decode (include/scail_vae.h); the layer-by-layer path below is the cross-check
+        self.use_c_exec = os.environ.get("SCAIL_C_VAE", "1") != "0"
+        self._cvae = None
 
     # ---- architecture tables (Encoder3d :283-306, Decoder3d :387-416) ----
     def encoder_plan(self):
@@ -171,7 +174,14 @@ class WanVAE_(nn.Module):
         W["mean"] = torch.tensor(LATENT_MEAN[:self.z_dim], device=dev)
         W["std"] = torch.tensor(LATENT_STD[:self.z_dim], device=dev)
         self._prepared = W
+        self._cvae = None
         return W
+
+    def _c(self):
+        if self._cvae is None:
+            from .cvae import CVae
+            self._cvae = CVae(self, self.prepare())
+        return self._cvae
 
     # ---- blocks (channels-last (T,H,W,C) bf16) ----
     def _res(self, W, n, x):
@@ -236,6 +246,8 @@ class WanVAE_(nn.Module):
         if (T - 1) % 4 or H % 8 or Wd % 8:
             raise ValueError("video needs T = 1 + 4n frames and H, W multiples of 8")
         W = self.prepare()
+        if self.use_c_exec:
+            return self._c().encode(video.float().to(next(self.parameters()).device).contiguous()).unsqueeze(0)
         x = ops.to_channels_last(video.float().to(next(self.parameters()).device), 8)
         x = ops.conv3d_cl(x, W["encoder.conv1"], (T, H, Wd))
         for kind, n, a, b in self.encoder_plan():
@@ -256,6 +268,8 @@ class WanVAE_(nn.Module):
             assert z.shape[0] == 1
             z = z[0]
         W = self.prepare()
+        if self.use_c_exec:
+            return self._c().decode(z.float().to(next(self.parameters()).device).contiguous()).unsqueeze(0)
         x = ops.to_channels_last(z.float().to(next(self.parameters()).device), self.z_dim, a=W["std"], b=W["mean"])
         x = ops.conv3d_cl(x, W["conv2"], x.shape[:3])
         x = ops.conv3d_cl(x, W["decoder.conv1"], x.shape[:3])

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-HEADERS = ["scail_hip.h", "scail_dit.h"]
+HEADERS = ["scail_hip.h", "scail_dit.h", "scail_vae.h"]
 
 
 def _header_source():

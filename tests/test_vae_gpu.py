@@ -153,3 +153,24 @@ def test_vae_wrapper_and_causality():
     torch.testing.assert_close(z[:, :, :2], z5, rtol=1e-3, atol=1e-3)
     x = vae.decode([z[0]])
     assert x.shape == (1, 3, 13, 32, 32) and float(x.abs().max()) <= 1.0
+
+
+def test_c_executor_equals_layerwise_path():
+    """include/scail_vae.h: encode / decode as one C call each enqueue the same kernels in the same order as the layer-by-layer
+    Python path -> bit-identical results (the golden tests above run through the C executor, the default)."""
+    from scail_amd.wan_vae import WanVAE_
+    m = WanVAE_(dim=32, z_dim=16, device=DEV)
+    g = torch.Generator().manual_seed(9)
+    vid = (torch.rand(1, 3, 9, 48, 64, generator=g) * 2 - 1).to(DEV)       # mid-block attention: 6 x 8 = 48 tokens per frame
+    assert m.use_c_exec
+    z_c = m.encode(vid)
+    x_c = m.decode(z_c)
+    assert m._cvae is not None
+    m.use_c_exec = False
+    z_p = m.encode(vid)
+    x_p = m.decode(z_p)
+    assert z_c.shape == (1, 16, 3, 6, 8) and x_c.shape == (1, 3, 9, 48, 64)
+    assert torch.equal(z_c, z_p) and torch.equal(x_c, x_p)
+    with pytest.raises(ValueError):
+        m.use_c_exec = True
+        m.encode(vid[:, :, :8])
