@@ -937,12 +937,14 @@ __global__ __launch_bounds__(512 / NQB) void flash_attn_w4_kernel(AttnParams p) 
 }
 
 int scail_gemm_tune(int v);
+int scail_gemm_group_m(int v);
 int scail_conv_tune(int v);
 static int g_attn_variant = 8 | (2 << 12);
 extern "C" int scail_tune_set(const char* knob, int value) {
     if (std::string(knob) == "attn_variant") { g_attn_variant = value; return 0; }
     if (std::string(knob) == "gemm_tile") return scail_gemm_tune(value);
     if (std::string(knob) == "conv_halo") return scail_conv_tune(value);
+    if (std::string(knob) == "gemm_group_m") return scail_gemm_group_m(value);
     scail_set_error(std::string("scail_tune_set: unknown knob ") + knob);
     return 1;
 }

@@ -28,6 +28,7 @@ struct GemmParams {
     int M, N, K;
     const u16* resid; int64_t ldr;
     const float* gate; int64_t gate_stride; int64_t rows_per_batch;
+    int group_m;   // m-tiles per tile group of the block -> tile map (q8 kernel; others use GROUP_M)
 };
 
 // Two instantiations share this body:
@@ -457,6 +458,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmParams p) {
     gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
 }
 
+// q8 tile-group height (m-tiles sharing an n sweep per group): 4 measured best on the four per-token GEMM shapes
+// (tools/gemm_group_probe.py: 1: -5 %, 2: -1 %, 3-4: best, 8: -1..2 %, 16: -8 %, 32: -18 %)
+static int g_group_m = 4;
+int scail_gemm_group_m(int v) { g_group_m = v > 0 ? v : 4; return 0; }
 static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 tile + LDS-DMA; 258: 256 tile + DMA ring
 int scail_gemm_tune(int v) { g_gemm_tile = v; return 0; }
 
@@ -527,10 +532,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmParams p) {
         const int q = nb >> 3, r = nb & 7, xcd = id & 7, loc = id >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int in_group = GROUP_M * tiles_n;
+    const int in_group = p.group_m * tiles_n;
     const int gid = wg / in_group;
-    const int first_m = gid * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int first_m = gid * p.group_m;
+    const int gsz = min(tiles_m - first_m, p.group_m);
     const int pid_m = first_m + (wg % in_group) % gsz;
     const int pid_n = (wg % in_group) / gsz;
     const int m0 = pid_m * BM, n0 = pid_n * BN;
@@ -794,6 +799,7 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
     p.x = x; p.lda = lda; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.resid = resid; p.ldr = ldr; p.gate = gate; p.gate_stride = gate_stride; p.rows_per_batch = rows_per_batch;
+    p.group_m = g_group_m;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case SCAIL_EPI_BIAS: return launch_gemm<SCAIL_EPI_BIAS>(p, s);
