@@ -163,9 +163,15 @@ int up_stage(Arena& a, const scail_vae_stage& s, Tens& x) {
     return 0;
 }
 
+// a slot holds the largest activation (full resolution, `dim` channels) or the mid-block attention's temporaries
+// (q, k, v, o of all latent frames + one frame's score matrix and V^T) -- the latter dominates for single-frame clips
 int64_t slot_bytes_for(const scail_vae_weights& w, int64_t T, int64_t H, int64_t W) {
     const int64_t dim = w.enc_conv1.N > w.dec_head.Cin ? w.enc_conv1.N : w.dec_head.Cin;
-    return align256(T * H * W * dim * 2);
+    const int64_t Tl = 1 + (T - 1) / 4, nt = (H / 8) * (W / 8), npad = (nt + 63) / 64 * 64;
+    const int64_t C = w.enc_attn.C > w.dec_attn.C ? w.enc_attn.C : w.dec_attn.C;
+    const int64_t attn = 4 * align256(Tl * nt * C * 2) + align256(nt * npad * 2) + align256(C * npad * 2);
+    const int64_t act = align256(T * H * W * dim * 2);
+    return act > attn ? act : attn;
 }
 
 }  // namespace

@@ -44,3 +44,14 @@ def test_bench_two_ranks_one_gpu(mode):
     assert "cpu_baseline" not in two
     # same seeds, same steps: the sharded run reproduces the single-rank latent (bf16 re-association only)
     assert abs(two["config"]["x_abs_mean"] - one["config"]["x_abs_mean"]) < 2e-3 * one["config"]["x_abs_mean"]
+
+
+def test_fullsize_request_two_steps():
+    """BASELINE config-2 SIZES end to end through the driver (SCAIL-14B shapes, 512x896x81f, random-init weights, 2 of the 50
+    sampler steps): VAE encode of the reference frame and the pose clip, the C-level sampler loop, VAE decode.  Guards the
+    full-size-only failure modes (workspace sizing, 32-bit offsets, tile counts) that the toy configurations cannot reach."""
+    r = subprocess.run([sys.executable, "tools/e2e_fullsize.py", "2"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert o["latent"] == [1, 16, 21, 64, 112] and o["video"] == [1, 3, 81, 512, 896]
+    assert o["finite"] and 0.0 <= o["vmin"] and o["vmax"] <= 1.0

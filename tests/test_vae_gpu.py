@@ -174,3 +174,8 @@ def test_c_executor_equals_layerwise_path():
     with pytest.raises(ValueError):
         m.use_c_exec = True
         m.encode(vid[:, :, :8])
+    # a single large frame: the attention score matrix (4096 x 4096), not an activation, sizes the workspace slots
+    img = (torch.rand(1, 3, 1, 512, 512, generator=g) * 2 - 1).to(DEV)
+    z1 = m.encode(img)
+    m.use_c_exec = False
+    assert torch.equal(z1, m.encode(img))
