@@ -166,3 +166,33 @@ def test_more_argument_validation_without_gpu(libpath):
     L.call("scail_gemm_bf16", A, 64, A, None, A, 16, 0, 16, 64, 0, None, 0, None, 0, 0, None)
     L.call("scail_flash_attn_bf16", A, 0, 128, A, 0, 0, 128, A, 0, 0, A, 0, 128, 1, 1, 0, 8, 1, 0.1, 0, None)
     L.call("scail_rms_silu", A, A, A, 0, 32, 1, None)
+
+
+def test_product_path_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under scail_amd/ (nor bench.py outside its cpu_baseline leg) may import it."""
+    import ast
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parents[1]
+    for f in sorted((root / "scail_amd").glob("*.py")):
+        tree = ast.parse(f.read_text())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n.split(".")[0] == "oracle" for n in names), f"{f.name} imports the oracle"
+    for f in sorted((root / "scail_amd" / "csrc").iterdir()):
+        bad = [ln for ln in f.read_text(errors="ignore").splitlines()
+               if "oracle" in ln and ("#include" in ln or "dlopen" in ln)]
+        assert not bad, f"{f.name} links the oracle: {bad}"
+    src = (root / "bench.py").read_text()
+    tree = ast.parse(src)
+    for node in tree.body:                      # module level: no oracle import; only inside the cpu_baseline function
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            mod = node.module if isinstance(node, ast.ImportFrom) else ",".join(a.name for a in node.names)
+            assert "oracle" not in (mod or "")
+    users = [n.name for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)
+             and any(isinstance(m, (ast.Import, ast.ImportFrom)) and "oracle" in ((getattr(m, "module", None) or "") + ",".join(a.name for a in m.names))
+                     for m in ast.walk(n))]
+    assert all("cpu" in u for u in users), users
