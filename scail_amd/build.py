@@ -9,12 +9,15 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-LIB = os.path.join(PKG, "libscail_hip.so")
 SOURCES = ["errors.hip", "rowops.hip", "gemm.hip", "attn.hip", "conv.hip", "dit_step.hip", "vae_exec.hip"]
 ARCH = "gfx950"
 # per-file extra flags (e.g. {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]} keeps MFMA results of the 256-thread
 # attention variants in arch VGPRs; measured, not needed by any default kernel)
 EXTRA_FLAGS = {}
+# SCAIL_ABLATIONS=1: also compile the timing-ablation kernel variants (wrong results on purpose) that tools/microbench.py
+# selects through scail_tune_set; the shipped library is built without them and rejects their codes.
+ABLATIONS = os.environ.get("SCAIL_ABLATIONS", "0") not in ("", "0")
+LIB = os.path.join(PKG, "libscail_hip_abl.so" if ABLATIONS else "libscail_hip.so")
 
 
 def _hipcc() -> str:
@@ -43,13 +46,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = _hipcc()
-    objdir = os.path.join(os.path.dirname(PKG), "build")
+    objdir = os.path.join(os.path.dirname(PKG), "build_abl" if ABLATIONS else "build")
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + (["-DSCAIL_ABLATIONS"] if ABLATIONS else []) + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -941,7 +941,19 @@ int scail_gemm_group_m(int v);
 int scail_conv_tune(int v);
 static int g_attn_variant = 8 | (2 << 12);
 extern "C" int scail_tune_set(const char* knob, int value) {
-    if (std::string(knob) == "attn_variant") { g_attn_variant = value; return 0; }
+    if (std::string(knob) == "attn_variant") {
+#ifndef SCAIL_ABLATIONS
+        // timing ablations (wrong results on purpose; tools/microbench.py): lock-step bits 4 / 5, software-pipelined sub-code 5
+        const int low = value & 0xFFFFF;
+        if (low == 18 || low == 34 || low == 50 || ((value & 8) && !(value & (512 | 1024)) && ((value >> 12) & 15) == 5)) {
+            scail_set_error("scail_tune_set: attn_variant " + std::to_string(value) +
+                            " is a timing ablation (wrong results); rebuild with SCAIL_ABLATIONS=1 to enable it");
+            return 1;
+        }
+#endif
+        g_attn_variant = value;
+        return 0;
+    }
     if (std::string(knob) == "gemm_tile") return scail_gemm_tune(value);
     if (std::string(knob) == "conv_halo") return scail_conv_tune(value);
     if (std::string(knob) == "gemm_group_m") return scail_gemm_group_m(value);
@@ -968,11 +980,15 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     if (Lq == 0 || n_batch == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[10] = {reinterpret_cast<const void*>(&flash_attn_kernel<258, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<2, 4>), reinterpret_cast<const void*>(&flash_attn_kernel<0, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<1, 8>),
-                              reinterpret_cast<const void*>(&flash_attn_kernel<2, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<3, 8>),
-                              reinterpret_cast<const void*>(&flash_attn_swp_kernel<9, 3>), reinterpret_cast<const void*>(&flash_attn_kernel<18, 8>),
-                              reinterpret_cast<const void*>(&flash_attn_kernel<34, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<50, 8>)};
-        for (int i = 0; i < 10; ++i) {
+        const void* fns[] = {reinterpret_cast<const void*>(&flash_attn_kernel<258, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<2, 4>), reinterpret_cast<const void*>(&flash_attn_kernel<0, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<1, 8>),
+                             reinterpret_cast<const void*>(&flash_attn_kernel<2, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<3, 8>),
+                             reinterpret_cast<const void*>(&flash_attn_swp_kernel<9, 3>),
+#ifdef SCAIL_ABLATIONS
+                             reinterpret_cast<const void*>(&flash_attn_kernel<18, 8>),
+                             reinterpret_cast<const void*>(&flash_attn_kernel<34, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<50, 8>),
+#endif
+        };
+        for (int i = 0; i < (int)(sizeof(fns) / sizeof(fns[0])); ++i) {
             hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i == 6 ? ATT_PP_LDS_BYTES : ATT_LDS_BYTES);
             if (e != hipSuccess) {
                 scail_set_error(std::string("flash_attn: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
@@ -1034,14 +1050,18 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+#ifdef SCAIL_ABLATIONS
             hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+#endif
             swp_attr = true;
         }
         if (sub == 1) hipLaunchKernelGGL((flash_attn_swp_kernel<5, 5>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 2) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 3) hipLaunchKernelGGL((flash_attn_swp_kernel<6, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         else if (sub == 4) hipLaunchKernelGGL((flash_attn_swp_kernel<3, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+#ifdef SCAIL_ABLATIONS
         else if (sub == 5) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4, 1>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+#endif
         else hipLaunchKernelGGL((flash_attn_swp_kernel<9, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
         return scail_check_launch("flash_attn");
     }
@@ -1054,9 +1074,11 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         hipLaunchKernelGGL((flash_attn_kernel<2, 4>), grid4, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
         return scail_check_launch("flash_attn");
     }
+#ifdef SCAIL_ABLATIONS
     if ((g_attn_variant & 0xFFFFF) == 18) { hipLaunchKernelGGL((flash_attn_kernel<18, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
     if ((g_attn_variant & 0xFFFFF) == 34) { hipLaunchKernelGGL((flash_attn_kernel<34, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
     if ((g_attn_variant & 0xFFFFF) == 50) { hipLaunchKernelGGL((flash_attn_kernel<50, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
+#endif
     switch (g_attn_variant & 3) {
         case 0: hipLaunchKernelGGL((flash_attn_kernel<0, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
         case 1: hipLaunchKernelGGL((flash_attn_kernel<1, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;

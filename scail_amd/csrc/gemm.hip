@@ -463,7 +463,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmParams p) {
 static int g_group_m = 4;
 int scail_gemm_group_m(int v) { g_group_m = v > 0 ? v : 4; return 0; }
 static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 tile + LDS-DMA; 258: 256 tile + DMA ring
-int scail_gemm_tune(int v) { g_gemm_tile = v; return 0; }
+// Codes >= 1000 select TIMING ABLATIONS of the big-tile kernels (most of them compute wrong results on purpose: loads or
+// fragment reads removed, all-L2-hit addressing, ...).  They exist for tools/microbench.py and are compiled in only when
+// the library is built with -DSCAIL_ABLATIONS (SCAIL_ABLATIONS=1 python -m scail_amd.build --force); the shipped library
+// rejects them.
+int scail_gemm_tune(int v) {
+    bool ok = false;
+    switch (v) {
+        case 0: case 128: case 256: case 257: case 258: case 259: case 260: case 261: case 262: case 266: ok = true; break;
+        default: break;
+    }
+#ifdef SCAIL_ABLATIONS
+    ok = ok || (v >= 1000 && v < 1600);
+#endif
+    if (!ok) {
+        scail_set_error("scail_tune_set: gemm_tile " + std::to_string(v) + (v >= 1000 && v < 1600
+                            ? " is a timing ablation (wrong results); rebuild with SCAIL_ABLATIONS=1 to enable it" : " is not a known tile code"));
+        return 1;
+    }
+    g_gemm_tile = v;
+    return 0;
+}
 
 
 // Measurement aid (tools/microbench.py): summed lifetime of the q8 workgroups in s_memtime ticks (= shader clock
@@ -748,13 +768,16 @@ template <int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (g_gemm_tile == 261) return launch_gemm_q8<EPI>(p, stream);
     if (g_gemm_tile == 266) return launch_gemm_t<256, 256, 2, 2, EPI, true>(p, stream);   // 4 waves, 128 x 128 per wave (AGPR accumulators)
+#ifdef SCAIL_ABLATIONS
     if (EPI == 0 && g_gemm_tile == 1101) return launch_gemm_q8<0, 1>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1102) return launch_gemm_q8<0, 2>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1103) return launch_gemm_q8<0, 3>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1104) return launch_gemm_q8<0, 4>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1108) return launch_gemm_q8<0, 8>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1112) return launch_gemm_q8<0, 12>(p, stream);
+#endif
     if (g_gemm_tile == 262) return launch_gemm_q8<EPI, 32>(p, stream);
+#ifdef SCAIL_ABLATIONS
     if (EPI == 0 && g_gemm_tile == 1300) return launch_gemm_q8<0, 128>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1301) return launch_gemm_q8<0, 129>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1302) return launch_gemm_q8<0, 130>(p, stream);
@@ -765,13 +788,18 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (EPI == 0 && g_gemm_tile == 1164) return launch_gemm_q8<0, 64>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1116) return launch_gemm_q8<0, 16>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1124) return launch_gemm_q8<0, 24>(p, stream);
+#endif
     if (g_gemm_tile == 259) return launch_gemm_pp<EPI>(p, stream);
+#ifdef SCAIL_ABLATIONS
     if (EPI == 0 && g_gemm_tile == 1001) return launch_gemm_t<256, 256, 2, 4, 0, true, 1>(p, stream);   // ablations
     if (EPI == 0 && g_gemm_tile == 1002) return launch_gemm_t<256, 256, 2, 4, 0, true, 2>(p, stream);
+#endif
     if (g_gemm_tile == 260) return launch_gemm_t<256, 256, 2, 4, EPI, true, 4>(p, stream);   // DMA issue spread over the k-steps
+#ifdef SCAIL_ABLATIONS
     if (EPI == 0 && g_gemm_tile == 1008) return launch_gemm_t<256, 256, 2, 4, EPI, true, 8>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1024) return launch_gemm_t<256, 256, 2, 4, EPI, true, 24>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1003) return launch_gemm_t<256, 256, 2, 4, 0, true, 3>(p, stream);
+#endif
     // measured at M = 97 664 (profiles/r01_pmc.md): 128 tile 820, 256 tile 1000, 256 + LDS-DMA 1090, 256 + DMA ring
     // of half k-tiles with counted vmcnt 1025, ping-pong 1000, quadrant-phase q8 1240-1290 TFLOP/s (default for the
     // big per-token GEMMs; the vendor library's assembly kernel reaches 1500 on the same shapes)

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscail_hip.so")
+# SCAIL_ABLATIONS=1 selects the measurement build that also holds the timing-ablation kernels (scail_amd/build.py)
+LIB_PATH = os.path.join(_HERE, "libscail_hip_abl.so" if os.environ.get("SCAIL_ABLATIONS", "0") not in ("", "0") else "libscail_hip.so")
 
 _p = C.c_void_p
 _i64 = C.c_int64

@@ -155,6 +155,11 @@ def test_more_argument_validation_without_gpu(libpath):
         ("gate needs rows_per_batch", "scail_gemm_bf16", (A, 64, A, None, A, 16, 8, 16, 64, 3, A, 16, A, 16, 0, None)),
         ("pointer alignment", "scail_gemm_bf16", (A + 4, 64, A, None, A, 16, 8, 16, 64, 0, None, 0, None, 0, 0, None)),
         ("unknown knob", "scail_tune_set", (b"no_such_knob", 1)),
+        # timing-ablation kernels (wrong results on purpose) are not in the shipped library
+        ("timing ablation", "scail_tune_set", (b"gemm_tile", 1101)),
+        ("timing ablation", "scail_tune_set", (b"attn_variant", 18)),
+        ("timing ablation", "scail_tune_set", (b"attn_variant", 8 | (5 << 12))),
+        ("not a known tile code", "scail_tune_set", (b"gemm_tile", 999)),
     ]
     for needle, fn, args in cases:
         with pytest.raises(L.ScailHipError, match=needle):

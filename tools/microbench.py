@@ -2,7 +2,9 @@
 """Kernel microbenchmarks on random data (HIP events on the launch stream), one JSON line per case.
   python tools/microbench.py attn [--L 48832] [--heads 8] [--iters 5]
   python tools/microbench.py gemm [--M 97664 --N 5120 --K 5120] [--epi 0]
-Used under rocprofv3 --pmc for counter collection (profiles/)."""
+Used under rocprofv3 --pmc for counter collection (profiles/).
+Timing-ablation variants (gemm_tile >= 1000, attn_variant 18 / 34 / 50 / swp sub-code 5; wrong results on purpose) need the
+measurement build: SCAIL_ABLATIONS=1 python -m scail_amd.build, then run this tool with SCAIL_ABLATIONS=1."""
 import argparse
 import json
 import os
