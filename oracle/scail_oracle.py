@@ -268,6 +268,33 @@ def rope_tables(cfg: DiTConfig, rope_T: int, rope_H: int, rope_W: int,
     return cos.contiguous(), sin.contiguous()
 
 
+def rope_tables_multi(cfg: DiTConfig, rope_T: int, rope_H: int, rope_W: int, n_char: int,
+                      H_shift: int = 0, W_shift: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """EXTENSION, not in the reference (BASELINE config 5, SURVEY 8d: the reference has exactly one reference frame and one
+    pose stream, dit...:1559): token order [ref_0 .. ref_{C-1} | noise | pose_0 .. pose_{C-1}].  Character 0 uses the
+    reference's positions; character k > 0 takes windows the reference leaves unused:
+      ref_k : t = 0, w window shifted by k * global_rope_W          (ref_0 at 0, the t = 0 plane is otherwise empty)
+      pose_k: t = 1..T, w window shifted by global_rope_W + k * rope_W (pose_0 at global_rope_W, pose_k right of it)
+    Parity for n_char > 1 is therefore unpinned by construction; n_char == 1 equals rope_tables()."""
+    hd = cfg.head_dim
+    hp = torch.arange(H_shift, H_shift + rope_H)
+    wp = torch.arange(W_shift, W_shift + rope_W)
+
+    def pool(x):
+        return F.avg_pool2d(x.permute(0, 3, 1, 2), kernel_size=2, stride=2).permute(0, 2, 3, 1)
+
+    cos, sin = [], []
+    for k in range(n_char):
+        a = rope_angles(cfg, torch.tensor([0]), hp, wp + k * cfg.global_rope_W)
+        cos.append(a.cos().reshape(-1, hd)); sin.append(a.sin().reshape(-1, hd))
+    a = rope_angles(cfg, torch.arange(1, rope_T + 1), hp, wp)
+    cos.append(a.cos().reshape(-1, hd)); sin.append(a.sin().reshape(-1, hd))
+    for k in range(n_char):
+        a = rope_angles(cfg, torch.arange(1, rope_T + 1), hp + cfg.global_rope_H, wp + cfg.global_rope_W + k * rope_W)
+        cos.append(pool(a.cos()).reshape(-1, hd)); sin.append(pool(a.sin()).reshape(-1, hd))
+    return torch.cat(cos, 0).contiguous(), torch.cat(sin, 0).contiguous()
+
+
 def rotate_half_interleaved(x: torch.Tensor) -> torch.Tensor:
     """dit...:336-340: (x0,x1,x2,x3,..) -> (-x1,x0,-x3,x2,..)."""
     x = x.reshape(*x.shape[:-1], -1, 2)
@@ -424,6 +451,8 @@ def dit_forward(cfg: DiTConfig, sd, x, timesteps, context, ref_concat, concat_sm
 
     x (B,T,16,H,W); timesteps (B,); context (B,Lt,text_dim); ref_concat (1|B,1,16,H,W);
     concat_smpl_render (1|B,T,16,H/2,W/2); image_clip_features (1|B,257,1280).
+    EXTENSION (BASELINE config 5, not in the reference): ref_concat with C > 1 frames and concat_smpl_render with C*T
+    frames are C characters, token order [ref_0..ref_{C-1} | noise | pose_0..pose_{C-1}], RoPE of rope_tables_multi().
     """
     B, T, C, H, W = x.shape
     x = x.float()
@@ -434,16 +463,19 @@ def dit_forward(cfg: DiTConfig, sd, x, timesteps, context, ref_concat, concat_sm
     ref = rep(ref_concat)
     pose = rep(concat_smpl_render)
     x20 = torch.cat([x, torch.zeros(B, T, 4, H, W)], dim=2)                       # :1468,1503
-    ref20 = torch.cat([ref, torch.ones(B, 1, 4, H, W)], dim=2)                    # :1483-1486
-    pose20 = torch.cat([pose, torch.ones(B, T, 4, H // 2, W // 2)], dim=2)        # :1496-1501
+    n_char = ref.shape[1]
+    assert pose.shape[1] == n_char * T
+    ref20 = torch.cat([ref, torch.ones(B, n_char, 4, H, W)], dim=2)               # :1483-1486
+    pose20 = torch.cat([pose, torch.ones(B, n_char * T, 4, H // 2, W // 2)], dim=2)   # :1496-1501
     text = text_embedding(cfg, sd, context.float())
     clip = rep(clip_proj(cfg, sd, image_clip_features.float()))
     emb, adaln = time_embeddings(cfg, sd, timesteps)
     pt, ph, pw = cfg.patch_size
     rope_T, rope_H, rope_W = T // pt, H // ph, W // pw
     seq_len = T * H * W // (pt * ph * pw)
-    ref_len = H * W // (pt * ph * pw)
-    cos, sin = rope_tables(cfg, rope_T, rope_H, rope_W, H_shift, W_shift)
+    ref_len = n_char * H * W // (pt * ph * pw)
+    cos, sin = (rope_tables(cfg, rope_T, rope_H, rope_W, H_shift, W_shift) if n_char == 1 else
+                rope_tables_multi(cfg, rope_T, rope_H, rope_W, n_char, H_shift, W_shift))
     h = patch_embed(cfg, sd, x20, ref20, pose20)
     hidden = [h]
     for i in range(cfg.num_layers):

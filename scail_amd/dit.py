@@ -335,13 +335,13 @@ class DiffusionTransformer(nn.Module):
             return fn(*a, **k)
         return self.kernel_timer.run(tag, fn, *a, **k)
 
-    def _rope(self, T, Hp, Wp, H_shift, W_shift, device):
-        key = (T, Hp, Wp, H_shift, W_shift)
+    def _rope(self, T, Hp, Wp, H_shift, W_shift, device, n_char=1):
+        key = (T, Hp, Wp, H_shift, W_shift, n_char)
         if key not in self._rope_cache:
             mt = (self.num_frames - 1) // self.time_compressed_rate + 1
             cos, sin = rope.build_tables(self.head_dim, T, Hp, Wp, H_shift, W_shift, self.global_rope_H,
                                          self.global_rope_W, max_T=mt, max_H=self.latent_height // 2,
-                                         max_W=self.latent_width // 2 + 120)
+                                         max_W=self.latent_width // 2 + 120, n_char=n_char)
             self._rope_cache[key] = (cos.to(device), sin.to(device))
         return self._rope_cache[key]
 
@@ -429,13 +429,21 @@ class DiffusionTransformer(nn.Module):
         B, T, _, H, Wd = x32.shape
         D, nh, eps = self.hidden_size, self.num_attention_heads, self.layernorm_epsilon
         hp, wp = H // 2, Wd // 2
-        Lref, Lnoise, Lpose = hp * wp, T * hp * wp, T * (H // 4) * (Wd // 4)
+        # n_char > 1: multi-character in-context concat, an EXTENSION (BASELINE config 5; the reference has one reference
+        # frame and one pose stream): ref (n, C, 16, H, W), pose (n, C*T, 16, H/2, W/2), tokens
+        # [ref_0..ref_{C-1} | noise | pose_0..pose_{C-1}], RoPE windows of rope.build_tables(n_char=C)
+        n_char = ref.shape[1]
+        if pose.shape[1] != n_char * T:
+            raise L.ScailHipError(f"concat_smpl_render needs {n_char} x {T} frames for {n_char} reference frame(s), got {pose.shape[1]}")
+        Lref1, Lnoise, Lpose1 = hp * wp, T * hp * wp, T * (H // 4) * (Wd // 4)
+        Lref, Lpose = n_char * Lref1, n_char * Lpose1
         Ltok = Lref + Lnoise + Lpose
         if ctx.shape[0] != B:
             raise L.ScailHipError("context batch must equal the (CFG-doubled) input batch")
         cond = self._conditioning(ctx, clip, cond_key)
-        cos, sin = self._rope(T, hp, wp, H_shift, W_shift, dev)
-        if self.use_c_step and self._tap is None and self.kernel_timer is None and not (self.sp is not None and self.sp.size > 1):
+        cos, sin = self._rope(T, hp, wp, H_shift, W_shift, dev, n_char)
+        if (n_char == 1 and self.use_c_step and self._tap is None and self.kernel_timer is None
+                and not (self.sp is not None and self.sp.size > 1)):
             # the whole evaluation as ONE call into the library (include/scail_dit.h); same kernels, same order
             if self._cstep is None:
                 from .cstep import CStep
@@ -452,7 +460,16 @@ class DiffusionTransformer(nn.Module):
         fin = ops.adaln_table(emb.repeat(1, 2).contiguous(), W["final_table"])[0]   # (B, 2D) fp32
 
         # ---- patch embedding straight into the token layout [ref | noise | pose] (:99-130) ----
-        tok = ops.patchify(x32, ref, pose, kpad=128, out=ws["tok"])
+        if n_char == 1:
+            tok = ops.patchify(x32, ref, pose, kpad=128, out=ws["tok"])
+        else:
+            tok = ws["tok"]
+            for c in range(n_char):         # per-character assembly with the single-character kernel (glue; not a hot path)
+                tk = ops.patchify(x32, ref[:, c:c + 1].contiguous(), pose[:, c * T:(c + 1) * T].contiguous(), kpad=128)
+                tok[:, c * Lref1:(c + 1) * Lref1].copy_(tk[:, :Lref1])
+                if c == 0:
+                    tok[:, Lref:Lref + Lnoise].copy_(tk[:, Lref1:Lref1 + Lnoise])
+                tok[:, Lref + Lnoise + c * Lpose1:Lref + Lnoise + (c + 1) * Lpose1].copy_(tk[:, Lref1 + Lnoise:])
         h = ws["h"]
         Lrn = Lref + Lnoise
         for b in range(B):

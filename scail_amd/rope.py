@@ -39,7 +39,7 @@ def _pair_angles(head_dim, theta, t_pos, h_pos, w_pos):
 
 def build_tables(head_dim: int, rope_T: int, rope_H: int, rope_W: int, H_shift: int = 0, W_shift: int = 0,
                  global_rope_H: int = 0, global_rope_W: int = 120, theta: float = 10000.0,
-                 max_T: int = None, max_H: int = None, max_W: int = None):
+                 max_T: int = None, max_H: int = None, max_W: int = None, n_char: int = 1):
     """cos, sin: (L, head_dim/2) fp32 CPU tensors for the token order [ref | noise | pose].
 
     noise: t = 1..T (grid_t :424), (h, w) = shift + index            (rotary      :543-551)
@@ -48,29 +48,38 @@ def build_tables(head_dim: int, rope_T: int, rope_H: int, rope_W: int, H_shift: 
            avg_pool2d(2) of cos and sin separately                    (rotary_pose :616-637)
     ``max_*`` (table extents of the reference: T=(num_frames-1)//4+1, H=latent_height//2,
     W=latent_width//2 + 120) are only used to reject windows the reference could not index.
+
+    n_char > 1 is an EXTENSION (BASELINE config 5; the reference has exactly one reference frame and one pose stream,
+    :1559): token order [ref_0..ref_{C-1} | noise | pose_0..pose_{C-1}]; character k > 0 takes windows the reference
+    leaves unused -- ref_k at t = 0 with the w window shifted by k * global_rope_W, pose_k at t = 1..T with the w window
+    shifted by global_rope_W + k * rope_W.  n_char == 1 is exactly the reference.
     """
     if max_T is not None and rope_T > max_T:
         raise ValueError(f"rope_T {rope_T} exceeds the table extent {max_T}")
     if max_H is not None and max(H_shift, global_rope_H + H_shift) + rope_H > max_H:
         raise ValueError("RoPE H window exceeds the table extent")
-    if max_W is not None and global_rope_W + W_shift + rope_W > max_W:
+    if n_char < 1:
+        raise ValueError("n_char must be >= 1")
+    if max_W is not None and max(global_rope_W + W_shift + n_char * rope_W, (n_char - 1) * global_rope_W + W_shift + rope_W) > max_W:
         raise ValueError("RoPE W window exceeds the table extent")
     if rope_H % 2 or rope_W % 2:
         raise ValueError("pose tokens need even patch-grid extents (2x2 pooling)")
     hp = torch.arange(H_shift, H_shift + rope_H)
     wp = torch.arange(W_shift, W_shift + rope_W)
     a_noise = _pair_angles(head_dim, theta, torch.arange(1, rope_T + 1), hp, wp)
-    a_ref = _pair_angles(head_dim, theta, torch.tensor([0]), hp, wp)
     hp2 = torch.arange(global_rope_H + H_shift, global_rope_H + H_shift + rope_H)
     wp2 = torch.arange(global_rope_W + W_shift, global_rope_W + W_shift + rope_W)
-    a_pose = _pair_angles(head_dim, theta, torch.arange(1, rope_T + 1), hp2, wp2)
 
     def pool(x):
         return F.avg_pool2d(x.permute(0, 3, 1, 2), kernel_size=2, stride=2).permute(0, 2, 3, 1)
 
     half = head_dim // 2
-    cos = torch.cat([a_ref.cos().reshape(-1, half), a_noise.cos().reshape(-1, half),
-                     pool(a_pose.cos()).reshape(-1, half)], dim=0).contiguous()
-    sin = torch.cat([a_ref.sin().reshape(-1, half), a_noise.sin().reshape(-1, half),
-                     pool(a_pose.sin()).reshape(-1, half)], dim=0).contiguous()
-    return cos, sin
+    segs = [_pair_angles(head_dim, theta, torch.tensor([0]), hp, wp + k * global_rope_W) for k in range(n_char)]
+    segs.append(a_noise)
+    cos = [a.cos().reshape(-1, half) for a in segs]
+    sin = [a.sin().reshape(-1, half) for a in segs]
+    for k in range(n_char):
+        a_pose = _pair_angles(head_dim, theta, torch.arange(1, rope_T + 1), hp2, wp2 + k * rope_W)
+        cos.append(pool(a_pose.cos()).reshape(-1, half))
+        sin.append(pool(a_pose.sin()).reshape(-1, half))
+    return torch.cat(cos, dim=0).contiguous(), torch.cat(sin, dim=0).contiguous()

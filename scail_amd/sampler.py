@@ -177,7 +177,8 @@ class RFSampler:
         if (getattr(network, "use_c_step", False) and step_callback is None and chunk_dim is None
                 and getattr(network, "kernel_timer", None) is None and getattr(network, "_tap", None) is None
                 and (network.sp is None or network.sp.size == 1)
-                and shared["ref_concat"].shape[0] == 1 and shared["concat_smpl_render"].shape[0] == 1):
+                and shared["ref_concat"].shape[0] == 1 and shared["concat_smpl_render"].shape[0] == 1
+                and shared["ref_concat"].shape[1] == 1):
             # the whole loop enqueued by ONE call into the library (scail_dit_sample); same kernels, same order
             return network.sample_c(x, sig, cfg, ctx, shared["ref_concat"], shared["concat_smpl_render"],
                                     shared["image_clip_features"], cond_key=("sample_hip", id(cond)))

@@ -1,7 +1,8 @@
 """Sequence-parallel data path at FULL SIZE on one GPU: N virtual ranks (threads, scail_amd.parallel.ThreadBackend), each with
 its own SCAIL-14B-shaped network built from the same seed, run ONE network evaluation on their H-slab of the 512x896x81f latent
 (rank-shifted RoPE, per-layer exchange in the chosen mode, gather to rank 0); compared with the single-rank evaluation.
-usage: e2e_sp_emulated.py <world> <allgather|ulysses> [layers]   (layers < 40 keeps the run short; shapes stay full size)"""
+usage: e2e_sp_emulated.py <world> <allgather|ulysses> [layers] [n_char]   (layers < 40 keeps the run short; shapes stay full
+size; n_char = 2 is the multi-character extension of BASELINE config 5: 60 032 tokens)"""
 import json
 import os
 import sys
@@ -16,6 +17,7 @@ from scail_amd.parallel import SequenceParallel, ThreadBackend
 
 world, mode = int(sys.argv[1]), sys.argv[2]
 layers = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+C = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dev = "cuda"
 P = dict(hidden_size=5120, num_layers=layers, num_attention_heads=40, inner_hidden_size=13824, text_dim=4096,
          time_freq_dim=256, time_embed_dim=5120)
@@ -24,8 +26,8 @@ mk = lambda: DiffusionTransformer(transformer_args=dict(model_parallel_size=1), 
 g = torch.Generator().manual_seed(1)
 T, H, W = 21, 64, 112
 x = torch.randn(2, T, 16, H, W, generator=g).to(dev)
-ref = torch.randn(1, 1, 16, H, W, generator=g).to(dev).to(torch.bfloat16)
-pose = torch.randn(1, T, 16, H // 2, W // 2, generator=g).to(dev).to(torch.bfloat16)
+ref = torch.randn(1, C, 16, H, W, generator=g).to(dev).to(torch.bfloat16)
+pose = torch.randn(1, C * T, 16, H // 2, W // 2, generator=g).to(dev).to(torch.bfloat16)
 ctx = torch.randn(2, 512, 4096, generator=g).to(dev).to(torch.bfloat16)
 clip = torch.randn(1, 257, 1280, generator=g).to(dev).to(torch.bfloat16)
 t = torch.tensor([700.0, 700.0], device=dev)
@@ -63,6 +65,6 @@ if errs:
     print(json.dumps(dict(case="sp emulated", world=world, mode=mode, errors=errs)))
     sys.exit(1)
 d = (outs[0] - single).abs()
-print(json.dumps(dict(case=f"SP emulated at full size: {world} virtual ranks, {mode}, {layers} layers", max_abs_diff=float(d.max()),
+print(json.dumps(dict(case=f"SP emulated at full size: {world} virtual ranks, {mode}, {layers} layers, {C} character(s)", max_abs_diff=float(d.max()),
                       mean_abs_diff=float(d.mean()), ref_abs_mean=float(single.abs().mean()), seconds=dt,
                       peak_mem_GB=torch.cuda.max_memory_allocated() / 1e9)))
