@@ -82,3 +82,27 @@ def test_sigmas50(golden_dir):
     s = O.flow_sigmas(50)
     assert torch.equal(s, g["sigmas"])
     assert s[0] == 1.0 and s[-1] == 0.0 and abs(float(s[1]) - 0.9959) < 1e-4
+
+
+def test_multi_character_rope_extension_is_consistent():
+    """BASELINE config 5 extension (not in the reference): one character == the pinned tables; the host tables
+    (scail_amd/rope.py) equal the oracle's; the second character's windows do not collide with any other segment's."""
+    from scail_amd import rope
+    cfg = O.DiTConfig(**O.TINY)
+    c1, s1 = O.rope_tables(cfg, 4, 4, 4)
+    c1m, s1m = O.rope_tables_multi(cfg, 4, 4, 4, 1)
+    assert torch.equal(c1, c1m) and torch.equal(s1, s1m)
+    c2, s2 = O.rope_tables_multi(cfg, 4, 4, 4, 2, H_shift=2)
+    ch, sh = rope.build_tables(cfg.head_dim, 4, 4, 4, H_shift=2, n_char=2)
+    assert torch.equal(c2[:, 0::2], ch) and torch.equal(s2[:, 0::2], sh)
+    lref, lnoise, lpose = 16, 64, 16
+    assert c2.shape[0] == 2 * lref + lnoise + 2 * lpose
+    # character 0 and the noise tokens keep the reference's positions
+    c0, s0 = O.rope_tables(cfg, 4, 4, 4, H_shift=2)
+    assert torch.equal(c2[:lref], c0[:lref]) and torch.equal(c2[2 * lref:2 * lref + lnoise], c0[lref:lref + lnoise])
+    assert torch.equal(c2[2 * lref + lnoise:2 * lref + lnoise + lpose], c0[lref + lnoise:])
+    # no two tokens share a position (rows of [cos | sin] are pairwise distinct)
+    rows = torch.cat([c2, s2], 1)
+    assert torch.unique(rows, dim=0).shape[0] == rows.shape[0]
+    with pytest.raises(ValueError, match="table extent"):
+        rope.build_tables(cfg.head_dim, 4, 4, 4, n_char=3, max_W=cfg.latent_width // 2 + 120)
