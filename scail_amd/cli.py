@@ -14,9 +14,13 @@ context (1,Lt,4096), uncond_context (1,Lt,4096), clip (1,257,1280); without it s
 from __future__ import annotations
 
 import argparse
+import os
 import time
 
-import torch
+# the host driver supports only dmabuf IPC: RCCL between the ranks of one node fails without this (set before HIP starts)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 from . import lib
 from .config import load_yaml_configs
