@@ -8,9 +8,13 @@ pose video (:355-391), build c / uc (:433-470), ``engine.sample`` (:476-483), VA
 The reference's first VAE encode of [ref + zeros] (:362-365) is skipped: ``concat_images`` only gates a
 branch and is never read by the network -- a zero-size placeholder is passed.
 
-Offline limits of this image: the UMT5 / CLIP encoders and mp4 decoding (decord, imageio, cv2) are not
-available, so requests are tensors: ``--inputs file.pt`` with keys ref (3,1,H,W) in [-1,1], pose (3,T,H,W),
-context (1,Lt,4096), uncond_context (1,Lt,4096), clip (1,257,1280); without it synthetic inputs are drawn."""
+Requests: ``--ref-image ref.jpg --pose-video <frames dir | .npy | animated .webp/.png/.gif> [--conditioning c.pt]`` runs
+the reference's preprocessing (centre crop, [-1, 1], half-resolution pose; scail_amd/preprocess.py) on files, or
+``--inputs file.pt`` passes tensors directly: ref (3,1,H,W) in [-1,1], pose (3,T,H,W), context (1,Lt,4096),
+uncond_context (1,Lt,4096), clip (1,257,1280); without either synthetic inputs are drawn.  ``--save-dir`` writes
+``0_output_000000.webp`` (lossless animated WebP; ``--format`` for APNG / GIF / .npy / frames) where the reference writes
+mp4.  Offline limits of this image: no mp4 codecs (decord, imageio, ffmpeg, cv2) and no T5 tokenizer files, hence the
+container formats above and text conditioning as tensors (the UMT5 / CLIP encoders themselves are scail_amd/umt5.py, clip.py)."""
 from __future__ import annotations
 
 import argparse
@@ -56,6 +60,26 @@ def synthetic_request(H, W, frames, text_dim, Lt, device, seed=0):
                 context=ctx.to(device), uncond_context=uc.to(device), clip=r(1, 257, 1280).to(device))
 
 
+def request_from_files(ref_image: str, pose_video: str, cfg, conditioning: str = None, device="cuda", seed=0, text_dim=4096):
+    """The reference's request assembly from files (sample_video.py:300-351): reference image + driving (pose) video ->
+    centre-cropped, [-1, 1], pose at half resolution (``smpl_downsample``).  Text / CLIP conditioning comes from
+    ``conditioning`` (a .pt with context, uncond_context, clip) -- the T5 tokenizer files are not available offline --
+    or is drawn synthetically."""
+    from . import preprocess, video_io
+    img = video_io.load_image_to_tensor_chw_normalized(ref_image)                       # (1, 3, H, W) in [-1, 1]
+    H, W = preprocess.target_size((img.shape[2], img.shape[3]), cfg.get("args", {}).get("sampling_image_size", [512, 896]))
+    img = preprocess.prepare_reference_image(img, (H, W))
+    pose = video_io.load_video_for_pose_sample(pose_video).permute(0, 3, 1, 2)         # T H W C -> T C H W (:339)
+    _, smpl = preprocess.prepare_pose_video(pose, (H, W), downsample=True)
+    req = synthetic_request(H, W, smpl.shape[0], text_dim, 512 if text_dim == 4096 else 12, device, seed)
+    if conditioning:
+        req.update({k: v.to(device) for k, v in torch.load(conditioning, map_location="cpu").items()
+                    if k in ("context", "uncond_context", "clip")})
+    req["ref"] = img.permute(1, 0, 2, 3).contiguous().to(device)                        # (3, 1, H, W)
+    req["pose"] = smpl.permute(1, 0, 2, 3).contiguous().to(device)                      # (3, T, H/2, W/2)
+    return req, (H, W)
+
+
 def run(cfg, inputs=None, steps=None, load=None, seed=1234, device="cuda", frames=None):
     lib.load()
     mc = dict(cfg["model"])
@@ -67,6 +91,8 @@ def run(cfg, inputs=None, steps=None, load=None, seed=1234, device="cuda", frame
     H, W = cfg.get("args", {}).get("sampling_image_size", [512, 896])
     net = engine.network
     frames = frames or min(81, net.num_frames)
+    if callable(inputs):                                      # file-based request: needs the network's text width
+        inputs = inputs(net.text_dim)
     req = inputs or synthetic_request(H, W, frames, net.text_dim, 512 if net.text_dim == 4096 else 12, device, seed)
     vae = engine.first_stage_model
     t0 = time.perf_counter()
@@ -97,13 +123,28 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--ref-image", default=None, help="reference image file (any Pillow format)")
+    ap.add_argument("--pose-video", default=None, help="driving video: directory of frames, .npy/.pt (T,H,W,3) or animated WebP/PNG/GIF")
+    ap.add_argument("--conditioning", default=None, help=".pt with context / uncond_context / clip tensors")
+    ap.add_argument("--save-dir", default=None, help="write <key>_000000.<ext> like the reference's save_multi_video_grid_and_mp4")
+    ap.add_argument("--format", default=".webp", help=".webp (lossless) | .png (APNG) | .gif | .npy | '' (directory of PNG frames)")
     a = ap.parse_args()
     cfg = TINY if a.tiny or not a.base else load_yaml_configs(*a.base)
     inputs = torch.load(a.inputs) if a.inputs else None
+    if a.ref_image or a.pose_video:
+        if not (a.ref_image and a.pose_video):
+            ap.error("--ref-image and --pose-video go together")
+        inputs = lambda text_dim: request_from_files(a.ref_image, a.pose_video, cfg, a.conditioning, seed=a.seed, text_dim=text_dim)[0]
     video, z, dt = run(cfg, inputs, a.steps, a.load, a.seed)
     print(f"sampled latent {tuple(z.shape)} -> video {tuple(video.shape)} in {dt:.2f} s")
     if a.out:
         torch.save({"video": video.cpu(), "latent": z.cpu()}, a.out)
+    if a.save_dir:
+        from . import video_io
+        samples = video.permute(0, 2, 1, 3, 4).contiguous().cpu()                      # B C T H W -> B T C H W (:493)
+        paths = video_io.save_multi_video_grid([samples], a.save_dir, fps=cfg.get("args", {}).get("sampling_fps", 16),
+                                               key="0_output", ext=a.format)
+        print("wrote", ", ".join(paths))
 
 
 if __name__ == "__main__":

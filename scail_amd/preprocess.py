@@ -9,7 +9,8 @@ The reference resizes with torchvision ``resize(..., BICUBIC)`` on uint8 tensors
 offline, so the resize is restated with ``torch.nn.functional.interpolate(mode="bicubic", antialias=True)`` followed
 by the uint8 round + clamp torchvision applies (its tensor path calls exactly that op) -- parity for this module is
 UNPINNED (no reference output could be generated here); the geometry (sizes, crop offsets, value ranges) is tested.
-Video decoding (decord) and mp4 writing (imageio) need packages that are absent offline and stay outside."""
+Video decoding (decord) and mp4 writing (imageio) need packages that are absent offline; ``scail_amd/video_io.py`` fills
+those roles with Pillow containers (frame directories, arrays, animated WebP / PNG / GIF)."""
 from __future__ import annotations
 
 from typing import Sequence, Tuple

@@ -351,6 +351,25 @@ def test_cli_tiny_end_to_end():
     assert torch.isfinite(video).all() and 0.0 <= float(video.min()) and float(video.max()) <= 1.0
 
 
+def test_cli_from_files_to_saved_video(tmp_path):
+    """The request as files (reference image + driving video) through preprocessing, VAE, sampler, VAE, and the saved result
+    read back (sample_video.py:300-351 / :484-507; containers: scail_amd/video_io.py)."""
+    import numpy as np
+    from PIL import Image
+    from scail_amd import cli, video_io
+    g = np.random.default_rng(0)
+    Image.fromarray(g.integers(0, 255, (80, 120, 3), dtype=np.uint8)).save(tmp_path / "ref.jpg")
+    np.save(tmp_path / "rendered.npy", g.integers(0, 255, (13, 70, 90, 3), dtype=np.uint8))
+    req = lambda text_dim: cli.request_from_files(str(tmp_path / "ref.jpg"), str(tmp_path / "rendered.npy"), cli.TINY, text_dim=text_dim)[0]
+    video, z, _ = cli.run(cli.TINY, req, steps=2)
+    assert video.shape == (1, 3, 13, 64, 64) and torch.isfinite(video).all() and 0.0 <= float(video.min()) and float(video.max()) <= 1.0
+    samples = video.permute(0, 2, 1, 3, 4).contiguous().cpu()
+    p = video_io.save_multi_video_grid([samples], str(tmp_path / "out"), fps=16, key="0_output")[0]
+    back = video_io.load_video_for_pose_sample(p)
+    assert back.shape == (13, 64, 64, 3)
+    assert np.array_equal(back.numpy(), (255.0 * samples[0].permute(0, 2, 3, 1)).numpy().astype(np.uint8))
+
+
 def test_multi_character_extension_vs_oracle(golden_dir, n_char=2):
     """BASELINE config 5 (multi-character in-context concat) is NOT in the reference (one reference frame, one pose stream,
     dit...:1559): an extension with token order [ref_0..ref_{C-1} | noise | pose_0..pose_{C-1}] and the RoPE windows of

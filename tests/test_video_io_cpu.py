@@ -1,0 +1,68 @@
+"""File IO either side of the path (scail_amd/video_io.py; reference sample_video.py:48-54, 181-217): round trips through
+every supported container, the reference's frame layout / quantisation, loud failure for formats that need absent codecs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from scail_amd import preprocess, video_io
+
+
+def _clip(T=5, H=12, W=20, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(1, T, 3, H, W, generator=g)
+
+
+@pytest.mark.parametrize("ext", [".webp", ".png", ".npy", ""])
+def test_lossless_round_trip(tmp_path, ext):
+    vid = _clip()
+    paths = video_io.save_video_as_grid(vid, str(tmp_path), fps=16, ext=ext)
+    assert [os.path.basename(p) for p in paths] == [f"000000{ext}"]
+    back = video_io.load_video_for_pose_sample(paths[0])
+    want = (255.0 * vid[0].permute(0, 2, 3, 1)).numpy().astype(np.uint8)          # truncation, like the reference
+    assert back.dtype == torch.uint8 and tuple(back.shape) == want.shape
+    assert np.array_equal(back.numpy(), want)
+
+
+def test_gif_round_trip_is_close(tmp_path):
+    vid = torch.zeros(1, 3, 3, 8, 8)
+    vid[0, 1, 0] = 1.0
+    vid[0, 2, 2] = 0.5
+    p = video_io.save_video_as_grid(vid, str(tmp_path), fps=8, ext=".gif")[0]
+    back = video_io.load_video_for_pose_sample(p).float() / 255.0
+    assert back.shape == (3, 8, 8, 3) and float((back - vid[0].permute(0, 2, 3, 1)).abs().max()) < 0.05
+
+
+def test_multi_video_grid_layout(tmp_path):
+    a, b = _clip(seed=1), _clip(seed=2)
+    p = video_io.save_multi_video_grid([a, b], str(tmp_path), fps=16, key="3_concat", ext=".png")[0]
+    assert os.path.basename(p) == "3_concat_000000.png"
+    back = video_io.load_video_for_pose_sample(p)
+    assert tuple(back.shape) == (5, 12, 40, 3)                                    # "n c h w -> h (n w) c"
+    q = lambda v: (255.0 * v[0].permute(0, 2, 3, 1)).numpy().astype(np.uint8)
+    assert np.array_equal(back[:, :, :20].numpy(), q(a)) and np.array_equal(back[:, :, 20:].numpy(), q(b))
+
+
+def test_formats_that_need_codecs_fail_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no video encoder"):
+        video_io.save_video_as_grid(_clip(), str(tmp_path), ext=".mp4")
+    f = tmp_path / "rendered.mp4"
+    f.write_bytes(b"\x00")
+    with pytest.raises(RuntimeError, match="no video decoder"):
+        video_io.load_video_for_pose_sample(str(f))
+
+
+def test_request_assembly_from_files(tmp_path):
+    """Reference image + driving video files -> the tensors the engine takes (sample_video.py:300-351)."""
+    from PIL import Image
+    from scail_amd import cli
+    g = np.random.default_rng(0)
+    Image.fromarray(g.integers(0, 255, (90, 160, 3), dtype=np.uint8)).save(tmp_path / "ref.png")
+    np.save(tmp_path / "rendered.npy", g.integers(0, 255, (5, 100, 150, 3), dtype=np.uint8))
+    img = video_io.load_image_to_tensor_chw_normalized(str(tmp_path / "ref.png"))
+    assert img.shape == (1, 3, 90, 160) and -1.0 <= float(img.min()) and float(img.max()) <= 1.0
+    req, (H, W) = cli.request_from_files(str(tmp_path / "ref.png"), str(tmp_path / "rendered.npy"), cli.TINY, device="cpu", text_dim=64)
+    assert (H, W) == (64, 64) == tuple(preprocess.target_size((90, 160), [64, 64]))
+    assert req["ref"].shape == (3, 1, 64, 64) and req["pose"].shape == (3, 5, 32, 32)
+    assert float(req["pose"].abs().max()) <= 1.0 + 1e-6 and req["context"].shape[-1] == 64
