@@ -13,8 +13,10 @@ the reference's preprocessing (centre crop, [-1, 1], half-resolution pose; scail
 ``--inputs file.pt`` passes tensors directly: ref (3,1,H,W) in [-1,1], pose (3,T,H,W), context (1,Lt,4096),
 uncond_context (1,Lt,4096), clip (1,257,1280); without either synthetic inputs are drawn.  ``--save-dir`` writes
 ``0_output_000000.webp`` (lossless animated WebP; ``--format`` for APNG / GIF / .npy / frames) where the reference writes
-mp4.  Offline limits of this image: no mp4 codecs (decord, imageio, ffmpeg, cv2) and no T5 tokenizer files, hence the
-container formats above and text conditioning as tensors (the UMT5 / CLIP encoders themselves are scail_amd/umt5.py, clip.py)."""
+mp4.  ``--prompt TEXT --tokenizer <HF dir | spiece.model> [--t5-ckpt ..] [--clip-ckpt ..]`` runs the UMT5 and CLIP encoders
+(scail_amd/umt5.py, clip.py) on the prompt and the reference image.  Offline limits of this image: no mp4 codecs (decord,
+imageio, ffmpeg, cv2), no tokenizer files and no checkpoints -- hence the container formats above, the tokenizer as a path
+argument, and random-init weights unless checkpoints are given."""
 from __future__ import annotations
 
 import argparse
@@ -58,6 +60,33 @@ def synthetic_request(H, W, frames, text_dim, Lt, device, seed=0):
     uc[:, :1] = r(1, 1, text_dim)
     return dict(ref=(torch.rand(3, 1, H, W, generator=g) * 2 - 1).to(device), pose=(torch.rand(3, frames, H // 2, W // 2, generator=g) * 2 - 1).to(device),
                 context=ctx.to(device), uncond_context=uc.to(device), clip=r(1, 257, 1280).to(device))
+
+
+def encode_conditioning(prompt: str, negative_prompt: str, ref: torch.Tensor, text_dim: int, tokenizer_path: str,
+                        t5_ckpt: str = None, clip_ckpt: str = None, device="cuda", max_length: int = 512):
+    """Prompt + reference image -> the conditioning tensors of the request (sample_video.py:397-400, :416-438): UMT5
+    states of the prompt and of the negative prompt (padded rows zeroed), CLIP ViT-H penultimate features of the reference
+    frame.  Both encoders run once and are released (the reference moves them back to the CPU).  Checkpoints are optional
+    (random init without them -- there are none offline); a text width other than 4096 builds a 2-layer encoder of that
+    width, for plumbing tests against small networks."""
+    from .clip import CLIPModel
+    from .tokenizer import HuggingfaceTokenizer
+    from .umt5 import T5EncoderModel
+    kw = {}
+    if text_dim != 4096:
+        if text_dim % 128:
+            raise ValueError("the plumbing-size text encoder needs a text width that is a multiple of 128")
+        vocab = HuggingfaceTokenizer(tokenizer_path).vocab_size
+        kw = dict(vocab=(vocab + 63) // 64 * 64, dim=text_dim, dim_attn=text_dim, dim_ffn=2 * text_dim,
+                  num_heads=max(1, text_dim // 64), num_layers=2)
+    t5 = T5EncoderModel(max_length=max_length, checkpoint_path=t5_ckpt, device=device, tokenizer_path=tokenizer_path, **kw)
+    ctx = t5.encode_text([prompt, negative_prompt])
+    del t5
+    clip = CLIPModel(device=device, checkpoint_path=clip_ckpt)
+    feats = clip.visual([ref.to(device)])                                               # (1, 257, 1280)
+    del clip
+    torch.cuda.empty_cache()
+    return dict(context=ctx[0:1].contiguous(), uncond_context=ctx[1:2].contiguous(), clip=feats)
 
 
 def request_from_files(ref_image: str, pose_video: str, cfg, conditioning: str = None, device="cuda", seed=0, text_dim=4096):
@@ -126,6 +155,11 @@ def main():
     ap.add_argument("--ref-image", default=None, help="reference image file (any Pillow format)")
     ap.add_argument("--pose-video", default=None, help="driving video: directory of frames, .npy/.pt (T,H,W,3) or animated WebP/PNG/GIF")
     ap.add_argument("--conditioning", default=None, help=".pt with context / uncond_context / clip tensors")
+    ap.add_argument("--prompt", default=None, help="text prompt (needs --tokenizer; UMT5 / CLIP run on the GPU, random-init without --t5-ckpt / --clip-ckpt)")
+    ap.add_argument("--negative-prompt", default="")
+    ap.add_argument("--tokenizer", default=None, help="Hugging Face tokenizer directory or SentencePiece .model file of umt5-xxl")
+    ap.add_argument("--t5-ckpt", default=None)
+    ap.add_argument("--clip-ckpt", default=None)
     ap.add_argument("--save-dir", default=None, help="write <key>_000000.<ext> like the reference's save_multi_video_grid_and_mp4")
     ap.add_argument("--format", default=".webp", help=".webp (lossless) | .png (APNG) | .gif | .npy | '' (directory of PNG frames)")
     a = ap.parse_args()
@@ -134,7 +168,14 @@ def main():
     if a.ref_image or a.pose_video:
         if not (a.ref_image and a.pose_video):
             ap.error("--ref-image and --pose-video go together")
-        inputs = lambda text_dim: request_from_files(a.ref_image, a.pose_video, cfg, a.conditioning, seed=a.seed, text_dim=text_dim)[0]
+        def inputs(text_dim):
+            req = request_from_files(a.ref_image, a.pose_video, cfg, a.conditioning, seed=a.seed, text_dim=text_dim)[0]
+            if a.prompt is not None:
+                if not a.tokenizer:
+                    ap.error("--prompt needs --tokenizer (tokenizer files are not bundled)")
+                req.update(encode_conditioning(a.prompt, a.negative_prompt, req["ref"], text_dim, a.tokenizer, a.t5_ckpt, a.clip_ckpt,
+                                               max_length=512 if text_dim == 4096 else 16))
+            return req
     video, z, dt = run(cfg, inputs, a.steps, a.load, a.seed)
     print(f"sampled latent {tuple(z.shape)} -> video {tuple(video.shape)} in {dt:.2f} s")
     if a.out:

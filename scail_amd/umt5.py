@@ -3,8 +3,8 @@
 ``T5Encoder`` mirrors the reference class (:270-316): same constructor arguments and state_dict keys
 (``token_embedding.weight``, ``blocks.N.{norm1,attn.{q,k,v,o},norm2,ffn.{gate.0,fc1,fc2},pos_embedding.embedding}``,
 ``norm.weight``), so ``models_t5_umt5-xxl-enc-bf16.pth`` loads unchanged.  ``T5EncoderModel`` mirrors the
-conditioner wrapper (:475-535) minus the tokenizer, which needs files that are not available offline:
-it takes token ids + mask.  Runs once per prompt (24 layers x 512 tokens = 4.8 TFLOP); all GEMMs go through
+conditioner wrapper (:475-535); the tokenizer (scail_amd/tokenizer.py) needs files that are not available offline, so it is
+only built when ``tokenizer_path`` is given (``encode_text(texts)``); ``forward`` takes token ids + mask.  Runs once per prompt (24 layers x 512 tokens = 4.8 TFLOP); all GEMMs go through
 ``scail_gemm_bf16`` (q,k,v fused into one GEMM; gate GEMM with the tanh-GELU epilogue; residual adds fused
 into the o / fc2 GEMMs), T5LayerNorm through ``scail_rmsnorm_rope`` (same formula, eps 1e-6), attention with
 the per-layer relative-position bias and key mask through ``scail_attn_small``."""
@@ -127,14 +127,38 @@ class T5EncoderModel(nn.Module):
     """Conditioner-side wrapper (umt5.py:475-535) without the tokenizer: ``forward(ids, mask)`` returns the encoder
     states with padded rows zeroed (``context * mask[:, :, None]``, :522)."""
 
-    def __init__(self, max_length=512, checkpoint_path=None, device="cuda", tokenizer_path=None, dtype=None, **encoder_kwargs):
+    def __init__(self, max_length=512, checkpoint_path=None, device="cuda", tokenizer_path=None, dtype=None,
+                 varlen_text=False, uncond_text_length=1, cond_length_multiple=1, **encoder_kwargs):
         super().__init__()
         self.max_length = max_length
+        self.varlen_text, self.uncond_text_length, self.cond_length_multiple = varlen_text, uncond_text_length, cond_length_multiple
         self.model = umt5_xxl_encoder(device=device, **encoder_kwargs).eval()
         if checkpoint_path is not None and __import__("os").path.exists(checkpoint_path):
             self.model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))
+        self.tokenizer = None
+        if tokenizer_path is not None:          # umt5.py:509-510; files are not in this image, so only when given
+            from .tokenizer import HuggingfaceTokenizer
+            self.tokenizer = HuggingfaceTokenizer(name=tokenizer_path, seq_len=max_length, clean="whitespace")
 
     @torch.no_grad()
     def forward(self, ids, mask):
         ctx = self.model(ids, mask)
         return ops.row_affine(ctx, rowscale=mask.to(ctx.device).float().reshape(-1).contiguous())
+
+    @torch.no_grad()
+    def encode_text(self, texts):
+        """The reference's ``__call__(texts)`` (umt5.py:512-535): tokenise, encode, zero the padded rows, and with
+        ``varlen_text`` cut a single prompt to its own length (rounded up to ``cond_length_multiple``; the empty prompt to
+        ``uncond_text_length``)."""
+        if self.tokenizer is None:
+            raise RuntimeError("T5EncoderModel was built without tokenizer_path; pass token ids to forward(ids, mask)")
+        ids, mask = self.tokenizer(texts, return_mask=True, add_special_tokens=True)
+        dev = next(self.model.parameters()).device
+        z = self.forward(ids.to(dev), mask.to(dev))
+        if self.varlen_text:
+            if z.shape[0] != 1:
+                raise AssertionError("varlen_text handles one prompt at a time")         # :524
+            n = int(mask[0].sum())
+            pad = (-n) % self.cond_length_multiple if n > 1 else self.uncond_text_length - n
+            z = z[:, :n + pad]
+        return z

@@ -370,6 +370,31 @@ def test_cli_from_files_to_saved_video(tmp_path):
     assert np.array_equal(back.numpy(), (255.0 * samples[0].permute(0, 2, 3, 1)).numpy().astype(np.uint8))
 
 
+def test_cli_prompt_to_conditioning(tmp_path):
+    """Prompt string + reference image -> UMT5 / CLIP conditioning -> sampler, all on the GPU (sample_video.py:397-438).
+    Tiny text width; SentencePiece model trained here; CLIP tower at full size with random weights."""
+    import io
+    spm = pytest.importorskip("sentencepiece")
+    from scail_amd import cli
+    buf = io.BytesIO()
+    spm.SentencePieceTrainer.train(sentence_iterator=iter(["the girl is dancing in the street", "a man walks his dog"] * 40), model_writer=buf,
+                                   vocab_size=40, model_type="unigram", hard_vocab_limit=False, minloglevel=2, pad_id=0, eos_id=1, unk_id=2, bos_id=-1)
+    (tmp_path / "spiece.model").write_bytes(buf.getvalue())
+    import copy
+    cfg = copy.deepcopy(cli.TINY)
+    cfg["model"]["network_config"]["params"]["text_dim"] = 128
+    req = cli.synthetic_request(64, 64, 13, 128, 12, DEV, 0)
+    cond = cli.encode_conditioning("the girl is dancing", "", req["ref"], 128, str(tmp_path / "spiece.model"), max_length=16)
+    assert cond["context"].shape == (1, 16, 128) and cond["uncond_context"].shape == (1, 16, 128) and cond["clip"].shape == (1, 257, 1280)
+    assert float(cond["uncond_context"].float()[0, 1:].abs().max()) == 0.0          # "" is one </s> row, the rest zeroed
+    assert float(cond["context"].float()[0, :3].abs().min(-1).values.max()) >= 0.0 and torch.isfinite(cond["clip"].float()).all()
+    req.update(cond)
+    video, z, _ = cli.run(cfg, req, steps=2)
+    assert video.shape == (1, 3, 13, 64, 64) and torch.isfinite(video).all()
+    with pytest.raises(ValueError, match="multiple of 128"):
+        cli.encode_conditioning("x", "", req["ref"], 64, str(tmp_path / "spiece.model"))
+
+
 def test_multi_character_extension_vs_oracle(golden_dir, n_char=2):
     """BASELINE config 5 (multi-character in-context concat) is NOT in the reference (one reference frame, one pose stream,
     dit...:1559): an extension with token order [ref_0..ref_{C-1} | noise | pose_0..pose_{C-1}] and the RoPE windows of

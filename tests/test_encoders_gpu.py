@@ -82,3 +82,29 @@ def test_encoders_full_size_shapes_and_wrappers():
     clip = CLIPModel(device=DEV, num_layers=3)
     feats = clip.visual([torch.rand(3, 1, 512, 896, device=DEV) * 2 - 1])
     assert feats.shape == (1, 257, 1280) and torch.isfinite(feats.float()).all()
+
+
+def test_text_conditioner_from_strings(tmp_path):
+    """T5EncoderModel.encode_text (reference ``__call__(texts)``, umt5.py:512-535): tokeniser -> encoder -> padded rows zeroed,
+    varlen cut.  Tiny encoder, SentencePiece model trained here (no tokenizer files ship offline)."""
+    import io
+    spm = pytest.importorskip("sentencepiece")
+    from scail_amd.umt5 import T5EncoderModel
+    corpus = ["the girl is dancing in the street", "a man walks his dog", "two people are dancing together"] * 30
+    buf = io.BytesIO()
+    spm.SentencePieceTrainer.train(sentence_iterator=iter(corpus), model_writer=buf, vocab_size=40, model_type="unigram",
+                                   hard_vocab_limit=False, minloglevel=2, pad_id=0, eos_id=1, unk_id=2, bos_id=-1)
+    (tmp_path / "spiece.model").write_bytes(buf.getvalue())
+    kw = dict(vocab=64, dim=128, dim_attn=128, dim_ffn=256, num_heads=2, num_layers=2, num_buckets=32, shared_pos=False)
+    m = T5EncoderModel(max_length=16, device=DEV, tokenizer_path=str(tmp_path / "spiece.model"), **kw)
+    z = m.encode_text(["the girl is dancing", ""])
+    ids, mask = m.tokenizer(["the girl is dancing", ""], return_mask=True)
+    assert z.shape == (2, 16, 128) and torch.isfinite(z.float()).all()
+    assert (z.float().cpu()[mask == 0] == 0).all() and (z.float().cpu()[mask == 1].abs().sum(-1) > 0).all()
+    torch.testing.assert_close(z, m(ids.to(DEV), mask.to(DEV)))
+    v = T5EncoderModel(max_length=16, device=DEV, tokenizer_path=str(tmp_path / "spiece.model"), varlen_text=True,
+                       cond_length_multiple=4, uncond_text_length=3, **kw)
+    n = int(mask[0].sum())
+    assert v.encode_text("the girl is dancing").shape[1] == (n + 3) // 4 * 4 and v.encode_text("").shape[1] == 3
+    with pytest.raises(RuntimeError, match="tokenizer_path"):
+        T5EncoderModel(max_length=16, device=DEV, **kw).encode_text("x")
