@@ -21,7 +21,9 @@ TARGET_MAP = {
     "sgm.modules.diffusionmodules.guiders.VanillaCFG": "scail_amd.sampler.VanillaCFG",
     "sgm.modules.diffusionmodules.wrappers.OpenAIWrapper": "scail_amd.sampler.OpenAIWrapper",
     "sgm.models.wan_vae.WanVAE": "scail_amd.wan_vae.WanVAE",
-    "sgm.modules.encoders.umt5.T5EncoderModel": "scail_amd.umt5.T5EncoderModel",   # ids + mask in (no tokenizer offline)
+    "sgm.modules.encoders.umt5.T5EncoderModel": "scail_amd.umt5.T5EncoderModel",   # strings (tokenizer_path) or ids + mask
+    "sgm.modules.GeneralConditioner": "scail_amd.conditioner.GeneralConditioner",
+    "sgm.modules.encoders.modules.GeneralConditioner": "scail_amd.conditioner.GeneralConditioner",
     "sgm.modules.encoders.clip.CLIPModel": "scail_amd.clip.CLIPModel",
 }
 

@@ -2,7 +2,8 @@
 (reference diffusion_video.py:41-174, :298-331, :456-587) on top of the HIP network.
 
 Only the inference members the CLI uses are reproduced: ``sample(cond, uc, batch_size, shape, ...)``,
-``encode_first_stage`` / ``decode_first_stage``, ``.model`` (OpenAIWrapper), ``.denoiser``, ``.sampler``.
+``encode_first_stage`` / ``decode_first_stage``, ``.model`` (OpenAIWrapper), ``.denoiser``, ``.sampler``, and -- opt-in --
+``.conditioner`` (scail_amd/conditioner.py) and ``.i2v_clip``.
 Training (``shared_step``, loss, EMA) is out of scope."""
 from __future__ import annotations
 
@@ -41,6 +42,14 @@ class SATVideoDiffusionEngine(nn.Module):
         fs = model_config.get("first_stage_config")
         if fs is not None and model_config.get("build_first_stage", False):
             self.first_stage_model = instantiate_from_config(fs)
+        # request-time encoders (diffusion_video.py:113-127: conditioner + i2v_clip).  The reference always builds them; here
+        # they are opt-in because their checkpoints / tokenizer files do not exist offline and they cost 13 GB of HBM.
+        self.use_i2v_clip = model_config.get("use_i2v_clip", False)
+        self.conditioner = self.i2v_clip = None
+        if model_config.get("build_conditioner", False) and "conditioner_config" in model_config:
+            self.conditioner = instantiate_from_config(model_config["conditioner_config"])
+        if model_config.get("build_i2v_clip", False) and "i2v_clip_config" in model_config:
+            self.i2v_clip = instantiate_from_config(model_config["i2v_clip_config"])
 
     @property
     def network(self) -> DiffusionTransformer:

@@ -141,7 +141,10 @@ class T5EncoderModel(nn.Module):
             self.tokenizer = HuggingfaceTokenizer(name=tokenizer_path, seq_len=max_length, clean="whitespace")
 
     @torch.no_grad()
-    def forward(self, ids, mask):
+    def forward(self, ids, mask=None):
+        """(ids, mask) token tensors, or -- like the reference's ``__call__(texts)`` -- a string / list of strings."""
+        if mask is None and (isinstance(ids, str) or (isinstance(ids, (list, tuple)) and all(isinstance(u, str) for u in ids))):
+            return self.encode_text(ids)
         ctx = self.model(ids, mask)
         return ops.row_affine(ctx, rowscale=mask.to(ctx.device).float().reshape(-1).contiguous())
 

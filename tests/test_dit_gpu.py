@@ -395,6 +395,49 @@ def test_cli_prompt_to_conditioning(tmp_path):
         cli.encode_conditioning("x", "", req["ref"], 64, str(tmp_path / "spiece.model"))
 
 
+def test_engine_conditioner_from_reference_style_config(tmp_path):
+    """``conditioner_config`` / ``i2v_clip_config`` with the reference's target strings build the MI355X encoders behind the
+    reference's GeneralConditioner protocol: get_batch -> get_unconditional_conditioning -> engine.sample
+    (sample_video.py:397-400, :416-438, :476-483)."""
+    import copy
+    import io
+    spm = pytest.importorskip("sentencepiece")
+    from scail_amd import cli
+    from scail_amd.conditioner import get_batch, get_unique_embedder_keys_from_conditioner
+    from scail_amd.engine import SATVideoDiffusionEngine
+    buf = io.BytesIO()
+    spm.SentencePieceTrainer.train(sentence_iterator=iter(["the girl is dancing in the street", "a man walks his dog"] * 40), model_writer=buf,
+                                   vocab_size=40, model_type="unigram", hard_vocab_limit=False, minloglevel=2, pad_id=0, eos_id=1, unk_id=2, bos_id=-1)
+    (tmp_path / "spiece.model").write_bytes(buf.getvalue())
+    mc = copy.deepcopy(cli.TINY["model"])
+    mc["network_config"]["params"]["text_dim"] = 128
+    mc.update(build_conditioner=True, build_i2v_clip=True, build_first_stage=False,
+              conditioner_config={"target": "sgm.modules.GeneralConditioner", "params": {"emb_models": [
+                  {"is_trainable": False, "input_key": "txt", "ucg_rate": 0.1, "legacy_ucg_val": "",
+                   "target": "sgm.modules.encoders.umt5.T5EncoderModel",
+                   "params": dict(tokenizer_path=str(tmp_path / "spiece.model"), max_length=16, vocab=64, dim=128, dim_attn=128,
+                                  dim_ffn=256, num_heads=2, num_layers=2)}]}},
+              i2v_clip_config={"target": "sgm.modules.encoders.clip.CLIPModel", "params": dict(num_layers=2)})
+    eng = SATVideoDiffusionEngine(mc, device=DEV)
+    assert eng.conditioner is not None and eng.i2v_clip is not None and eng.use_i2v_clip
+    batch, batch_uc = get_batch(get_unique_embedder_keys_from_conditioner(eng.conditioner),
+                                {"prompt": "the girl is dancing", "negative_prompt": "", "num_frames": torch.tensor([4])}, [1])
+    c, uc = eng.conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc, force_uc_zero_embeddings=[])
+    assert set(c) == {"crossattn"} and c["crossattn"].shape == (1, 16, 128) and uc["crossattn"].shape == (1, 16, 128)
+    assert float((c["crossattn"].float() - uc["crossattn"].float()).abs().max()) > 0
+    _, uc0 = eng.conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc, force_uc_zero_embeddings=["txt"])
+    assert float(uc0["crossattn"].float().abs().max()) == 0.0
+    g = torch.Generator().manual_seed(3)
+    ref_img = (torch.rand(1, 3, 1, 64, 64, generator=g) * 2 - 1).to(DEV)                     # b c t h w
+    feats = eng.i2v_clip.visual(ref_img)
+    assert feats.shape == (1, 257, 1280)
+    shared = dict(concat_images=torch.zeros(1, device=DEV), image_clip_features=feats.to(torch.bfloat16),
+                  ref_concat=torch.randn(1, 1, 16, 8, 8, generator=g).to(DEV).to(torch.bfloat16),
+                  concat_smpl_render=torch.randn(1, 4, 16, 4, 4, generator=g).to(DEV).to(torch.bfloat16))
+    z = eng.sample(dict(c, **shared), uc=dict(uc, **shared), batch_size=1, shape=(4, 16, 8, 8), num_steps=2)
+    assert z.shape == (1, 4, 16, 8, 8) and torch.isfinite(z.float()).all()
+
+
 def test_multi_character_extension_vs_oracle(golden_dir, n_char=2):
     """BASELINE config 5 (multi-character in-context concat) is NOT in the reference (one reference frame, one pose stream,
     dit...:1559): an extension with token order [ref_0..ref_{C-1} | noise | pose_0..pose_{C-1}] and the RoPE windows of
