@@ -2,6 +2,7 @@
 
     python -m scail_amd.cli --base <model.yaml> [<sampling.yaml>] [--load DIR] [--steps N] [--out out.pt]
     python -m scail_amd.cli --tiny          # BASELINE.json configs[0] shape: 2-layer / 128-dim DiT, 4x8x8 latent, 2 steps
+    python -m scail_amd.cli --base ... --request "the girl is dancing@@examples/001" [--input-file requests.txt]
 
 Order of work per request (same as the reference): VAE-encode the reference frame and the half-resolution
 pose video (:355-391), build c / uc (:433-470), ``engine.sample`` (:476-483), VAE-decode (:491-494).
@@ -62,6 +63,47 @@ def synthetic_request(H, W, frames, text_dim, Lt, device, seed=0):
                 context=ctx.to(device), uncond_context=uc.to(device), clip=r(1, 257, 1280).to(device))
 
 
+REF_IMAGE_PATTERNS = ["ref.jpg", "ref.png", "ref_image.jpg", "ref_image.png"]                # sample_video.py:289
+# the reference looks for rendered_aligned.mp4 / rendered.mp4 (:296); the containers this image can decode come first
+POSE_PATTERNS = [stem + ext for stem in ("rendered_aligned", "rendered") for ext in ("", ".webp", ".png", ".gif", ".npy", ".pt", ".mp4")]
+
+
+def find_file_with_patterns(directory: str, patterns):
+    """sample_video.py:64-70."""
+    import os
+    for pat in patterns:
+        p = os.path.join(directory, pat)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def parse_request(line: str):
+    """One request line of the reference CLI, ``<prompt>@@<example_dir>`` (sample_video.py:76, :284-300): the directory holds
+    the reference image and the rendered pose video.  -> (prompt, example_dir, image_path, pose_path)."""
+    parts = line.strip().split("@@")
+    if len(parts) != 2:
+        raise ValueError(f"expected '<prompt>@@<example_dir>', got {line!r}")
+    text, input_dir = parts[0], parts[1]
+    if text == "None":
+        text = ""
+    image_path = find_file_with_patterns(input_dir, REF_IMAGE_PATTERNS)
+    if image_path is None:
+        raise FileNotFoundError(f"Reference image not found in {input_dir}. Tried: {REF_IMAGE_PATTERNS}")
+    pose_path = find_file_with_patterns(input_dir, POSE_PATTERNS)
+    if pose_path is None:
+        raise FileNotFoundError(f"Pose video not found in {input_dir}. Tried: {POSE_PATTERNS}")
+    return text, input_dir, image_path, pose_path
+
+
+def read_from_file(path: str, rank: int = 0, world_size: int = 1):
+    """sample_video.py:82-91: request lines of a text file, dealt round-robin to the data-parallel ranks."""
+    with open(path) as f:
+        for cnt, line in enumerate(f):
+            if cnt % world_size == rank and line.strip():
+                yield line.strip(), cnt
+
+
 def encode_conditioning(prompt: str, negative_prompt: str, ref: torch.Tensor, text_dim: int, tokenizer_path: str,
                         t5_ckpt: str = None, clip_ckpt: str = None, device="cuda", max_length: int = 512):
     """Prompt + reference image -> the conditioning tensors of the request (sample_video.py:397-400, :416-438): UMT5
@@ -109,7 +151,7 @@ def request_from_files(ref_image: str, pose_video: str, cfg, conditioning: str =
     return req, (H, W)
 
 
-def run(cfg, inputs=None, steps=None, load=None, seed=1234, device="cuda", frames=None):
+def build_engine(cfg, load=None, device="cuda"):
     lib.load()
     mc = dict(cfg["model"])
     mc["build_first_stage"] = True
@@ -117,6 +159,11 @@ def run(cfg, inputs=None, steps=None, load=None, seed=1234, device="cuda", frame
     if load:
         from .checkpoint import load_checkpoint
         load_checkpoint(engine, load, force_inference=cfg.get("args", {}).get("force_inference", True))
+    return engine
+
+
+def run(cfg, inputs=None, steps=None, load=None, seed=1234, device="cuda", frames=None, engine=None):
+    engine = engine or build_engine(cfg, load, device)
     H, W = cfg.get("args", {}).get("sampling_image_size", [512, 896])
     net = engine.network
     frames = frames or min(81, net.num_frames)
@@ -162,8 +209,34 @@ def main():
     ap.add_argument("--clip-ckpt", default=None)
     ap.add_argument("--save-dir", default=None, help="write <key>_000000.<ext> like the reference's save_multi_video_grid_and_mp4")
     ap.add_argument("--format", default=".webp", help=".webp (lossless) | .png (APNG) | .gif | .npy | '' (directory of PNG frames)")
+    ap.add_argument("--request", action="append", default=[], help="'<prompt>@@<example_dir>' (the reference's cli input line); repeatable")
+    ap.add_argument("--input-file", default=None, help="text file of request lines (the reference's --input-type txt)")
+    ap.add_argument("--output-dir", default="outputs", help="results of --request / --input-file go to <output-dir>/<example>/")
     a = ap.parse_args()
     cfg = TINY if a.tiny or not a.base else load_yaml_configs(*a.base)
+    lines = [(r, i) for i, r in enumerate(a.request)] + (list(read_from_file(a.input_file)) if a.input_file else [])
+    if lines:
+        import os
+        from . import video_io
+        engine = build_engine(cfg, a.load)
+        td = engine.network.text_dim
+        for line, cnt in lines:
+            text, input_dir, image_path, pose_path = parse_request(line)
+            print(cnt, ": ", text)
+            req = request_from_files(image_path, pose_path, cfg, a.conditioning, seed=a.seed, text_dim=td)[0]
+            if a.tokenizer:
+                req.update(encode_conditioning(text, a.negative_prompt, req["ref"], td, a.tokenizer, a.t5_ckpt, a.clip_ckpt,
+                                               max_length=512 if td == 4096 else 16))
+            video, z, dt = run(cfg, req, a.steps, seed=a.seed, engine=engine)
+            save_dir = os.path.join(a.output_dir, os.path.basename(os.path.normpath(input_dir)))
+            os.makedirs(save_dir, exist_ok=True)
+            with open(os.path.join(save_dir, "text.txt"), "w") as f:                   # sample_video.py:413-414
+                f.write(text)
+            samples = video.permute(0, 2, 1, 3, 4).contiguous().cpu()
+            paths = video_io.save_multi_video_grid([samples], save_dir, fps=cfg.get("args", {}).get("sampling_fps", 16),
+                                                   key=f"{os.path.basename(os.path.normpath(input_dir))}_output", ext=a.format)
+            print(f"  latent {tuple(z.shape)} -> video {tuple(video.shape)} in {dt:.2f} s; wrote {', '.join(paths)}")
+        return
     inputs = torch.load(a.inputs) if a.inputs else None
     if a.ref_image or a.pose_video:
         if not (a.ref_image and a.pose_video):

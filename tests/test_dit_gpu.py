@@ -370,6 +370,28 @@ def test_cli_from_files_to_saved_video(tmp_path):
     assert np.array_equal(back.numpy(), (255.0 * samples[0].permute(0, 2, 3, 1)).numpy().astype(np.uint8))
 
 
+def test_cli_request_line_command(tmp_path):
+    """`python -m scail_amd.cli --tiny --request '<prompt>@@<example_dir>'`: the reference's request format end to end, results in
+    <output-dir>/<example>/ (sample_video.py:284-300, :410-414, :506)."""
+    import subprocess
+    import sys
+    import numpy as np
+    from PIL import Image
+    from scail_amd import video_io
+    d = tmp_path / "001"
+    d.mkdir()
+    g = np.random.default_rng(1)
+    Image.fromarray(g.integers(0, 255, (72, 96, 3), dtype=np.uint8)).save(d / "ref.png")
+    np.save(d / "rendered.npy", g.integers(0, 255, (9, 72, 96, 3), dtype=np.uint8))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "scail_amd.cli", "--tiny", "--steps", "2", "--request", f"a girl is dancing@@{d}",
+                        "--output-dir", str(tmp_path / "out"), "--format", ".png"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (tmp_path / "out" / "001" / "text.txt").read_text() == "a girl is dancing"
+    back = video_io.load_video_for_pose_sample(str(tmp_path / "out" / "001" / "001_output_000000.png"))
+    assert back.shape == (9, 64, 64, 3)
+
+
 def test_cli_prompt_to_conditioning(tmp_path):
     """Prompt string + reference image -> UMT5 / CLIP conditioning -> sampler, all on the GPU (sample_video.py:397-438).
     Tiny text width; SentencePiece model trained here; CLIP tower at full size with random weights."""

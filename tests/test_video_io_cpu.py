@@ -66,3 +66,29 @@ def test_request_assembly_from_files(tmp_path):
     assert (H, W) == (64, 64) == tuple(preprocess.target_size((90, 160), [64, 64]))
     assert req["ref"].shape == (3, 1, 64, 64) and req["pose"].shape == (3, 5, 32, 32)
     assert float(req["pose"].abs().max()) <= 1.0 + 1e-6 and req["context"].shape[-1] == 64
+
+
+def test_request_line_parsing(tmp_path):
+    """'<prompt>@@<example_dir>' lines of the reference CLI (sample_video.py:76, :82-91, :284-300)."""
+    from PIL import Image
+    from scail_amd import cli
+    d = tmp_path / "001"
+    d.mkdir()
+    with pytest.raises(FileNotFoundError, match="Reference image not found"):
+        cli.parse_request(f"a girl@@{d}")
+    Image.new("RGB", (8, 8)).save(d / "ref_image.png")
+    with pytest.raises(FileNotFoundError, match="Pose video not found"):
+        cli.parse_request(f"a girl@@{d}")
+    (d / "rendered.mp4").write_bytes(b"\x00")
+    np.save(d / "rendered.npy", np.zeros((2, 8, 8, 3), np.uint8))
+    text, input_dir, image_path, pose_path = cli.parse_request(f"None@@{d}")
+    assert text == "" and input_dir == str(d) and image_path.endswith("ref_image.png")
+    assert pose_path.endswith("rendered.npy")                           # a decodable container wins over the mp4
+    (d / "rendered_aligned.gif").write_bytes(b"x")
+    assert cli.parse_request(f"x@@{d}")[3].endswith("rendered_aligned.gif")
+    with pytest.raises(ValueError, match="@@"):
+        cli.parse_request("no separator")
+    f = tmp_path / "req.txt"
+    f.write_text(f"a@@{d}\n\nb@@{d}\nc@@{d}\n")
+    assert [c for _, c in cli.read_from_file(str(f), rank=1, world_size=2)] == [3]
+    assert [t.split("@@")[0] for t, _ in cli.read_from_file(str(f))] == ["a", "b", "c"]
