@@ -152,10 +152,20 @@ def request_from_files(ref_image: str, pose_video: str, cfg, conditioning: str =
 
 
 def build_engine(cfg, load=None, device="cuda"):
+    """Under ``python -m torch.distributed.run`` the whole world is one sequence-parallel group (the reference's CLI: dp = 1,
+    sample_video.py:229): every rank builds the engine, encodes the request and joins ``engine.sample``; SP rank 0 decodes
+    and saves (:484-507)."""
     lib.load()
     mc = dict(cfg["model"])
     mc["build_first_stage"] = True
-    engine = SATVideoDiffusionEngine(mc, device=device)
+    sp = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from . import parallel
+        backend = os.environ.get("SCAIL_DIST_BACKEND", "nccl")          # "gloo": ranks sharing one GPU (tests only)
+        if backend == "nccl":
+            device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+        sp = parallel.init_from_env(backend)
+    engine = SATVideoDiffusionEngine(mc, device=device, sp=sp)
     if load:
         from .checkpoint import load_checkpoint
         load_checkpoint(engine, load, force_inference=cfg.get("args", {}).get("force_inference", True))
@@ -183,6 +193,9 @@ def run(cfg, inputs=None, steps=None, load=None, seed=1234, device="cuda", frame
     uc = dict(crossattn=req["uncond_context"], **shared)
     torch.manual_seed(seed)
     z = engine.sample(c, uc=uc, batch_size=1, shape=(T, C, h, w), num_steps=steps)
+    if engine.sp is not None and engine.sp.size > 1 and engine.sp.rank != 0:
+        torch.cuda.synchronize()
+        return None, None, time.perf_counter() - t0                         # only SP rank 0 holds the gathered latent (:484)
     z = z.permute(0, 2, 1, 3, 4).contiguous()                               # B T C H W -> B C T H W (:484-485)
     x = engine.decode_first_stage(z.float())
     video = torch.clamp((x + 1.0) / 2.0, 0.0, 1.0)                          # (:494)
@@ -228,6 +241,8 @@ def main():
                 req.update(encode_conditioning(text, a.negative_prompt, req["ref"], td, a.tokenizer, a.t5_ckpt, a.clip_ckpt,
                                                max_length=512 if td == 4096 else 16))
             video, z, dt = run(cfg, req, a.steps, seed=a.seed, engine=engine)
+            if video is None:
+                continue
             save_dir = os.path.join(a.output_dir, os.path.basename(os.path.normpath(input_dir)))
             os.makedirs(save_dir, exist_ok=True)
             with open(os.path.join(save_dir, "text.txt"), "w") as f:                   # sample_video.py:413-414
@@ -250,6 +265,8 @@ def main():
                                                max_length=512 if text_dim == 4096 else 16))
             return req
     video, z, dt = run(cfg, inputs, a.steps, a.load, a.seed)
+    if video is None:
+        return
     print(f"sampled latent {tuple(z.shape)} -> video {tuple(video.shape)} in {dt:.2f} s")
     if a.out:
         torch.save({"video": video.cpu(), "latent": z.cpu()}, a.out)

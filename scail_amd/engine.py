@@ -75,7 +75,7 @@ class SATVideoDiffusionEngine(nn.Module):
             randn = sp.chunk(randn, chunk_dim)
             cond, uc = dict(cond), dict(uc)
             for k in ("concat_images", "ref_concat", "concat_pose", "concat_smpl_render"):
-                if k in cond:
+                if k in cond and cond[k].dim() > chunk_dim:                # a placeholder concat_images (never read) has no such axis
                     cond[k] = sp.chunk(cond[k], chunk_dim)
                     uc[k] = sp.chunk(uc[k], chunk_dim)
             if "smpl_tiled" in cond:                                       # one more leading (tile) axis, :518-524

@@ -55,3 +55,30 @@ def test_fullsize_request_two_steps():
     o = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert o["latent"] == [1, 16, 21, 64, 112] and o["video"] == [1, 3, 81, 512, 896]
     assert o["finite"] and 0.0 <= o["vmin"] and o["vmax"] <= 1.0
+
+
+def test_cli_two_ranks_one_gpu(tmp_path):
+    """The CLI under the multi-rank launch line (sequence parallel over the token axis; both ranks on GPU 0 with host-staged
+    exchanges): rank 0 writes the same video as the single-process run, up to bf16 re-association."""
+    import numpy as np
+    from PIL import Image
+    from scail_amd import video_io
+    d = tmp_path / "001"
+    d.mkdir()
+    g = np.random.default_rng(1)
+    Image.fromarray(g.integers(0, 255, (72, 96, 3), dtype=np.uint8)).save(d / "ref.png")
+    np.save(d / "rendered.npy", g.integers(0, 255, (9, 72, 96, 3), dtype=np.uint8))
+    args = ["--tiny", "--steps", "2", "--request", f"a girl is dancing@@{d}", "--format", ".png"]
+
+    def go(cmd, out, env_extra=None):
+        env = dict(os.environ)
+        env.update(env_extra or {})
+        r = subprocess.run(cmd + args + ["--output-dir", str(out)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return video_io.load_video_for_pose_sample(str(out / "001" / "001_output_000000.png")).float()
+
+    one = go([sys.executable, "-m", "scail_amd.cli"], tmp_path / "one")
+    two = go([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29643", "-m", "scail_amd.cli"], tmp_path / "two", {"SCAIL_DIST_BACKEND": "gloo"})
+    assert one.shape == two.shape == (9, 64, 64, 3)
+    assert float((one - two).abs().mean()) < 2.0 and float((one - two).abs().max()) <= 40.0      # 8-bit levels
