@@ -193,23 +193,31 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 // distinct 16-byte bank groups.
 //   CS = 48, two W buffers (one barrier per tap row, 27 MFMAs per wave between barriers): 118.8 KB LDS, 1 workgroup / CU
 //   CS = 32, one W buffer (two barriers per tap row, 18 MFMAs):                             63.2 KB LDS, 2 workgroups / CU
+//   CS = 32, one W buffer, NF = 2 output frames (36 MFMAs between barriers):                77.6 KB LDS, 2 workgroups / CU (default)
+// Timing ablations of the NF = 1 kernel (96 channels, 512 x 896): no W global loads +16 %, no W loads / LDS stores +24 %,
+// no patch reloads +7.5 %, W fragments read once instead of per 32-channel block +6 %, no barriers +3.4 % -- the W stream
+// is what NF = 2 halves.
 // ------------------------------------------------------------------------------------------------
 #define HT_TH 8
 #define HT_TW 16
-#define HT_PVOX (3 * (HT_TH + 2) * (HT_TW + 2))
+#define HT_FVOX ((HT_TH + 2) * (HT_TW + 2))   // patch voxels per input frame
 // SWZ: no padding; instead the 16-byte chunk index inside a voxel / W tap is XOR-ed with (index >> 2) & 3 of the voxel /
 // row (needs CS == 32: 4 chunks): the two W buffers then fit next to the patch in half the LDS of a CU.
-template <int CS, int NWB, bool SWZ = false, int BN = 96> struct HaloCfg {
+// NF: output frames per workgroup.  NF = 2 keeps a 4-frame patch and runs every W fragment against both frames: the W tile
+// (the dominant L2 -> LDS stream: 0.5 MB per 128 output voxels at NF = 1) is staged and read once per 256 output voxels,
+// the patch costs 4 input frames per 2 outputs instead of 3 per 1, and there are half as many barriers per MFMA.
+template <int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1> struct HaloCfg {
     static constexpr int PS = SWZ ? CS : CS + 8, WS = SWZ ? 3 * CS : 3 * CS + 8;   // strides in elements
-    static constexpr int PCH = HT_PVOX * (CS / 8), WCH = BN * 3 * (CS / 8);
+    static constexpr int PVOX = (NF + 2) * HT_FVOX;
+    static constexpr int PCH = PVOX * (CS / 8), WCH = BN * 3 * (CS / 8);
     static constexpr int NP = (PCH + 255) / 256, NWL = (WCH + 255) / 256;  // chunks per thread
-    static constexpr int LDS = (HT_PVOX * PS + NWB * BN * WS) * 2;
+    static constexpr int LDS = (PVOX * PS + NWB * BN * WS) * 2;
 };
 
-template <int EPI, int CS, int NWB, bool SWZ = false, int BN = 96>   // BN = 96 (three 32-channel blocks) or 32 (narrow outputs: the RGB head)
+template <int EPI, int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1>   // BN = 96 (three 32-channel blocks) or 32 (narrow outputs: the RGB head)
 __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_kernel(ConvParams p) {
-    using Cfg = HaloCfg<CS, NWB, SWZ, BN>;
-    constexpr int NBLK = BN / 32;
+    using Cfg = HaloCfg<CS, NWB, SWZ, BN, NF>;
+    constexpr int NBLK = BN / 32, HT_PVOX = Cfg::PVOX;
     static_assert(!SWZ || CS == 32, "the swizzle works on 4 chunks per voxel");
     constexpr int PS = Cfg::PS, WS = Cfg::WS, PCH = Cfg::PCH, WCH = Cfg::WCH, NP = Cfg::NP, NWL = Cfg::NWL, CPV = CS / 8;
     static_assert(NP <= 13 && NWL <= 7, "staging register sets below");
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
     const int tn = bid % tiles_n; bid /= tiles_n;
     const int tw = bid % tiles_w; bid /= tiles_w;
     const int th = bid % tiles_h;
-    const int to = bid / tiles_h;
+    const int to = (bid / tiles_h) * NF;         // first output frame of this workgroup
     const int n0 = tn * BN, h0 = th * HT_TH, w0 = tw * HT_TW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
     int64_t psrc##i_ = -1; int pdst##i_ = 0;                                                           \
     if (i_ < NP && pc##i_ < PCH) {                                                                     \
         const int vox_ = pc##i_ / CPV, ch_ = pc##i_ - vox_ * CPV;                                      \
-        const int dt_ = vox_ / ((HT_TH + 2) * (HT_TW + 2)), rem_ = vox_ - dt_ * ((HT_TH + 2) * (HT_TW + 2)); \
+        const int dt_ = vox_ / HT_FVOX, rem_ = vox_ - dt_ * HT_FVOX;                                   \
         const int rr_ = rem_ / (HT_TW + 2), cc_ = rem_ - rr_ * (HT_TW + 2);                            \
         const int ti_ = to + dt_ - p.pt, hi_ = h0 + rr_ - p.ph, wi_ = w0 + cc_ - p.pw;                 \
         if (ti_ >= 0 && ti_ < p.Ti && hi_ >= 0 && hi_ < p.Hi && wi_ >= 0 && wi_ < p.Wi)                \
@@ -273,11 +281,13 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
 #pragma unroll
     for (int ks = 0; ks < CS / 16; ++ks) wsw[ks] = SWZ ? (((ks * 2 + g) ^ ((l31 >> 2) & 3)) << 3) : ks * 16;
 
-    f32x16 acc[NBLK];
+    f32x16 acc[NF][NBLK];
 #pragma unroll
-    for (int a = 0; a < NBLK; ++a)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+        for (int a = 0; a < NBLK; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[f][a][e] = 0.f;
 
     const int nslice = p.Cin / CS;
     for (int sl = 0; sl < nslice; ++sl) {
@@ -298,14 +308,19 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
             const u16* wr_ = wb + cur * BN * WS;
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
-                const int psw = SWZ ? (((pv0 + toff + dw) >> 2) & 3) : 0;       // this tap's voxel: its swizzle bits
 #pragma unroll
                 for (int ks = 0; ks < CS / 16; ++ks) {
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(pr_ + dw * PS + (SWZ ? (((ks * 2 + g) ^ psw) << 3) : ks * 16));
+                    bf16x8 xf[NF];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const int psw = SWZ ? (((pv0 + toff + f * HT_FVOX + dw) >> 2) & 3) : 0;   // this tap's voxel: its swizzle bits
+                        xf[f] = *reinterpret_cast<const bf16x8*>(pr_ + (f * HT_FVOX + dw) * PS + (SWZ ? (((ks * 2 + g) ^ psw) << 3) : ks * 16));
+                    }
 #pragma unroll
                     for (int nb = 0; nb < NBLK; ++nb) {
                         const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr_ + nb * 32 * WS + dw * CS + wsw[ks]);
-                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nb], 0, 0, 0);
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) acc[f][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[f], acc[f][nb], 0, 0, 0);
                     }
                 }
             }
@@ -317,8 +332,10 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
 
     // ---- epilogue: lane = voxel vloc, rows n = n0 + nb * 32 + 8 rr + 4 g + e ----
     const int ho = h0 + (vloc >> 4), wo = w0 + (vloc & 15);
-    if (ho < p.Ho && wo < p.Wo) {
-        const int64_t vox = ((int64_t)(to * p.ot_mul + p.ot_off) * p.Ho + ho) * p.Wo + wo;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+    if (ho < p.Ho && wo < p.Wo && to + f < p.To) {
+        const int64_t vox = ((int64_t)((to + f) * p.ot_mul + p.ot_off) * p.Ho + ho) * p.Wo + wo;
 #pragma unroll
         for (int nb = 0; nb < NBLK; ++nb) {
 #pragma unroll
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
                 if (n >= p.N) continue;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[nb][4 * rr + e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[f][nb][4 * rr + e];
                 if (p.bias != nullptr) {
                     const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                     v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -500,7 +517,7 @@ __global__ void from_channels_last_kernel(const u16* __restrict__ x, int64_t ldx
 // ================================================================================================
 // C ABI
 // ================================================================================================
-static int g_conv_halo = 3;
+static int g_conv_halo = 4;
 int scail_conv_tune(int v) { g_conv_halo = v; return 0; }
 
 extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
@@ -525,31 +542,36 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
                   "pointer alignment");
     if (p.M == 0) return 0;
     // 3x3x3 stride-1 causal convolutions: halo-tile kernel.  Knob conv_halo: 0 off, 1 = 48-channel slices / 1 workgroup
-    // per CU, 3 (default) = 32-channel slices, one padded W buffer (two barriers per tap row), 2 workgroups per CU,
+    // per CU, 4 (default) = 3 with TWO output frames per workgroup (4-frame patch, every W fragment used for both frames:
+    // +22-25 % on the 96 / 192 / 384-channel shapes, bit-identical), 3 = 32-channel slices, one padded W buffer (two
+    // barriers per tap row), 2 workgroups per CU,
     // 2 = 32-channel slices, swizzled unpadded layout with two W buffers (one barrier per tap row), 2 workgroups per CU --
     // measured equal (283 / 490 ms vs 281 / 487 ms encode / decode): the barrier is not what bounds the kernel
     if (g_conv_halo && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups &&
         p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
         p.Cin % ((g_conv_halo == 1 && p.N > 32) ? 48 : 32) == 0 && (p.N <= 32 || p.N >= 48)) {
-#define HALO_LAUNCH(EPI_, CS_, NWB_, SWZ_, BN_)                                                                             \
+#define HALO_LAUNCH(EPI_, CS_, NWB_, SWZ_, BN_, ...)                                                                        \
     {                                                                                                              \
-        constexpr int lds_ = HaloCfg<CS_, NWB_, SWZ_, BN_>::LDS;                                                            \
+        constexpr int lds_ = HaloCfg<CS_, NWB_, SWZ_, BN_, ##__VA_ARGS__>::LDS;                                             \
         static bool attr_ = false;                                                                                 \
         if (!attr_) {                                                                                              \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_>),           \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_, ##__VA_ARGS__>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) {             \
                 scail_set_error("conv3d: hipFuncSetAttribute failed");                                             \
                 return 2;                                                                                          \
             }                                                                                                      \
             attr_ = true;                                                                                          \
         }                                                                                                          \
-        hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
+        hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_, ##__VA_ARGS__>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
     }
         const int hbn = p.N <= 32 ? 32 : 96;
-        const int64_t tiles = (int64_t)p.To * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW) * ((p.N + hbn - 1) / hbn);
+        const int nf = (g_conv_halo == 4 && hbn == 96 && p.To >= 2) ? 2 : 1;        // output frames per workgroup (an odd last frame pair wastes half a tile: 1 / 81)
+        const int64_t tiles = (int64_t)((p.To + nf - 1) / nf) * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW) * ((p.N + hbn - 1) / hbn);
         SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
         if (hbn == 32) {
             if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 32) else HALO_LAUNCH(0, 32, 1, false, 32)
+        } else if (nf == 2) {
+            if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96, 2) else HALO_LAUNCH(0, 32, 1, false, 96, 2)
         } else if (g_conv_halo == 1) {
             if (resid != nullptr) HALO_LAUNCH(3, 48, 2, false, 96) else HALO_LAUNCH(0, 48, 2, false, 96)
         } else if (g_conv_halo == 2) {

@@ -32,21 +32,21 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm()))
 
 
-@pytest.fixture(params=[3, 2, 1, 0])
+@pytest.fixture(params=[4, 3, 2, 1, 0])
 def conv_halo(request):
     """every path of the 3x3x3 convolution: halo-tile kernel with 32-channel slices padded / one W buffer (default),
     32-channel slices swizzled / two W buffers, 48-channel slices, and the gather kernel"""
     from scail_amd import lib as L
     L.tune_set("conv_halo", request.param)
     yield request.param
-    L.tune_set("conv_halo", 3)
+    L.tune_set("conv_halo", 4)
 
 
 @pytest.mark.parametrize("cin,cout,k,thw", [(16, 32, (3, 3, 3), (5, 10, 12)), (96, 96, (3, 3, 3), (5, 10, 12)),
                                            (96, 192, (1, 1, 1), (5, 10, 12)), (32, 64, (3, 1, 1), (5, 10, 12)),
                                            (8, 96, (3, 3, 3), (5, 10, 12)), (192, 96, (3, 3, 3), (3, 17, 35)),
                                            (96, 200, (3, 3, 3), (2, 8, 16)), (64, 48, (3, 3, 3), (4, 9, 33)), (96, 3, (3, 3, 3), (3, 11, 21)),
-                                           (32, 24, (3, 3, 3), (2, 8, 16))])
+                                           (32, 24, (3, 3, 3), (2, 8, 16)), (96, 96, (3, 3, 3), (1, 10, 12)), (192, 192, (3, 3, 3), (7, 9, 20))])
 def test_causal_conv3d(cin, cout, k, thw, conv_halo):
     from scail_amd import ops
     g = torch.Generator().manual_seed(0)
