@@ -206,17 +206,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 // NF: output frames per workgroup.  NF = 2 keeps a 4-frame patch and runs every W fragment against both frames: the W tile
 // (the dominant L2 -> LDS stream: 0.5 MB per 128 output voxels at NF = 1) is staged and read once per 256 output voxels,
 // the patch costs 4 input frames per 2 outputs instead of 3 per 1, and there are half as many barriers per MFMA.
-template <int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1> struct HaloCfg {
+// KT: temporal taps (3, or 1 for the 1x3x3 convolution behind the nearest 2x upsample: UPS, patch voxel (h, w) reads input
+// (h >> 1, w >> 1); no temporal halo, 3 tap rows per slice).
+template <int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1, int KT = 3, bool UPS = false> struct HaloCfg {
     static constexpr int PS = SWZ ? CS : CS + 8, WS = SWZ ? 3 * CS : 3 * CS + 8;   // strides in elements
-    static constexpr int PVOX = (NF + 2) * HT_FVOX;
+    static constexpr int PVOX = (NF + KT - 1) * HT_FVOX;
     static constexpr int PCH = PVOX * (CS / 8), WCH = BN * 3 * (CS / 8);
     static constexpr int NP = (PCH + 255) / 256, NWL = (WCH + 255) / 256;  // chunks per thread
     static constexpr int LDS = (PVOX * PS + NWB * BN * WS) * 2;
 };
 
-template <int EPI, int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1>   // BN = 96 (three 32-channel blocks) or 32 (narrow outputs: the RGB head)
+template <int EPI, int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1, int KT = 3, bool UPS = false>   // BN = 96 (three 32-channel blocks) or 32 (narrow outputs: the RGB head)
 __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_kernel(ConvParams p) {
-    using Cfg = HaloCfg<CS, NWB, SWZ, BN, NF>;
+    using Cfg = HaloCfg<CS, NWB, SWZ, BN, NF, KT>;
     constexpr int NBLK = BN / 32, HT_PVOX = Cfg::PVOX;
     static_assert(!SWZ || CS == 32, "the swizzle works on 4 chunks per voxel");
     constexpr int PS = Cfg::PS, WS = Cfg::WS, PCH = Cfg::PCH, WCH = Cfg::WCH, NP = Cfg::NP, NWL = Cfg::NWL, CPV = CS / 8;
@@ -246,8 +248,8 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
         const int dt_ = vox_ / HT_FVOX, rem_ = vox_ - dt_ * HT_FVOX;                                   \
         const int rr_ = rem_ / (HT_TW + 2), cc_ = rem_ - rr_ * (HT_TW + 2);                            \
         const int ti_ = to + dt_ - p.pt, hi_ = h0 + rr_ - p.ph, wi_ = w0 + cc_ - p.pw;                 \
-        if (ti_ >= 0 && ti_ < p.Ti && hi_ >= 0 && hi_ < p.Hi && wi_ >= 0 && wi_ < p.Wi)                \
-            psrc##i_ = (((int64_t)ti_ * p.Hi + hi_) * p.Wi + wi_) * p.Cin + ch_ * 8;                   \
+        if (ti_ >= 0 && ti_ < p.Ti && hi_ >= 0 && hi_ < p.Ho && wi_ >= 0 && wi_ < p.Wo)                \
+            psrc##i_ = (((int64_t)ti_ * p.Hi + (UPS ? hi_ >> 1 : hi_)) * p.Wi + (UPS ? wi_ >> 1 : wi_)) * p.Cin + ch_ * 8; \
         pdst##i_ = vox_ * PS + (SWZ ? ((ch_ ^ ((vox_ >> 2) & 3)) << 3) : ch_ * 8);                     \
     }                                                                                                  \
     uint4 pr##i_ = make_uint4(0, 0, 0, 0);
@@ -299,9 +301,9 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
         HT_W7(HT_WSTORE, 0)
         __syncthreads();
 #pragma unroll 1
-        for (int row = 0; row < 9; ++row) {          // row = dt * 3 + dh
+        for (int row = 0; row < 3 * KT; ++row) {     // row = dt * 3 + dh
             const int cur = (NWB == 2) ? (row & 1) : 0;
-            if (row + 1 < 9) { HT_W7(HT_WLOAD, (row + 1) * 3 * p.Cin + c0) }
+            if (row + 1 < 3 * KT) { HT_W7(HT_WLOAD, (row + 1) * 3 * p.Cin + c0) }
             const int dt = row / 3, dh = row - dt * 3;
             const int toff = (dt * (HT_TH + 2) + dh) * (HT_TW + 2);
             const u16* pr_ = pa + toff * PS;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
                 }
             }
             if (NWB == 1) __syncthreads();           // single buffer: every wave has read this row's tile
-            if (row + 1 < 9) { HT_W7(HT_WSTORE, (NWB == 2) ? (cur ^ 1) : 0) }
+            if (row + 1 < 3 * KT) { HT_W7(HT_WSTORE, (NWB == 2) ? (cur ^ 1) : 0) }
             __syncthreads();
         }
     }
@@ -579,6 +581,16 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
         } else {
             if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96) else HALO_LAUNCH(0, 32, 1, false, 96)
         }
+        return scail_check_launch("conv3d_cl");
+    }
+    // the 1x3x3 convolution behind the nearest 2x upsample (Resample 'upsample2d/3d', wan_vae.py:110-121): halo tile with
+    // the upsampling folded into the patch load, two output frames per workgroup
+    if (g_conv_halo == 4 && p.kt == 1 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.ups &&
+        p.pt == 0 && p.ph == 1 && p.pw == 1 && p.Ho == 2 * p.Hi && p.Wo == 2 * p.Wi && p.To == p.Ti && p.To >= 2 &&
+        p.Cin % 32 == 0 && p.N >= 48) {
+        const int64_t tiles = (int64_t)((p.To + 1) / 2) * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW) * ((p.N + 95) / 96);
+        SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
+        if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96, 2, 1, true) else HALO_LAUNCH(0, 32, 1, false, 96, 2, 1, true)
         return scail_check_launch("conv3d_cl");
     }
     // N tile: of 128 / 96 / 64 the one with the fewest padding columns (ties -> the wider tile)

@@ -65,7 +65,7 @@ def test_causal_conv3d(cin, cout, k, thw, conv_halo):
     torch.testing.assert_close(_pl(y2)[:cout], ref + r, rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("C,T,H,W", [(32, 5, 8, 12), (192, 2, 9, 21)])
+@pytest.mark.parametrize("C,T,H,W", [(32, 5, 8, 12), (192, 2, 9, 21), (384, 3, 6, 10)])
 def test_resample_convs(C, T, H, W, conv_halo):
     from scail_amd import ops
     g = torch.Generator().manual_seed(1)
