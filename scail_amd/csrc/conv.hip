@@ -182,8 +182,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 
 // ------------------------------------------------------------------------------------------------
 // Halo-tile kernel for the 3x3x3 stride-1 causal convolutions (all ResidualBlock convs: 26 of the 33 decoder convs).
-// (Also tried for the 1x3x3 conv behind the 2x upsample, patch load doing the upsampling: only 3 tap rows per patch
-// load -- 8 % SLOWER end to end than the gather kernel, so those stay there.)
+// (The 1x3x3 conv behind the 2x upsample uses it too, KT = 1 / UPS below; with ONE output frame per workgroup -- only 3 tap rows per patch
+// load -- that was 8 % slower than the gather kernel, with two frames it is 65 % faster.)
 // The gather kernel above fetches every input voxel once per tap (27x) and restages it through registers; here a
 // workgroup owns an 8 x 16 block of ONE output frame, keeps the 3-frame (8+2) x (16+2) input patch of a CS-channel
 // slice resident in LDS and reads the A fragments of every tap straight from it at the tap's offset: the patch is
