@@ -168,6 +168,16 @@ int scail_cfg_euler(float* x, const float* v, int64_t n, float cfg_scale, float 
 int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
                     const scail_bf16* resid, int64_t ldr, const int32_t* geom, void* stream);
 
+/*
+ * The same convolution with RMS_norm + SiLU fused into the epilogue (ResidualBlock: residual.2 conv -> residual.3 RMS_norm ->
+ * residual.4 SiLU, wan_vae.py:190-196): y = SiLU(RMS_norm(conv(x) + bias) * gamma), RMS_norm as in scail_rms_silu, applied
+ * to the bf16-rounded convolution output.  Only the raw convolution output's round trip through HBM disappears; the
+ * arithmetic is that of the two separate calls.  3x3x3, stride 1, 'same' spatial extent, Cin % 32 == 0, N <= 96 (one
+ * output tile holds every channel of a voxel); anything else is rejected.  gamma fp32 [N], 16-byte aligned.
+ */
+int scail_conv3d_cl_norm(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
+                         const float* gamma, const int32_t* geom, void* stream);
+
 /* RMS_norm over channels (F.normalize * sqrt(C) * gamma, :39-54) + optional SiLU; x,y (nvox, C), gamma fp32. */
 int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* gamma, int64_t nvox, int64_t C, int silu,
                    void* stream);

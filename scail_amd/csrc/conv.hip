@@ -23,6 +23,7 @@ struct ConvParams {
     const float* bias; // (N) or null
     u16* y; int64_t ldc;          // output voxel v -> y + v * ldc
     const u16* resid; int64_t ldr;
+    const float* gamma;           // EPI 4 (halo kernel, N <= tile width): RMS_norm gamma, output = SiLU(RMS_norm(conv))
     int Ti, Hi, Wi, Cin;
     int To, Ho, Wo;               // output extents covered by this launch (M = To*Ho*Wo)
     int kt, kh, kw, st, sh, sw, pt, ph, pw, ups;
@@ -334,6 +335,53 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
 
     // ---- epilogue: lane = voxel vloc, rows n = n0 + nb * 32 + 8 rr + 4 g + e ----
     const int ho = h0 + (vloc >> 4), wo = w0 + (vloc & 15);
+    if (EPI == 4) {
+        // conv -> RMS_norm -> SiLU in one pass (ResidualBlock residual.2 -> .3 -> .4, wan_vae.py:190-196): the workgroup's
+        // single N tile holds every channel of a voxel, 48 (BN = 96) of them in this lane and the rest in lane ^ 32.
+        // Same arithmetic as rms_silu_kernel on the bf16-rounded conv output: x * sqrt(C) / max(||x||, 1e-12) * gamma, SiLU.
+        const float sC = sqrtf((float)p.N);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            float ss = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int n = n0 + nb * 32 + 8 * rr + 4 * g;
+                    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n < p.N && p.bias != nullptr) bb = *reinterpret_cast<const float4*>(p.bias + n);
+                    const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float vr = (n < p.N) ? bf2f(f2bf(acc[f][nb][4 * rr + e] + b4[e])) : 0.f;
+                        acc[f][nb][4 * rr + e] = vr;
+                        ss += vr * vr;
+                    }
+                }
+            ss += __shfl_xor(ss, 32, 64);
+            const float inv = sC / fmaxf(sqrtf(ss), 1e-12f);
+            if (ho < p.Ho && wo < p.Wo && to + f < p.To) {
+                const int64_t vox = ((int64_t)((to + f) * p.ot_mul + p.ot_off) * p.Ho + ho) * p.Wo + wo;
+#pragma unroll
+                for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int n = n0 + nb * 32 + 8 * rr + 4 * g;
+                        if (n >= p.N) continue;
+                        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + n);
+                        const float g4[4] = {gm.x, gm.y, gm.z, gm.w};
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[f][nb][4 * rr + e] * inv * g4[e]);
+                        uint2 o;
+                        o.x = pack_bf16x2(v[0], v[1]);
+                        o.y = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(p.y + vox * p.ldc + n) = o;
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f)
     if (ho < p.Ho && wo < p.Wo && to + f < p.To) {
@@ -522,11 +570,11 @@ __global__ void from_channels_last_kernel(const u16* __restrict__ x, int64_t ldx
 static int g_conv_halo = 4;
 int scail_conv_tune(int v) { g_conv_halo = v; return 0; }
 
-extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
-                               const scail_bf16* resid, int64_t ldr, const int32_t* geom, void* stream) {
+static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
+                       const scail_bf16* resid, int64_t ldr, const float* gamma, const int32_t* geom, void* stream) {
     // geom: Ti Hi Wi Cin | To Ho Wo | kt kh kw | st sh sw | pt ph pw | ups | ot_mul ot_off | N Kpad
     ConvParams p;
-    p.x = x; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc; p.resid = resid; p.ldr = ldr;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc; p.resid = resid; p.ldr = ldr; p.gamma = gamma;
     p.Ti = geom[0]; p.Hi = geom[1]; p.Wi = geom[2]; p.Cin = geom[3];
     p.To = geom[4]; p.Ho = geom[5]; p.Wo = geom[6];
     p.kt = geom[7]; p.kh = geom[8]; p.kw = geom[9];
@@ -549,9 +597,10 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
     // barriers per tap row), 2 workgroups per CU,
     // 2 = 32-channel slices, swizzled unpadded layout with two W buffers (one barrier per tap row), 2 workgroups per CU --
     // measured equal (283 / 490 ms vs 281 / 487 ms encode / decode): the barrier is not what bounds the kernel
-    if (g_conv_halo && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups &&
+    const bool fuse = gamma != nullptr;       // conv + RMS_norm + SiLU: always the halo kernel, whatever the knob says
+    if ((g_conv_halo || fuse) && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups &&
         p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
-        p.Cin % ((g_conv_halo == 1 && p.N > 32) ? 48 : 32) == 0 && (p.N <= 32 || p.N >= 48)) {
+        p.Cin % ((g_conv_halo == 1 && p.N > 32 && !fuse) ? 48 : 32) == 0 && (fuse || p.N <= 32 || p.N >= 48)) {
 #define HALO_LAUNCH(EPI_, CS_, NWB_, SWZ_, BN_, ...)                                                                        \
     {                                                                                                              \
         constexpr int lds_ = HaloCfg<CS_, NWB_, SWZ_, BN_, ##__VA_ARGS__>::LDS;                                             \
@@ -567,7 +616,15 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
         hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_, ##__VA_ARGS__>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
     }
         const int hbn = p.N <= 32 ? 32 : 96;
-        const int nf = (g_conv_halo == 4 && hbn == 96 && p.To >= 2) ? 2 : 1;        // output frames per workgroup (an odd last frame pair wastes half a tile: 1 / 81)
+        const int nf = ((g_conv_halo == 4 || fuse) && hbn == 96 && p.To >= 2) ? 2 : 1;   // output frames per workgroup (an odd last frame pair wastes half a tile: 1 / 81)
+        if (fuse) {                                                        // fused RMS_norm + SiLU epilogue: one N tile
+            SCAIL_REQUIRE(p.N <= 96 && resid == nullptr && (reinterpret_cast<uintptr_t>(gamma) & 15) == 0,
+                          "conv + norm fusion needs N <= 96, no residual, 16-byte aligned gamma");
+            const int64_t tiles = (int64_t)((p.To + nf - 1) / nf) * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW);
+            SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
+            if (hbn == 32) HALO_LAUNCH(4, 32, 1, false, 32) else if (nf == 2) HALO_LAUNCH(4, 32, 1, false, 96, 2) else HALO_LAUNCH(4, 32, 1, false, 96)
+            return scail_check_launch("conv3d_cl_norm");
+        }
         const int64_t tiles = (int64_t)((p.To + nf - 1) / nf) * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW) * ((p.N + hbn - 1) / hbn);
         SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
         if (hbn == 32) {
@@ -583,6 +640,7 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
         }
         return scail_check_launch("conv3d_cl");
     }
+    SCAIL_REQUIRE(gamma == nullptr, "conv + norm fusion covers the 3x3x3 stride-1 convolutions with Cin % 32 == 0 and N <= 96 only");
     // the 1x3x3 convolution behind the nearest 2x upsample (Resample 'upsample2d/3d', wan_vae.py:110-121): halo tile with
     // the upsampling folded into the patch load, two output frames per workgroup
     if (g_conv_halo == 4 && p.kt == 1 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.ups &&
@@ -624,6 +682,17 @@ extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const f
         if (bn == 64) CONV_LAUNCH(0, 64, 4, 1) else if (bn == 96) CONV_LAUNCH(0, 96, 4, 1) else CONV_LAUNCH(0, 128, 2, 2)
     }
     return scail_check_launch("conv3d_cl");
+}
+
+extern "C" int scail_conv3d_cl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
+                               const scail_bf16* resid, int64_t ldr, const int32_t* geom, void* stream) {
+    return conv3d_impl(x, w, bias, y, ldc, resid, ldr, nullptr, geom, stream);
+}
+
+extern "C" int scail_conv3d_cl_norm(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
+                                    const float* gamma, const int32_t* geom, void* stream) {
+    SCAIL_REQUIRE(gamma != nullptr, "null argument");
+    return conv3d_impl(x, w, bias, y, ldc, nullptr, 0, gamma, geom, stream);
 }
 
 extern "C" int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* gamma, int64_t nvox, int64_t C, int silu,

@@ -294,6 +294,26 @@ def conv3d_cl(x, wp, out_shape, stride=(1, 1, 1), pad=None, ups=False, out=None,
     return out
 
 
+def conv_norm_fusable(wp, x_channels: int) -> bool:
+    """Whether conv3d_cl_norm covers this convolution (3x3x3, Cin % 32 == 0, at most 96 output channels)."""
+    return tuple(wp["k"]) == (3, 3, 3) and x_channels % 32 == 0 and wp["N"] <= 96
+
+
+def conv3d_cl_norm(x, wp, gamma, out=None):
+    """SiLU(RMS_norm(causal 3x3x3 conv(x)) * gamma) in one kernel (scail_conv3d_cl_norm): x (T,H,W,Cin) bf16 -> (T,H,W,N)."""
+    import ctypes as C
+    _chk(x, bf16, "conv3d_cl_norm.x"); _chk(gamma, f32, "conv3d_cl_norm.gamma")
+    assert x.is_contiguous() and x.dim() == 4 and x.shape[3] == wp["Cin"] and gamma.numel() == wp["N"]
+    T, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty(T, H, W, wp["N"], device=x.device, dtype=bf16)
+    assert out.is_contiguous() and out.shape == (T, H, W, wp["N"])
+    geom = (C.c_int32 * 21)(T, H, W, Cin, T, H, W, 3, 3, 3, 1, 1, 1, 2, 1, 1, 0, 1, 0, wp["N"], wp["Kpad"])
+    L.call("scail_conv3d_cl_norm", x.data_ptr(), wp["w"].data_ptr(), wp["b"].data_ptr(), out.data_ptr(), out.shape[3],
+           gamma.data_ptr(), C.cast(geom, C.c_void_p), _stream())
+    return out
+
+
 def rms_silu(x, gamma, silu=True, out=None):
     """x (..., C) channels-last bf16 contiguous; gamma fp32 (C)."""
     _chk(x, bf16, "rms_silu.x"); _chk(gamma, f32, "rms_silu.gamma")

@@ -188,8 +188,11 @@ class WanVAE_(nn.Module):
         T, H, Wd, _ = x.shape
         h = ops.conv3d_cl(x, W[n + ".shortcut"], (T, H, Wd)) if (n + ".shortcut") in W else x
         y = ops.rms_silu(x, W[n + ".residual.0.gamma"])
-        y = ops.conv3d_cl(y, W[n + ".residual.2"], (T, H, Wd))
-        ops.rms_silu(y, W[n + ".residual.3.gamma"], out=y)
+        if ops.conv_norm_fusable(W[n + ".residual.2"], y.shape[3]):       # conv -> RMS_norm -> SiLU in one kernel
+            y = ops.conv3d_cl_norm(y, W[n + ".residual.2"], W[n + ".residual.3.gamma"])
+        else:
+            y = ops.conv3d_cl(y, W[n + ".residual.2"], (T, H, Wd))
+            ops.rms_silu(y, W[n + ".residual.3.gamma"], out=y)
         return ops.conv3d_cl(y, W[n + ".residual.6"], (T, H, Wd), resid=h)
 
     def _attn(self, W, n, x):

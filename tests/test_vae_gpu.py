@@ -85,6 +85,33 @@ def test_resample_convs(C, T, H, W, conv_halo):
     torch.testing.assert_close(_pl(yu), refu, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("cin,cout,thw", [(96, 96, (5, 10, 12)), (32, 32, (4, 9, 17)), (64, 64, (2, 8, 16)), (96, 96, (1, 16, 16)),
+                                          (192, 96, (3, 11, 21)), (32, 40, (3, 8, 16))])
+def test_conv_with_fused_rms_silu(cin, cout, thw):
+    """scail_conv3d_cl_norm == scail_conv3d_cl followed by scail_rms_silu (the raw conv output just never goes to HBM), and
+    matches the oracle's conv -> RMS_norm -> SiLU."""
+    from scail_amd import ops
+    g = torch.Generator().manual_seed(5)
+    T, H, W = thw
+    x = bfr(torch.randn(cin, T, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    gam = 1 + 0.1 * torch.randn(cout, generator=g)
+    wp = ops.prep_conv_weight(w.to(DEV), b.to(DEV))
+    assert ops.conv_norm_fusable(wp, cin)
+    fused = ops.conv3d_cl_norm(_cl(x), wp, gam.to(DEV))
+    two = ops.rms_silu(ops.conv3d_cl(_cl(x), wp, (T, H, W)), gam.to(DEV))
+    torch.testing.assert_close(fused.float(), two.float(), rtol=1e-2, atol=1e-2)        # summation order of the norm only
+    assert float((fused.float() - two.float()).abs().mean()) < 1e-4
+    ref = F.silu(V.rms_norm(V.causal_conv3d(x[None], w, b), gam)[0])
+    torch.testing.assert_close(_pl(fused)[:cout], ref, rtol=2e-2, atol=2e-2)
+    big = ops.prep_conv_weight(bfr(torch.randn(128, cin, 3, 3, 3, generator=g)).to(DEV), torch.zeros(128, device=DEV))
+    assert not ops.conv_norm_fusable(big, cin)
+    from scail_amd import lib as L
+    with pytest.raises(L.ScailHipError, match="N <= 96"):
+        ops.conv3d_cl_norm(_cl(x), big, torch.ones(128, device=DEV))
+
+
 def test_rms_silu_softmax_transpose():
     from scail_amd import ops
     g = torch.Generator().manual_seed(2)
