@@ -15,7 +15,7 @@ four elementwise torch ops; the arithmetic is the same fp32 expression.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict
 
 import numpy as np
 import torch

@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Dict, List, Tuple
+from typing import Dict, Tuple
 
 import torch
 from torch import nn
