@@ -224,7 +224,7 @@ def main():
                    "parallelism": f"sp{world}" + (f"-{sp_mode}" if sp is not None else ""), "cond_cache": False, "noise_tokens": Lnoise, "all_tokens_x_batch": 2 * L,
                    "step_tflop": fl / 1e12, "step_mfma_frac": fl / t_step / (world * PEAK_BF16_TFLOPS * 1e12),
                    "finite": finite, "x_abs_mean": x_abs_mean},
-        "roofline": {"bound": "mfma", "kernel": "flash_attn_swp_kernel<4,4> (self-attention)", "achieved": ach,
+        "roofline": {"bound": "mfma", "kernel": "flash_attn_swp_kernel<4, 4, 0, 1> (self-attention)", "achieved": ach,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
                      "traffic": traffic, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,
                      "launches_timed": len(timer.events.get("self_attn", []))},
