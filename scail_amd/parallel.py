@@ -216,9 +216,6 @@ class SequenceParallel:
         B = xn.shape[0]
         Hn = nh // N
         Dn = Hn * 128
-        ops.gemm(xn, lw["qkv_w"], lw["qkv_b"], out=qkv)
-        ops.rmsnorm_rope(qkv[..., D:2 * D], lw["kn"], cos, sin, rows_per_batch=Ltok, eps=eps)
-        ops.rmsnorm_rope(qkv[..., :D], lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
         key = ("u", B, Ltok)
         if key not in self._buf:
             dev = xn.device
@@ -230,6 +227,10 @@ class SequenceParallel:
         send, recv, vtg, oseg, back = bf["send"], bf["recv"], bf["vtg"], bf["oseg"], bf["back"]
         fwd = []
         for b in range(B):                                                  # (dst rank, q|k|v, L, Dn) per batch element
+            # projection + norm + RoPE per element: the exchange of element b runs under the projection of element b+1
+            ops.gemm(xn[b], lw["qkv_w"], lw["qkv_b"], out=qkv[b])
+            ops.rmsnorm_rope(qkv[b:b + 1, :, D:2 * D], lw["kn"], cos, sin, rows_per_batch=Ltok, eps=eps)
+            ops.rmsnorm_rope(qkv[b:b + 1, :, :D], lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
             send[b].copy_(qkv[b].view(Ltok, 3, N, Dn).permute(2, 1, 0, 3))
             fwd.append(self.backend.all_to_all(recv[b], send[b], async_op=True))   # recv[b][src] = its tokens, my heads
         bwd = []
@@ -248,9 +249,9 @@ class SequenceParallel:
         return att
 
     def self_attention_allgather(self, net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps):
-        """xn (B, Lloc, D) -> att (B, Lloc, D): K/V projection, K norm+RoPE, V^T staging, all-gather of both per CFG
-        batch element, Q projection + norm + RoPE under the first gather, then attention over all ranks' keys element
-        by element -- the gather of element b+1 runs (on RCCL's stream) under the attention of element b."""
+        """xn (B, Lloc, D) -> att (B, Lloc, D): per CFG batch element K/V projection, K norm+RoPE, V^T staging and the
+        all-gather of both (so the gather of element b runs under the projection of element b+1), Q projection + norm +
+        RoPE under the last gather, then attention over all ranks' keys element by element."""
         D, nh = net.hidden_size, net.num_attention_heads
         B = xn.shape[0]
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
@@ -264,11 +265,11 @@ class SequenceParallel:
                 vtg=torch.empty(B, self.size, 1, nh, 128, Lp, device=dev, dtype=torch.bfloat16))}
         bufs = self._buf[key]
         kloc, kg, vtg = bufs["kloc"], bufs["kg"], bufs["vtg"]
-        ops.gemm(xn, lw["qkv_w"][D:], lw["qkv_b"][D:], out=qkv[..., D:])           # K and V columns
-        ops.rmsnorm_rope(k, lw["kn"], cos, sin, out=kloc, rows_per_batch=Ltok, eps=eps)
-        ops.transpose_v(v, nh, out=vt_loc)
         hs = []
-        for b in range(B):
+        for b in range(B):      # K / V projection per element: the gather of element b runs under the projection of element b+1
+            ops.gemm(xn[b], lw["qkv_w"][D:], lw["qkv_b"][D:], out=qkv[b, :, D:])    # K and V columns
+            ops.rmsnorm_rope(k[b:b + 1], lw["kn"], cos, sin, out=kloc[b:b + 1], rows_per_batch=Ltok, eps=eps)
+            ops.transpose_v(v[b:b + 1], nh, out=vt_loc[b:b + 1])
             hs.append((self.backend.all_gather_into(kg[b], kloc[b:b + 1]), self.backend.all_gather_into(vtg[b], vt_loc[b:b + 1])))
         ops.gemm(xn, lw["qkv_w"][:D], lw["qkv_b"][:D], out=q)                       # overlaps the exchange
         ops.rmsnorm_rope(q, lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
