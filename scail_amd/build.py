@@ -11,8 +11,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 SOURCES = ["errors.hip", "rowops.hip", "gemm.hip", "attn.hip", "conv.hip", "dit_step.hip", "vae_exec.hip"]
 ARCH = "gfx950"
-# per-file extra flags (e.g. {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]} keeps MFMA results of the 256-thread
-# attention variants in arch VGPRs; measured, not needed by any default kernel)
+# per-file extra flags hook (e.g. {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]} keeps MFMA results of 256-thread
+# kernels in arch VGPRs: used while measuring the removed 4-wave attention variants; no shipped kernel needs one)
 EXTRA_FLAGS = {}
 # SCAIL_ABLATIONS=1: also compile the timing-ablation kernel variants (wrong results on purpose) that tools/microbench.py
 # selects through scail_tune_set; the shipped library is built without them and rejects their codes.

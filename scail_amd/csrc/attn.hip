@@ -584,363 +584,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
 // bits 4/5 are ablations (wrong results): no softmax -14 % time, no staging/barrier -15 %, neither -35 %.
 
 // ================================================================================================
-// 4 waves x 64 query rows ("w4").  The chip is power-limited under this kernel (profiles/r01_power.md), and
-// doubling the K / V^T fragment reads of the 8-wave kernel costs +18 % time: LDS traffic per FLOP is what to cut.
-// Here a wave owns TWO 32-row query blocks, so every K / V^T fragment read from LDS feeds two MFMAs, and Q (64 rows
-// x 128 = 64 VGPRs) stays in registers: 128 KB of LDS reads per 64-key tile and CU instead of 320 KB.  One wave
-// per SIMD with the 512-register budget (O accumulators 128 -> AGPRs, Q 64, two score buffers 2 x 32, P 16).
-// The software pipeline runs on HALF tiles (32 keys; a full second 64-key score tile does not fit): unit
-// u = (tile, half):  QK^T(u+1) MFMAs || exp / sum / pack of unit u;  P(u).V(u) MFMAs || row max of unit u+1.
-// LDS staging, slots and the barrier stay per 64-key tile.
+// Removed after measurement (kept in the history and in DESIGN.md section 4.2): a half-tile (32-key) pipeline with Q in
+// registers -- 8 waves x 32 rows (-5 %) and 4 waves x 64 rows, one wave per SIMD with 512 registers, register / LDS-DMA
+// staging, P.V as inline asm with AGPR accumulators (610-850 TFLOP/s against 1120 here: with one wave per SIMD every VALU
+// dependency of the softmax is exposed).
 // ================================================================================================
-// scores of half F_ (keys 32 F_ .. +31) of the tile in K slot slot_, both query blocks
-#define W4_K_ISSUE(slot_, F_)                                                                     \
-    {                                                                                             \
-        const u16* ks_ = Ks + ((slot_) * KVBLK + 32 * (F_) + ql) * KLD;                           \
-        _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks)                                    \
-            kfr[ks] = *reinterpret_cast<const bf16x8*>(ks_ + koff[ks]);                           \
-    }
-#define W4_QK_MFMA(S_)                                                                            \
-    {                                                                                             \
-        _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                        \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) S_[qb][e] = 0.f;                       \
-        _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks) {                                  \
-            _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                    \
-                S_[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[qb][ks], S_[qb], 0, 0, 0); \
-        }                                                                                         \
-    }
-#define W4_QK(S_, slot_, F_) W4_K_ISSUE(slot_, F_) W4_QK_MFMA(S_)
-// O += V^T[:, keys of half F_] . P^T
-#define W4_V_ISSUE(slot_, F_)                                                                     \
-    {                                                                                             \
-        const u16* vs_ = Vs + ((slot_) * HD + ql) * VLD;                                          \
-        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                          \
-            _Pragma("unroll") for (int d = 0; d < HD / 32; ++d)                                   \
-                vfr[k2][d] = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * VLD + voff[2 * (F_) + k2]); \
-    }
-// AO (4-wave kernel): the P.V MFMAs are written as inline asm with the accumulators constrained to AGPRs, the QK^T MFMAs
-// stay builtins compiled in VGPR form (-mllvm -amdgpu-mfma-vgpr-form, scail_amd/build.py): O (128 registers, touched only
-// by these MFMAs and the rare rescale) lives in AGPRs, the scores the softmax VALU works on in arch VGPRs.  hipcc alone
-// puts either everything (default for > 256-register kernels: every softmax operand then goes through v_accvgpr_read,
-// which interlocks with the matrix pipe) or nothing into AGPRs.  Hazards: back-to-back accumulation into the same
-// vDst needs no software wait; the epilogue's reads of O are preceded by explicit s_nops (W4_AO_DRAIN).
-#define W4_PV_MFMA()                                                                              \
-    {                                                                                             \
-        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                                        \
-            _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) {                                 \
-                _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) {                              \
-                    if (AO) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"                \
-                                         : "+a"(o[qb][d]) : "v"(vfr[k2][d]), "v"(pf[qb][k2]));    \
-                    else o[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[k2][d], pf[qb][k2], o[qb][d], 0, 0, 0); \
-                }                                                                                 \
-            }                                                                                     \
-        }                                                                                         \
-    }
-#define W4_AO_DRAIN asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
-#define W4_PV(slot_, F_) W4_V_ISSUE(slot_, F_) W4_PV_MFMA()
-// 1024 K chunks + 1024 V^T chunks of 16 B per tile, 4 + 4 per thread
-#define W4_LOAD_K(tt_)                                                                                    \
-    {                                                                                                     \
-        const int seg_ = (tt_) / tps, key0_ = ((tt_) - seg_ * tps) * KVBLK;                               \
-        const u16* kp_ = kbase + (int64_t)seg_ * p.k_ss;                                                  \
-        kr0 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow, p.Lk - 1) * p.k_rs);       \
-        kr1 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + KR, p.Lk - 1) * p.k_rs);  \
-        if (NQB == 2) {                                                                                   \
-            kr2 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + 2 * KR, p.Lk - 1) * p.k_rs);  \
-            kr3 = *reinterpret_cast<const uint4*>(kp_ + (int64_t)min(key0_ + krow + 3 * KR, p.Lk - 1) * p.k_rs);  \
-        }                                                                                                 \
-    }
-#define W4_LOAD_V(tt_)                                                                                    \
-    {                                                                                                     \
-        const int seg_ = (tt_) / tps, key0_ = ((tt_) - seg_ * tps) * KVBLK;                               \
-        const u16* vp_ = vbase + (int64_t)seg_ * p.vt_ss + key0_;                                         \
-        vr0 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)vrow * p.Lkp);                               \
-        vr1 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + VR) * p.Lkp);                        \
-        if (NQB == 2) {                                                                                   \
-            vr2 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + 2 * VR) * p.Lkp);                \
-            vr3 = *reinterpret_cast<const uint4*>(vp_ + (int64_t)(vrow + 3 * VR) * p.Lkp);                \
-        }                                                                                                 \
-    }
-#define W4_STORE_K(slot_)                                                                          \
-    {                                                                                              \
-        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow) * KLD + kcc * 8) = kr0;           \
-        *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + KR) * KLD + kcc * 8) = kr1;      \
-        if (NQB == 2) {                                                                            \
-            *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + 2 * KR) * KLD + kcc * 8) = kr2;  \
-            *reinterpret_cast<uint4*>(Ks + ((slot_) * KVBLK + krow + 3 * KR) * KLD + kcc * 8) = kr3;  \
-        }                                                                                          \
-    }
-#define W4_STORE_V(slot_)                                                                          \
-    {                                                                                              \
-        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow) * VLD + vcc * 8) = vr0;              \
-        *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + VR) * VLD + vcc * 8) = vr1;         \
-        if (NQB == 2) {                                                                            \
-            *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + 2 * VR) * VLD + vcc * 8) = vr2; \
-            *reinterpret_cast<uint4*>(Vs + ((slot_) * HD + vrow + 3 * VR) * VLD + vcc * 8) = vr3; \
-        }                                                                                          \
-    }
-#define W4_ROWMAX(S_, OUT_)                                                                       \
-    _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) {                                            \
-        float mx_ = S_[qb][0];                                                                    \
-        _Pragma("unroll") for (int r = 1; r < 16; ++r) mx_ = fmaxf(mx_, S_[qb][r]);               \
-        const unsigned mi_ = __float_as_uint(mx_);                                                \
-        const auto sw_ = __builtin_amdgcn_permlane32_swap(mi_, mi_, false, false);                \
-        OUT_[qb] = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                       \
-    }
-#define W4_SOFTMAX(S_, MX_)                                                                       \
-    bool moved_ = false;                                                                          \
-    float alpha_[NQB];                                                                              \
-    _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) {                                            \
-        const float m_new_ = fmaxf(m_run[qb], MX_[qb]);                                           \
-        alpha_[qb] = __builtin_amdgcn_exp2f((m_run[qb] - m_new_) * sl2);                          \
-        const float msc_ = m_new_ * sl2;                                                          \
-        float rs_ = 0.f;                                                                          \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
-            const float pv_ = __builtin_amdgcn_exp2f(S_[qb][r] * sl2 - msc_);                     \
-            S_[qb][r] = pv_;                                                                      \
-            rs_ += pv_;                                                                           \
-        }                                                                                         \
-        l_run[qb] = l_run[qb] * alpha_[qb] + rs_;                                                 \
-        moved_ = moved_ || !__all(m_new_ == m_run[qb]);                                           \
-        m_run[qb] = m_new_;                                                                       \
-        _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                                        \
-            uint4 u_;                                                                             \
-            const int r0 = k2 * 8;                                                                \
-            u_.x = pack_bf16x2(S_[qb][r0 + 0], S_[qb][r0 + 1]);                                   \
-            u_.y = pack_bf16x2(S_[qb][r0 + 2], S_[qb][r0 + 3]);                                   \
-            u_.z = pack_bf16x2(S_[qb][r0 + 4], S_[qb][r0 + 5]);                                   \
-            u_.w = pack_bf16x2(S_[qb][r0 + 6], S_[qb][r0 + 7]);                                   \
-            pf[qb][k2] = __builtin_bit_cast(bf16x8, u_);                                          \
-        }                                                                                         \
-    }
-// keys of half F_ of tile T_ past the segment's ragged end -> -inf
-#define W4_MASK(S_, T_, F_)                                                                       \
-    if (tail < KVBLK && ((T_) % tps) == tps - 1) {                                                \
-        _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                          \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                      \
-                const int key = 32 * (F_) + (r & 3) + 8 * (r >> 2) + 4 * g;                       \
-                if (key >= tail) S_[qb][r] = -INFINITY;                                           \
-            }                                                                                     \
-    }
-// Issue order of a 16-MFMA block (8 fragment reads, each feeding the two query blocks): three reads up front, then
-// per fragment  MFMA | read of the fragment three pairs ahead | n VALU | MFMA | n VALU  -- with one wave per SIMD
-// nothing else covers the LDS latency, so the reads have to run ~6 MFMAs (190 cycles) ahead of their use.
-#define W4_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
-#define W4_PAIR(N_) W4_SGB(0x008, 1) W4_SGB(0x100, 1) W4_SGB(0x402, N_) W4_SGB(0x008, 1) W4_SGB(0x402, N_)
-#define W4_PIPE(N_) W4_SGB(0x100, 3) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_) W4_PAIR(N_)
-// O *= alpha (rare: only when a row max moved).  In the 4-wave kernel O lives in AGPRs; written as one
-// read-multiply-write per register so that this cold block needs ONE temporary instead of pulling all 128 accumulators
-// into VGPRs at once (which made hipcc spill loop invariants of the hot path to scratch).
-#define W4_RESCALE(acc_, a_)                                                                      \
-    if (AO) {                                                                               \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                          \
-            float t_, c_ = acc_[e];                                                               \
-            asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_mul_f32 %0, %0, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %1, %0\n\ts_nop 1" \
-                         : "=&v"(t_), "+a"(c_) : "v"(a_));                                          \
-            acc_[e] = c_;                                                                         \
-        }                                                                                         \
-    } else {                                                                                      \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) acc_[e] *= a_;                             \
-    }
-// one unit: SC_ = masked scores of (T_, F_) with row max MXC_; SN_/MXN_ = the NEXT unit (NT_, NF_) in K slot NSLOT_
-#define W4_UNIT(SC_, SN_, MXC_, MXN_, T_, F_, NT_, NF_, NSLOT_, HAS_NEXT_, N2SLOT_, N2F_, HAS_N2_)   \
-    {                                                                                              \
-        if (XPF) {   /* operands of a block are requested one block earlier (see W4 header comment) */ \
-            W4_V_ISSUE((T_) & 1, F_)                                                               \
-            if (HAS_NEXT_) W4_QK_MFMA(SN_)                                                         \
-        } else {                                                                                   \
-            if (HAS_NEXT_) W4_QK(SN_, NSLOT_, NF_)                                                 \
-        }                                                                                          \
-        W4_SOFTMAX(SC_, MXC_)                                                                      \
-        if (HAS_NEXT_) { W4_PIPE(GA) }                                                             \
-        _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb) { SWP_PIN(pf[qb][0]) SWP_PIN(pf[qb][1]) } \
-        if (XPF) {                                                                                 \
-            _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2)                                       \
-                _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) SWP_PIN(vfr[k2][d])            \
-        }                                                                                          \
-        if (moved_) {                                                                              \
-            _Pragma("unroll") for (int qb = 0; qb < NQB; ++qb)                                       \
-                _Pragma("unroll") for (int d = 0; d < HD / 32; ++d) W4_RESCALE(o[qb][d], alpha_[qb]) \
-        }                                                                                          \
-        if (HAS_NEXT_) W4_MASK(SN_, NT_, NF_)                                                      \
-        if (XPF) {                                                                                 \
-            if (HAS_N2_) W4_K_ISSUE(N2SLOT_, N2F_)                                                 \
-            W4_PV_MFMA()                                                                           \
-        } else {                                                                                   \
-            W4_PV((T_) & 1, F_)                                                                    \
-        }                                                                                          \
-        if (HAS_NEXT_) {                                                                           \
-            W4_ROWMAX(SN_, MXN_)                                                                   \
-            W4_PIPE(GB)                                                                            \
-        }                                                                                          \
-        if (XPF && (HAS_N2_)) {                                                                    \
-            _Pragma("unroll") for (int ks = 0; ks < HD / 16; ++ks) SWP_PIN(kfr[ks])                \
-        }                                                                                          \
-    }
-// LDS-DMA staging (DMA = true): K piece j = rows 4j..4j+3 (lane -> row 4j + (l >> 4), chunk l & 15), V^T piece j = rows
-// 8j..8j+7 (lane -> row 8j + (l >> 3), chunk l & 7), 16 pieces each per tile; unpadded rows, XOR swizzle on the source
-// address and on the fragment reads.  K ring of THREE slots (K(T+2) lands while K(T) and K(T+1) are still read).
-#define W4_DMA(tt_, kslot_, vslot_, DO_K_, DO_V_)                                                           \
-    {                                                                                                       \
-        const int seg_ = (tt_) / tps, key0_ = ((tt_) - seg_ * tps) * KVBLK;                                 \
-        const u16* kp_ = p.k + b * p.k_bs + (int64_t)h * HD + (int64_t)seg_ * p.k_ss;                       \
-        const u16* vp_ = p.vt + b * p.vt_bs + (int64_t)h * HD * p.Lkp + (int64_t)seg_ * p.vt_ss + key0_;    \
-        _Pragma("unroll") for (int i_ = 0; i_ < PPW; ++i_) {                                                \
-            const int j_ = wave * PPW + i_;                                                                 \
-            if (DO_K_) {                                                                                    \
-                const int kr_ = 4 * j_ + dk_row;                                                            \
-                const u16* src_ = kp_ + (int64_t)min(key0_ + kr_, p.Lk - 1) * p.k_rs + ((dk_c ^ (kr_ & 15)) << 3);  \
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,       \
-                    (__attribute__((address_space(3))) void*)(Ks + ((kslot_) * KVBLK + 4 * j_) * KLD), 16, 0, 0);    \
-            }                                                                                               \
-            if (DO_V_) {                                                                                    \
-                const int vr_ = 8 * j_ + dv_row;                                                            \
-                const u16* src_ = vp_ + (int64_t)vr_ * p.Lkp + ((dv_c ^ ((vr_ >> 1) & 7)) << 3);            \
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,       \
-                    (__attribute__((address_space(3))) void*)(Vs + ((vslot_) * HD + 8 * j_) * VLD), 16, 0, 0);       \
-            }                                                                                               \
-        }                                                                                                   \
-    }
-// one 64-key tile = two units + the staging of K(T+2) / V(T+1) and the barrier
-#define W4_TILE(T_, HAS_NEXT_)                                                                     \
-    {                                                                                              \
-        const int cur_ = (T_) & 1;                                                                 \
-        const int kc_ = DMA ? (T_) % 3 : cur_, kn_ = DMA ? ((T_) + 1) % 3 : (cur_ ^ 1);            \
-        if (DMA) {                                                                                 \
-            W4_DMA(min((T_) + 2, ntiles - 1), ((T_) + 2) % 3, 0, true, false)                      \
-            W4_DMA(min((T_) + 1, ntiles - 1), 0, cur_ ^ 1, false, true)                            \
-        } else {                                                                                   \
-            W4_LOAD_K(min((T_) + 2, ntiles - 1))                                                   \
-            W4_LOAD_V(min((T_) + 1, ntiles - 1))                                                   \
-        }                                                                                          \
-        W4_UNIT(sa, sb, mxa, mxb, T_, 0, T_, 1, kc_, true, kn_, 0, HAS_NEXT_)                      \
-        W4_UNIT(sb, sa, mxb, mxa, T_, 1, (T_) + 1, 0, kn_, HAS_NEXT_, kn_, 1, HAS_NEXT_)           \
-        if (DMA) {                                                                                 \
-            __builtin_amdgcn_s_waitcnt(0x0F70);                                                    \
-        } else {                                                                                   \
-            W4_STORE_K(cur_)                                                                       \
-            W4_STORE_V(cur_ ^ 1)                                                                   \
-        }                                                                                          \
-        __syncthreads();                                                                           \
-    }
-
-template <int NQB, int GA, int GB, bool DMA = false, bool XPF = false, bool AO = false>   // NQB query blocks of 32 rows per wave: 2 -> 4 waves (one per SIMD), 1 -> 8 waves;
-                                                                         // XPF: the K / V^T fragments of a block are read from LDS during the PREVIOUS block
-__global__ __launch_bounds__(512 / NQB) void flash_attn_w4_kernel(AttnParams p) {
-    constexpr int NTH = 512 / NQB, KR = NTH / 16, VR = NTH / 8;   // threads, tile rows per staging pass
-    constexpr int KLD = DMA ? HD : K_LD, VLD = DMA ? KVBLK : V_LD, NKS = DMA ? 3 : 2, PPW = 2 * NQB;
-    extern __shared__ __attribute__((aligned(16))) u16 smem[];
-    u16* Ks = smem;                              // [2][KVBLK][K_LD]
-    u16* Vs = smem + NKS * KVBLK * KLD;          // [2][HD][VLD]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ql = lane & 31, g = lane >> 5;
-    const int h = blockIdx.y;
-    const int64_t b = blockIdx.z;
-    const int q0 = blockIdx.x * QBLK + wave * 32 * NQB;
-    const int dk_row = lane >> 4, dk_c = lane & 15, dv_row = lane >> 3, dv_c = lane & 7;
-    int koff[HD / 16], voff[4];
-#pragma unroll
-    for (int ks = 0; ks < HD / 16; ++ks) koff[ks] = DMA ? (((2 * ks + g) ^ (ql & 15)) << 3) : (ks * 16 + g * 8);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) voff[ks] = DMA ? (((2 * ks + g) ^ ((ql >> 1) & 7)) << 3) : (ks * 16 + g * 8);
-    const unsigned long long clk0 = p.probe ? __builtin_amdgcn_s_memtime() : 0ull;
-
-    bf16x8 qf[NQB][HD / 16];
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        const int qrow = min(q0 + 32 * qb + ql, p.Lq - 1);
-        const u16* qp = p.q + b * p.q_bs + (int64_t)qrow * p.q_rs + (int64_t)h * HD + g * 8;
-#pragma unroll
-        for (int ks = 0; ks < HD / 16; ++ks) qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-    }
-    const int krow = tid >> 4, kcc = tid & 15;     // K chunk: row = (tid >> 4) + KR i
-    const int vrow = tid >> 3, vcc = tid & 7;      // V chunk: row = (tid >> 3) + VR i
-    const u16* kbase = p.k + b * p.k_bs + (int64_t)h * HD + kcc * 8;
-    const u16* vbase = p.vt + b * p.vt_bs + (int64_t)h * HD * p.Lkp + vcc * 8;
-    const int tps = p.Lkp / KVBLK;
-    const int ntiles = tps * p.n_seg;
-    const int tail = p.Lk - (tps - 1) * KVBLK;
-    const float sl2 = p.sl2;
-    uint4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
-
-    f32x16 o[NQB][HD / 32];
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb)
-#pragma unroll
-        for (int d = 0; d < HD / 32; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[qb][d][e] = 0.f;
-    float m_run[NQB], l_run[NQB];
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
-    f32x16 sa[NQB], sb[NQB];
-    bf16x8 pf[NQB][2];
-    bf16x8 kfr[HD / 16], vfr[2][HD / 32];     // K fragments of one 32-key half, V^T fragments of one half
-
-    // prologue: K(0) -> slot 0, K(1) -> slot 1, V(0) -> slot 0; scores of unit (0, 0)
-    if (DMA) {
-        W4_DMA(0, 0, 0, true, true)
-        W4_DMA(min(1, ntiles - 1), 1, 0, true, false)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-    } else {
-        W4_LOAD_K(0)
-        W4_LOAD_V(0)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        W4_STORE_K(0)
-        W4_STORE_V(0)
-        W4_LOAD_K(min(1, ntiles - 1))
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        W4_STORE_K(1)
-    }
-    __syncthreads();
-    float mxa[NQB], mxb[NQB];
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) mxb[qb] = 0.f;
-    W4_QK(sa, 0, 0)
-    W4_MASK(sa, 0, 0)
-    W4_ROWMAX(sa, mxa)
-    if (XPF) W4_K_ISSUE(0, 1)      // fragments of unit (0, 1), consumed by the first block of the loop
-
-    int t = 0;
-    for (; t + 1 < ntiles; ++t) W4_TILE(t, true)
-    W4_TILE(t, false)
-    if (AO) { W4_AO_DRAIN }
-
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-        const float inv = 1.0f / l_tot;
-        const int qrow = q0 + 32 * qb + ql;
-        if (qrow < p.Lq) {
-            u16* op = p.o + b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * HD + 4 * g;
-#pragma unroll
-            for (int d = 0; d < HD / 32; ++d) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = o[qb][d][4 * rr + e] * inv;
-                    uint2* dst = reinterpret_cast<uint2*>(op + d * 32 + rr * 8);
-                    if (p.accumulate) {
-                        const uint2 old = *dst;
-                        v[0] += bf_lo(old.x); v[1] += bf_hi(old.x);
-                        v[2] += bf_lo(old.y); v[3] += bf_hi(old.y);
-                    }
-                    uint2 w;
-                    w.x = pack_bf16x2(v[0], v[1]);
-                    w.y = pack_bf16x2(v[2], v[3]);
-                    *dst = w;
-                }
-            }
-        }
-    }
-    if (p.probe && tid == 0) {
-        atomicAdd(&g_attn_clk[0], (unsigned long long)__builtin_amdgcn_s_memtime() - clk0);
-        atomicAdd(&g_attn_clk[1], 1ull);
-    }
-}
 
 int scail_gemm_tune(int v);
 int scail_gemm_group_m(int v);
@@ -951,12 +599,16 @@ extern "C" int scail_tune_set(const char* knob, int value) {
 #ifndef SCAIL_ABLATIONS
         // timing ablations (wrong results on purpose; tools/microbench.py): lock-step bits 4 / 5, software-pipelined sub-code 5
         const int low = value & 0xFFFFF;
-        if (low == 18 || low == 34 || low == 50 || ((value & 8) && !(value & (512 | 1024)) && ((value >> 12) & 15) == 5)) {
+        if (low == 18 || low == 34 || low == 50 || ((value & 8) && ((value >> 12) & 15) == 5)) {
             scail_set_error("scail_tune_set: attn_variant " + std::to_string(value) +
                             " is a timing ablation (wrong results); rebuild with SCAIL_ABLATIONS=1 to enable it");
             return 1;
         }
 #endif
+        if (value & (512 | 1024 | 2048)) {
+            scail_set_error("scail_tune_set: attn_variant " + std::to_string(value) + " selects a removed kernel (half-tile pipelines)");
+            return 1;
+        }
         g_attn_variant = value;
         return 0;
     }
@@ -1013,41 +665,6 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     p.accumulate = accumulate;
     p.probe = (g_attn_variant >> 20) & 1;
     dim3 grid((unsigned)((Lq + QBLK - 1) / QBLK), (unsigned)heads, (unsigned)n_batch);
-    if (g_attn_variant & (512 | 1024)) {   // half-tile pipeline, Q in registers: 512 = 4 waves x 64 rows, 1024 = 8 waves x 32 rows
-        const int sub = (g_attn_variant >> 12) & 15;
-        static bool w4_attr = false;
-        if (!w4_attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<1, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<1, 5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<1, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<1, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-            w4_attr = true;
-        }
-        constexpr int w4dma_lds = (3 * KVBLK * HD + 2 * HD * KVBLK) * 2;
-        static bool w4d_attr = false;
-        if (!w4d_attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 6, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4dma_lds);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_w4_kernel<2, 8, 2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
-            w4d_attr = true;
-        }
-        if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 4) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, true, true, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
-        else if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 5) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, true, false, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
-        else if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 2) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, true, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
-        else if ((g_attn_variant & 512) && sub == 3) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, false, true>), grid, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
-        else if ((g_attn_variant & 512) && (g_attn_variant & 2048) && sub == 1) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 6, 2, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
-        else if ((g_attn_variant & 512) && (g_attn_variant & 2048)) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2, true>), grid, dim3(256), w4dma_lds, (hipStream_t)stream, p);
-        else if (g_attn_variant & 512) hipLaunchKernelGGL((flash_attn_w4_kernel<2, 8, 2>), grid, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
-        else if (sub == 1) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 5, 2>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
-        else if (sub == 2) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 3, 2>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
-        else if (sub == 3) hipLaunchKernelGGL((flash_attn_w4_kernel<1, 4, 3>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((flash_attn_w4_kernel<1, 4, 2>), grid, dim3(512), ATT_LDS_BYTES, (hipStream_t)stream, p);
-        return scail_check_launch("flash_attn");
-    }
     if (g_attn_variant & 8) {
         const int sub = (g_attn_variant >> 12) & 15;     // A/B of the interleave density
         static bool swp_attr = false;

@@ -160,6 +160,7 @@ def test_more_argument_validation_without_gpu(libpath):
         ("timing ablation", "scail_tune_set", (b"attn_variant", 18)),
         ("timing ablation", "scail_tune_set", (b"attn_variant", 8 | (5 << 12))),
         ("not a known tile code", "scail_tune_set", (b"gemm_tile", 999)),
+        ("removed kernel", "scail_tune_set", (b"attn_variant", 512)),
     ]
     for needle, fn, args in cases:
         with pytest.raises(L.ScailHipError, match=needle):
