@@ -12,8 +12,8 @@
 // stores and float4 bias / gate loads in the epilogue.
 //
 // Block -> tile map: XCD-aware remap (block b runs on XCD b % 8; give each XCD a contiguous range
-// of tiles so neighbours share operand panels in that XCD's L2), then grouped ordering (8 m-tiles
-// per group, m fastest) so the 64 co-resident tiles of an XCD touch 8 + 8 operand panels.
+// of tiles so neighbours share operand panels in that XCD's L2), then grouped ordering (g_group_m = 4 m-tiles
+// per group, m fastest) so the co-resident tiles of an XCD share a few operand panels.
 #include "common.h"
 
 #define BK 64
@@ -245,224 +245,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 256 x 256 tile, 8 waves, LDS-DMA into a 4-deep ring of HALF k-tiles (32 k each, 16 KB per operand),
-// prefetch distance 3: the barrier that ends half-tile h only needs half-tile h+1 (issued two barriers
-// earlier) -> counted s_waitcnt vmcnt(8) leaves the two youngest half-tiles in flight across it, so the
-// matrix pipes never idle behind a fresh load.  Raw s_barrier (a __syncthreads() would drain vmcnt to 0).
-// LDS image per half-tile: [256 rows][32 elements] (64-B rows, 4 x 16-B chunks), chunk index XOR-ed with
-// (row >> 2) & 3 on the DMA source address and on the fragment reads -> conflict-free ds_read_b128.
+// Removed after measurement (in the history; numbers in DESIGN.md section 4.1): a 4-deep ring of HALF k-tiles with
+// counted vmcnt (1025 TFLOP/s) and a ping-pong of the two wave rows on half k-tiles with raised MFMA priority (1000),
+// both below the lock-step LDS-DMA kernel (1090) and the quadrant-phase kernel below (1250-1340).
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_ring_kernel(GemmParams p) {
-    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, HK = 32, NS = 4;
-    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
-    extern __shared__ __attribute__((aligned(16))) u16 smem[];
-    u16* Xs = smem;                     // [NS][BM][HK]
-    u16* Ws = smem + NS * BM * HK;      // [NS][BN][HK]
-
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nb = tiles_m * tiles_n;
-    int wg;
-    {
-        const int id = blockIdx.x;
-        const int q = nb >> 3, r = nb & 7, xcd = id & 7, loc = id >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int in_group = GROUP_M * tiles_n;
-    const int gid = wg / in_group;
-    const int first_m = gid * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int pid_m = first_m + (wg % in_group) % gsz;
-    const int pid_n = (wg % in_group) / gsz;
-    const int m0 = pid_m * BM, n0 = pid_n * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, g = lane >> 5;
-
-    // DMA pieces: 1 KiB = 16 rows x 64 B; lane -> row 16 j + (l >> 2), chunk l & 3; 16 pieces per operand
-    // per half-tile, 2 per wave.  Row pointers (clamped) are fixed for the whole k loop.
-    const int d_row = lane >> 2, d_c = lane & 3;
-    const int ra0 = 16 * (wave * 2) + d_row, ra1 = ra0 + 16;
-    const int sw0 = ((d_c ^ ((ra0 >> 2) & 3)) << 3), sw1 = ((d_c ^ ((ra1 >> 2) & 3)) << 3);
-    const u16* xa0 = p.x + (int64_t)min(m0 + ra0, p.M - 1) * p.lda + sw0;
-    const u16* xa1 = p.x + (int64_t)min(m0 + ra1, p.M - 1) * p.lda + sw1;
-    const u16* wb0 = p.w + (int64_t)min(n0 + ra0, p.N - 1) * p.K + sw0;
-    const u16* wb1 = p.w + (int64_t)min(n0 + ra1, p.N - 1) * p.K + sw1;
-#define RING_ISSUE(h_)                                                                                         \
-    {                                                                                                          \
-        const int k0_ = (h_) * HK, s_ = (h_) & (NS - 1);                                                       \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xa0 + k0_),           \
-            (__attribute__((address_space(3))) void*)(Xs + (s_ * BM + 16 * (wave * 2)) * HK), 16, 0, 0);       \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xa1 + k0_),           \
-            (__attribute__((address_space(3))) void*)(Xs + (s_ * BM + 16 * (wave * 2 + 1)) * HK), 16, 0, 0);   \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb0 + k0_),           \
-            (__attribute__((address_space(3))) void*)(Ws + (s_ * BN + 16 * (wave * 2)) * HK), 16, 0, 0);       \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb1 + k0_),           \
-            (__attribute__((address_space(3))) void*)(Ws + (s_ * BN + 16 * (wave * 2 + 1)) * HK), 16, 0, 0);   \
-    }
-    const int fo0 = (((0 + g) ^ ((l31 >> 2) & 3)) << 3), fo1 = (((2 + g) ^ ((l31 >> 2) & 3)) << 3);
-
-    f32x16 acc[NI][MI];
-#pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-    const int nh = p.K / HK;
-    RING_ISSUE(0)
-    if (nh > 1) RING_ISSUE(1)
-    if (nh > 2) RING_ISSUE(2)
-    // half-tile 0 landed: at most min(nh,3)-1 younger groups of 4 may stay in flight
-    if (nh > 2) __builtin_amdgcn_s_waitcnt(0x0F78);        // vmcnt(8)
-    else if (nh > 1) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
-    else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    for (int h = 0; h < nh; ++h) {
-        if (h + 3 < nh) RING_ISSUE(h + 3)
-        const int s_ = h & (NS - 1);
-        const u16* xs = Xs + (s_ * BM + wm * WTM + l31) * HK;
-        const u16* ws = Ws + (s_ * BN + wn * WTN + l31) * HK;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int fo = ks ? fo1 : fo0;
-            bf16x8 wf[NI], xf[MI];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * HK + fo);
-#pragma unroll
-            for (int i = 0; i < MI; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * HK + fo);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-        }
-        // half-tile h+1 must have landed (this wave's pieces; the barrier extends it to all waves) and this
-        // wave's LDS reads of slot s_ must be complete before slot s_ is refilled after the barrier
-        if (h + 3 < nh) __builtin_amdgcn_s_waitcnt(0x0078);        // vmcnt(8)  lgkmcnt(0)
-        else if (h + 2 < nh) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4)  lgkmcnt(0)
-        else __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0)  lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-    }
-    gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ping-pong variant of the ring kernel.  The two wave rows (waves 0-3 / 4-7; wave w and w+4 share a SIMD)
-// run one barrier interval apart: in every interval one wave of each SIMD issues its 16-MFMA cluster for
-// half k-tile h at raised priority while its partner issues the LDS-DMA for half-tile h+3 and reads the 12
-// fragments of its next half-tile -- the matrix pipe never waits for LDS and the reads never wait for the
-// pipe.  Two raw barriers per half-tile; counted vmcnt(8) keeps two half-tiles in flight across them.
-//   interval 2h   : g0 reads h      | g1 MFMA h-1
-//   interval 2h+1 : g0 MFMA h       | g1 reads h
-// Slot (h+3)&3 was last read (by g1) in interval 2h-1, so it may be refilled from interval 2h on; every
-// wave has its share of half-tile h+1 landed before each barrier it signals, so half-tile h is complete
-// for both groups when they read it.
-// ------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(GemmParams p) {
-    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, HK = 32, NS = 4;
-    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 32, NI = WTN / 32;
-    extern __shared__ __attribute__((aligned(16))) u16 smem[];
-    u16* Xs = smem;
-    u16* Ws = smem + NS * BM * HK;
-
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int nb = tiles_m * tiles_n;
-    int wg;
-    {
-        const int id = blockIdx.x;
-        const int q = nb >> 3, r = nb & 7, xcd = id & 7, loc = id >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int in_group = GROUP_M * tiles_n;
-    const int gid = wg / in_group;
-    const int first_m = gid * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int pid_m = first_m + (wg % in_group) % gsz;
-    const int pid_n = (wg % in_group) / gsz;
-    const int m0 = pid_m * BM, n0 = pid_n * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int grp = wm;
-    const int l31 = lane & 31, g = lane >> 5;
-
-    const int d_row = lane >> 2, d_c = lane & 3;
-    const int ra0 = 16 * (wave * 2) + d_row, ra1 = ra0 + 16;
-    const int sw0 = ((d_c ^ ((ra0 >> 2) & 3)) << 3), sw1 = ((d_c ^ ((ra1 >> 2) & 3)) << 3);
-    const u16* xa0 = p.x + (int64_t)min(m0 + ra0, p.M - 1) * p.lda + sw0;
-    const u16* xa1 = p.x + (int64_t)min(m0 + ra1, p.M - 1) * p.lda + sw1;
-    const u16* wb0 = p.w + (int64_t)min(n0 + ra0, p.N - 1) * p.K + sw0;
-    const u16* wb1 = p.w + (int64_t)min(n0 + ra1, p.N - 1) * p.K + sw1;
-    const int fo0 = (((0 + g) ^ ((l31 >> 2) & 3)) << 3), fo1 = (((2 + g) ^ ((l31 >> 2) & 3)) << 3);
-
-    f32x16 acc[NI][MI];
-#pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-    const int nh = p.K / HK;
-    RING_ISSUE(0)
-    RING_ISSUE(min(1, nh - 1))      // clamped re-loads keep the in-flight count uniform (always 4 per issue)
-    RING_ISSUE(min(2, nh - 1))
-    __builtin_amdgcn_s_waitcnt(0x0F78);     // vmcnt(8): half-tile 0 landed
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    for (int h = 0; h < nh; ++h) {
-        // ---- read interval ----
-        {
-            const int hn = min(h + 3, nh - 1);    // past the end: harmless re-load of the last half-tile into a dead slot
-            const int k0_ = hn * HK, s2_ = (h + 3) & (NS - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xa0 + k0_),
-                (__attribute__((address_space(3))) void*)(Xs + (s2_ * BM + 16 * (wave * 2)) * HK), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xa1 + k0_),
-                (__attribute__((address_space(3))) void*)(Xs + (s2_ * BM + 16 * (wave * 2 + 1)) * HK), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb0 + k0_),
-                (__attribute__((address_space(3))) void*)(Ws + (s2_ * BN + 16 * (wave * 2)) * HK), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wb1 + k0_),
-                (__attribute__((address_space(3))) void*)(Ws + (s2_ * BN + 16 * (wave * 2 + 1)) * HK), 16, 0, 0);
-        }
-        const int s_ = h & (NS - 1);
-        const u16* xs = Xs + (s_ * BM + wm * WTM + l31) * HK;
-        const u16* ws = Ws + (s_ * BN + wn * WTN + l31) * HK;
-        bf16x8 wf[2][NI], xf[2][MI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) { wf[0][i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * HK + fo0); wf[1][i] = *reinterpret_cast<const bf16x8*>(ws + i * 32 * HK + fo1); }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) { xf[0][i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * HK + fo0); xf[1][i] = *reinterpret_cast<const bf16x8*>(xs + i * 32 * HK + fo1); }
-        // own share of half-tile h+1 landed (h+2, h+3 may fly); fragment reads complete before the slot can be refilled
-        __builtin_amdgcn_s_waitcnt(0x0078);     // vmcnt(8) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        // ---- MFMA interval ----
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_waitcnt(0x0F70);         // drain the clamped tail loads before the LDS goes away
-    gemm_epilogue<EPI, MI, NI, WTM, WTN>(acc, p, m0, n0, wm, wn, l31, g);
-}
 
 // q8 tile-group height (m-tiles sharing an n sweep per group): 4 measured best on the four per-token GEMM shapes
 // (tools/gemm_group_probe.py: 1: -5 %, 2: -1 %, 3-4: best, 8: -1..2 %, 16: -8 %, 32: -18 %)
 static int g_group_m = 4;
 int scail_gemm_group_m(int v) { g_group_m = v > 0 ? v : 4; return 0; }
-static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 tile + LDS-DMA; 258: 256 tile + DMA ring
+static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 tile + LDS-DMA; 260: + DMA spread over the k-steps; 261: q8; 262: q8, MFMA-wave priority; 266: 4 waves
 // Codes >= 1000 select TIMING ABLATIONS of the big-tile kernels (most of them compute wrong results on purpose: loads or
 // fragment reads removed, all-L2-hit addressing, ...).  They exist for tools/microbench.py and are compiled in only when
 // the library is built with -DSCAIL_ABLATIONS (SCAIL_ABLATIONS=1 python -m scail_amd.build --force); the shipped library
@@ -470,7 +262,7 @@ static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 t
 int scail_gemm_tune(int v) {
     bool ok = false;
     switch (v) {
-        case 0: case 128: case 256: case 257: case 258: case 259: case 260: case 261: case 262: case 266: ok = true; break;
+        case 0: case 128: case 256: case 257: case 260: case 261: case 262: case 266: ok = true; break;
         default: break;
     }
 #ifdef SCAIL_ABLATIONS
@@ -710,42 +502,6 @@ static int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
     return scail_check_launch("gemm_bf16");
 }
 
-template <int EPI>
-static int launch_gemm_ring(const GemmParams& p, hipStream_t stream) {
-    constexpr int lds = 4 * (256 + 256) * 32 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            scail_set_error(std::string("gemm: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
-            return 2;
-        }
-        attr_set = true;
-    }
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<EPI>), dim3((unsigned)tiles), dim3(512), lds, stream, p);
-    return scail_check_launch("gemm_bf16");
-}
-
-template <int EPI>
-static int launch_gemm_pp(const GemmParams& p, hipStream_t stream) {
-    constexpr int lds = 4 * (256 + 256) * 32 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_pp_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) {
-            scail_set_error(std::string("gemm: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
-            return 2;
-        }
-        attr_set = true;
-    }
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-    hipLaunchKernelGGL((gemm_bf16_pp_kernel<EPI>), dim3((unsigned)tiles), dim3(512), lds, stream, p);
-    return scail_check_launch("gemm_bf16");
-}
-
 template <int EPI, int ABL = 0>
 static int launch_gemm_q8(const GemmParams& p, hipStream_t stream) {
     constexpr int lds = 2 * (256 + 256) * BK * 2;   // 128 KB
@@ -789,7 +545,6 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (EPI == 0 && g_gemm_tile == 1116) return launch_gemm_q8<0, 16>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1124) return launch_gemm_q8<0, 24>(p, stream);
 #endif
-    if (g_gemm_tile == 259) return launch_gemm_pp<EPI>(p, stream);
 #ifdef SCAIL_ABLATIONS
     if (EPI == 0 && g_gemm_tile == 1001) return launch_gemm_t<256, 256, 2, 4, 0, true, 1>(p, stream);   // ablations
     if (EPI == 0 && g_gemm_tile == 1002) return launch_gemm_t<256, 256, 2, 4, 0, true, 2>(p, stream);
@@ -803,7 +558,6 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     // measured at M = 97 664 (profiles/r01_pmc.md): 128 tile 820, 256 tile 1000, 256 + LDS-DMA 1090, 256 + DMA ring
     // of half k-tiles with counted vmcnt 1025, ping-pong 1000, quadrant-phase q8 1240-1290 TFLOP/s (default for the
     // big per-token GEMMs; the vendor library's assembly kernel reaches 1500 on the same shapes)
-    if (g_gemm_tile == 258) return launch_gemm_ring<EPI>(p, stream);
     if (g_gemm_tile == 256) return launch_gemm_t<256, 256, 2, 4, EPI, false>(p, stream);
     const bool big = g_gemm_tile == 0 && p.M >= 2048 && p.N >= 1024;
     // q8 addresses a tile through a 2 GB buffer descriptor with 32-bit lane offsets
