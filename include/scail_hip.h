@@ -182,7 +182,8 @@ int scail_conv3d_cl_norm(const scail_bf16* x, const scail_bf16* w, const float* 
 int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* gamma, int64_t nvox, int64_t C, int silu,
                    void* stream);
 
-/* In-place row softmax of scale * s (AttentionBlock, :252); n % 8 == 0, n <= 8192. */
+/* In-place row softmax of scale * s over the first n columns of each row (AttentionBlock, :252); 1 <= n <= 32768; rows are
+ * padded to a multiple of 8 columns in memory (ld % 8 == 0, ld >= ceil8(n)) and columns n .. ceil8(n) are written as zeros. */
 int scail_softmax_rows(scail_bf16* s, int64_t ld, int64_t rows, int64_t n, float scale, void* stream);
 
 /* Batched 2-D transpose (R x C, row stride ldi) -> (C x R, row stride ldo). */

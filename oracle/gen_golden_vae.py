@@ -1,4 +1,4 @@
-"""Generate tests/golden/vae_tiny.npz by running the REAL reference WanVAE_ (chunked, feature caches)
+"""Generate tests/golden/vae_tiny.npz and vae_tiny2.npz by running the REAL reference WanVAE_ (chunked, feature caches)
 on CPU in fp32.  Build-container only.  Usage: python oracle/gen_golden_vae.py"""
 from __future__ import annotations
 
@@ -36,6 +36,25 @@ def main():
     np.savez_compressed(os.path.join(OUT, "vae_tiny.npz"), seed=4321, dim=32, video=video.numpy(), mu=mu.numpy(),
                         z_in=z_in.numpy(), rec=rec.numpy(), mu1=mu1.numpy())
     print("vae_tiny: mu", tuple(mu.shape), float(mu.abs().mean()), "rec", tuple(rec.shape), float(rec.abs().mean()))
+
+    # second case: 48 base channels (48 / 96 / 192 / 192: the 96- and 192-channel kernel paths of the full model), 17 frames
+    # (five streaming chunks in the reference), portrait 40 x 24, other seed
+    cfg = V.VAEConfig(dim=48, z_dim=16)
+    sd = V.make_state_dict(cfg, seed=99)
+    model = ref.WanVAE_(dim=cfg.dim, z_dim=cfg.z_dim, dim_mult=list(cfg.dim_mult), num_res_blocks=2, attn_scales=[],
+                        temperal_downsample=list(cfg.temperal_downsample), dropout=0.0).eval()
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    g = torch.Generator().manual_seed(6)
+    video = (torch.rand(1, 3, 17, 40, 24, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    z_in = torch.randn(1, 16, 4, 5, 3, generator=g).to(torch.bfloat16).float()
+    with torch.no_grad():
+        mu = model.encode(video, scale)
+        rec = model.decode(z_in, scale).clamp(-1, 1)
+        mu1 = model.encode(video[:, :, :1], scale)
+    np.savez_compressed(os.path.join(OUT, "vae_tiny2.npz"), seed=99, dim=48, video=video.numpy(), mu=mu.numpy(),
+                        z_in=z_in.numpy(), rec=rec.numpy(), mu1=mu1.numpy())
+    print("vae_tiny2: mu", tuple(mu.shape), float(mu.abs().mean()), "rec", tuple(rec.shape), float(rec.abs().mean()))
 
 
 if __name__ == "__main__":

@@ -474,20 +474,25 @@ __global__ __launch_bounds__(256) void rms_silu_kernel(const u16* __restrict__ x
 // ------------------------------------------------------------------------------------------------
 // softmax over rows in place (mid-block attention, wan_vae.py:252), scale folded in; n <= 8192
 // ------------------------------------------------------------------------------------------------
-#define SM_MAXV 4
+// n valid columns (any n >= 1; the row is padded to a multiple of 8 in memory): columns n .. ceil8(n) are written as zeros.
+// MAXV 16-byte chunks per thread: 4 -> n <= 8192 (the 512p mid block: 7168 tokens per frame), 16 -> n <= 32768.
+template <int MAXV>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(u16* __restrict__ s, int64_t ld, int n, float scale) {
     __shared__ float red[4];
     u16* row = s + (int64_t)blockIdx.x * ld;
-    const int nvec = n >> 3;
-    float v[SM_MAXV][8];
+    const int nvec = (n + 7) >> 3;
+    float v[MAXV][8];
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < SM_MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {
         const int c = threadIdx.x + j * 256;
         if (c < nvec) {
             unpack8(*reinterpret_cast<const uint4*>(row + c * 8), v[j]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, v[j][e]);
+            for (int e = 0; e < 8; ++e) {
+                if (c * 8 + e >= n) v[j][e] = -INFINITY;      // ragged tail
+                mx = fmaxf(mx, v[j][e]);
+            }
         }
     }
 #pragma unroll
@@ -499,12 +504,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(u16* __restrict__ s, 
     const float sl2 = scale * 1.4426950408889634f;
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < SM_MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {
         const int c = threadIdx.x + j * 256;
         if (c < nvec) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                v[j][e] = __builtin_amdgcn_exp2f((v[j][e] - mx) * sl2);
+                v[j][e] = __builtin_amdgcn_exp2f((v[j][e] - mx) * sl2);      // exp2(-inf) = 0 for the tail
                 sum += v[j][e];
             }
         }
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(u16* __restrict__ s, 
     sum = block_sum_256(sum, red);
     const float inv = 1.0f / sum;
 #pragma unroll
-    for (int j = 0; j < SM_MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {
         const int c = threadIdx.x + j * 256;
         if (c < nvec) {
 #pragma unroll
@@ -716,9 +721,11 @@ extern "C" int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* g
 }
 
 extern "C" int scail_softmax_rows(scail_bf16* s, int64_t ld, int64_t rows, int64_t n, float scale, void* stream) {
-    SCAIL_REQUIRE(n % 8 == 0 && n <= 256 * 8 * SM_MAXV && ld % 8 == 0, "n must be a multiple of 8, <= 8192");
+    SCAIL_REQUIRE(n >= 1 && n <= 32768 && ld % 8 == 0 && ld >= (n + 7) / 8 * 8 && (reinterpret_cast<uintptr_t>(s) & 15) == 0,
+                  "need 1 <= n <= 32768, ld a multiple of 8 that covers ceil8(n), 16-byte aligned rows");
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, ld, (int)n, scale);
+    if (n <= 8192) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, ld, (int)n, scale);
+    else hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, ld, (int)n, scale);
     return scail_check_launch("softmax_rows");
 }
 

@@ -92,12 +92,12 @@ int res_block(Arena& a, const scail_vae_res& r, Tens& x) {
 
 // AttentionBlock (wan_vae.py:221-262): per frame, single head over the H*W tokens; consumes x
 int attn_block(Arena& a, const scail_vae_attn& at, Tens& x) {
-    const int64_t T = x.T, nt = x.H * x.W, C = x.C, npad = (nt + 63) / 64 * 64;
-    SCAIL_REQUIRE(C == at.C && nt % 8 == 0 && nt <= 8192, "scail_vae: mid-block attention needs (H/8)*(W/8) to be a multiple of 8 and <= 8192");
+    const int64_t T = x.T, nt = x.H * x.W, C = x.C, npad = (nt + 63) / 64 * 64, nt8 = (nt + 7) / 8 * 8;
+    SCAIL_REQUIRE(C == at.C && nt <= 32768, "scail_vae: mid-block attention handles up to 32768 tokens per frame ((H/8)*(W/8))");
     Tens y = a.get(x.T, x.H, x.W, C); VAE_CHK(a)
     VAE_TRY(scail_rms_silu(x.p, y.p, at.gamma, x.vox(), C, 0, a.stream));
     Tens tmp = a.get(1, 1, 1, 0); VAE_CHK(a)          // one slot, carved up below
-    const int64_t act = align256(T * nt * C * 2);
+    const int64_t act = align256((T * nt + 8) * C * 2);       // + 8 rows: the score GEMM reads k rows up to ceil8(nt) of the last frame
     SCAIL_REQUIRE(4 * act + align256(nt * npad * 2) + align256(C * npad * 2) <= a.slot_bytes, "scail_vae: attention temporaries exceed a slot");
     char* tb = reinterpret_cast<char*>(tmp.p);
     scail_bf16 *q = reinterpret_cast<scail_bf16*>(tb), *k = reinterpret_cast<scail_bf16*>(tb + act),
@@ -115,7 +115,8 @@ int attn_block(Arena& a, const scail_vae_attn& at, Tens& x) {
     const float scale = 1.0f / std::sqrt((float)C);
     for (int64_t f = 0; f < T; ++f) {
         const scail_bf16 *qf = q + f * nt * C, *kf = k + f * nt * C, *vf = v + f * nt * C;
-        VAE_TRY(scail_gemm_bf16(qf, C, kf, nullptr, S, npad, nt, nt, C, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, a.stream));
+        // N = ceil8(nt): the up to 7 extra score columns come from the next frame's keys (or the pad rows) and are zeroed by the softmax
+        VAE_TRY(scail_gemm_bf16(qf, C, kf, nullptr, S, npad, nt, nt8, C, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, a.stream));
         VAE_TRY(scail_softmax_rows(S, npad, nt, nt, scale, a.stream));
         VAE_TRY(scail_transpose2d(vf, C, nt * C, vt, npad, C * npad, nt, C, 1, a.stream));
         VAE_TRY(scail_gemm_bf16(S, npad, vt, nullptr, o + f * nt * C, C, nt, C, npad, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, a.stream));
@@ -178,7 +179,7 @@ int64_t slot_bytes_for(const scail_vae_weights& w, int64_t T, int64_t H, int64_t
     const int64_t dim = w.enc_conv1.N > w.dec_head.Cin ? w.enc_conv1.N : w.dec_head.Cin;
     const int64_t Tl = 1 + (T - 1) / 4, nt = (H / 8) * (W / 8), npad = (nt + 63) / 64 * 64;
     const int64_t C = w.enc_attn.C > w.dec_attn.C ? w.enc_attn.C : w.dec_attn.C;
-    const int64_t attn = 4 * align256(Tl * nt * C * 2) + align256(nt * npad * 2) + align256(C * npad * 2);
+    const int64_t attn = 4 * align256((Tl * nt + 8) * C * 2) + align256(nt * npad * 2) + align256(C * npad * 2);
     const int64_t act = align256(T * H * W * dim * 2);
     return act > attn ? act : attn;
 }

@@ -198,17 +198,19 @@ class WanVAE_(nn.Module):
     def _attn(self, W, n, x):
         T, H, Wd, C = x.shape
         nt = H * Wd
-        if nt % 8 or nt > 8192:
-            raise NotImplementedError(f"mid-block attention needs (H/8)*(W/8) = {nt} to be a multiple of 8 and <= 8192")
+        if nt > 32768:
+            raise NotImplementedError(f"mid-block attention handles up to 32768 tokens per frame, got (H/8)*(W/8) = {nt}")
         y = ops.rms_silu(x, W[n + ".norm.gamma"], silu=False).view(T * nt, C)
-        q, k, v = (ops.gemm(y, *W[n + "." + nm]) for nm in "qkv")
-        npad = (nt + 63) // 64 * 64
+        kbuf = torch.zeros(T * nt + 8, C, device=x.device, dtype=torch.bfloat16)    # + 8 rows: score GEMM reads up to ceil8(nt) keys
+        q, v = (ops.gemm(y, *W[n + "." + nm]) for nm in "qv")
+        ops.gemm(y, *W[n + ".k"], out=kbuf[:T * nt])
+        npad, nt8 = (nt + 63) // 64 * 64, (nt + 7) // 8 * 8
         S = torch.zeros(nt, npad, device=x.device, dtype=torch.bfloat16)
         vt = torch.zeros(1, C, npad, device=x.device, dtype=torch.bfloat16)
         o = torch.empty(T * nt, C, device=x.device, dtype=torch.bfloat16)
         for f in range(T):
             sl = slice(f * nt, (f + 1) * nt)
-            ops.gemm(q[sl], k[sl], out=S[:, :nt])
+            ops.gemm(q[sl], kbuf[f * nt:f * nt + nt8], out=S[:, :nt8])      # the <= 7 extra columns are zeroed by the softmax
             ops.softmax_rows_(S, nt, 1.0 / math.sqrt(C))
             ops.transpose2d(v[sl].unsqueeze(0), vt)
             ops.gemm(S, vt[0], out=o[sl])

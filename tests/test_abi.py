@@ -150,7 +150,8 @@ def test_more_argument_validation_without_gpu(libpath):
         ("kpad must be", "scail_patchify", (A, A, A, A, 2, 1, 1, 1, 8, 8, 72, None)),
         ("cond batch must be 1 or n_batch", "scail_patchify", (A, A, A, A, 4, 2, 1, 1, 8, 8, 128, None)),
         ("C must be a multiple of 8", "scail_rms_silu", (A, A, A, 4, 20, 1, None)),
-        ("n must be a multiple of 8, <= 8192", "scail_softmax_rows", (A, 16384, 1, 16384, 1.0, None)),
+        ("need 1 <= n <= 32768", "scail_softmax_rows", (A, 40000, 1, 40000, 1.0, None)),
+        ("need 1 <= n <= 32768", "scail_softmax_rows", (A, 8, 1, 15, 1.0, None)),          # ld does not cover ceil8(n)
         ("RESID epilogue needs resid", "scail_gemm_bf16", (A, 64, A, None, A, 16, 8, 16, 64, 3, None, 0, None, 0, 0, None)),
         ("gate needs rows_per_batch", "scail_gemm_bf16", (A, 64, A, None, A, 16, 8, 16, 64, 3, A, 16, A, 16, 0, None)),
         ("pointer alignment", "scail_gemm_bf16", (A + 4, 64, A, None, A, 16, 8, 16, 64, 0, None, 0, None, 0, 0, None)),

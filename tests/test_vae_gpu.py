@@ -126,14 +126,23 @@ def test_rms_silu_softmax_transpose():
     ops.softmax_rows_(sg, 120, 0.5)
     torch.testing.assert_close(sg[:, :120].float().cpu(), torch.softmax(0.5 * s[:, :120], -1), rtol=2e-2, atol=2e-3)
     assert torch.equal(sg[:, 120:].float().cpu(), s[:, 120:])
+    # ragged n (columns n .. ceil8(n) come back as zeros) and rows longer than 8192
+    for n, ld in ((15, 64), (123, 128), (9001, 9024), (20000, 20032)):
+        s = bfr(torch.randn(3, ld, generator=g) * 2)
+        sg = s.to(torch.bfloat16).to(DEV)
+        ops.softmax_rows_(sg, n, 0.7)
+        got = sg.float().cpu()
+        torch.testing.assert_close(got[:, :n], torch.softmax(0.7 * s[:, :n], -1), rtol=2e-2, atol=2e-3)
+        assert float(got[:, n:(n + 7) // 8 * 8].abs().max() if n % 8 else 0.0) == 0.0
+        torch.testing.assert_close(got[:, (n + 7) // 8 * 8:], s[:, (n + 7) // 8 * 8:])          # beyond ceil8(n): untouched
     t = bfr(torch.randn(2, 70, 96, generator=g))
     out = torch.zeros(2, 96, 128, device=DEV, dtype=torch.bfloat16)
     ops.transpose2d(t.to(torch.bfloat16).to(DEV), out)
     assert torch.equal(out[:, :, :70].float().cpu(), t.transpose(1, 2)) and float(out[:, :, 70:].abs().max()) == 0
 
 
-def _load(golden_dir):
-    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, "vae_tiny.npz")).items()}
+def _load(golden_dir, name="vae_tiny.npz"):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, name)).items()}
 
 
 def _model(g):
@@ -146,8 +155,9 @@ def _model(g):
     return cfg, sd, m
 
 
-def test_vae_encode_vs_reference_golden(golden_dir):
-    g = _load(golden_dir)
+@pytest.mark.parametrize("name", ["vae_tiny.npz", "vae_tiny2.npz"])
+def test_vae_encode_vs_reference_golden(golden_dir, name):
+    g = _load(golden_dir, name)
     cfg, sd, m = _model(g)
     mu = m.encode(g["video"].to(DEV)).cpu()
     assert mu.shape == g["mu"].shape
@@ -157,8 +167,9 @@ def test_vae_encode_vs_reference_golden(golden_dir):
     torch.testing.assert_close(mu1, g["mu1"], rtol=3e-2, atol=3e-2)
 
 
-def test_vae_decode_vs_reference_golden(golden_dir):
-    g = _load(golden_dir)
+@pytest.mark.parametrize("name", ["vae_tiny.npz", "vae_tiny2.npz"])
+def test_vae_decode_vs_reference_golden(golden_dir, name):
+    g = _load(golden_dir, name)
     cfg, sd, m = _model(g)
     rec = m.decode(g["z_in"].to(DEV)).clamp(-1, 1).cpu()
     assert rec.shape == g["rec"].shape

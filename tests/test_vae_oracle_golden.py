@@ -1,15 +1,18 @@
 """Pin the whole-sequence VAE oracle (oracle/wan_vae_oracle.py) to outputs of the REAL chunked
-reference WanVAE_ (tests/golden/vae_tiny.npz, oracle/gen_golden_vae.py)."""
+reference WanVAE_ (tests/golden/vae_tiny.npz, vae_tiny2.npz; oracle/gen_golden_vae.py)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import wan_vae_oracle as V
 
+FIXTURES = ["vae_tiny.npz", "vae_tiny2.npz"]      # dim 32, 9 frames 32x48; dim 48 (96 / 192-channel stages), 17 frames 40x24
 
-def _load(golden_dir):
-    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, "vae_tiny.npz")).items()}
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, name)).items()}
 
 
 def test_vae_state_dict_param_count():
@@ -18,8 +21,9 @@ def test_vae_state_dict_param_count():
     assert abs(n - 126.9e6) < 0.2e6           # 126.9 M parameters
 
 
-def test_encode_matches_reference(golden_dir):
-    g = _load(golden_dir)
+@pytest.mark.parametrize("name", FIXTURES)
+def test_encode_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
     cfg = V.VAEConfig(dim=int(g["dim"]), z_dim=16)
     sd = V.make_state_dict(cfg, seed=int(g["seed"]))
     with torch.no_grad():
@@ -29,8 +33,9 @@ def test_encode_matches_reference(golden_dir):
     torch.testing.assert_close(mu1, g["mu1"], rtol=1e-4, atol=1e-4)
 
 
-def test_decode_matches_reference(golden_dir):
-    g = _load(golden_dir)
+@pytest.mark.parametrize("name", FIXTURES)
+def test_decode_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
     cfg = V.VAEConfig(dim=int(g["dim"]), z_dim=16)
     sd = V.make_state_dict(cfg, seed=int(g["seed"]))
     with torch.no_grad():
