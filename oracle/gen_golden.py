@@ -36,23 +36,23 @@ def bf16r(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def tiny_inputs(seed=7, B=2, T=4, H=8, W=8, Lt=12, n_clip=5, text_dim=64):
+def tiny_inputs(seed=7, B=2, T=4, H=8, W=8, Lt=12, n_clip=5, text_dim=64, n_cond=1):
     g = torch.Generator().manual_seed(seed)
     x = bf16r(torch.randn(B, T, 16, H, W, generator=g))
     ctx = bf16r(torch.randn(B, Lt, text_dim, generator=g))
     ctx[:, Lt // 2:] = 0            # zeroed padding rows, umt5.py:516-522
-    ref = bf16r(torch.randn(1, 1, 16, H, W, generator=g))
-    pose = bf16r(torch.randn(1, T, 16, H // 2, W // 2, generator=g))
-    clip = bf16r(torch.randn(1, n_clip, 1280, generator=g))
+    ref = bf16r(torch.randn(n_cond, 1, 16, H, W, generator=g))
+    pose = bf16r(torch.randn(n_cond, T, 16, H // 2, W // 2, generator=g))
+    clip = bf16r(torch.randn(n_cond, n_clip, 1280, generator=g))
     t = torch.tensor([731.0, 731.0])
     return dict(x=x, ctx=ctx, ref=ref, pose=pose, clip=clip, t=t)
 
 
-def gen_dit_tiny(name="dit_tiny", cfgd=None):
+def gen_dit_tiny(name="dit_tiny", cfgd=None, inputs=None):
     cfg = O.DiTConfig(**(cfgd or O.TINY))
     sd = O.make_state_dict(cfg, seed=1234)
     net = ref_shims.build_reference_dit(cfg, sd)
-    inp = tiny_inputs()
+    inp = inputs or tiny_inputs()
     hidden = []
     mix = net.mixins["adaln_layer"]
     orig = mix.layer_forward
@@ -199,9 +199,17 @@ def gen_sampler_long(cfg, sd, net, inp):
     print("sampler_long_tiny: xT abs-mean", float(xT.abs().mean()))
 
 
+def gen_dit_shapes():
+    """Ragged everything: portrait latent (12 x 8 -> 6 x 4 patches, pose 3 x 2), odd frame count, 77 text tokens (two key tiles,
+    the second ragged), 129 = 2 x 64 + 1 CLIP tokens (a one-key ragged tile like the real 257), conditioning tensors given per batch element (the n == B branch
+    of the CFG repeat, dit...:1479-1495)."""
+    return gen_dit_tiny("dit_shapes", O.TINY, tiny_inputs(seed=21, B=2, T=3, H=12, W=8, Lt=77, n_clip=129, n_cond=2))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
+    gen_dit_shapes()
     gen_dit_tiny("dit_config1", O.CONFIG1)
     cfg, sd, net, inp = gen_dit_tiny()
     gen_rope(cfg, net)

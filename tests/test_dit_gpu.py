@@ -42,7 +42,7 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm()))
 
 
-@pytest.mark.parametrize("name,cfgd", [("dit_tiny.npz", O.TINY), ("dit_config1.npz", O.CONFIG1)])
+@pytest.mark.parametrize("name,cfgd", [("dit_tiny.npz", O.TINY), ("dit_config1.npz", O.CONFIG1), ("dit_shapes.npz", O.TINY)])
 def test_dit_forward_vs_reference_golden(golden_dir, name, cfgd):
     g = _load(golden_dir, name)
     cfg, sd, net = _net(cfgd, int(g["seed"]))
@@ -61,7 +61,7 @@ def test_dit_forward_vs_reference_golden(golden_dir, name, cfgd):
     assert _cos(out.float().cpu(), g["out"]) >= 0.999
 
 
-@pytest.mark.parametrize("name,cfgd", [("dit_tiny.npz", O.TINY), ("dit_config1.npz", O.CONFIG1)])
+@pytest.mark.parametrize("name,cfgd", [("dit_tiny.npz", O.TINY), ("dit_config1.npz", O.CONFIG1), ("dit_shapes.npz", O.TINY)])
 def test_c_step_executor_equals_host_orchestration_and_golden(golden_dir, name, cfgd):
     """include/scail_dit.h: the whole evaluation as one C call.  It enqueues the same kernels in the same order as the
     Python orchestration, so the two must agree BIT FOR BIT; and it must match the reference golden like the other path.

@@ -23,7 +23,7 @@ def test_state_dict_spec_matches_survey_count():
 import pytest
 
 
-@pytest.mark.parametrize("name,cfgd", [("dit_tiny.npz", O.TINY), ("dit_config1.npz", O.CONFIG1)])
+@pytest.mark.parametrize("name,cfgd", [("dit_tiny.npz", O.TINY), ("dit_config1.npz", O.CONFIG1), ("dit_shapes.npz", O.TINY)])
 def test_dit_forward_matches_reference(golden_dir, name, cfgd):
     g = _load(golden_dir, name)
     cfg = O.DiTConfig(**cfgd)
