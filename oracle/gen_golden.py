@@ -199,6 +199,28 @@ def gen_sampler_long(cfg, sd, net, inp):
     print("sampler_long_tiny: xT abs-mean", float(xT.abs().mean()))
 
 
+def gen_rope_sp_w():
+    """Sequence-parallel W split (portrait latents: chunk_dim 4, diffusion_video.py:504-552): rank r of 2 holds columns
+    [r*W/2, (r+1)*W/2) and shifts its RoPE window by r*(W/2/patch) (dit...:1583-1585).  Drives the reference mixin directly like the
+    H-split case in gen_dit_tiny.  8 x 12 patches split into two 8 x 6 slabs, 2 frames."""
+    cfg = O.DiTConfig(**O.TINY)
+    net = ref_shims.build_reference_dit(cfg, O.make_state_dict(cfg, seed=1234))
+    pos = net.mixins["pos_embed"]
+    g = torch.Generator().manual_seed(12)
+    res = {}
+    for r in range(2):
+        kw = dict(rope_T=2, rope_H=8, rope_W=6, rope_H_shift=0, rope_W_shift=r * 6, global_rope_H=0, global_rope_W=120)
+        Lr, Ln, Lp = 8 * 6, 2 * 8 * 6, 2 * 4 * 3
+        q = torch.randn(1, 1, Lr + Ln + Lp, cfg.head_dim, generator=g)
+        with torch.no_grad():
+            qr = torch.cat([pos.rotary_ref(q[:, :, :Lr], **kw), pos.rotary(q[:, :, Lr:Lr + Ln], **kw),
+                            pos.rotary_pose(q[:, :, -Lp:], **kw)], dim=2)
+        res[f"q{r}"] = q.numpy()
+        res[f"qr{r}"] = qr.numpy()
+    np.savez_compressed(os.path.join(OUT, "rope_tiny_sp_w.npz"), **res)
+    print("rope_tiny_sp_w written")
+
+
 def gen_dit_shapes():
     """Ragged everything: portrait latent (12 x 8 -> 6 x 4 patches, pose 3 x 2), odd frame count, 77 text tokens (two key tiles,
     the second ragged), 129 = 2 x 64 + 1 CLIP tokens (a one-key ragged tile like the real 257), conditioning tensors given per batch element (the n == B branch
@@ -210,6 +232,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     gen_dit_shapes()
+    gen_rope_sp_w()
     gen_dit_tiny("dit_config1", O.CONFIG1)
     cfg, sd, net, inp = gen_dit_tiny()
     gen_rope(cfg, net)

@@ -51,6 +51,18 @@ def test_rope_tables_sequence_parallel_shift(golden_dir):
         torch.testing.assert_close(O.apply_rope(g[f"q{r}"], cos, sin), g[f"qr{r}"], rtol=1e-5, atol=2e-6)
 
 
+def test_rope_tables_sequence_parallel_w_shift(golden_dir):
+    """Portrait latents are split along W (chunk_dim 4): rank-shifted W window, also inside the pooled pose tables."""
+    from scail_amd import rope
+    g = _load(golden_dir, "rope_tiny_sp_w.npz")
+    cfg = O.DiTConfig(**O.TINY)
+    for r in range(2):
+        cos, sin = O.rope_tables(cfg, 2, 8, 6, W_shift=r * 6)
+        torch.testing.assert_close(O.apply_rope(g[f"q{r}"], cos, sin), g[f"qr{r}"], rtol=1e-5, atol=2e-6)
+        ch, sh = rope.build_tables(cfg.head_dim, 2, 8, 6, W_shift=r * 6)              # the host tables the HIP kernel consumes
+        assert torch.equal(cos[:, 0::2], ch) and torch.equal(sin[:, 0::2], sh)
+
+
 def test_sampler_matches_reference(golden_dir):
     g = _load(golden_dir, "sampler_tiny.npz")
     d = _load(golden_dir, "dit_tiny.npz")
