@@ -39,9 +39,9 @@ def _worker(rank, world, port, golden, q):
         sp.backend.all_gather_into(vg, v.contiguous(), async_op=False)
         return torch.cat(list(kg), dim=2), torch.cat(list(vg), dim=2)
 
-    Hs = x.shape[3] // world
+    shift = rank * (x.shape[cd] // world // 2)            # rank-shifted RoPE window along the split axis (dit...:1578-1585)
     out = O.dit_forward(cfg, sd, sp.chunk(x, cd), g["t"], g["ctx"], sp.chunk(g["ref"], cd), sp.chunk(g["pose"], cd),
-                        g["clip"], H_shift=rank * (Hs // 2), kv_gather=kv_gather)
+                        g["clip"], H_shift=shift if cd == 3 else 0, W_shift=shift if cd == 4 else 0, kv_gather=kv_gather)
     full = sp.gather_to_rank0(out, cd)
     # the ulysses exchange primitive: out[s] <- rank s's inp[my rank]
     inp = torch.arange(world * 3, dtype=torch.float32).reshape(world, 3) + 100 * rank
@@ -55,11 +55,12 @@ def _worker(rank, world, port, golden, q):
 
 
 @pytest.mark.timeout(300)
-def test_sp2_gloo_matches_reference_golden(golden_dir):
+@pytest.mark.parametrize("fixture", ["dit_tiny.npz", "dit_shapes.npz"])     # square latent: H split; portrait 12 x 8: W split
+def test_sp2_gloo_matches_reference_golden(golden_dir, fixture):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 400
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, os.path.join(golden_dir, "dit_tiny.npz"), q)) for r in range(2)]
+    port = 29500 + (os.getpid() + len(fixture)) % 400
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, os.path.join(golden_dir, fixture), q)) for r in range(2)]
     [p.start() for p in procs]
     err = q.get(timeout=240)
     [p.join(60) for p in procs]
