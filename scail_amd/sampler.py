@@ -132,7 +132,12 @@ class RFDiscretization:
 
 
 class RFSampler:
-    """sampling.py:920-982.  Only the shipped branch (hunyuan_schedule) is implemented."""
+    """sampling.py:920-982.  Only the shipped branch (hunyuan_schedule) is implemented.
+
+    One deliberate difference: a ``num_steps`` ARGUMENT (``__call__`` / ``sample_hip`` / ``engine.sample``) overrides the configured
+    step count here.  In the reference the argument only reaches the discretization, whose result the hunyuan schedule then
+    replaces with ``make_flow_timesteps(0, self.num_steps, ...)`` (:936-942) -- i.e. it is silently ignored; the reference's own
+    engine never passes it (diffusion_video.py:565-569).  Leave it ``None`` for the reference's behaviour."""
 
     def __init__(self, schedule_shift=False, hunyuan_schedule=False, shift_scale=7, mode="normal", distill=False,
                  discretization_config=None, num_steps=None, guider_config=None, verbose=False, device="cuda"):
