@@ -1,0 +1,74 @@
+"""Compute-only time of ONE sequence-parallel rank's share of the config-2 sampler step, on one GPU: the collectives are
+replaced by local copies (results are meaningless, the launch sequence and every kernel shape are those of rank 0 in an
+N-rank run).  Gives the compute part of the strong-scaling efficiency -- (T_1 / N) / T_N -- without an N-GPU node; the
+exchange time comes on top.
+usage: sp_rank_compute.py [N ...]      e.g. 1 2 4 8"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scail_amd import ops
+from scail_amd.dit import DiffusionTransformer
+from scail_amd.parallel import SequenceParallel, _Handle
+
+
+class LocalCopyBackend:
+    """Same interface as parallel.TorchDistBackend; every 'peer' contribution is this rank's own data."""
+
+    def __init__(self, size):
+        self.rank, self.size = 0, size
+
+    def broadcast(self, t):
+        pass
+
+    def all_gather_into(self, out, inp, async_op=True):
+        for r in range(self.size):
+            out[r].copy_(inp.reshape(out[r].shape))
+        return _Handle(None)
+
+    def all_to_all(self, out, inp, async_op=False):
+        out.copy_(inp)
+        return _Handle(None)
+
+    def gather_cat(self, t, dim):
+        return t
+
+
+dev = "cuda"
+net = DiffusionTransformer(transformer_args=dict(model_parallel_size=1), num_frames=81, latent_width=300, latent_height=300,
+                           hidden_size=5120, num_layers=40, num_attention_heads=40, inner_hidden_size=13824, text_dim=4096,
+                           time_freq_dim=256, time_embed_dim=5120, share_adaln=True, use_i2v_clip=True, device=dev, init_seed=1234)
+net.cache_conditioning = False
+g = torch.Generator().manual_seed(1)
+T, H, W = 21, 64, 112
+ctx = torch.randn(2, 512, 4096, generator=g).to(dev).to(torch.bfloat16)
+clip = torch.randn(1, 257, 1280, generator=g).to(dev).to(torch.bfloat16)
+base = None
+for N in [int(a) for a in (sys.argv[1:] or ["1", "2", "4", "8"])]:
+    sp = SequenceParallel(LocalCopyBackend(N)) if N > 1 else None
+    net.sp = sp
+    h = H // N
+    x = torch.randn(1, T, 16, h, W, generator=g).to(dev)
+    ref = torch.randn(1, 1, 16, h, W, generator=g).to(dev).to(torch.bfloat16)
+    pose = torch.randn(1, T, 16, h // 2, W // 2, generator=g).to(dev).to(torch.bfloat16)
+    kw = dict(concat_images=torch.zeros(1, device=dev), image_clip_features=clip, ref_concat=ref, concat_smpl_render=pose,
+              chunk_dim=3 if N > 1 else None)
+
+    def step():
+        v = net.forward_f32(torch.cat([x, x], 0), torch.tensor([700.0, 700.0], device=dev), ctx, None, **kw)
+        ops.cfg_euler_(x, v, 4.0, -0.01)
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    base = base or dt * N
+    print(json.dumps(dict(ranks=N, mode=(sp.resolve_mode(40) if sp else "-"), s_per_step_one_rank=dt,
+                          compute_only_efficiency=(base / N) / dt)), flush=True)
