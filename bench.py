@@ -17,8 +17,10 @@ The JSON line also carries
   roofline     MFMA roofline of the dominant kernel (self-attention flash kernel): algorithmic
                4*Lq*Lk*128*heads*B FLOP per launch / mean launch time measured with HIP events on the
                launch stream inside the timed region; peak 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md);
-  cpu_baseline the CPU oracle (fp32 port of the reference block) timed on this box's host cores on a
-               bounded sample, converted to the metric by algorithmic FLOPs (rank 0, N = 1 only).
+  cpu_baseline the CPU oracle (fp32 port of the reference block) timed on this box's host cores after a warm-up at
+               several sequence lengths; t(L) = a L + b L^2 fitted and evaluated at the bench length (rank 0, N = 1);
+  config.vae   BASELINE config 4 (Wan2.1 VAE encode + decode at 81 x 512 x 896) run once after the timed region,
+               with both roofline fractions (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -77,9 +79,13 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
 
-def cpu_baseline(p, n_threads=None):
-    """Time the CPU oracle (fp32 restatement of the reference block, oracle/scail_oracle.py) on a bounded
-    sample: ONE transformer block at the real width on a (5, 32, 56) latent (L = 3 248 tokens, B = 2)."""
+def cpu_baseline(p, n_threads=None, budget_s=28.0):
+    """Time the CPU oracle (fp32 restatement of the reference block, oracle/scail_oracle.py; reference
+    dit_video_crossattn_sc_xc.py:1009-1051) on a bounded sample: ONE transformer block at the real width, B = 2, after one
+    untimed warm-up call, at several sequence lengths (latents (T, 32, 56), T = 1, 3, 5, 9 -> L = 1008 ... 5488 tokens; as
+    many as fit the time budget, at least two), and fit  t(L) = a L + b L^2  by least squares (the
+    per-token projections / MLP / norms scale with L, self-attention with L^2 -- at the bench length attention is 62 % of
+    the FLOPs, at the sample lengths 5-15 %, so a single-length FLOP extrapolation would misprice it)."""
     from oracle import scail_oracle as O
     n_threads = n_threads or os.cpu_count()
     torch.set_num_threads(n_threads)
@@ -89,17 +95,73 @@ def cpu_baseline(p, n_threads=None):
     D = cfg.hidden_size
     sd = {k: torch.randn(s, generator=g) * 0.02 for k, s in O.state_dict_spec(cfg).items()
           if ".layers.0." in k or "adaln_layer" in k}
-    T, H, W, Lt, Lc = 5, 32, 56, 512, 257
-    cos, sin = O.rope_tables(cfg, T, H // 2, W // 2)
-    Ls = cos.shape[0]
-    h = torch.randn(2, Ls, D, generator=g)
+    Lt, Lc = 512, 257
     adaln, text, clip = torch.randn(2, 6 * D, generator=g), torch.randn(2, Lt, D, generator=g), torch.randn(2, Lc, D, generator=g)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        O.block(cfg, sd, 0, h, adaln, text, clip, cos, sin)
-        dt = time.perf_counter() - t0
-    fl = step_flops(dict(p, num_layers=1), Ls, Lt, Lc)
-    return dt, fl, Ls, n_threads
+
+    def run(T):
+        cos, sin = O.rope_tables(cfg, T, 16, 28)
+        h = torch.randn(2, cos.shape[0], D, generator=g)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            O.block(cfg, sd, 0, h, adaln, text, clip, cos, sin)
+            return cos.shape[0], time.perf_counter() - t0
+
+    run(1)                                   # warm-up: thread pool, allocator, oneDNN / BLAS kernel selection
+    pts, spent = [], 0.0
+    for T in (1, 3, 5, 9):
+        if len(pts) >= 2:
+            Ls, ts = pts[-1]
+            Ln = (1 + T) * 448 + T * 112
+            if spent + ts * (Ln / Ls) ** 1.5 > budget_s:
+                break
+        Ls, dt = run(T)
+        pts.append((Ls, dt))
+        spent += dt
+    # least squares for t = a L + b L^2 (no intercept); b clamped at 0 if timing noise drives it negative
+    s11 = sum(L * L for L, _ in pts); s12 = sum(L ** 3 for L, _ in pts); s22 = sum(L ** 4 for L, _ in pts)
+    y1 = sum(L * t for L, t in pts); y2 = sum(L * L * t for L, t in pts)
+    det = s11 * s22 - s12 * s12
+    a, b = (y1 * s22 - y2 * s12) / det, (y2 * s11 - y1 * s12) / det
+    if b < 0 or a < 0:
+        b = max(b, 0.0)
+        a = max((y1 - b * s12) / s11, 0.0)
+    return a, b, pts, n_threads
+
+
+def _git_blob_sha1(path):
+    """git's blob id of a file (sha1 of 'blob <size>\\0' + content): ties a committed PMC measurement to the kernel source."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+VAE_ALG = {"encode": (188.3e12, 148.7e9), "decode": (316.5e12, 229.4e9)}      # SURVEY.md 8d, 81 x 512 x 896
+
+
+def vae_leg(dev):
+    """BASELINE config 4 (Wan2.1 VAE encode + decode only, 512p x 81 f) after the timed DiT region: one warm-up and one
+    timed call per direction, HIP events on the launch stream; algorithmic 188.3 / 316.5 TFLOP and 148.7 / 229.4 GB
+    (every conv reads its input once and writes its output once, norm + SiLU fused)."""
+    from scail_amd.wan_vae import WanVAE_
+    m = WanVAE_(dim=96, z_dim=16, device=dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    video = torch.rand(1, 3, 81, 512, 896, device=dev, generator=g) * 2 - 1
+    z = torch.randn(1, 16, 21, 64, 112, device=dev, generator=g)
+    res = {"workload": "Wan2.1 VAE encode + decode, 81x512x896, random-init weights, synthetic video", "dtype": "bf16"}
+    for name, fn, arg in (("encode", m.encode, video), ("decode", m.decode, z)):
+        fn(arg)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); out = fn(arg); e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        fl, by = VAE_ALG[name]
+        res[name + "_ms"] = ms
+        res[name + "_achieved_mfma"] = {"TFLOP/s": fl / ms / 1e9, "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS}
+        res[name + "_achieved_hbm"] = {"GB/s": by / ms / 1e6, "frac": by / ms / 1e6 / 8000.0}
+        res[name + "_finite"] = bool(torch.isfinite(out).all().item())
+        del out
+    return res
 
 
 def main():
@@ -110,6 +172,7 @@ def main():
     ap.add_argument("--config", default=os.environ.get("SCAIL_BENCH_CONFIG", "14b"), choices=list(CONFIGS))
     ap.add_argument("--layers", type=int, default=None, help="DEBUG ONLY: fewer layers (result flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the config-4 VAE leg after the timed region")
     ap.add_argument("--cfg-scale", type=float, default=4.0)
     args = ap.parse_args()
 
@@ -207,10 +270,14 @@ def main():
     attn_flops = 4.0 * attn_Lq * L * 128 * attn_heads * attn_B
     ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms else None
     fl = step_flops(p, L, Lt, Lc)
-    traffic = None                      # measured offline with rocprofv3 --pmc (cannot run inside the bench)
+    # HBM/fabric bytes per launch of the dominant kernel: measured offline with rocprofv3 --pmc (separate passes, guide
+    # corrections; profiles/), committed with the git blob id of the kernel source it was measured on -- dropped (null)
+    # when attn.hip has changed since or the launch shape differs, so the field cannot go stale silently
+    traffic = None
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))["flash_attn_self"]
-        if tr["shape"] == {"B": attn_B, "heads": attn_heads, "Lq": attn_Lq, "Lk": L}:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["flash_attn_self"]
+        blob = _git_blob_sha1(os.path.join(ROOT, "scail_amd", "csrc", "attn.hip"))
+        if tr["shape"] == {"B": attn_B, "heads": attn_heads, "Lq": attn_Lq, "Lk": L} and tr.get("attn_hip_blob") == blob:
             traffic = tr["traffic_bytes"]
     except Exception:
         pass
@@ -231,14 +298,19 @@ def main():
     }
     if args.layers is not None:
         out["config"]["INVALID_debug_layers"] = args.layers
+    if rank == 0 and world == 1 and not args.no_vae:
+        out["config"]["vae"] = vae_leg(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        dt, cfl, Ls, nt = cpu_baseline(p)
-        rate = cfl / dt
+        a, b, pts, nt = cpu_baseline(p)
+        t_layer = a * L + b * L * L                      # one block, B = 2, at the bench length
+        t_cpu = p["num_layers"] * t_layer
         out["cpu_baseline"] = {
-            "value": Lnoise / (fl / rate), "unit": "latent tokens/s", "cores": nt, "kind": "port",
-            "sample": f"oracle block (fp32, torch CPU, {nt} threads) at full width D={p['hidden_size']}, B=2, L={Ls} tokens "
-                      f"(latent 5x32x56): {dt:.2f} s for {cfl / 1e12:.2f} TFLOP = {rate / 1e12:.3f} TFLOP/s; value = "
-                      f"noise tokens / (step FLOPs / that rate), i.e. EXTRAPOLATED by algorithmic FLOPs"}
+            "value": Lnoise / t_cpu, "unit": "latent tokens/s", "cores": nt, "kind": "port",
+            "sample": f"oracle block (fp32, torch CPU, {nt} threads) at full width D={p['hidden_size']}, B=2, after one warm-up call, "
+                      f"timed at L = " + ", ".join(f"{Ls} ({dt:.2f} s)" for Ls, dt in pts) + f"; least-squares fit t(L) = a L + b L^2 "
+                      f"with a = {a:.3e} s/token, b = {b:.3e} s/token^2 -> {t_layer:.1f} s per block at L = {L} "
+                      f"(attention share {b * L * L / t_layer:.0%}), x {p['num_layers']} layers = {t_cpu:.0f} s per step "
+                      f"(embeddings / final layer < 0.1 % not included)"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
