@@ -79,20 +79,59 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
 
-def cpu_baseline(p, n_threads=None, budget_s=28.0):
+def _nnls3(pts):
+    """Non-negative least squares of t = c + a L + b L^2 over the measured (L, t) points: every subset of active terms is
+    solved by ordinary least squares and the feasible (all coefficients >= 0) solution with the smallest residual wins."""
+    import itertools
+    import numpy as np
+    Ls = np.array([q[0] for q in pts], dtype=np.float64)
+    ts = np.array([q[1] for q in pts], dtype=np.float64)
+    cols = [np.ones_like(Ls), Ls, Ls * Ls]
+    best = None
+    for k in range(1, min(3, len(pts)) + 1):
+        for act in itertools.combinations(range(3), k):
+            A = np.stack([cols[i] for i in act], 1)
+            sol, *_ = np.linalg.lstsq(A, ts, rcond=None)
+            if (sol < 0).any():
+                continue
+            res = float(((A @ sol - ts) ** 2).sum())
+            if best is None or res < best[0] - 1e-12 or (abs(res - best[0]) <= 1e-12 and k > best[2]):
+                coef = [0.0, 0.0, 0.0]
+                for i, v in zip(act, sol):
+                    coef[i] = float(v)
+                best = (res, coef, k)
+    return best[1]
+
+
+def cpu_baseline(p, budget_s=28.0):
     """Time the CPU oracle (fp32 restatement of the reference block, oracle/scail_oracle.py; reference
-    dit_video_crossattn_sc_xc.py:1009-1051) on a bounded sample: ONE transformer block at the real width, B = 2, after one
-    untimed warm-up call, at several sequence lengths (latents (T, 32, 56), T = 1, 3, 5, 9 -> L = 1008 ... 5488 tokens; as
-    many as fit the time budget, at least two), and fit  t(L) = a L + b L^2  by least squares (the
-    per-token projections / MLP / norms scale with L, self-attention with L^2 -- at the bench length attention is 62 % of
-    the FLOPs, at the sample lengths 5-15 %, so a single-length FLOP extrapolation would misprice it)."""
+    dit_video_crossattn_sc_xc.py:1009-1051) on a bounded sample: ONE transformer block at the real width, B = 2.
+      1. thread count: the block's largest projection (2016 x 5120 x 15360) is timed at 32 / 64 / 128 / all hardware
+         threads and the fastest is used (all 256 SMT threads of the GPU box's host are NOT the fastest for torch CPU);
+      2. one untimed warm-up call, then timed calls at several sequence lengths (latents (T, 32, 56), T = 1, 3, 5, 9 ->
+         L = 1008 ... 5488 tokens; as many as fit the time budget, at least two);
+      3. non-negative least squares fit  t(L) = c + a L + b L^2  (projections / MLP / norms scale with L,
+         self-attention with L^2 -- at the bench length attention is 62 % of the FLOPs, at the sample lengths 5-15 %, so
+         a single-length FLOP extrapolation would misprice it), evaluated at the bench length by the caller."""
     from oracle import scail_oracle as O
-    n_threads = n_threads or os.cpu_count()
-    torch.set_num_threads(n_threads)
-    cfg = O.DiTConfig(hidden_size=p["hidden_size"], num_layers=1, num_attention_heads=p["num_attention_heads"],
-                      inner_hidden_size=p["inner_hidden_size"], text_dim=64, time_embed_dim=p["hidden_size"])
+    import torch.nn.functional as F
+    hw = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
-    D = cfg.hidden_size
+    D = p["hidden_size"]
+    xw, ww = torch.randn(2016, D, generator=g), torch.randn(3 * D, D, generator=g) * 0.02
+    probe = {}
+    for nt in sorted({min(hw, 32), min(hw, 64), min(hw, 128), hw}):
+        torch.set_num_threads(nt)
+        with torch.no_grad():
+            F.linear(xw, ww)
+            t0 = time.perf_counter()
+            F.linear(xw, ww)
+            probe[nt] = time.perf_counter() - t0
+    n_threads = min(probe, key=probe.get)
+    torch.set_num_threads(n_threads)
+    del xw, ww
+    cfg = O.DiTConfig(hidden_size=D, num_layers=1, num_attention_heads=p["num_attention_heads"],
+                      inner_hidden_size=p["inner_hidden_size"], text_dim=64, time_embed_dim=D)
     sd = {k: torch.randn(s, generator=g) * 0.02 for k, s in O.state_dict_spec(cfg).items()
           if ".layers.0." in k or "adaln_layer" in k}
     Lt, Lc = 512, 257
@@ -106,8 +145,8 @@ def cpu_baseline(p, n_threads=None, budget_s=28.0):
             O.block(cfg, sd, 0, h, adaln, text, clip, cos, sin)
             return cos.shape[0], time.perf_counter() - t0
 
-    run(1)                                   # warm-up: thread pool, allocator, oneDNN / BLAS kernel selection
-    pts, spent = [], 0.0
+    _, spent = run(1)                        # warm-up: thread pool, allocator, BLAS kernel selection (counts against the budget)
+    pts = []
     for T in (1, 3, 5, 9):
         if len(pts) >= 2:
             Ls, ts = pts[-1]
@@ -117,15 +156,8 @@ def cpu_baseline(p, n_threads=None, budget_s=28.0):
         Ls, dt = run(T)
         pts.append((Ls, dt))
         spent += dt
-    # least squares for t = a L + b L^2 (no intercept); b clamped at 0 if timing noise drives it negative
-    s11 = sum(L * L for L, _ in pts); s12 = sum(L ** 3 for L, _ in pts); s22 = sum(L ** 4 for L, _ in pts)
-    y1 = sum(L * t for L, t in pts); y2 = sum(L * L * t for L, t in pts)
-    det = s11 * s22 - s12 * s12
-    a, b = (y1 * s22 - y2 * s12) / det, (y2 * s11 - y1 * s12) / det
-    if b < 0 or a < 0:
-        b = max(b, 0.0)
-        a = max((y1 - b * s12) / s11, 0.0)
-    return a, b, pts, n_threads
+    c, a, b = _nnls3(pts)
+    return c, a, b, pts, n_threads, probe
 
 
 def _git_blob_sha1(path):
@@ -301,14 +333,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_vae:
         out["config"]["vae"] = vae_leg(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        a, b, pts, nt = cpu_baseline(p)
-        t_layer = a * L + b * L * L                      # one block, B = 2, at the bench length
+        c0, a, b, pts, nt, probe = cpu_baseline(p)
+        t_layer = c0 + a * L + b * L * L                 # one block, B = 2, at the bench length
         t_cpu = p["num_layers"] * t_layer
         out["cpu_baseline"] = {
             "value": Lnoise / t_cpu, "unit": "latent tokens/s", "cores": nt, "kind": "port",
-            "sample": f"oracle block (fp32, torch CPU, {nt} threads) at full width D={p['hidden_size']}, B=2, after one warm-up call, "
-                      f"timed at L = " + ", ".join(f"{Ls} ({dt:.2f} s)" for Ls, dt in pts) + f"; least-squares fit t(L) = a L + b L^2 "
-                      f"with a = {a:.3e} s/token, b = {b:.3e} s/token^2 -> {t_layer:.1f} s per block at L = {L} "
+            "sample": f"oracle block (fp32, torch CPU, {nt} threads = fastest of "
+                      + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in sorted(probe.items())) + f" on the 2016x5120x15360 projection) at full width "
+                      f"D={p['hidden_size']}, B=2, after one warm-up call, timed at L = "
+                      + ", ".join(f"{Ls} ({dt:.2f} s)" for Ls, dt in pts) + f"; non-negative least-squares fit t(L) = c + a L + b L^2 "
+                      f"with c = {c0:.2f} s, a = {a:.3e} s/token, b = {b:.3e} s/token^2 -> {t_layer:.1f} s per block at L = {L} "
                       f"(attention share {b * L * L / t_layer:.0%}), x {p['num_layers']} layers = {t_cpu:.0f} s per step "
                       f"(embeddings / final layer < 0.1 % not included)"}
     if rank == 0:

@@ -196,6 +196,12 @@ class DiffusionTransformer(nn.Module):
         """Random init in the spirit of the reference (N(0,0.02) linears sat/mpu/utils.py:89-94, zero
         biases, unit norm weights, randn/sqrt(D) AdaLN tables dit...:888-893,814-816), generated
         directly in bf16 on ``device`` so a 14B model never exists in fp32 on the host."""
+        if seed is None:
+            # init_seed=None: shapes only (meta tensors); the caller attaches real storage with
+            # load_state_dict(sd, assign=True) -- e.g. the parameters of a live reference network (scail_amd/sat_mixins.py)
+            for name, shape in self.param_spec().items():
+                _register(self, name, nn.Parameter(torch.empty(shape, device="meta", dtype=self.dtype), requires_grad=False))
+            return
         dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
         g = torch.Generator(device=dev).manual_seed(seed)
         D = self.hidden_size
@@ -298,16 +304,30 @@ class DiffusionTransformer(nn.Module):
                     and torch.equal(c["ctx"], ctx) and torch.equal(c["clip"], clip):
                 return c
         W = self.prepare()
-        D, H = self.hidden_size, self.num_attention_heads
-        B, Lt, _ = ctx.shape
-        Bc, Lc, _ = clip.shape
         text = ops.gemm(ctx, W["text_embedding.0.w"], W["text_embedding.0.b"], epilogue=L.EPI_GELU_TANH)
         text = ops.gemm(text, W["text_embedding.2.w"], W["text_embedding.2.b"])
         cl = ops.layernorm_affine(clip, W["clip_proj.proj.0.w"], W["clip_proj.proj.0.b"], eps=1e-5)
         cl = ops.gemm(cl, W["clip_proj.proj.1.w"], W["clip_proj.proj.1.b"], epilogue=L.EPI_GELU_ERF)
         cl = ops.gemm(cl, W["clip_proj.proj.3.w"], W["clip_proj.proj.3.b"])
         cl = ops.layernorm_affine(cl, W["clip_proj.proj.4.w"], W["clip_proj.proj.4.b"], eps=1e-5)
-        dev = ctx.device
+        c = self.kv_conditioning(text, cl)
+        c["key"] = cond_key
+        if self.cache_conditioning:
+            if cond_key is None:
+                c["ctx"], c["clip"] = ctx.clone(), clip.clone()
+            self._cond_cache = c
+        return c
+
+    def kv_conditioning(self, text: torch.Tensor, cl: torch.Tensor) -> Dict:
+        """Per-layer cross-attention keys (post-RMSNorm) and transposed values from the EMBEDDED conditioning: text
+        (B, Lt, D) = text_embedding(context), cl (Bc, Lc, D) = clip_proj(image_clip_features), both bf16 -- what the
+        reference hands every layer as ``encoder_outputs`` / ``image_clip_features`` (dit...:1505-1515, 1116-1142).
+        Also the entry the SAT block seam uses (scail_amd/sat_mixins.py), where the reference's own modules embed."""
+        W = self.prepare()
+        D, H = self.hidden_size, self.num_attention_heads
+        B, Lt, _ = text.shape
+        Bc, Lc, _ = cl.shape
+        dev = text.device
         Ltp, Lcp = (Lt + 63) // 64 * 64, (Lc + 63) // 64 * 64
         nl = self.num_layers
         k_text = torch.empty(nl, B, Lt, D, device=dev, dtype=torch.bfloat16)
@@ -323,12 +343,7 @@ class DiffusionTransformer(nn.Module):
             ops.gemm(cl, lw["clipkv_w"], lw["clipkv_b"], out=kvc)
             ops.rmsnorm_rope(kvc[..., :D], lw["clipkn"], out=k_clip[i], eps=self.layernorm_epsilon)
             ops.transpose_v(kvc[..., D:], H, out=vt_clip[i])
-        c = dict(key=cond_key, k_text=k_text, vt_text=vt_text, k_clip=k_clip, vt_clip=vt_clip)
-        if self.cache_conditioning:
-            if cond_key is None:
-                c["ctx"], c["clip"] = ctx.clone(), clip.clone()
-            self._cond_cache = c
-        return c
+        return dict(k_text=k_text, vt_text=vt_text, k_clip=k_clip, vt_clip=vt_clip)
 
     def _timed(self, tag, fn, *a, **k):
         if self.kernel_timer is None:
