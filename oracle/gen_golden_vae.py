@@ -1,4 +1,4 @@
-"""Generate tests/golden/vae_tiny.npz and vae_tiny2.npz by running the REAL reference WanVAE_ (chunked, feature caches)
+"""Generate tests/golden/vae_tiny.npz, vae_tiny2.npz and vae_dim96.npz by running the REAL reference WanVAE_ (chunked, feature caches)
 on CPU in fp32.  Build-container only.  Usage: python oracle/gen_golden_vae.py"""
 from __future__ import annotations
 
@@ -55,6 +55,25 @@ def main():
     np.savez_compressed(os.path.join(OUT, "vae_tiny2.npz"), seed=99, dim=48, video=video.numpy(), mu=mu.numpy(),
                         z_in=z_in.numpy(), rec=rec.numpy(), mu1=mu1.numpy())
     print("vae_tiny2: mu", tuple(mu.shape), float(mu.abs().mean()), "rec", tuple(rec.shape), float(rec.abs().mean()))
+
+    # third case: the FULL model's widths (96 base channels -> 96 / 192 / 384 / 384: every kernel path the 14B pipeline's VAE
+    # takes, incl. the fused conv -> RMS_norm -> SiLU epilogue that needs all 96 channels in one N tile), 9 frames, 32 x 32
+    cfg = V.VAEConfig(dim=96, z_dim=16)
+    sd = V.make_state_dict(cfg, seed=7)
+    model = ref.WanVAE_(dim=cfg.dim, z_dim=cfg.z_dim, dim_mult=list(cfg.dim_mult), num_res_blocks=2, attn_scales=[],
+                        temperal_downsample=list(cfg.temperal_downsample), dropout=0.0).eval()
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    g = torch.Generator().manual_seed(8)
+    video = (torch.rand(1, 3, 9, 32, 32, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    z_in = torch.randn(1, 16, 3, 4, 4, generator=g).to(torch.bfloat16).float()
+    with torch.no_grad():
+        mu = model.encode(video, scale)
+        rec = model.decode(z_in, scale).clamp(-1, 1)
+        mu1 = model.encode(video[:, :, :1], scale)
+    np.savez_compressed(os.path.join(OUT, "vae_dim96.npz"), seed=7, dim=96, video=video.numpy(), mu=mu.numpy(),
+                        z_in=z_in.numpy(), rec=rec.numpy(), mu1=mu1.numpy())
+    print("vae_dim96: mu", tuple(mu.shape), float(mu.abs().mean()), "rec", tuple(rec.shape), float(rec.abs().mean()))
 
 
 if __name__ == "__main__":

@@ -298,8 +298,11 @@ class WanVAE:
         self.std = torch.tensor(LATENT_STD[:z_dim], dtype=torch.float32, device=device)
         self.scale = [self.mean, 1.0 / self.std]
         self.model = WanVAE_(dim=dim, z_dim=z_dim, device=device).eval().requires_grad_(False)
-        if vae_pth is not None and os.path.exists(vae_pth):
-            self.model.load_state_dict(torch.load(vae_pth, map_location=device))
+        if vae_pth is not None:
+            if not os.path.exists(vae_pth):
+                raise FileNotFoundError(f"vae_pth {vae_pth} does not exist (pass vae_pth=None for random-init weights)")
+            from .checkpoint import load_vae_pth
+            load_vae_pth(self.model, vae_pth, device=device)        # strict, like wan_vae.py:607-616
 
     def encode(self, videos):
         """videos: iterable of [C, T, H, W] -> latent float (wan_vae.py:648-657)."""

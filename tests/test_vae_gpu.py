@@ -155,7 +155,7 @@ def _model(g):
     return cfg, sd, m
 
 
-@pytest.mark.parametrize("name", ["vae_tiny.npz", "vae_tiny2.npz"])
+@pytest.mark.parametrize("name", ["vae_tiny.npz", "vae_tiny2.npz", "vae_dim96.npz"])
 def test_vae_encode_vs_reference_golden(golden_dir, name):
     g = _load(golden_dir, name)
     cfg, sd, m = _model(g)
@@ -167,7 +167,7 @@ def test_vae_encode_vs_reference_golden(golden_dir, name):
     torch.testing.assert_close(mu1, g["mu1"], rtol=3e-2, atol=3e-2)
 
 
-@pytest.mark.parametrize("name", ["vae_tiny.npz", "vae_tiny2.npz"])
+@pytest.mark.parametrize("name", ["vae_tiny.npz", "vae_tiny2.npz", "vae_dim96.npz"])
 def test_vae_decode_vs_reference_golden(golden_dir, name):
     g = _load(golden_dir, name)
     cfg, sd, m = _model(g)

@@ -8,7 +8,7 @@ import torch
 
 from oracle import wan_vae_oracle as V
 
-FIXTURES = ["vae_tiny.npz", "vae_tiny2.npz"]      # dim 32, 9 frames 32x48; dim 48 (96 / 192-channel stages), 17 frames 40x24
+FIXTURES = ["vae_tiny.npz", "vae_tiny2.npz", "vae_dim96.npz"]      # dim 32, 9 frames 32x48; dim 48 (96 / 192-channel stages), 17 frames 40x24; dim 96 = the full model width (96 / 192 / 384), 9 frames 32x32
 
 
 def _load(golden_dir, name):
