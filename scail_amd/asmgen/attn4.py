@@ -1,0 +1,581 @@
+"""attn4 -- hand-scheduled flash attention for the SCAIL DiT self-attention on gfx950 (generator of csrc/attn4.s).
+
+Reference call site: F.scaled_dot_product_attention in sat/transformer_defaults.py:67-72 reached from
+dit_video_crossattn_sc_xc.py:1058-1105 (no mask, scale 1/sqrt(128)); same C entry point as the 8-wave kernel of
+csrc/attn.hip (scail_flash_attn_bf16), which selects this kernel for long key sequences (Lk % 64 == 0, no accumulate).
+
+Shape of the kernel (MI355X guide: "4-wave, one-wave-per-SIMD" attention structure):
+  * workgroup = 256 query rows = 4 waves x 64 rows; ONE wave per SIMD with the whole 512-register file:
+      AGPR  a[0:127]   O^T accumulators  [4 d-blocks][2 row-blocks] x 16
+            a[128:191] Q fragments       [2 row-blocks][8 k-steps] x 4   (loaded once)
+            a[192:255] K fragments of the next key tile [2 key-blocks][8 k-steps] x 4
+      VGPR  v[0:63] / v[64:127]  two score tiles S (64 keys x 64 rows): the tile being exponentiated and the tile the QK^T
+            MFMAs are writing; the bf16 P fragments overwrite the score registers they came from
+            v[128:191] V^T fragments [4 d-blocks][4 k-steps] x 4,  v[192:] addresses, softmax state, temporaries
+  * MFMA formulation identical to attn.hip: S^T = K Q^T (lane = query row, registers = keys), O^T += V^T P^T with the SAME
+    lane's score registers as B operand (V^T stored with key bits 2<->3 swapped inside 16-key groups: scail_transpose_v).
+  * K / V^T tiles of 64 keys arrive by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction, XOR-swizzled on the
+    SOURCE address, same involution on the fragment reads) into rings of RD slots, K RD+1 tiles ahead and V^T RD-1; one
+    s_barrier per tile; counted vmcnt leaves (RD-2) tiles of DMA in flight across it.
+  * software pipeline per tile t (64 MFMAs):  phase A: QK^T(t+1)  ||  exp / sum / bf16-pack of S(t)  ||  V^T(t) fragment reads
+                                              phase B: P(t) V(t)  ||  row max of S(t+1)             ||  K(t+2) fragment reads
+    The non-MFMA instructions are placed into the gaps between MFMAs by sched.schedule (<= CAP per gap).
+  * online softmax with a LAZY running max: the O / l rescale (an out-of-line subroutine) runs only when some row's tile
+    maximum exceeds the running maximum by more than ``thr`` (raw-score units; kernel argument): exact arithmetic otherwise
+    (P <= 2^(thr * scale * log2 e)), and on random or real data it fires once per block.
+
+Limits of this version (the C entry falls back to the 8-wave kernel otherwise): Lk % 64 == 0, head_dim 128, no accumulate;
+Lq * q_rs, Lk * k_rs and 128 * Lkp below 2^31 elements (32-bit byte offsets inside one (batch, head) slice).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import List
+
+from . import isa, sched
+from .isa import A, S, V, I32, F32, Neg, VCC, EXEC, M0, Instr
+
+KERNARG_SIZE = 136
+KERNARG_FMT = "<4Q9q5iff4x"          # q k vt o | q_bs q_rs k_ss k_bs k_rs vt_ss vt_bs o_bs o_rs | heads Lq Lk Lkp n_seg | sl2 thr
+
+
+def pack_args(q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr) -> bytes:
+    b = struct.pack(KERNARG_FMT, q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr)
+    assert len(b) == KERNARG_SIZE
+    return b
+
+
+@dataclass
+class Cfg:
+    rd: int = 4            # ring depth (2 or 4); unroll = max(2, rd)
+    cap: int = 5           # fillers per MFMA gap
+    lookahead: float = 1.0
+    name: str = "scail_attn4"
+
+    @property
+    def unroll(self): return max(2, self.rd)
+    @property
+    def pk(self): return self.rd + 1       # K prefetch distance (tiles)
+    @property
+    def pv(self): return self.rd - 1
+    @property
+    def vm_keep(self): return 8 * (self.pk - 3)     # DMA instructions left in flight across the per-tile barrier
+    @property
+    def lds_bytes(self): return 2 * self.rd * 16384
+
+
+# ---- register map -------------------------------------------------------------------------------
+def O(db, rb): return A((db * 2 + rb) * 16, 16)
+def Qf(rb, ks): return A(128 + (rb * 8 + ks) * 4, 4)
+def Kf(kb, ks): return A(192 + (kb * 8 + ks) * 4, 4)
+def Sb(i, kb, rb): return V(i * 64 + (kb * 2 + rb) * 16, 16)
+def Vtf(db, ks): return V(128 + (db * 4 + ks) * 4, 4)
+
+
+KADDR = [V(192 + i) for i in range(8)]
+VADDR = [V(200 + i) for i in range(4)]
+KDMA = [V(204 + i) for i in range(4)]
+VDMA = [V(208 + i) for i in range(4)]
+M_ = [V(212), V(213)]
+MC = [V(214), V(215)]
+L_ = [[V(216 + rb * 4 + j) for j in range(4)] for rb in range(2)]
+MX = [V(224), V(225)]
+ALPHA = [V(226), V(227)]
+TMP = [V(228 + i) for i in range(20)]        # v228..v247
+OOFF = [V(248), V(249)]
+ROW = [V(250), V(251)]
+LANE, VT0, VT1, VT2 = V(252), V(253), V(254), V(255)
+
+# SGPRs
+S_KARG = S(0, 2)
+S_QB, S_H, S_B = S(2), S(3), S(4)
+S_Q, S_K, S_VT, S_O = S(8, 2), S(10, 2), S(12, 2), S(14, 2)
+S_QBS, S_QRS, S_KSS, S_KBS = S(16, 2), S(18, 2), S(20, 2), S(22, 2)
+S_KRS, S_VTSS, S_VTBS, S_OBS = S(24, 2), S(26, 2), S(28, 2), S(30, 2)
+S_ORS = S(32, 2)
+S_HEADS, S_LQ, S_LK, S_LKP, S_NSEG, S_C, S_THR = S(36), S(37), S(38), S(39), S(40), S(41), S(42)
+S_KRSRC, S_VRSRC = S(44, 4), S(48, 4)
+S_KOFF, S_VOFF, S_KSTEP, S_VSTEP, S_KMAX, S_VMAX = S(52), S(53), S(54), S(55), S(56), S(57)
+S_T, S_NT, S_SEG, S_WAVE = S(58), S(59), S(60), S(61)
+S_KLDS, S_VLDS = S(62), S(63)
+S_RET = S(64, 2)
+ST = [S(66 + i) for i in range(14)]          # s66..s79 temporaries
+S_SAVE = S(80, 2)
+
+
+class Gen:
+    def __init__(self, cfg: Cfg):
+        self.cfg = cfg
+        self.out: List[Instr] = []
+
+    def emit(self, x):
+        if isinstance(x, Instr):
+            self.out.append(x)
+        else:
+            self.out.extend(x)
+
+    # =============================================================================================
+    # building blocks (each returns a list in PROGRAM ORDER)
+    # =============================================================================================
+    def qk_mfmas(self, nxt: int) -> List[Instr]:
+        """S_next[kb][rb] = sum_ks K[kb][ks] x Q[rb][ks]  (key-block major: S[0][*] completes after 16 MFMAs)."""
+        out = []
+        for kb in range(2):
+            for ks in range(8):
+                for rb in range(2):
+                    d = Sb(nxt, kb, rb)
+                    out.append(isa.mfma(d, Kf(kb, ks), Qf(rb, ks), I32(0) if ks == 0 else d, tag="qk"))
+        return out
+
+    def pv_mfmas(self, cur: int) -> List[Instr]:
+        """O[db][rb] += V^T[db][ks] x P[rb][ks];  P[rb][ks] = S_cur[ks >> 1][rb] registers 8 (ks & 1) .. +3 (packed bf16)."""
+        out = []
+        for ks in range(4):
+            for db in range(4):
+                for rb in range(2):
+                    p = Sb(cur, ks >> 1, rb).sub(8 * (ks & 1), 4)
+                    out.append(isa.mfma(O(db, rb), Vtf(db, ks), p, O(db, rb), tag="pv"))
+        return out
+
+    def softmax_finish(self, cur: int, t0: float, t1: float) -> List[Instr]:
+        """p = exp2(s c - m c), l += p, pack pairs to bf16 in place (k-step major = the order P.V consumes them)."""
+        out = []
+        for ks in range(4):
+            kb, r0 = ks >> 1, 8 * (ks & 1)
+            for rb in range(2):
+                s = Sb(cur, kb, rb)
+                for j in range(8):
+                    r = s.sub(r0 + j)
+                    out.append(isa.vop("v_fma_f32", r, r, S_C, Neg(MC[rb])))
+                    out.append(isa.vop("v_exp_f32", r, r))
+                    out.append(isa.vop("v_add_f32", L_[rb][j & 3], L_[rb][j & 3], r))
+                for i in range(4):
+                    out.append(isa.vop("v_cvt_pk_bf16_f32", s.sub(r0 + i), s.sub(r0 + 2 * i), s.sub(r0 + 2 * i + 1)))
+        n = len(out)
+        for k, ins in enumerate(out):
+            ins.target_gap = t0 + (t1 - t0) * k / n
+        return out
+
+    def rowmax(self, nxt: int, t_kb0: float, t_kb1: float, t_fin: float) -> List[Instr]:
+        """MX[rb] = max over the 64 keys of S_next (both lanes of the row), then VCC = any(MX - M > thr)."""
+        out = []
+        for rb in range(2):
+            acc = TMP[rb]
+            for kb, tg in ((0, t_kb0), (1, t_kb1)):
+                s = Sb(nxt, kb, rb)
+                vals = [s.sub(r) for r in range(16)]
+                grp: List[Instr] = []
+                if kb == 0:
+                    grp.append(isa.vop("v_max3_f32", acc, vals[0], vals[1], vals[2]))
+                    vals = vals[3:]
+                while len(vals) >= 2:
+                    grp.append(isa.vop("v_max3_f32", acc, acc, vals[0], vals[1]))
+                    vals = vals[2:]
+                if vals:
+                    grp.append(isa.vop("v_max_f32", acc, acc, vals[0]))
+                for k, ins in enumerate(grp):
+                    ins.target_gap = tg + rb * 0.4 + k * 1.0
+                out.extend(grp)
+        fin = []
+        for rb in range(2):
+            acc, cp = TMP[rb], TMP[2 + rb]
+            fin.append(isa.vop("v_mov_b32", cp, acc))
+            fin.append(isa.permlane32_swap(acc, cp))                                  # acc = {lo, lo}, cp = {hi, hi}
+            fin.append(isa.vop("v_max_f32", MX[rb], acc, cp))
+            fin.append(isa.vop("v_sub_f32", TMP[4 + rb], MX[rb], M_[rb]))
+        fin.append(isa.vop("v_max_f32", TMP[4], TMP[4], TMP[5]))
+        fin.append(isa.v_cmp("v_cmp_gt_f32", TMP[4], S_THR))
+        for k, ins in enumerate(fin):
+            ins.target_gap = t_fin + 0.5 * k
+        return out + fin
+
+    def v_frag_reads(self, slot: int, t0: float, step: float) -> List[Instr]:
+        out = []
+        k = 0
+        for ks in range(4):
+            for db in range(4):
+                out.append(isa.ds_read_b128(Vtf(db, ks), VADDR[ks], slot * 16384 + db * 4096, target_gap=t0 + step * k))
+                k += 1
+        return out
+
+    def k_frag_reads(self, slot: int, t0: float, step: float) -> List[Instr]:
+        out = []
+        k = 0
+        for kb in range(2):
+            for ks in range(8):
+                out.append(isa.ds_read_b128(Kf(kb, ks), KADDR[ks], slot * 16384 + kb * 8192, target_gap=t0 + step * k))
+                k += 1
+        return out
+
+    def dma_tile(self, which: str, slot: int, t0: float, step: float) -> List[Instr]:
+        """4 LDS-DMA pieces of this wave for one K or V^T tile, then advance (and clamp) the stream offset."""
+        lds, offs, rsrc, off, stp, mx = ((S_KLDS, KDMA, S_KRSRC, S_KOFF, S_KSTEP, S_KMAX) if which == "k" else
+                                         (S_VLDS, VDMA, S_VRSRC, S_VOFF, S_VSTEP, S_VMAX))
+        out = [isa.sop("s_add_u32", M0, lds, I32(slot * 16384), target_gap=t0 - 0.6)]
+        for i in range(4):
+            out.append(isa.buffer_load_lds(offs[i], rsrc, off, 1024 * i, target_gap=t0 + step * i, tag="dma"))
+        out.append(isa.sop("s_add_u32", off, off, stp, target_gap=t0 + step * 3 + 0.3))
+        out.append(isa.sop("s_min_u32", off, off, mx, target_gap=t0 + step * 3 + 0.6))
+        return out
+
+    # ---------------------------------------------------------------------------------------------
+    def iter_block(self, p: int, tail: bool) -> List[Instr]:
+        """One pipelined tile iteration at unroll position p (tile t = p mod unroll), scheduled."""
+        c = self.cfg
+        cur, nxt = p & 1, (p + 1) & 1
+        rd = c.rd
+        blk: List[Instr] = []
+        if not tail:
+            blk += self.dma_tile("k", (p + c.pk) % rd, 1.0, 2.0)
+            blk += self.dma_tile("v", (p + c.pv) % rd, 9.0, 2.0)
+        blk += self.v_frag_reads(p % rd, 2.0 if not tail else 0.0, 1.5 if not tail else 1.0)
+        if not tail:
+            blk += self.qk_mfmas(nxt)
+        blk += self.softmax_finish(cur, 0.0, 54.0 if not tail else 20.0)
+        blk += self.pv_mfmas(cur)
+        if not tail:
+            blk += self.k_frag_reads((p + 2) % rd, 18.0, 2.0)
+            blk += self.rowmax(nxt, 21.0, 38.0, 52.0)
+        seq = sched.schedule(blk, cap=c.cap, lookahead=c.lookahead)
+        seq = sched.insert_lgkm_waits(seq)
+        return seq
+
+    def iter_end(self, p: int, kind: str) -> List[Instr]:
+        """block end of a full iteration: fragment reads landed, DMA of the tile needed next landed, workgroup barrier, then the
+        (rare) lazy-rescale call."""
+        c = self.cfg
+        skip = f"L_{kind}{p}_norescale"
+        return [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep), isa.barrier(),
+                isa.branch("s_cbranch_vccz", skip), isa.s_call(S_RET, "L_rescale"), isa.label(skip)]
+
+    # =============================================================================================
+    def rescale_sub(self) -> List[Instr]:
+        out = [isa.label("L_rescale"), isa.nop(15), isa.nop(15)]
+        for rb in range(2):
+            mn, d = TMP[6 + rb], TMP[8 + rb]
+            out += [isa.vop("v_max_f32", mn, M_[rb], MX[rb]),
+                    isa.vop("v_sub_f32", d, M_[rb], mn),
+                    isa.vop("v_mul_f32", d, d, S_C),
+                    isa.vop("v_exp_f32", ALPHA[rb], d),
+                    isa.vop("v_mov_b32", M_[rb], mn),
+                    isa.vop("v_mul_f32", MC[rb], mn, S_C)]
+            for j in range(4):
+                out.append(isa.vop("v_mul_f32", L_[rb][j], L_[rb][j], ALPHA[rb]))
+        k = 0
+        for db in range(4):
+            for rb in range(2):
+                for r in range(16):
+                    t = TMP[10 + (k % 8)]
+                    k += 1
+                    o = O(db, rb).sub(r)
+                    out += [isa.vop("v_accvgpr_read_b32", t, o), isa.vop("v_mul_f32", t, t, ALPHA[rb]),
+                            isa.vop("v_accvgpr_write_b32", o, t)]
+        out.append(isa.nop(3))
+        out.append(Instr("s_setpc_b64", [], [S_RET], cls=isa.BRANCH))
+        return sched.pad_hazards(out[:1]) + sched.pad_hazards(out[1:])
+
+    # =============================================================================================
+    def addr64_madd(self, ptr: isa.Reg, stride64: isa.Reg, mult: isa.Reg, shift: int) -> List[Instr]:
+        """ptr(64) += (stride64 << shift) * mult  (mult: 32-bit SGPR)."""
+        t0, t1, t2, t3 = ST[0], ST[1], ST[2], ST[3]
+        st = S(ST[4].idx, 2)
+        return [isa.sop("s_lshl_b64", st, stride64, I32(shift)),
+                isa.sop("s_mul_i32", t0, st.sub(0), mult), isa.sop("s_mul_hi_u32", t1, st.sub(0), mult),
+                isa.sop("s_mul_i32", t2, st.sub(1), mult), isa.sop("s_add_u32", t1, t1, t2),
+                isa.sop("s_add_u32", ptr.sub(0), ptr.sub(0), t0), isa.sop("s_addc_u32", ptr.sub(1), ptr.sub(1), t1)]
+
+    def prologue(self) -> List[Instr]:
+        c = self.cfg
+        o: List[Instr] = [isa.label(c.name)]
+        o += [isa.s_load(8, S(8, 8), S_KARG, 0), isa.s_load(8, S(16, 8), S_KARG, 32), isa.s_load(8, S(24, 8), S_KARG, 64),
+              isa.s_load(2, S_ORS, S_KARG, 96), isa.s_load(8, S(36, 8), S_KARG, 104),
+              isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", VT0, I32(6), V(0)),
+              isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, VT0)]
+        # ---- per (batch, head) base pointers ----
+        o += self.addr64_madd(S_Q, S_QBS, S_B, 1) + self.addr64_madd(S_K, S_KBS, S_B, 1)
+        o += self.addr64_madd(S_VT, S_VTBS, S_B, 1) + self.addr64_madd(S_O, S_OBS, S_B, 1)
+        hb = ST[6]
+        o += [isa.sop("s_lshl_b32", hb, S_H, I32(8))]                              # h * 128 elements * 2 bytes
+        for ptr in (S_Q, S_K, S_O):
+            o += [isa.sop("s_add_u32", ptr.sub(0), ptr.sub(0), hb), isa.sop("s_addc_u32", ptr.sub(1), ptr.sub(1), I32(0))]
+        # vt += h * 128 * Lkp * 2 bytes
+        o += [isa.sop("s_lshl_b32", ST[7], S_LKP, I32(8)), isa.sop("s_mul_i32", ST[8], ST[7], S_H), isa.sop("s_mul_hi_u32", ST[9], ST[7], S_H),
+              isa.sop("s_add_u32", S_VT.sub(0), S_VT.sub(0), ST[8]), isa.sop("s_addc_u32", S_VT.sub(1), S_VT.sub(1), ST[9])]
+        # ---- buffer descriptors (raw, no bounds: every address is inside the slice by construction) ----
+        for rs, ptr in ((S_KRSRC, S_K), (S_VRSRC, S_VT)):
+            o += [isa.sop("s_mov_b32", rs.sub(0), ptr.sub(0)), isa.sop("s_and_b32", rs.sub(1), ptr.sub(1), I32(0xFFFF)),
+                  isa.sop("s_mov_b32", rs.sub(2), I32(0x7FFFFFFF)), isa.sop("s_mov_b32", rs.sub(3), I32(0x00020000))]
+        # ---- scalars ----
+        krsb, lkpb = ST[10], ST[11]
+        o += [isa.sop("s_lshl_b32", krsb, S_KRS.sub(0), I32(1)),                    # K row stride in bytes
+              isa.sop("s_lshl_b32", lkpb, S_LKP, I32(1)),                          # V^T row stride in bytes
+              isa.sop("s_lshl_b32", S_KSTEP, krsb, I32(6)), isa.sop("s_mov_b32", S_VSTEP, I32(128)),
+              isa.sop("s_lshr_b32", S_NT, S_LKP, I32(6)), isa.sop("s_sub_u32", ST[12], S_NT, I32(1)),
+              isa.sop("s_mul_i32", S_KMAX, ST[12], S_KSTEP), isa.sop("s_lshl_b32", S_VMAX, ST[12], I32(7)),
+              isa.sop("s_lshl_b32", S_KLDS, S_WAVE, I32(12)), isa.sop("s_add_u32", S_VLDS, S_KLDS, I32(c.rd * 16384)),
+              isa.sop("s_mov_b32", S_SEG, I32(0))]
+        # ---- lane geometry ----
+        ql, g = VT1, VT2
+        o += [isa.vop("v_and_b32", ql, I32(31), LANE), isa.vop("v_lshrrev_b32", g, I32(5), LANE)]
+        t = TMP
+        # K fragment addresses: row ql (256 B), 16-byte chunk (2 ks + g) ^ (ql & 15)
+        o += [isa.vop("v_and_b32", t[0], I32(15), ql), isa.vop("v_lshlrev_b32", t[1], I32(8), ql)]
+        for ks in range(8):
+            o += [isa.vop("v_or_b32", t[2], I32(2 * ks), g), isa.vop("v_xor_b32", t[2], t[2], t[0]),
+                  isa.vop("v_lshl_add_u32", KADDR[ks], t[2], I32(4), t[1])]
+        # V^T fragment addresses: row ql (128 B), chunk (2 ks + g) ^ ((ql >> 1) & 7), in the V ring
+        o += [isa.vop("v_lshrrev_b32", t[0], I32(1), ql), isa.vop("v_and_b32", t[0], I32(7), t[0]),
+              isa.vop("v_lshlrev_b32", t[1], I32(7), ql), isa.vop("v_add_u32", t[1], I32(c.rd * 16384), t[1])]
+        for ks in range(4):
+            o += [isa.vop("v_or_b32", t[2], I32(2 * ks), g), isa.vop("v_xor_b32", t[2], t[2], t[0]),
+                  isa.vop("v_lshl_add_u32", VADDR[ks], t[2], I32(4), t[1])]
+        # LDS-DMA source offsets.  K piece i of this wave: tile rows 16 w + 4 i + (lane >> 4), chunk (lane & 15) ^ (row & 15)
+        o += [isa.vop("v_lshrrev_b32", t[0], I32(4), LANE), isa.vop("v_and_b32", t[1], I32(15), LANE),
+              isa.vop("v_lshlrev_b32", t[3], I32(4), S_WAVE)]       # 16 w
+        for i in range(4):
+            o += [isa.vop("v_add_u32", t[4], I32(4 * i), t[0]),                     # row & 15
+                  isa.vop("v_xor_b32", t[5], t[1], t[4]), isa.vop("v_add_u32", t[6], t[4], t[3]),
+                  isa.vop("v_mul_lo_u32", t[6], t[6], krsb), isa.vop("v_lshl_add_u32", t[6], t[5], I32(4), t[6]),
+                  isa.vop("v_subrev_u32", KDMA[i], I32(1024 * i), t[6])]
+        # V^T piece i: rows 32 w + 8 i + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)
+        o += [isa.vop("v_lshrrev_b32", t[0], I32(3), LANE), isa.vop("v_and_b32", t[1], I32(7), LANE),
+              isa.vop("v_lshlrev_b32", t[3], I32(5), S_WAVE)]       # 32 w
+        for i in range(4):
+            o += [isa.vop("v_add_u32", t[4], I32(8 * i), t[0]), isa.vop("v_add_u32", t[6], t[4], t[3]),
+                  isa.vop("v_lshrrev_b32", t[5], I32(1), t[6]), isa.vop("v_and_b32", t[5], I32(7), t[5]),
+                  isa.vop("v_xor_b32", t[5], t[1], t[5]),
+                  isa.vop("v_mul_lo_u32", t[6], t[6], lkpb), isa.vop("v_lshl_add_u32", t[6], t[5], I32(4), t[6]),
+                  isa.vop("v_subrev_u32", VDMA[i], I32(1024 * i), t[6])]
+        # query rows of this lane: row = 256 qb + 64 w + 32 rb + ql ; Q loads straight into the accumulator file
+        qrsb, orsb, lqm1 = ST[12], ST[13], ST[9]
+        o += [isa.sop("s_lshl_b32", qrsb, S_QRS.sub(0), I32(1)), isa.sop("s_lshl_b32", orsb, S_ORS.sub(0), I32(1)),
+              isa.sop("s_sub_u32", lqm1, S_LQ, I32(1)),
+              isa.sop("s_lshl_b32", ST[8], S_QB, I32(8)), isa.sop("s_lshl_b32", ST[7], S_WAVE, I32(6)),
+              isa.sop("s_add_u32", ST[8], ST[8], ST[7])]
+        for rb in range(2):
+            o += [isa.vop("v_add_u32", ROW[rb], ST[8], ql)]
+            if rb:
+                o += [isa.vop("v_add_u32", ROW[rb], I32(32), ROW[rb])]
+            o += [isa.vop("v_min_u32", t[0], ROW[rb], lqm1), isa.vop("v_mul_lo_u32", t[0], t[0], qrsb),
+                  isa.vop("v_lshl_add_u32", t[1 + rb], g, I32(4), t[0]),
+                  isa.vop("v_mul_lo_u32", t[3], ROW[rb], orsb), isa.vop("v_lshl_add_u32", OOFF[rb], g, I32(3), t[3])]
+        for rb in range(2):
+            for ks in range(8):
+                o.append(isa.global_load(4, Qf(rb, ks), t[1 + rb], 32 * ks, saddr=S_Q))
+        # softmax state
+        for i in range(128):
+            o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
+        for rb in range(2):
+            o += [isa.vop("v_mov_b32", M_[rb], F32(-1e30)), isa.vop("v_mul_f32", MC[rb], M_[rb], S_C)]
+            for j in range(4):
+                o.append(isa.vop("v_mov_b32", L_[rb][j], I32(0)))
+        return sched.pad_hazards(o)
+
+    def segment_start(self) -> List[Instr]:
+        """(Re)start the tile pipeline on the current key segment: first DMAs, scores and row max of tile 0."""
+        c = self.cfg
+        o: List[Instr] = [isa.label("L_seg_start"), isa.sop("s_mov_b32", S_KOFF, I32(0)), isa.sop("s_mov_b32", S_VOFF, I32(0)),
+                          isa.sop("s_mov_b32", S_T, I32(0))]
+        for j in range(c.rd):
+            o += self.dma_tile("k", j % c.rd, 0, 0)
+        for j in range(c.pv):
+            o += self.dma_tile("v", j % c.rd, 0, 0)
+        o += [isa.waitcnt(vmcnt=0), isa.barrier()]
+        o += self.k_frag_reads(0, 0, 0)
+        o += [isa.waitcnt(lgkmcnt=0), isa.barrier()]
+        o += self.dma_tile("k", c.rd % c.rd, 0, 0)                 # K(rd) into slot 0, whose fragments are in registers now
+        o += self.qk_mfmas(0)
+        o += self.k_frag_reads(1 % c.rd, 0, 0)
+        o += [isa.nop(15)]
+        o += self.rowmax(0, 0, 0, 0)
+        o += [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep if c.rd > 2 else 0), isa.barrier(),
+              isa.branch("s_cbranch_vccz", "L_seg_norescale"), isa.s_call(S_RET, "L_rescale"), isa.label("L_seg_norescale")]
+        return sched.pad_hazards(sched.insert_lgkm_waits(o))
+
+    def loops(self) -> List[Instr]:
+        c = self.cfg
+        U = c.unroll
+        o: List[Instr] = []
+        r = ST[0]
+        # dispatch: R = T - t remaining tiles (t multiple of U);  R >= U + 2 -> U full iterations in the hot loop
+        o += [isa.label("L_dispatch"), isa.sop("s_sub_u32", r, S_NT, S_T), isa.sop("s_cmp_ge_u32", None, r, I32(U + 2)),
+              isa.branch("s_cbranch_scc0", "L_rem0")]
+        o += [isa.label("L_hot")]
+        for p in range(U):
+            o += self.iter_block(p, tail=False) + self.iter_end(p, "hot")
+        o += [isa.sop("s_add_u32", S_T, S_T, I32(U)), isa.branch("s_branch", "L_dispatch")]
+        # remainder chain: positions 0 .. U-1, each either the last tile (-> tail) or one more full iteration
+        for p in range(U):
+            o += [isa.label(f"L_rem{p}"), isa.sop("s_sub_u32", r, S_NT, S_T), isa.sop("s_cmp_eq_u32", None, r, I32(1)),
+                  isa.branch("s_cbranch_scc1", f"L_tail{p}")]
+            o += self.iter_block(p, tail=False) + self.iter_end(p, "rem")
+            o += [isa.sop("s_add_u32", S_T, S_T, I32(1))]
+        o += [isa.branch("s_branch", "L_tail0")]
+        for p in range(U):
+            o += [isa.label(f"L_tail{p}")] + self.iter_block(p, tail=True)
+            o += [isa.nop(15), isa.nop(15), isa.waitcnt(vmcnt=0), isa.waitcnt(lgkmcnt=0), isa.barrier(), isa.branch("s_branch", "L_seg_end")]
+        return o
+
+    def segment_end_and_epilogue(self) -> List[Instr]:
+        o: List[Instr] = [isa.label("L_seg_end"), isa.sop("s_add_u32", S_SEG, S_SEG, I32(1)), isa.sop("s_cmp_lt_u32", None, S_SEG, S_NSEG),
+                          isa.branch("s_cbranch_scc0", "L_epilogue")]
+        # next segment: advance both descriptors by the segment strides (bytes, 64-bit)
+        st = S(ST[4].idx, 2)
+        for rs, ss in ((S_KRSRC, S_KSS), (S_VRSRC, S_VTSS)):
+            o += [isa.sop("s_lshl_b64", st, ss, I32(1)), isa.sop("s_add_u32", rs.sub(0), rs.sub(0), st.sub(0)),
+                  isa.sop("s_addc_u32", rs.sub(1), rs.sub(1), st.sub(1))]
+        o += [isa.branch("s_branch", "L_seg_start")]
+        # ---- epilogue: O / l -> bf16, rows of this lane: d = 32 db + 8 rr + 4 g + e ----
+        e: List[Instr] = [isa.label("L_epilogue")]
+        inv = [TMP[0], TMP[1]]
+        for rb in range(2):
+            a, b = TMP[2], TMP[3]
+            e += [isa.vop("v_add_f32", L_[rb][0], L_[rb][0], L_[rb][1]), isa.vop("v_add_f32", L_[rb][2], L_[rb][2], L_[rb][3]),
+                  isa.vop("v_add_f32", a, L_[rb][0], L_[rb][2]), isa.vop("v_mov_b32", b, a),
+                  isa.permlane32_swap(a, b), isa.vop("v_add_f32", a, a, b), isa.vop("v_rcp_f32", inv[rb], a)]
+        for rb in range(2):
+            e += [isa.v_cmp("v_cmp_lt_u32", ROW[rb], S_LQ), Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+            k = 0
+            for db in range(4):
+                for rr in range(4):
+                    base = 4 + 6 * (k % 2)
+                    k += 1
+                    f = [TMP[base + i] for i in range(4)]
+                    w = V(TMP[base + 4].idx, 2)
+                    assert w.idx % 2 == 0
+                    for i in range(4):
+                        e += [isa.vop("v_accvgpr_read_b32", f[i], O(db, rb).sub(4 * rr + i)), isa.vop("v_mul_f32", f[i], f[i], inv[rb])]
+                    e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
+                          isa.global_store(2, OOFF[rb], w, 64 * db + 16 * rr, saddr=S_O, extra_reads=[EXEC])]
+            e += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+        e += [isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
+        return o + sched.pad_hazards(e)
+
+    # =============================================================================================
+    def program(self) -> List[Instr]:
+        prog = self.prologue() + self.segment_start() + self.loops() + self.segment_end_and_epilogue() + self.rescale_sub()
+        pre = f"L_{self.cfg.name}"                     # labels are per kernel (several variants may share one .s file)
+        for i in prog:
+            if i.label and i.label.startswith("L_"):
+                new = pre + i.label[1:]
+                if getattr(i, "text", None):
+                    i.text = i.text.replace(i.label, new)
+                i.label = new
+        return prog
+
+
+HEAD = """// GENERATED by scail_amd/asmgen/attn4.py -- do not edit; regenerate with `python -m scail_amd.asmgen.attn4`.
+// Hand-scheduled 4-wave flash attention for gfx950; see the generator's docstring for the register map and the pipeline.
+\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.amdhsa_code_object_version 6
+"""
+
+
+def kernel_text(c: Cfg) -> str:
+    body = isa.render(Gen(c).program())
+    return f"""// ---- kernel {c.name}: ring depth {c.rd}, <= {c.cap} fillers per MFMA gap, lookahead {c.lookahead} ----
+\t.text
+\t.protected\t{c.name}
+\t.globl\t{c.name}
+\t.p2align\t8
+\t.type\t{c.name},@function
+{body}.L{c.name}_end:
+\t.size\t{c.name}, .L{c.name}_end-{c.name}
+\t.section\t.rodata,"a",@progbits
+\t.p2align\t6, 0x0
+\t.amdhsa_kernel {c.name}
+\t\t.amdhsa_group_segment_fixed_size {c.lds_bytes}
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size {KERNARG_SIZE}
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 1
+\t\t.amdhsa_system_sgpr_workgroup_id_z 1
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr 512
+\t\t.amdhsa_next_free_sgpr 96
+\t\t.amdhsa_accum_offset 256
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_round_mode_32 0
+\t\t.amdhsa_float_round_mode_16_64 0
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t.end_amdhsa_kernel
+"""
+
+
+def metadata(cfgs) -> str:
+    ks = "".join(f"""  - .agpr_count:     256
+    .args:
+      - .offset:         0
+        .size:           {KERNARG_SIZE}
+        .value_kind:     by_value
+    .group_segment_fixed_size: {c.lds_bytes}
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: {KERNARG_SIZE}
+    .max_flat_workgroup_size: 256
+    .name:           {c.name}
+    .private_segment_fixed_size: 0
+    .sgpr_count:     102
+    .sgpr_spill_count: 0
+    .symbol:         {c.name}.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     512
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+""" for c in cfgs)
+    return f"""\t.amdgpu_metadata
+---
+amdhsa.kernels:
+{ks}amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+amdhsa.version:
+  - 1
+  - 2
+...
+\t.end_amdgpu_metadata
+"""
+
+
+def assembly(cfgs) -> str:
+    return HEAD + "".join(kernel_text(c) for c in cfgs) + metadata(cfgs)
+
+
+DEFAULT = Cfg(rd=4, cap=5, name="scail_attn4")
+
+
+def variant_cfgs():
+    """A/B variants for GPU tuning runs (ablation build only): ring depth x fillers per gap x lookahead."""
+    out = []
+    for rd in (4, 2):
+        for cap in (4, 5, 6, 8):
+            out.append(Cfg(rd=rd, cap=cap, name=f"scail_attn4_r{rd}c{cap}"))
+    out.append(Cfg(rd=4, cap=5, lookahead=3.0, name="scail_attn4_r4c5l3"))
+    out.append(Cfg(rd=4, cap=6, lookahead=3.0, name="scail_attn4_r4c6l3"))
+    return out
+
+
+def main():
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(os.path.dirname(here), "csrc", "attn4.s")
+    if "--variants" in sys.argv:
+        dst = sys.argv[sys.argv.index("--variants") + 1]
+        open(dst, "w").write(assembly([DEFAULT] + variant_cfgs()))
+        print(dst)
+        return
+    text = assembly([DEFAULT])
+    if "--check" in sys.argv:
+        sys.exit(0 if open(out).read() == text else 1)
+    if not os.path.exists(out) or open(out).read() != text:
+        open(out, "w").write(text)
+    print(out, len(text.splitlines()), "lines")
+
+
+if __name__ == "__main__":
+    main()

@@ -590,10 +590,59 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void flash_attn_swp_kernel(AttnPara
 // dependency of the softmax is exposed).
 // ================================================================================================
 
+// ================================================================================================
+// attn4: the hand-scheduled 4-wave kernel (one wave per SIMD, 64 query rows per wave, O / Q / K fragments in the accumulator
+// file, LDS-DMA rings, lazy rescale).  It is written as gfx950 assembly GENERATED by scail_amd/asmgen/attn4.py (csrc/attn4.s),
+// assembled by build.py into a code object whose bytes are embedded here and loaded with hipModuleLoadData on first use.
+// Kernel argument block = asmgen/attn4.py KERNARG_FMT.
+// ================================================================================================
+static const unsigned char k_attn4_hsaco[] = {
+#include "attn4_hsaco.inc"
+};
+struct Attn4Args {
+    const void* q; const void* k; const void* vt; void* o;
+    int64_t q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs;
+    int32_t heads, Lq, Lk, Lkp, n_seg;
+    float sl2, thr;
+    int32_t pad;
+};
+static_assert(sizeof(Attn4Args) == 136, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
+static hipModule_t g_attn4_module = nullptr;
+static std::string g_attn4_name = "scail_attn4";
+static hipFunction_t g_attn4_fn = nullptr;
+static float g_attn4_thr_log2 = 8.0f;      // lazy-rescale threshold: P <= 2^thr
+
+static int attn4_function(hipFunction_t* fn) {
+    if (g_attn4_module == nullptr) {
+        hipError_t e = hipModuleLoadData(&g_attn4_module, k_attn4_hsaco);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("attn4: hipModuleLoadData failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+    }
+    if (g_attn4_fn == nullptr) {
+        hipError_t e = hipModuleGetFunction(&g_attn4_fn, g_attn4_module, g_attn4_name.c_str());
+        if (e != hipSuccess) {
+            scail_set_error("attn4: kernel " + g_attn4_name + " is not in the embedded code object: " + hipGetErrorString(e));
+            return 2;
+        }
+    }
+    *fn = g_attn4_fn;
+    return 0;
+}
+
+// Shapes the 4-wave kernel covers (the 8-wave kernels above serve everything else): whole 64-key tiles, no accumulate, at least
+// a few tiles of keys, and every byte offset inside one (batch, head) slice below 2^31.
+static bool attn4_eligible(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate) {
+    const int64_t lim = (1ll << 30);     // elements -> 2^31 bytes
+    return Lk % 64 == 0 && Lk >= 512 && accumulate == 0 && Lq * q_rs < lim && Lk * k_rs < lim && Lq * o_rs < lim && 128 * Lk < lim;
+}
+
 int scail_gemm_tune(int v);
 int scail_gemm_group_m(int v);
 int scail_conv_tune(int v);
 static int g_attn_variant = 8 | (2 << 12);
+static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
 extern "C" int scail_tune_set(const char* knob, int value) {
     if (std::string(knob) == "attn_variant") {
 #ifndef SCAIL_ABLATIONS
@@ -611,6 +660,21 @@ extern "C" int scail_tune_set(const char* knob, int value) {
         }
         g_attn_variant = value;
         return 0;
+    }
+    if (std::string(knob) == "attn4") { g_attn4_mode = value != 0; return 0; }              // 0: 8-wave kernels only
+    if (std::string(knob) == "attn4_thr") { g_attn4_thr_log2 = (float)value; return 0; }    // lazy-rescale threshold (log2 units)
+    if (std::string(knob) == "attn4_kernel") {
+        // A/B of the generated schedules: value = ring depth * 100 + fillers per gap * 10 + (1: lookahead 3); 0 = default.
+        // The variants exist only in the code object of the ablation build (SCAIL_ABLATIONS=1).
+        std::string name = "scail_attn4";
+        if (value != 0) {
+            name += "_r" + std::to_string(value / 100) + "c" + std::to_string((value / 10) % 10);
+            if (value % 10) name += "l3";
+        }
+        g_attn4_name = name;
+        g_attn4_fn = nullptr;
+        hipFunction_t fn;
+        return attn4_function(&fn);
     }
     if (std::string(knob) == "gemm_tile") return scail_gemm_tune(value);
     if (std::string(knob) == "conv_halo") return scail_conv_tune(value);
@@ -654,6 +718,27 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
             }
         }
         attr_set = true;
+    }
+    if (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate)) {
+        hipFunction_t fn;
+        if (int rc = attn4_function(&fn)) return rc;
+        Attn4Args a;
+        a.q = q; a.k = k; a.vt = vt; a.o = o;
+        a.q_bs = q_bs; a.q_rs = q_rs; a.k_ss = k_ss; a.k_bs = k_bs; a.k_rs = k_rs; a.vt_ss = vt_ss; a.vt_bs = vt_bs;
+        a.o_bs = o_bs; a.o_rs = o_rs;
+        a.heads = (int32_t)heads; a.Lq = (int32_t)Lq; a.Lk = (int32_t)Lk; a.Lkp = (int32_t)Lkp; a.n_seg = (int32_t)n_seg;
+        a.sl2 = scale * 1.4426950408889634f;
+        a.thr = g_attn4_thr_log2 / a.sl2;
+        a.pad = 0;
+        size_t sz = sizeof(a);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((Lq + 255) / 256), (unsigned)heads, (unsigned)n_batch, 256, 1, 1, 0,
+                                             (hipStream_t)stream, nullptr, extra);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("attn4: launch failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        return 0;
     }
     AttnParams p;
     p.q = q; p.q_bs = q_bs; p.q_rs = q_rs;

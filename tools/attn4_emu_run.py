@@ -1,0 +1,107 @@
+"""Run the generated attn4 kernel (scail_amd/asmgen/attn4.py) in the CPU emulator (tools/asm_emu.py) on a small attention
+problem.  TEST INFRASTRUCTURE (used by tests/test_attn4_emu_cpu.py and for debugging the generator)."""
+from __future__ import annotations
+
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from scail_amd.asmgen import attn4, sched  # noqa: E402
+from tools import asm_emu as E  # noqa: E402
+
+
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    return E.bf16_round(x.astype(np.float32)).astype(np.uint16)
+
+
+def from_bf16_bits(h: np.ndarray) -> np.ndarray:
+    return E.bf16_to_f32(h.astype(np.uint32))
+
+
+def transpose_v(v_bits: np.ndarray, heads: int) -> np.ndarray:
+    """scail_transpose_v: (B, Lk, H*128) -> (B, H, 128, ceil64(Lk)), keys permuted inside each 16-group (bits 2 <-> 3), zero pad."""
+    B, Lk, D = v_bits.shape
+    Lkp = (Lk + 63) // 64 * 64
+    out = np.zeros((B, heads, 128, Lkp), dtype=np.uint16)
+    p = np.arange(Lkp)
+    key = (p & ~12) | (((p >> 3) & 1) << 2) | (((p >> 2) & 1) << 3)
+    valid = key < Lk
+    vv = v_bits.reshape(B, Lk, heads, 128)
+    out[:, :, :, p[valid]] = np.transpose(vv[:, key[valid]], (0, 2, 3, 1))
+    return out
+
+
+def reference(q, k, v, heads):
+    """fp64 softmax(q k^T / sqrt(128)) v on the bf16-rounded operands: q (B, Lq, H*128), k / v (B, Lk, H*128)."""
+    B, Lq, D = q.shape
+    out = np.zeros((B, Lq, D))
+    for b in range(B):
+        for h in range(heads):
+            sl = slice(h * 128, (h + 1) * 128)
+            s = q[b, :, sl].astype(np.float64) @ k[b, :, sl].astype(np.float64).T / math.sqrt(128.0)
+            s -= s.max(axis=1, keepdims=True)
+            p = np.exp(s)
+            out[b, :, sl] = (p / p.sum(axis=1, keepdims=True)) @ v[b, :, sl].astype(np.float64)
+    return out
+
+
+def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = True, thr_log2: float = 8.0, program=None):
+    """q (B, Lq, H*128) fp32; ksegs / vsegs: lists (one per segment) of (B, Lk, H*128) fp32.  Returns O (B, Lq, H*128) fp32
+    and the emulator statistics of the last workgroup."""
+    B, Lq, D = q.shape
+    n_seg = len(ksegs)
+    Lk = ksegs[0].shape[1]
+    assert Lk % 64 == 0
+    Lkp = Lk
+    mem = E.Memory(size=1 << 26)
+    qb = to_bf16_bits(q)
+    kb = np.stack([to_bf16_bits(x) for x in ksegs])                       # (S, B, Lk, D)
+    vt = np.stack([transpose_v(to_bf16_bits(x), heads) for x in vsegs])    # (S, B, H, 128, Lkp)
+    pq = mem.alloc("q", qb)
+    pk = mem.alloc("k", kb)
+    pvt = mem.alloc("vt", vt)
+    po = mem.alloc("o", np.zeros((B, Lq, D), dtype=np.uint16))
+    prog = program if program is not None else attn4.Gen(cfg).program()
+    sl2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+    args = attn4.pack_args(pq, pk, pvt, po, Lq * D, D, B * Lk * D, Lk * D, D, B * heads * 128 * Lkp, heads * 128 * Lkp, Lq * D, D,
+                           heads, Lq, Lk, Lkp, n_seg, sl2, thr_log2 / sl2)
+    stats = None
+    for b in range(B):
+        for h in range(heads):
+            for blk in range((Lq + 255) // 256):
+                emu = E.Emu(prog, mem, n_waves=4, lds_bytes=cfg.lds_bytes, lazy=lazy)
+                emu.launch(args, block_id=(blk, h, b))
+                stats = emu.waves[0].stats
+    return from_bf16_bits(mem.read_back("o")), stats
+
+
+def check_static(cfg: attn4.Cfg):
+    """hazard re-check of every scheduled block (loop bodies circularly)."""
+    g = attn4.Gen(cfg)
+    errs = []
+    for p in range(cfg.unroll):
+        body = g.iter_block(p, tail=False) + g.iter_end(p, "hot")
+        nxt = g.iter_block((p + 1) % cfg.unroll, tail=False)
+        errs += sched.check_hazards(body + nxt)
+        errs += sched.check_hazards(body + g.iter_block((p + 1) % cfg.unroll, tail=True))
+    errs += sched.check_hazards(g.prologue() + g.segment_start() + g.iter_block(0, tail=False))
+    return errs
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    cfg = attn4.Cfg(rd=int(os.environ.get("RD", "4")), cap=int(os.environ.get("CAP", "5")))
+    B, H, Lq, Lk = 1, 1, 256, int(os.environ.get("LK", "512"))
+    q = rng.standard_normal((B, Lq, H * 128)).astype(np.float32)
+    k = rng.standard_normal((B, Lk, H * 128)).astype(np.float32)
+    v = rng.standard_normal((B, Lk, H * 128)).astype(np.float32)
+    print("static hazards:", check_static(cfg)[:5])
+    o, st = run(cfg, q, [k], [v], H, lazy=os.environ.get("LAZY", "1") == "1")
+    ref = reference(from_bf16_bits(to_bf16_bits(q)), from_bf16_bits(to_bf16_bits(k)), from_bf16_bits(to_bf16_bits(v)), H)
+    print("max abs err", np.abs(o - ref).max(), "stats", st)
