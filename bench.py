@@ -304,12 +304,16 @@ def main():
     fl = step_flops(p, L, Lt, Lc)
     # HBM/fabric bytes per launch of the dominant kernel: measured offline with rocprofv3 --pmc (separate passes, guide
     # corrections; profiles/), committed with the git blob id of the kernel source it was measured on -- dropped (null)
-    # when attn.hip has changed since or the launch shape differs, so the field cannot go stale silently
+    # when the kernel source (the generated csrc/attn4.s, or attn.hip for shapes the 8-wave kernel serves) has changed since
+    # or the launch shape differs, so the field cannot go stale silently
     traffic = None
+    which = lib.load().scail_flash_attn_kernel_for(3 * p["hidden_size"], 3 * p["hidden_size"], p["hidden_size"], attn_Lq, L, 0)
+    ksrc = "attn4.s" if which == 4 else "attn.hip"
+    kname = "scail_attn4 (hand-scheduled 4-wave flash attention, csrc/attn4.s)" if which == 4 else "flash_attn_swp_kernel<4, 4, 0, 1>"
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["flash_attn_self"]
-        blob = _git_blob_sha1(os.path.join(ROOT, "scail_amd", "csrc", "attn.hip"))
-        if tr["shape"] == {"B": attn_B, "heads": attn_heads, "Lq": attn_Lq, "Lk": L} and tr.get("attn_hip_blob") == blob:
+        blob = _git_blob_sha1(os.path.join(ROOT, "scail_amd", "csrc", ksrc))
+        if tr["shape"] == {"B": attn_B, "heads": attn_heads, "Lq": attn_Lq, "Lk": L} and tr.get("source") == ksrc and tr.get("source_blob") == blob:
             traffic = tr["traffic_bytes"]
     except Exception:
         pass
@@ -323,7 +327,7 @@ def main():
                    "parallelism": f"sp{world}" + (f"-{sp_mode}" if sp is not None else ""), "cond_cache": False, "noise_tokens": Lnoise, "all_tokens_x_batch": 2 * L,
                    "step_tflop": fl / 1e12, "step_mfma_frac": fl / t_step / (world * PEAK_BF16_TFLOPS * 1e12),
                    "finite": finite, "x_abs_mean": x_abs_mean},
-        "roofline": {"bound": "mfma", "kernel": "flash_attn_swp_kernel<4, 4, 0, 1> (self-attention)", "achieved": ach,
+        "roofline": {"bound": "mfma", "kernel": kname + " (self-attention)", "achieved": ach,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
                      "traffic": traffic, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,
                      "launches_timed": len(timer.events.get("self_attn", []))},

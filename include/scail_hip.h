@@ -115,6 +115,14 @@ int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t q_rs,
                           int64_t n_batch, int64_t heads, int64_t Lq, int64_t Lk, int64_t n_seg,
                           float scale, int accumulate, void* stream);
 
+/*
+ * Which kernel scail_flash_attn_bf16 runs for a shape: 4 = the hand-scheduled 4-wave kernel (csrc/attn4.s, generated by
+ * scail_amd/asmgen/attn4.py: one wave per SIMD, 64 query rows per wave; needs Lk % 64 == 0, Lk >= 512, no accumulate and
+ * 32-bit byte offsets inside one (batch, head) slice), 8 = the 8-wave kernels of csrc/attn.hip (everything else: ragged key
+ * counts, the short text / CLIP key sets, accumulate).  Host-only query; lets a caller (and the tests) see the path taken.
+ */
+int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate);
+
 /* Sinusoidal timestep embedding in fp64 like sgm/modules/diffusionmodules/util.py:207-231:
  * out[b, :dim/2] = cos(t*f), out[b, dim/2:] = sin(t*f), f_j = exp(-ln(1e4) j/(dim/2)). fp32 out. */
 int scail_timestep_embedding(const float* t, float* out, int64_t n, int64_t dim, void* stream);

@@ -36,12 +36,32 @@ from typing import List
 from . import isa, sched
 from .isa import A, S, V, I32, F32, Neg, VCC, EXEC, M0, Instr
 
-KERNARG_SIZE = 136
-KERNARG_FMT = "<4Q9q5iff4x"          # q k vt o | q_bs q_rs k_ss k_bs k_rs vt_ss vt_bs o_bs o_rs | heads Lq Lk Lkp n_seg | sl2 thr
+KERNARG_SIZE = 152
+# q k vt o | q_bs q_rs k_ss k_bs k_rs vt_ss vt_bs o_bs o_rs | heads Lq Lk Lkp n_seg | sl2 thr | nqb magic_nqb magic_heads xcd_mode pad
+KERNARG_FMT = "<4Q9q5iffiIIi4x"
 
 
-def pack_args(q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr) -> bytes:
-    b = struct.pack(KERNARG_FMT, q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr)
+def magic31(d: int) -> int:
+    """x // d == (2 x * magic31(d)) >> 32 for the small x the kernel divides (x * d < 2^31)."""
+    return -(-(1 << 31) // d)
+
+
+def grid_blocks(n_batch: int, heads: int, Lq: int) -> int:
+    return ((Lq + 255) // 256) * heads * n_batch
+
+
+def xcd_mode(n_batch: int, heads: int) -> int:
+    """1: workgroup id -> (XCD = id % 8 works on (batch, head) pairs = XCD mod 8), so the 32 CUs of an XCD stream the SAME K / V^T
+    through their L2 (the hardware places consecutive workgroup ids on consecutive XCDs); needs pairs % 8 == 0."""
+    return 1 if (n_batch * heads) % 8 == 0 else 0
+
+
+def pack_args(q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=1,
+              mode=None) -> bytes:
+    nqb = (Lq + 255) // 256
+    mode = xcd_mode(n_batch, heads) if mode is None else mode
+    b = struct.pack(KERNARG_FMT, q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr,
+                    nqb, magic31(nqb), magic31(heads), mode)
     assert len(b) == KERNARG_SIZE
     return b
 
@@ -52,6 +72,11 @@ class Cfg:
     cap: int = 5           # fillers per MFMA gap
     lookahead: float = 1.0
     name: str = "scail_attn4"
+    dma_k_at: float = 1.0  # MFMA gap of the first K piece, pieces dma_step gaps apart; V^T pieces from dma_v_at
+    dma_v_at: float = 9.0
+    dma_step: float = 2.0
+    sm_end: float = 54.0   # the exp / sum / pack stream is spread over gaps [0, sm_end]
+    abl: str = ""          # TIMING ABLATIONS (wrong results; ablation build only): "dma" / "lds" / "valu" / "bar" / "max" removed
 
     @property
     def unroll(self): return max(2, self.rd)
@@ -94,7 +119,8 @@ S_Q, S_K, S_VT, S_O = S(8, 2), S(10, 2), S(12, 2), S(14, 2)
 S_QBS, S_QRS, S_KSS, S_KBS = S(16, 2), S(18, 2), S(20, 2), S(22, 2)
 S_KRS, S_VTSS, S_VTBS, S_OBS = S(24, 2), S(26, 2), S(28, 2), S(30, 2)
 S_ORS = S(32, 2)
-S_HEADS, S_LQ, S_LK, S_LKP, S_NSEG, S_C, S_THR = S(36), S(37), S(38), S(39), S(40), S(41), S(42)
+S_HEADS, S_LQ, S_LK, S_LKP, S_NSEG, S_C, S_THR, S_NQB = S(36), S(37), S(38), S(39), S(40), S(41), S(42), S(43)
+S_MAGQ, S_MAGH, S_XMODE = S(84), S(85), S(86)
 S_KRSRC, S_VRSRC = S(44, 4), S(48, 4)
 S_KOFF, S_VOFF, S_KSTEP, S_VSTEP, S_KMAX, S_VMAX = S(52), S(53), S(54), S(55), S(56), S(57)
 S_T, S_NT, S_SEG, S_WAVE = S(58), S(59), S(60), S(61)
@@ -147,7 +173,8 @@ class Gen:
                 s = Sb(cur, kb, rb)
                 for j in range(8):
                     r = s.sub(r0 + j)
-                    out.append(isa.vop("v_fma_f32", r, r, S_C, Neg(MC[rb])))
+                    if "fma" not in self.cfg.abl.split(","):
+                        out.append(isa.vop("v_fma_f32", r, r, S_C, Neg(MC[rb])))
                     out.append(isa.vop("v_exp_f32", r, r))
                     out.append(isa.vop("v_add_f32", L_[rb][j & 3], L_[rb][j & 3], r))
                 for i in range(4):
@@ -226,17 +253,22 @@ class Gen:
         cur, nxt = p & 1, (p + 1) & 1
         rd = c.rd
         blk: List[Instr] = []
-        if not tail:
-            blk += self.dma_tile("k", (p + c.pk) % rd, 1.0, 2.0)
-            blk += self.dma_tile("v", (p + c.pv) % rd, 9.0, 2.0)
-        blk += self.v_frag_reads(p % rd, 2.0 if not tail else 0.0, 1.5 if not tail else 1.0)
+        abl = c.abl.split(",")
+        if not tail and "dma" not in abl:
+            blk += self.dma_tile("k", (p + c.pk) % rd, c.dma_k_at, c.dma_step)
+            blk += self.dma_tile("v", (p + c.pv) % rd, c.dma_v_at, c.dma_step)
+        if "lds" not in abl:
+            blk += self.v_frag_reads(p % rd, 2.0 if not tail else 0.0, 1.5 if not tail else 1.0)
         if not tail:
             blk += self.qk_mfmas(nxt)
-        blk += self.softmax_finish(cur, 0.0, 54.0 if not tail else 20.0)
+        if "valu" not in abl:
+            blk += self.softmax_finish(cur, 0.0, c.sm_end if not tail else 20.0)
         blk += self.pv_mfmas(cur)
         if not tail:
-            blk += self.k_frag_reads((p + 2) % rd, 18.0, 2.0)
-            blk += self.rowmax(nxt, 21.0, 38.0, 52.0)
+            if "lds" not in abl:
+                blk += self.k_frag_reads((p + 2) % rd, 18.0, 2.0)
+            if "valu" not in abl and "max" not in abl:
+                blk += self.rowmax(nxt, 21.0, 38.0, 52.0)
         seq = sched.schedule(blk, cap=c.cap, lookahead=c.lookahead)
         seq = sched.insert_lgkm_waits(seq)
         return seq
@@ -246,6 +278,10 @@ class Gen:
         (rare) lazy-rescale call."""
         c = self.cfg
         skip = f"L_{kind}{p}_norescale"
+        if "bar" in c.abl.split(","):
+            return [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep)]
+        if "valu" in c.abl.split(",") or "max" in c.abl.split(","):
+            return [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep), isa.barrier()]
         return [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep), isa.barrier(),
                 isa.branch("s_cbranch_vccz", skip), isa.s_call(S_RET, "L_rescale"), isa.label(skip)]
 
@@ -291,7 +327,19 @@ class Gen:
         o += [isa.s_load(8, S(8, 8), S_KARG, 0), isa.s_load(8, S(16, 8), S_KARG, 32), isa.s_load(8, S(24, 8), S_KARG, 64),
               isa.s_load(2, S_ORS, S_KARG, 96), isa.s_load(8, S(36, 8), S_KARG, 104),
               isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", VT0, I32(6), V(0)),
+              isa.s_load(4, S(84, 4), S_KARG, 136),
               isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, VT0)]
+        # ---- 1-D workgroup id -> (query block, head, batch); xcd_mode 1: ids congruent mod 8 (= one XCD) share (batch, head)
+        #      pairs, so the 32 CUs of an XCD stream the same K / V^T tiles through their L2 ----
+        wid, xcd, j, qd, pair, tt = S(2), ST[0], ST[1], ST[2], ST[3], ST[4]
+        o += [isa.sop("s_and_b32", xcd, wid, I32(7)), isa.sop("s_lshr_b32", j, wid, I32(3)),
+              isa.sop("s_cmp_lg_u32", None, S_XMODE, I32(0)), isa.sop("s_cselect_b32", j, j, wid),
+              isa.sop("s_lshl_b32", tt, j, I32(1)), isa.sop("s_mul_hi_u32", qd, tt, S_MAGQ),            # qd = j / nqb
+              isa.sop("s_mul_i32", tt, qd, S_NQB), isa.sop("s_sub_u32", S_QB, j, tt),                   # qb = j % nqb
+              isa.sop("s_lshl_b32", tt, qd, I32(3)), isa.sop("s_add_u32", tt, tt, xcd),
+              isa.sop("s_cmp_lg_u32", None, S_XMODE, I32(0)), isa.sop("s_cselect_b32", pair, tt, qd),
+              isa.sop("s_lshl_b32", tt, pair, I32(1)), isa.sop("s_mul_hi_u32", S_B, tt, S_MAGH),         # b = pair / heads
+              isa.sop("s_mul_i32", tt, S_B, S_HEADS), isa.sop("s_sub_u32", S_H, pair, tt)]
         # ---- per (batch, head) base pointers ----
         o += self.addr64_madd(S_Q, S_QBS, S_B, 1) + self.addr64_madd(S_K, S_KBS, S_B, 1)
         o += self.addr64_madd(S_VT, S_VTBS, S_B, 1) + self.addr64_madd(S_O, S_OBS, S_B, 1)
@@ -549,13 +597,21 @@ DEFAULT = Cfg(rd=4, cap=5, name="scail_attn4")
 
 
 def variant_cfgs():
-    """A/B variants for GPU tuning runs (ablation build only): ring depth x fillers per gap x lookahead."""
+    """A/B variants for GPU tuning runs (ablation build only); the kernel name encodes the knobs, tools/attn4_tune.py lists them."""
     out = []
-    for rd in (4, 2):
-        for cap in (4, 5, 6, 8):
-            out.append(Cfg(rd=rd, cap=cap, name=f"scail_attn4_r{rd}c{cap}"))
-    out.append(Cfg(rd=4, cap=5, lookahead=3.0, name="scail_attn4_r4c5l3"))
-    out.append(Cfg(rd=4, cap=6, lookahead=3.0, name="scail_attn4_r4c6l3"))
+    for rd, cap in ((4, 4), (4, 6), (2, 5)):
+        out.append(Cfg(rd=rd, cap=cap, name=f"scail_attn4_r{rd}c{cap}"))
+    # placement of the 8 LDS-DMA pieces inside the 64-gap body
+    out.append(Cfg(name="scail_attn4_dmalate", dma_k_at=49.0, dma_v_at=56.0, dma_step=1.7))
+    out.append(Cfg(name="scail_attn4_dmamid", dma_k_at=26.0, dma_v_at=42.0, dma_step=4.0))
+    out.append(Cfg(name="scail_attn4_dmaspread", dma_k_at=2.0, dma_v_at=34.0, dma_step=8.0))
+    out.append(Cfg(name="scail_attn4_sm48", sm_end=48.0))
+    out.append(Cfg(name="scail_attn4_sm60", sm_end=60.0))
+    # timing ablations (WRONG RESULTS): what each instruction class costs beside the 64 MFMAs of a tile
+    for abl in ("dma", "lds", "valu", "bar", "max", "dma,lds", "dma,lds,valu", "dma,lds,valu,bar", "fma"):
+        out.append(Cfg(name="scail_attn4_abl_" + abl.replace(",", "_"), abl=abl))
+    out.append(Cfg(name="scail_attn4_abl_fma_c4", abl="fma", cap=4))
+    out.append(Cfg(name="scail_attn4_abl_fma_sm44", abl="fma", sm_end=44.0))
     return out
 
 

@@ -604,13 +604,17 @@ struct Attn4Args {
     int64_t q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs;
     int32_t heads, Lq, Lk, Lkp, n_seg;
     float sl2, thr;
+    int32_t nqb;                 // query blocks of 256 rows
+    uint32_t magic_nqb, magic_heads;   // ceil(2^31 / d): x / d == (2 x * magic) >> 32 for the workgroup-id decode
+    int32_t xcd_mode;            // 1: ids congruent mod 8 (one XCD) share (batch, head) pairs -> K / V^T reuse in that XCD's L2
     int32_t pad;
 };
-static_assert(sizeof(Attn4Args) == 136, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
+static_assert(sizeof(Attn4Args) == 152, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
 static hipModule_t g_attn4_module = nullptr;
 static std::string g_attn4_name = "scail_attn4";
 static hipFunction_t g_attn4_fn = nullptr;
 static float g_attn4_thr_log2 = 8.0f;      // lazy-rescale threshold: P <= 2^thr
+static int g_attn4_xcd = 1;                // XCD-aware workgroup-id decode (A/B knob "attn4_xcd")
 
 static int attn4_function(hipFunction_t* fn) {
     if (g_attn4_module == nullptr) {
@@ -638,11 +642,15 @@ static bool attn4_eligible(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq,
     return Lk % 64 == 0 && Lk >= 512 && accumulate == 0 && Lq * q_rs < lim && Lk * k_rs < lim && Lq * o_rs < lim && 128 * Lk < lim;
 }
 
+static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
+extern "C" int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate) {
+    return (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate)) ? 4 : 8;
+}
+
 int scail_gemm_tune(int v);
 int scail_gemm_group_m(int v);
 int scail_conv_tune(int v);
 static int g_attn_variant = 8 | (2 << 12);
-static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
 extern "C" int scail_tune_set(const char* knob, int value) {
     if (std::string(knob) == "attn_variant") {
 #ifndef SCAIL_ABLATIONS
@@ -663,14 +671,12 @@ extern "C" int scail_tune_set(const char* knob, int value) {
     }
     if (std::string(knob) == "attn4") { g_attn4_mode = value != 0; return 0; }              // 0: 8-wave kernels only
     if (std::string(knob) == "attn4_thr") { g_attn4_thr_log2 = (float)value; return 0; }    // lazy-rescale threshold (log2 units)
-    if (std::string(knob) == "attn4_kernel") {
-        // A/B of the generated schedules: value = ring depth * 100 + fillers per gap * 10 + (1: lookahead 3); 0 = default.
-        // The variants exist only in the code object of the ablation build (SCAIL_ABLATIONS=1).
-        std::string name = "scail_attn4";
-        if (value != 0) {
-            name += "_r" + std::to_string(value / 100) + "c" + std::to_string((value / 10) % 10);
-            if (value % 10) name += "l3";
-        }
+    if (std::string(knob) == "attn4_xcd") { g_attn4_xcd = value != 0; return 0; }
+    if (std::string(knob).rfind("attn4_kernel", 0) == 0) {
+        // A/B of the generated schedules: knob = "attn4_kernel" (default kernel) or "attn4_kernel:<suffix>" -> kernel
+        // scail_attn4_<suffix> of the embedded code object (the variants exist only in the ablation build, SCAIL_ABLATIONS=1)
+        std::string k(knob), name = "scail_attn4";
+        if (k.size() > 13) name += "_" + k.substr(13);
         g_attn4_name = name;
         g_attn4_fn = nullptr;
         hipFunction_t fn;
@@ -729,10 +735,14 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         a.heads = (int32_t)heads; a.Lq = (int32_t)Lq; a.Lk = (int32_t)Lk; a.Lkp = (int32_t)Lkp; a.n_seg = (int32_t)n_seg;
         a.sl2 = scale * 1.4426950408889634f;
         a.thr = g_attn4_thr_log2 / a.sl2;
+        a.nqb = (int32_t)((Lq + 255) / 256);
+        a.magic_nqb = (uint32_t)(((1ull << 31) + a.nqb - 1) / a.nqb);
+        a.magic_heads = (uint32_t)(((1ull << 31) + heads - 1) / heads);
+        a.xcd_mode = (g_attn4_xcd && (heads * n_batch) % 8 == 0) ? 1 : 0;
         a.pad = 0;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((Lq + 255) / 256), (unsigned)heads, (unsigned)n_batch, 256, 1, 1, 0,
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)(a.nqb * heads * n_batch), 1, 1, 256, 1, 1, 0,
                                              (hipStream_t)stream, nullptr, extra);
         if (e != hipSuccess) {
             scail_set_error(std::string("attn4: launch failed: ") + hipGetErrorString(e));

@@ -277,6 +277,71 @@ def test_flash_attn_properties_long(ops):
 
 
 # ------------------------------------------------------------------------------------------------
+# attn4: the hand-scheduled 4-wave kernel (csrc/attn4.s) that scail_flash_attn_bf16 selects for Lk % 64 == 0, Lk >= 512
+def _which(q, k, o, accumulate=False):
+    from scail_amd import lib as L
+    return L.load().scail_flash_attn_kernel_for(q.stride(1), k.stride(1), o.stride(1), q.shape[1], k.shape[1], 1 if accumulate else 0)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 1, 256, 512), (2, 2, 300, 576), (1, 2, 700, 1024), (1, 3, 130, 832), (1, 2, 520, 1088)])
+def test_attn4_vs_oracle(ops, B, H, Lq, Lk):
+    """every remainder path of the unrolled tile loop (8, 9, 16, 13, 17 tiles), ragged query blocks, several heads / batch
+    elements (XCD-aware and plain workgroup-id decode), against the fp32 oracle; the 8-wave kernel on the same inputs."""
+    from scail_amd import lib as L
+    D = H * 128
+    q, k, v = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3)
+    ref = _attn_ref(q, k, v, H)
+    qg, kg = gpu_bf16(q), gpu_bf16(k)
+    vt = ops.transpose_v(gpu_bf16(v), H)
+    o = torch.empty(B, Lq, D, device=DEV, dtype=torch.bfloat16)
+    assert _which(qg, kg, o) == 4
+    ops.flash_attn(qg, kg, vt, out=o)
+    close(o, ref, rtol=2e-2, atol=1e-2, msg=f"attn4 Lq={Lq} Lk={Lk}")
+    L.tune_set("attn4", 0)
+    try:
+        assert _which(qg, kg, o) == 8
+        o8 = ops.flash_attn(qg, kg, vt)
+    finally:
+        L.tune_set("attn4", 1)
+    close(o8, ref, rtol=2e-2, atol=1e-2, msg="8-wave kernel on the same inputs")
+    close(o, o8.float(), rtol=2e-2, atol=1e-2, msg="attn4 vs 8-wave")
+
+
+def test_attn4_strided_views_segments_and_lazy_rescale(ops):
+    from scail_amd import lib as L
+    B, H, Lt = 2, 2, 640
+    D = H * 128
+    qkv = rnd(B, Lt, 3 * D, seed=1)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    k = k.clone()
+    k[0, 600, :128] = bfr(q[0, 7, :128] * 3.0)          # late dominant keys: the lazy running max must jump (rescale subroutine)
+    k[1, 90, 128:] = bfr(q[1, 300, 128:] * 2.0)
+    qkv = torch.cat([q, k, v], -1)
+    ref = _attn_ref(q, k, v, H)
+    g = gpu_bf16(qkv)
+    vt = ops.transpose_v(g[..., 2 * D:], H)
+    o = torch.empty(B, Lt, D, device=DEV, dtype=torch.bfloat16)
+    assert _which(g[..., :D], g[..., D:2 * D], o) == 4
+    for thr in (8, 0, 2):                               # thr 0: rescale whenever any row maximum moves
+        L.tune_set("attn4_thr", thr)
+        ops.flash_attn(g[..., :D], g[..., D:2 * D], vt, out=o)
+        close(o, ref, atol=1e-2, msg=f"attn4 on views of the qkv buffer, thr {thr}")
+    L.tune_set("attn4_thr", 8)
+    # key segments (sequence-parallel all-gather layout): 3 x 512 keys
+    S, Ls, Lq = 3, 512, 200
+    q = rnd(1, Lq, D, seed=4)
+    ks, vs = rnd(S, 1, Ls, D, seed=5), rnd(S, 1, Ls, D, seed=6)
+    ref = _attn_ref(q, torch.cat(list(ks), 1), torch.cat(list(vs), 1), H)
+    kg = gpu_bf16(ks)
+    vtg = torch.stack([ops.transpose_v(gpu_bf16(vs[s]), H) for s in range(S)])
+    o = ops.flash_attn(gpu_bf16(q), kg[0], vtg[0], n_seg=S, k_seg_stride=kg.stride(0), vt_seg_stride=vtg.stride(0))
+    close(o, ref, atol=1e-2, msg="attn4 segmented keys")
+    # shapes outside its limits go to the 8-wave kernels
+    assert _which(g[..., :D], g[:, :500, D:2 * D], o) == 8 and _which(g[..., :D], g[..., D:2 * D], o, accumulate=True) == 8
+    assert _which(g[..., :D], g[:, :448, D:2 * D], o) == 8
+
+
+# ------------------------------------------------------------------------------------------------
 def test_small_ops(ops):
     from scail_amd import lib as L
     t = torch.tensor([0.0, 1000.0, 731.0, 995.9])

@@ -51,7 +51,7 @@ def reference(q, k, v, heads):
     return out
 
 
-def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = True, thr_log2: float = 8.0, program=None):
+def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = True, thr_log2: float = 8.0, program=None, mode=None):
     """q (B, Lq, H*128) fp32; ksegs / vsegs: lists (one per segment) of (B, Lk, H*128) fp32.  Returns O (B, Lq, H*128) fp32
     and the emulator statistics of the last workgroup."""
     B, Lq, D = q.shape
@@ -70,14 +70,12 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     prog = program if program is not None else attn4.Gen(cfg).program()
     sl2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
     args = attn4.pack_args(pq, pk, pvt, po, Lq * D, D, B * Lk * D, Lk * D, D, B * heads * 128 * Lkp, heads * 128 * Lkp, Lq * D, D,
-                           heads, Lq, Lk, Lkp, n_seg, sl2, thr_log2 / sl2)
+                           heads, Lq, Lk, Lkp, n_seg, sl2, thr_log2 / sl2, n_batch=B, mode=mode)
     stats = None
-    for b in range(B):
-        for h in range(heads):
-            for blk in range((Lq + 255) // 256):
-                emu = E.Emu(prog, mem, n_waves=4, lds_bytes=cfg.lds_bytes, lazy=lazy)
-                emu.launch(args, block_id=(blk, h, b))
-                stats = emu.waves[0].stats
+    for wid in range(attn4.grid_blocks(B, heads, Lq)):
+        emu = E.Emu(prog, mem, n_waves=4, lds_bytes=cfg.lds_bytes, lazy=lazy)
+        emu.launch(args, block_id=(wid, 0, 0))
+        stats = emu.waves[0].stats
     return from_bf16_bits(mem.read_back("o")), stats
 
 

@@ -49,14 +49,16 @@ def main():
     ap.add_argument("--L", type=int, default=48832)
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--iters", type=int, default=3)
-    ap.add_argument("--variants", default="0,440,450,460,480,240,250,260,280,451,461")
+    ap.add_argument("--variants", default=",dmamid,sm48")
+    ap.add_argument("--ablations", default="abl_fma,abl_fma_c4,abl_fma_sm44")
     ap.add_argument("--skip-check", action="store_true")
     ap.add_argument("--full", action="store_true", help="also time the 40-head launch of the best variant")
     a = ap.parse_args()
     lib.load()
     g = torch.Generator(device=DEV).manual_seed(0)
     rn = lambda *s: torch.randn(*s, device=DEV, generator=g).to(torch.bfloat16)
-    variants = [int(x) for x in a.variants.split(",")]
+    variants = a.variants.split(",")
+    setk = lambda v: lib.tune_set("attn4_kernel" + (":" + v if v else ""), 0)
 
     if not a.skip_check:
         # ---- correctness: ragged Lq, several tile counts (all remainder paths), spiked keys (rescale), 2 segments ----
@@ -76,7 +78,7 @@ def main():
             e_old = check("old", o_old, ref, rows)
             lib.tune_set("attn4", 1)
             for var in variants:
-                lib.tune_set("attn4_kernel", var)
+                setk(var)
                 for thr in (8, 0):
                     lib.tune_set("attn4_thr", thr)
                     o = ops.flash_attn(q, ks[0], vts[0], **kw)
@@ -101,24 +103,27 @@ def main():
                       "max_err": check("old", out, ref, rows)}), flush=True)
     lib.tune_set("attn4", 1)
     results = []
-    for var in variants:
-        lib.tune_set("attn4_kernel", var)
+    for var in variants + [x for x in a.ablations.split(",") if x]:
+        setk(var)
         out.zero_()
         med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), a.iters)
         err = check("new", out, ref, rows)
         results.append((med, var))
         print(json.dumps({"kernel": f"attn4 variant {var}", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9, "max_err": err}), flush=True)
     if a.full:
-        bestvar = min(results)[1]
-        lib.tune_set("attn4_kernel", bestvar)
+        bestvar = min(r for r in results if not r[1].startswith("abl"))[1]
+        setk(bestvar)
         D = 40 * 128
         qkv = rn(2, a.L, 3 * D)
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         vt = ops.transpose_v(v, 40)
         out = torch.empty(2, a.L, D, device=DEV, dtype=torch.bfloat16)
         fl = 4.0 * a.L * a.L * 128 * 40 * 2
-        med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), 3)
-        print(json.dumps({"kernel": f"attn4 variant {bestvar}, 40 heads", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9}), flush=True)
+        for xcd in (1, 0, 1, 0):
+            lib.tune_set("attn4_xcd", xcd)
+            med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), 3)
+            print(json.dumps({"kernel": f"attn4 variant {bestvar}, 40 heads, xcd-aware ids {xcd}", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9}), flush=True)
+        lib.tune_set("attn4_xcd", 1)
         lib.tune_set("attn4", 0)
         med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), 3)
         print(json.dumps({"kernel": "8-wave swp, 40 heads", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9}), flush=True)
