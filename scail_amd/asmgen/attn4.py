@@ -76,6 +76,8 @@ class Cfg:
     dma_v_at: float = 9.0
     dma_step: float = 2.0
     sm_end: float = 54.0   # the exp / sum / pack stream is spread over gaps [0, sm_end]
+    sm_group: int = 1      # 1: element by element (dependent neighbours); 8 / 16: stage by stage over 8 / 16 elements
+    max_chains: int = 1    # independent partial-maximum chains per row block in the row max
     abl: str = ""          # TIMING ABLATIONS (wrong results; ablation build only): "dma" / "lds" / "valu" / "bar" / "max" removed
 
     @property
@@ -167,18 +169,39 @@ class Gen:
     def softmax_finish(self, cur: int, t0: float, t1: float) -> List[Instr]:
         """p = exp2(s c - m c), l += p, pack pairs to bf16 in place (k-step major = the order P.V consumes them)."""
         out = []
+        nofma = "fma" in self.cfg.abl.split(",")
         for ks in range(4):
             kb, r0 = ks >> 1, 8 * (ks & 1)
-            for rb in range(2):
-                s = Sb(cur, kb, rb)
-                for j in range(8):
-                    r = s.sub(r0 + j)
-                    if "fma" not in self.cfg.abl.split(","):
-                        out.append(isa.vop("v_fma_f32", r, r, S_C, Neg(MC[rb])))
-                    out.append(isa.vop("v_exp_f32", r, r))
-                    out.append(isa.vop("v_add_f32", L_[rb][j & 3], L_[rb][j & 3], r))
-                for i in range(4):
-                    out.append(isa.vop("v_cvt_pk_bf16_f32", s.sub(r0 + i), s.sub(r0 + 2 * i), s.sub(r0 + 2 * i + 1)))
+            if self.cfg.sm_group <= 1:
+                # element by element: fma -> exp -> add back to back (every instruction waits for the one before it)
+                for rb in range(2):
+                    s = Sb(cur, kb, rb)
+                    for j in range(8):
+                        r = s.sub(r0 + j)
+                        if not nofma:
+                            out.append(isa.vop("v_fma_f32", r, r, S_C, Neg(MC[rb])))
+                        out.append(isa.vop("v_exp_f32", r, r))
+                        out.append(isa.vop("v_add_f32", L_[rb][j & 3], L_[rb][j & 3], r))
+                    for i in range(4):
+                        out.append(isa.vop("v_cvt_pk_bf16_f32", s.sub(r0 + i), s.sub(r0 + 2 * i), s.sub(r0 + 2 * i + 1)))
+                continue
+            # software-pipelined by class: with ONE wave per SIMD nothing hides a dependent VALU's latency (v_exp_f32 is a
+            # long-latency transcendental), so the k-step's 16 (or 8) elements go stage by stage: all scale-shifts, all exps,
+            # all row-sum adds, all packs -- every consumer sits >= sm_group instructions behind its producer
+            rbs = [(0, 1)] if self.cfg.sm_group >= 16 else [(0,), (1,)]
+            for grp in rbs:
+                el = [(rb, Sb(cur, kb, rb), j) for rb in grp for j in range(8)]
+                if not nofma:
+                    for rb, s, j in el:
+                        out.append(isa.vop("v_fma_f32", s.sub(r0 + j), s.sub(r0 + j), S_C, Neg(MC[rb])))
+                for rb, s, j in el:
+                    out.append(isa.vop("v_exp_f32", s.sub(r0 + j), s.sub(r0 + j)))
+                for rb, s, j in el:
+                    out.append(isa.vop("v_add_f32", L_[rb][j & 3], L_[rb][j & 3], s.sub(r0 + j)))
+                for rb in grp:
+                    s = Sb(cur, kb, rb)
+                    for i in range(4):
+                        out.append(isa.vop("v_cvt_pk_bf16_f32", s.sub(r0 + i), s.sub(r0 + 2 * i), s.sub(r0 + 2 * i + 1)))
         n = len(out)
         for k, ins in enumerate(out):
             ins.target_gap = t0 + (t1 - t0) * k / n
@@ -187,22 +210,38 @@ class Gen:
     def rowmax(self, nxt: int, t_kb0: float, t_kb1: float, t_fin: float) -> List[Instr]:
         """MX[rb] = max over the 64 keys of S_next (both lanes of the row), then VCC = any(MX - M > thr)."""
         out = []
+        nch = self.cfg.max_chains
         for rb in range(2):
             acc = TMP[rb]
+            chains = [acc] + [TMP[10 + rb * 4 + c] for c in range(1, nch)]      # partial maxima (independent dependency chains)
             for kb, tg in ((0, t_kb0), (1, t_kb1)):
                 s = Sb(nxt, kb, rb)
-                vals = [s.sub(r) for r in range(16)]
+                lists = [[s.sub(r) for r in range(16)][c::nch] for c in range(nch)]
+                steps: List[List[Instr]] = []
+                for c, vals in enumerate(lists):
+                    ops_c: List[Instr] = []
+                    if kb == 0:
+                        ops_c.append(isa.vop("v_max3_f32", chains[c], vals[0], vals[1], vals[2]))
+                        vals = vals[3:]
+                    while len(vals) >= 2:
+                        ops_c.append(isa.vop("v_max3_f32", chains[c], chains[c], vals[0], vals[1]))
+                        vals = vals[2:]
+                    if vals:
+                        ops_c.append(isa.vop("v_max_f32", chains[c], chains[c], vals[0]))
+                    steps.append(ops_c)
                 grp: List[Instr] = []
-                if kb == 0:
-                    grp.append(isa.vop("v_max3_f32", acc, vals[0], vals[1], vals[2]))
-                    vals = vals[3:]
-                while len(vals) >= 2:
-                    grp.append(isa.vop("v_max3_f32", acc, acc, vals[0], vals[1]))
-                    vals = vals[2:]
-                if vals:
-                    grp.append(isa.vop("v_max_f32", acc, acc, vals[0]))
+                for k in range(max(len(x) for x in steps)):          # round-robin over the chains
+                    grp += [x[k] for x in steps if k < len(x)]
+                if kb == 1 and nch > 1:                              # fold the partial maxima
+                    rest = chains[1:]
+                    while len(rest) >= 2:
+                        grp.append(isa.vop("v_max3_f32", acc, acc, rest[0], rest[1]))
+                        rest = rest[2:]
+                    if rest:
+                        grp.append(isa.vop("v_max_f32", acc, acc, rest[0]))
+                span = 8.0 / max(len(grp), 1)
                 for k, ins in enumerate(grp):
-                    ins.target_gap = tg + rb * 0.4 + k * 1.0
+                    ins.target_gap = tg + rb * 0.4 * span + k * span
                 out.extend(grp)
         fin = []
         for rb in range(2):
@@ -607,6 +646,11 @@ def variant_cfgs():
     out.append(Cfg(name="scail_attn4_dmaspread", dma_k_at=2.0, dma_v_at=34.0, dma_step=8.0))
     out.append(Cfg(name="scail_attn4_sm48", sm_end=48.0))
     out.append(Cfg(name="scail_attn4_sm60", sm_end=60.0))
+    # dependency distance of the softmax VALU stream (one wave per SIMD: nothing else hides a dependent instruction's latency)
+    for g, m in ((8, 1), (16, 1), (16, 2), (16, 4), (8, 4)):
+        out.append(Cfg(name=f"scail_attn4_g{g}m{m}", sm_group=g, max_chains=m))
+    out.append(Cfg(name="scail_attn4_g16m4c6", sm_group=16, max_chains=4, cap=6))
+    out.append(Cfg(name="scail_attn4_g16m4c4", sm_group=16, max_chains=4, cap=4))
     # timing ablations (WRONG RESULTS): what each instruction class costs beside the 64 MFMAs of a tile
     for abl in ("dma", "lds", "valu", "bar", "max", "dma,lds", "dma,lds,valu", "dma,lds,valu,bar", "fma"):
         out.append(Cfg(name="scail_attn4_abl_" + abl.replace(",", "_"), abl=abl))

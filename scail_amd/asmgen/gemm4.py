@@ -1,0 +1,457 @@
+"""gemm4 -- hand-scheduled bf16 GEMM  y = epi(x W^T + b)  for the big per-token projections of the SCAIL DiT on gfx950
+(generator of csrc/gemm4.s).  Replaces F.linear in ColumnParallelLinear / RowParallelLinear (sat/mpu/layers.py:237, 435) and the
+gate / residual / GELU ops around it (dit_video_crossattn_sc_xc.py:1036, 1042, 1050; sat/transformer_defaults.py:163-176); same C
+entry point as the kernels of csrc/gemm.hip (scail_gemm_bf16), which selects this kernel for M >= 2048, N % 256 == 0, K % 64 == 0.
+
+Shape (the structure of the vendor's own MI355X GEMM: 256 x 256 x 64 macro tile, 4 waves, one per SIMD):
+  * workgroup = one 256 (m) x 256 (n) tile of y, 4 waves as 2 (m) x 2 (n), wave tile 128 x 128 = 4 x 4 blocks of 32 x 32;
+    the 256 fp32 accumulators per lane fill the whole accumulator file a[0:255]; the arch VGPRs hold only fragments and addresses
+  * MFMA issued "transposed" like gemm.hip: A = W fragment (rows n), B = x fragment (columns m) -> a lane's accumulator registers
+    run along n: 4 consecutive n per register quad -> 8-byte bf16 stores, float4 bias / gate loads
+  * x and W k-tiles (256 rows x 64 k = 32 KB each) arrive by LDS-DMA (buffer_load_dwordx4 ... lds) in whole 128-byte rows,
+    XOR-swizzled on the source address (chunk ^ ((row >> 1) & 7)), two 64 KB slots; fragments are read per 16-wide k-step into a
+    double-buffered register set; per k-tile ONE s_barrier, placed before the LAST k-step: at that point every wave has read its
+    last fragments of the tile, so the slot can be refilled (tile t+2) while k-step 3 computes and the first fragments of tile t+1
+    are read -- no exposed LDS latency at tile boundaries
+  * tile order = a host-built table (XCD-aware + grouped: the 32 tiles resident on an XCD share 4 + 8 operand panels in its L2),
+    read with one s_load per workgroup: no integer division in the kernel
+  * epilogues as separate kernels: bias (0), bias + GELU-tanh (1), residual + gate * (. + bias) (3), residual + (. + bias) (4);
+    bias may be NULL
+
+Limits (the C entry keeps gemm.hip's kernels otherwise): N % 256 == 0, K % 64 == 0, K >= 128, M * ld < 2^31 elements.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import List
+
+from . import isa, sched
+from .isa import A, S, V, I32, F32, Neg, VCC, EXEC, M0, Instr
+
+KERNARG_SIZE = 112
+KERNARG_FMT = "<7Q4q4i8x"      # x w bias y resid gate table | lda ldc ldr gs | M N K rows_per_batch
+
+
+def pack_args(x, w, bias, y, resid, gate, table, lda, ldc, ldr, gs, M, N, K, rpb) -> bytes:
+    b = struct.pack(KERNARG_FMT, x, w, bias, y, resid, gate, table, lda, ldc, ldr, gs, M, N, K, rpb)
+    assert len(b) == KERNARG_SIZE
+    return b
+
+
+def tile_table(M: int, N: int, group_m: int = 4):
+    """Tile order (list of (m_tile << 16 | n_tile... stored as m_tile | n_tile << 16): workgroup id b runs on XCD b % 8; each XCD
+    gets a contiguous range of the GROUPED order (group_m m-tiles x all n-tiles column by column), so the 32 tiles in flight on an
+    XCD cover ~4 m-panels x 8 n-panels."""
+    tm, tn = (M + 255) // 256, N // 256
+    order = []
+    for g0 in range(0, tm, group_m):
+        rows = range(g0, min(g0 + group_m, tm))
+        for n in range(tn):
+            for m in rows:
+                order.append(m | (n << 16))
+    T = len(order)
+    per = (T + 7) // 8
+    table = []
+    for b in range(per * 8):
+        xcd, j = b & 7, b >> 3
+        lin = xcd * per + j
+        table.append(order[lin] if lin < T else 0xFFFFFFFF)
+    return table
+
+
+@dataclass
+class Cfg:
+    epi: int = 0           # 0 bias, 1 bias + GELU-tanh, 3 resid + gate * (acc + bias), 4 resid + (acc + bias)
+    cap: int = 3           # fillers per MFMA gap
+    dma_from: float = 48.0  # first gap of the 16 LDS-DMA pieces of tile t+2 (after the barrier at 47.5)
+    dma_step: float = 1.0
+    name: str = "scail_gemm4_e0"
+    abl: str = ""
+
+
+def ACC(nb, mb): return A((nb * 4 + mb) * 16, 16)
+def FW(buf, nb): return V(buf * 32 + nb * 4, 4)            # W fragments (MFMA A operand)
+def FX(buf, mb): return V(buf * 32 + 16 + mb * 4, 4)       # x fragments (MFMA B operand)
+
+
+XADDR = [[V(64 + s * 4 + ks) for ks in range(4)] for s in range(2)]
+WADDR = [[V(72 + s * 4 + ks) for ks in range(4)] for s in range(2)]
+XDMA = [V(80 + i) for i in range(8)]
+WDMA = [V(88 + i) for i in range(8)]
+T_ = [V(96 + i) for i in range(32)]          # v96..127 temporaries (prologue / epilogue)
+LANE = V(128)
+
+S_KARG = S(0, 2)
+S_WG = S(2)
+S_X, S_W, S_BIAS, S_Y = S(8, 2), S(10, 2), S(12, 2), S(14, 2)
+S_RES, S_GATE = S(16, 2), S(18, 2)
+S_TAB = S(20, 2)
+S_LDA, S_LDC, S_LDR, S_GS = S(24, 2), S(26, 2), S(28, 2), S(30, 2)
+S_M, S_N, S_K, S_RPB = S(32), S(33), S(34), S(35)
+S_XRSRC, S_WRSRC = S(36, 4), S(40, 4)
+S_KOFF, S_KMAX, S_T, S_KT = S(44), S(45), S(46), S(47)
+S_WAVE, S_WM, S_WN = S(48), S(49), S(50)
+S_M0T, S_N0T = S(51), S(52)                  # tile origin (rows / columns)
+S_XLDS, S_WLDS = S(53), S(54)                # LDS byte offset of this wave's DMA region inside a slot
+ST = [S(56 + i) for i in range(16)]          # s56..s71 temporaries
+S_SAVE = S(72, 2)
+
+
+class Gen:
+    def __init__(self, cfg: Cfg):
+        self.cfg = cfg
+
+    # ---------------------------------------------------------------------------------------------
+    def mfmas(self, ks: int) -> List[Instr]:
+        buf = ks & 1
+        return [isa.mfma(ACC(nb, mb), FW(buf, nb), FX(buf, mb), ACC(nb, mb), tag=f"k{ks}") for nb in range(4) for mb in range(4)]
+
+    def frag_reads(self, slot: int, ks: int, t0: float, step: float) -> List[Instr]:
+        buf = ks & 1
+        out = []
+        for i in range(4):
+            out.append(isa.ds_read_b128(FW(buf, i), WADDR[slot][ks], 4096 * i, target_gap=t0 + step * (2 * i)))
+            out.append(isa.ds_read_b128(FX(buf, i), XADDR[slot][ks], 4096 * i, target_gap=t0 + step * (2 * i + 1)))
+        return out
+
+    def dma_tile(self, slot: int, t0: float, step: float, advance: bool = True) -> List[Instr]:
+        """16 LDS-DMA pieces of this wave (8 x rows, 8 W rows: 64 rows of each operand tile) for the k-tile at S_KOFF."""
+        out = []
+        k = 0
+        for lds, offs, rsrc in ((S_XLDS, XDMA, S_XRSRC), (S_WLDS, WDMA, S_WRSRC)):
+            for half in range(2):
+                out.append(isa.sop("s_add_u32", M0, lds, I32(slot * 65536 + half * 4096), target_gap=t0 + step * k - 0.5))
+                for i in range(4):
+                    out.append(isa.buffer_load_lds(offs[half * 4 + i], rsrc, S_KOFF, 1024 * i, target_gap=t0 + step * k, tag="dma"))
+                    k += 1
+        if advance:
+            out.append(isa.sop("s_add_u32", S_KOFF, S_KOFF, I32(128), target_gap=t0 + step * k))
+            out.append(isa.sop("s_min_u32", S_KOFF, S_KOFF, S_KMAX, target_gap=t0 + step * k + 0.1))
+        return out
+
+    def body(self, p: int) -> List[Instr]:
+        """One k-tile (64 MFMAs) on slot p: k-steps 0-2, barrier, refill of slot p with tile t+2 || k-step 3 || first fragments
+        of tile t+1 from slot p^1."""
+        c = self.cfg
+        abl = c.abl.split(",")
+        blk: List[Instr] = []
+        reads_p: List[Instr] = []
+        for ks in range(3):
+            r = self.frag_reads(p, ks + 1, 16.0 * ks + 1.0, 1.5) if "lds" not in abl else []
+            reads_p += r
+            blk += r
+            blk += self.mfmas(ks)
+        w1 = isa.waitcnt(lgkmcnt=0, target_gap=47.3)
+        w2 = isa.waitcnt(vmcnt=0, target_gap=47.4)
+        bar = isa.barrier(target_gap=47.5)
+        w1.after, w2.after, bar.after = list(reads_p), [], list(reads_p) + [w1, w2]
+        sync = [w1, w2] + ([bar] if "bar" not in abl else [])
+        blk += sync
+        dma = self.dma_tile(p, c.dma_from, c.dma_step) if "dma" not in abl else []
+        nxt = self.frag_reads(p ^ 1, 0, 49.0, 1.5) if "lds" not in abl else []
+        for i in dma + nxt:
+            i.after = sync
+        blk += dma + nxt
+        blk += self.mfmas(3)
+        return sched.schedule(blk, cap=c.cap, lookahead=1.0)      # LDS waits are added by loop(): fragment reads cross body boundaries
+
+    # ---------------------------------------------------------------------------------------------
+    def addr64_madd(self, ptr: isa.Reg, a, b, shift: int) -> List[Instr]:
+        """ptr(64) += (a * b) << shift   (a, b: 32-bit SGPRs / immediates, unsigned)."""
+        lo, hi = ST[0], ST[1]
+        st = S(ST[2].idx, 2)
+        return [isa.sop("s_mul_i32", lo, a, b), isa.sop("s_mul_hi_u32", hi, a, b),
+                isa.sop("s_mov_b32", st.sub(0), lo), isa.sop("s_mov_b32", st.sub(1), hi), isa.sop("s_lshl_b64", st, st, I32(shift)),
+                isa.sop("s_add_u32", ptr.sub(0), ptr.sub(0), st.sub(0)), isa.sop("s_addc_u32", ptr.sub(1), ptr.sub(1), st.sub(1))]
+
+    def prologue(self) -> List[Instr]:
+        c = self.cfg
+        o: List[Instr] = [isa.label(c.name)]
+        o += [isa.s_load(8, S(8, 8), S_KARG, 0), isa.s_load(4, S(16, 4), S_KARG, 32), isa.s_load(2, S_TAB, S_KARG, 48),
+              isa.s_load(8, S(24, 8), S_KARG, 56), isa.s_load(4, S(32, 4), S_KARG, 88),
+              isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", T_[0], I32(6), V(0)),
+              isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, T_[0])]
+        # tile of this workgroup from the host-built order table
+        ent = ST[4]
+        o += [isa.sop("s_lshl_b32", ST[5], S_WG, I32(2)), isa.sop("s_add_u32", S_TAB.sub(0), S_TAB.sub(0), ST[5]),
+              isa.sop("s_addc_u32", S_TAB.sub(1), S_TAB.sub(1), I32(0)), isa.s_load(1, ent, S_TAB, 0), isa.waitcnt(lgkmcnt=0),
+              isa.sop("s_cmp_eq_u32", None, ent, I32(0xFFFFFFFF)), isa.branch("s_cbranch_scc1", "L_exit"),
+              isa.sop("s_and_b32", ST[5], ent, I32(0xFFFF)), isa.sop("s_lshr_b32", ST[6], ent, I32(16)),
+              isa.sop("s_lshl_b32", S_M0T, ST[5], I32(8)), isa.sop("s_lshl_b32", S_N0T, ST[6], I32(8)),
+              isa.sop("s_lshr_b32", S_WM, S_WAVE, I32(1)), isa.sop("s_and_b32", S_WN, S_WAVE, I32(1))]
+        # descriptors: x rows from m0 (base += m0 * lda * 2), W rows from n0 (base += n0 * K * 2)
+        o += self.addr64_madd(S_X, S_M0T, S_LDA.sub(0), 1) + self.addr64_madd(S_W, S_N0T, S_K, 1)
+        for rs, ptr in ((S_XRSRC, S_X), (S_WRSRC, S_W)):
+            o += [isa.sop("s_mov_b32", rs.sub(0), ptr.sub(0)), isa.sop("s_and_b32", rs.sub(1), ptr.sub(1), I32(0xFFFF)),
+                  isa.sop("s_mov_b32", rs.sub(2), I32(0xFFFFFFFF)), isa.sop("s_mov_b32", rs.sub(3), I32(0x00020000))]
+        ldab, kb2 = ST[6], ST[7]
+        o += [isa.sop("s_lshl_b32", ldab, S_LDA.sub(0), I32(1)), isa.sop("s_lshl_b32", kb2, S_K, I32(1)),
+              isa.sop("s_lshr_b32", S_KT, S_K, I32(6)), isa.sop("s_sub_u32", ST[8], S_KT, I32(1)), isa.sop("s_lshl_b32", S_KMAX, ST[8], I32(7)),
+              isa.sop("s_mov_b32", S_KOFF, I32(0)), isa.sop("s_mov_b32", S_T, I32(0)),
+              isa.sop("s_lshl_b32", S_XLDS, S_WAVE, I32(13)), isa.sop("s_add_u32", S_WLDS, S_XLDS, I32(32768))]
+        ql, g, t = T_[1], T_[2], T_
+        o += [isa.vop("v_and_b32", ql, I32(31), LANE), isa.vop("v_lshrrev_b32", g, I32(5), LANE)]
+        # fragment read addresses: row r (128 B), chunk (2 ks + g) ^ ((r >> 1) & 7); x rows 128 wm + 32 mb + ql, W rows 128 wn + ...
+        o += [isa.vop("v_lshrrev_b32", t[3], I32(1), ql), isa.vop("v_and_b32", t[3], I32(7), t[3]), isa.vop("v_lshlrev_b32", t[4], I32(7), ql),
+              isa.vop("v_lshlrev_b32", t[5], I32(14), S_WM), isa.vop("v_add_u32", t[5], t[5], t[4]),                     # x: wm * 128 rows * 128 B
+              isa.vop("v_lshlrev_b32", t[6], I32(14), S_WN), isa.vop("v_add_u32", t[6], t[6], t[4]),
+              isa.vop("v_add_u32", t[6], I32(32768), t[6])]
+        for ks in range(4):
+            o += [isa.vop("v_or_b32", t[7], I32(2 * ks), g), isa.vop("v_xor_b32", t[7], t[7], t[3]),
+                  isa.vop("v_lshl_add_u32", XADDR[0][ks], t[7], I32(4), t[5]), isa.vop("v_lshl_add_u32", WADDR[0][ks], t[7], I32(4), t[6]),
+                  isa.vop("v_add_u32", XADDR[1][ks], I32(65536), XADDR[0][ks]), isa.vop("v_add_u32", WADDR[1][ks], I32(65536), WADDR[0][ks])]
+        # LDS-DMA source offsets: piece i of this wave = tile rows 64 w + 8 i + (lane >> 3), 16-byte chunk (lane & 7) ^ ((row >> 1) & 7)
+        mlast = ST[9]
+        o += [isa.sop("s_sub_u32", mlast, S_M, S_M0T), isa.sop("s_sub_u32", mlast, mlast, I32(1)),         # last valid x row of the tile
+              isa.vop("v_lshrrev_b32", t[3], I32(3), LANE), isa.vop("v_and_b32", t[4], I32(7), LANE),
+              isa.vop("v_lshlrev_b32", t[5], I32(6), S_WAVE)]
+        for i in range(8):
+            o += [isa.vop("v_add_u32", t[6], I32(8 * i), t[3]), isa.vop("v_add_u32", t[6], t[6], t[5]),           # row in tile
+                  isa.vop("v_lshrrev_b32", t[7], I32(1), t[6]), isa.vop("v_and_b32", t[7], I32(7), t[7]), isa.vop("v_xor_b32", t[7], t[4], t[7]),
+                  isa.vop("v_min_u32", t[8], t[6], mlast), isa.vop("v_mul_lo_u32", t[8], t[8], ldab),
+                  isa.vop("v_lshl_add_u32", t[8], t[7], I32(4), t[8]), isa.vop("v_subrev_u32", XDMA[i], I32(1024 * (i & 3)), t[8]),
+                  isa.vop("v_mul_lo_u32", t[9], t[6], kb2), isa.vop("v_lshl_add_u32", t[9], t[7], I32(4), t[9]),
+                  isa.vop("v_subrev_u32", WDMA[i], I32(1024 * (i & 3)), t[9])]
+        for i in range(256):
+            o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
+        # pipeline fill: tiles 0 and 1, first fragments of tile 0
+        o += self.dma_tile(0, 0, 0) + self.dma_tile(1, 0, 0)
+        o += [isa.waitcnt(vmcnt=0), isa.barrier()]
+        o = sched.pad_hazards(sched.insert_lgkm_waits(o))
+        return o + self.frag_reads(0, 0, 0, 0)          # the 8 reads stay in flight into the first body (see loop())
+
+    def loop(self) -> List[Instr]:
+        """The k-loop, two bodies (slot 0 / slot 1).  The first fragments of tile t+1 are read at the end of body t and consumed
+        at the start of body t+1: the counted LDS waits of a body start from the 8 reads its predecessor left in flight."""
+        first = self.frag_reads(0, 0, 0, 0)
+        sig = lambda q: [tuple(i.writes()) for i in q]
+        c0: List[Instr] = []
+        c1: List[Instr] = []
+        b0 = sched.insert_lgkm_waits(self.body(0), carry_in=first, carry_out=c0)
+        b1 = sched.insert_lgkm_waits(self.body(1), carry_in=c0, carry_out=c1)
+        if "lds" not in self.cfg.abl.split(","):
+            assert sig(c0) == sig(first) and sig(c1) == sig(first), "a body must leave exactly the next tile's first fragment reads in flight"
+        o: List[Instr] = [isa.label("L_loop")]
+        o += b0
+        o += [isa.sop("s_add_u32", S_T, S_T, I32(1)), isa.sop("s_cmp_lt_u32", None, S_T, S_KT), isa.branch("s_cbranch_scc0", "L_done")]
+        o += b1
+        o += [isa.sop("s_add_u32", S_T, S_T, I32(1)), isa.sop("s_cmp_lt_u32", None, S_T, S_KT), isa.branch("s_cbranch_scc1", "L_loop")]
+        o += [isa.label("L_done"), isa.waitcnt(vmcnt=0), isa.waitcnt(lgkmcnt=0), isa.nop(15), isa.nop(15)]
+        return o
+
+    # ---------------------------------------------------------------------------------------------
+    def epilogue(self) -> List[Instr]:
+        """y[m][n .. n+3] for the lane's rows m = m0 + 128 wm + 32 mb + (lane & 31), n = n0 + 128 wn + 32 nb + 8 rr + 4 g."""
+        c = self.cfg
+        e: List[Instr] = []
+        ql, g, t = T_[1], T_[2], T_
+        nw = ST[4]            # n0 + 128 wn (first column of the wave)
+        e += [isa.sop("s_lshl_b32", nw, S_WN, I32(7)), isa.sop("s_add_u32", nw, nw, S_N0T)]
+        e += self.addr64_madd(S_Y, nw, I32(1), 1)
+        # bias quads: BQ[nb][rr] = bias[nw + 32 nb + 8 rr + 4 g .. +3]  (zeros when bias == NULL)
+        BQ = [[V(nb * 16 + rr * 4, 4) for rr in range(4)] for nb in range(4)]           # v0..v63 (fragment registers are dead)
+        for i in range(64):
+            e.append(isa.vop("v_mov_b32", V(i), I32(0)))
+        e += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias")]
+        e += self.addr64_madd(S_BIAS, nw, I32(1), 2)
+        e += [isa.vop("v_lshlrev_b32", t[3], I32(4), g)]                       # 4 g floats = 16 g bytes
+        for nb in range(4):
+            for rr in range(4):
+                e.append(isa.global_load(4, BQ[nb][rr], t[3], (32 * nb + 8 * rr) * 4, saddr=S_BIAS))
+        e += [isa.waitcnt(vmcnt=0), isa.label("L_nobias")]
+        # rows
+        mw = ST[5]
+        e += [isa.sop("s_lshl_b32", mw, S_WM, I32(7)), isa.sop("s_add_u32", mw, mw, S_M0T)]
+        ldcb = ST[6]
+        e += [isa.sop("s_lshl_b32", ldcb, S_LDC.sub(0), I32(1))]
+        RCP, KC0, KC1 = V(129), V(132), V(133)
+        if c.epi in (3, 4):
+            e += self.addr64_madd(S_RES, nw, I32(1), 1)
+            e += [isa.sop("s_lshl_b32", ST[7], S_LDR.sub(0), I32(1))]
+        if c.epi == 3:
+            e += self.addr64_madd(S_GATE, nw, I32(1), 2)
+            e += [isa.vop("v_cvt_f32_u32", RCP, S_RPB), isa.vop("v_rcp_f32", RCP, RCP),
+                  isa.sop("s_cmp_eq_u32", None, S_RPB, I32(0)), isa.sop("s_cselect_b32", ST[9], I32(0), I32(0xFFFFFFFF)),
+                  isa.sop("s_lshl_b32", ST[12], S_GS.sub(0), I32(2))]
+        if c.epi == 1:
+            K0, K1 = 0.7978845608028654, 0.044715
+            sc = 2.0 * 1.4426950408889634
+            e += [isa.vop("v_mov_b32", KC0, F32(K0 * sc)), isa.vop("v_mov_b32", KC1, F32(K0 * K1 * sc))]
+        for mb in range(4):
+            row, yoff, roff, goff, bq = V(134), V(135), V(136), V(137), V(138)
+            e += [isa.vop("v_add_u32", row, mw, ql)]
+            if mb:
+                e += [isa.vop("v_add_u32", row, I32(32 * mb), row)]
+            e += [isa.vop("v_mul_lo_u32", yoff, row, ldcb), isa.vop("v_lshl_add_u32", yoff, g, I32(3), yoff)]
+            if c.epi in (3, 4):
+                e += [isa.vop("v_mul_lo_u32", roff, row, ST[7]), isa.vop("v_lshl_add_u32", roff, g, I32(3), roff)]
+            if c.epi == 3:
+                # batch index of the row: floor((m + 0.5) / rows_per_batch); rows_per_batch == 0 -> 0
+                e += [isa.vop("v_cvt_f32_u32", bq, row), isa.vop("v_add_f32", bq, F32(0.5), bq), isa.vop("v_mul_f32", bq, bq, RCP),
+                      isa.vop("v_cvt_u32_f32", bq, bq), isa.vop("v_and_b32", bq, ST[9], bq),
+                      isa.vop("v_mul_lo_u32", goff, bq, ST[12]), isa.vop("v_lshl_add_u32", goff, g, I32(4), goff)]
+            e += [isa.v_cmp("v_cmp_lt_u32", row, S_M),
+                  Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+            k = 0
+            for nb in range(4):
+                for rr in range(4):
+                    base = 140 + 16 * (k % 2)         # two rotating register groups
+                    k += 1
+                    f = [V(base + i) for i in range(4)]
+                    w, rp, r_, u2, gq = V(base + 4, 2), V(base + 6, 2), V(base + 8), [V(base + 9), V(base + 10)], V(base + 12, 4)
+                    noff = (32 * nb + 8 * rr)
+                    if c.epi in (3, 4):
+                        e.append(isa.global_load(2, rp, roff, noff * 2, saddr=S_RES, extra_reads=[EXEC]))
+                    if c.epi == 3:
+                        e.append(isa.global_load(4, gq, goff, noff * 4, saddr=S_GATE, extra_reads=[EXEC]))
+                    for i in range(4):
+                        e += [isa.vop("v_accvgpr_read_b32", f[i], ACC(nb, mb).sub(4 * rr + i)),
+                              isa.vop("v_add_f32", f[i], f[i], BQ[nb][rr].sub(i))]
+                    if c.epi == 1:
+                        for i in range(4):           # gelu_tanh(v) = v - v / (exp2(2 log2e k0 (v + k1 v^3)) + 1)
+                            u = u2[i & 1]
+                            e += [isa.vop("v_mul_f32", u, f[i], f[i]), isa.vop("v_fma_f32", u, u, KC1, KC0),
+                                  isa.vop("v_mul_f32", u, u, f[i]), isa.vop("v_exp_f32", u, u), isa.vop("v_add_f32", u, F32(1.0), u),
+                                  isa.vop("v_rcp_f32", u, u), isa.vop("v_fma_f32", f[i], Neg(f[i]), u, f[i])]
+                    if c.epi in (3, 4):
+                        e.append(isa.waitcnt(vmcnt=0))
+                        if c.epi == 3:
+                            for i in range(4):
+                                e.append(isa.vop("v_mul_f32", f[i], f[i], gq.sub(i)))
+                        for i in range(4):           # + residual (bf16 pairs: low half << 16, high half & 0xffff0000)
+                            src = rp.sub(i >> 1)
+                            e += [isa.vop("v_lshlrev_b32", r_, I32(16), src) if (i & 1) == 0 else isa.vop("v_and_b32", r_, I32(0xFFFF0000), src),
+                                  isa.vop("v_add_f32", f[i], f[i], r_)]
+                    e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
+                          isa.global_store(2, yoff, w, noff * 2, saddr=S_Y, extra_reads=[EXEC])]
+            e += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+        e += [isa.label("L_exit"), isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
+        return self._pad_between_labels(e)
+
+    @staticmethod
+    def _pad_between_labels(seq: List[Instr]) -> List[Instr]:
+        return sched.pad_hazards(seq)
+
+    def program(self) -> List[Instr]:
+        prog = self.prologue() + self.loop() + self.epilogue()
+        pre = f"L_{self.cfg.name}"
+        for i in prog:
+            if i.label and i.label.startswith("L_"):
+                new = pre + i.label[1:]
+                if getattr(i, "text", None):
+                    i.text = i.text.replace(i.label, new)
+                i.label = new
+        return prog
+
+
+HEAD = """// GENERATED by scail_amd/asmgen/gemm4.py -- do not edit; regenerate with `python -m scail_amd.asmgen.gemm4`.
+// Hand-scheduled 4-wave bf16 GEMM for gfx950 (256 x 256 x 64 tile, accumulators in a[0:255]); see the generator's docstring.
+\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.amdhsa_code_object_version 6
+"""
+
+
+def kernel_text(c: Cfg) -> str:
+    body = isa.render(Gen(c).program())
+    return f"""// ---- kernel {c.name}: epilogue {c.epi}, <= {c.cap} fillers per MFMA gap ----
+\t.text
+\t.protected\t{c.name}
+\t.globl\t{c.name}
+\t.p2align\t8
+\t.type\t{c.name},@function
+{body}.L{c.name}_end:
+\t.size\t{c.name}, .L{c.name}_end-{c.name}
+\t.section\t.rodata,"a",@progbits
+\t.p2align\t6, 0x0
+\t.amdhsa_kernel {c.name}
+\t\t.amdhsa_group_segment_fixed_size 131072
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size {KERNARG_SIZE}
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 1
+\t\t.amdhsa_system_sgpr_workgroup_id_z 1
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr 512
+\t\t.amdhsa_next_free_sgpr 96
+\t\t.amdhsa_accum_offset 256
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_round_mode_32 0
+\t\t.amdhsa_float_round_mode_16_64 0
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t.end_amdhsa_kernel
+"""
+
+
+def metadata(cfgs) -> str:
+    ks = "".join(f"""  - .agpr_count:     256
+    .args:
+      - .offset:         0
+        .size:           {KERNARG_SIZE}
+        .value_kind:     by_value
+    .group_segment_fixed_size: 131072
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: {KERNARG_SIZE}
+    .max_flat_workgroup_size: 256
+    .name:           {c.name}
+    .private_segment_fixed_size: 0
+    .sgpr_count:     102
+    .sgpr_spill_count: 0
+    .symbol:         {c.name}.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     512
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+""" for c in cfgs)
+    return f"""\t.amdgpu_metadata
+---
+amdhsa.kernels:
+{ks}amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+amdhsa.version:
+  - 1
+  - 2
+...
+\t.end_amdgpu_metadata
+"""
+
+
+def assembly(cfgs) -> str:
+    return HEAD + "".join(kernel_text(c) for c in cfgs) + metadata(cfgs)
+
+
+DEFAULTS = [Cfg(epi=0, name="scail_gemm4_e0"), Cfg(epi=1, name="scail_gemm4_e1"), Cfg(epi=3, name="scail_gemm4_e3"),
+            Cfg(epi=4, name="scail_gemm4_e4")]
+
+
+def variant_cfgs():
+    out = []
+    for cap in (2, 4):
+        out.append(Cfg(epi=0, cap=cap, name=f"scail_gemm4_e0_c{cap}"))
+    out.append(Cfg(epi=0, dma_step=2.0, name="scail_gemm4_e0_dma2"))
+    out.append(Cfg(epi=0, dma_from=52.0, dma_step=0.75, name="scail_gemm4_e0_dmalate"))
+    for abl in ("dma", "lds", "bar", "dma,lds"):
+        out.append(Cfg(epi=0, abl=abl, name="scail_gemm4_e0_abl_" + abl.replace(",", "_")))
+    return out
+
+
+def main():
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(os.path.dirname(here), "csrc", "gemm4.s")
+    text = assembly(DEFAULTS)
+    if "--check" in sys.argv:
+        sys.exit(0 if open(out).read() == text else 1)
+    if not os.path.exists(out) or open(out).read() != text:
+        open(out, "w").write(text)
+    print(out, len(text.splitlines()), "lines")
+
+
+if __name__ == "__main__":
+    main()

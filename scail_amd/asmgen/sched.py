@@ -161,11 +161,13 @@ def schedule(block: Sequence[Instr], cap: int = 5, lookahead: float = 1.0, trail
     return out
 
 
-def insert_lgkm_waits(seq: Sequence[Instr], assume_outstanding: int = 0) -> List[Instr]:
+def insert_lgkm_waits(seq: Sequence[Instr], carry_in: Sequence[Instr] = (), carry_out: List[Instr] = None) -> List[Instr]:
     """Counted ``s_waitcnt lgkmcnt(n)`` before the first instruction that touches the destination of an outstanding
-    ds_read / s_load (LDS operations retire in order; n = number of younger LGKM operations allowed to stay in flight)."""
+    ds_read / s_load (LDS operations retire in order; n = number of younger LGKM operations allowed to stay in flight).
+    ``carry_in``: LGKM operations still outstanding when the block is entered (issued by the preceding block, oldest first);
+    ``carry_out`` (a list) receives the operations outstanding at the end of this block."""
     out: List[Instr] = []
-    q: List[Instr] = []          # outstanding LGKM ops, oldest first
+    q: List[Instr] = list(carry_in)          # outstanding LGKM ops, oldest first
     for ins in seq:
         if ins.op == "s_waitcnt" and getattr(ins, "lgkmcnt", None) is not None:
             del q[:max(0, len(q) - ins.lgkmcnt)]
@@ -183,6 +185,8 @@ def insert_lgkm_waits(seq: Sequence[Instr], assume_outstanding: int = 0) -> List
         out.append(ins)
         if ins.cls in (isa.DS_READ, isa.DS_WRITE) or ins.op.startswith("s_load"):
             q.append(ins)
+    if carry_out is not None:
+        carry_out[:] = q
     return out
 
 

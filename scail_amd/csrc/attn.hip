@@ -648,6 +648,7 @@ extern "C" int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o
 }
 
 int scail_gemm_tune(int v);
+int scail_gemm4_knob(const char* knob, int value);
 int scail_gemm_group_m(int v);
 int scail_conv_tune(int v);
 static int g_attn_variant = 8 | (2 << 12);
@@ -682,6 +683,7 @@ extern "C" int scail_tune_set(const char* knob, int value) {
         hipFunction_t fn;
         return attn4_function(&fn);
     }
+    if (std::string(knob).rfind("gemm4", 0) == 0) return scail_gemm4_knob(knob, value);     // "gemm4" on / off, "gemm4_kernel:<suffix>"
     if (std::string(knob) == "gemm_tile") return scail_gemm_tune(value);
     if (std::string(knob) == "conv_halo") return scail_conv_tune(value);
     if (std::string(knob) == "gemm_group_m") return scail_gemm_group_m(value);

@@ -15,6 +15,10 @@
 // of tiles so neighbours share operand panels in that XCD's L2), then grouped ordering (g_group_m = 4 m-tiles
 // per group, m fastest) so the co-resident tiles of an XCD share a few operand panels.
 #include "common.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #define BK 64
 #define LDT 72  // padded LDS row, elements (144 B)
@@ -566,6 +570,99 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     return launch_gemm_t<128, 128, 2, 2, EPI, false>(p, stream);
 }
 
+// ================================================================================================
+// gemm4: the hand-scheduled 4-wave kernels (256 x 256 x 64 tile, one wave per SIMD, the 256 accumulators of a lane in a[0:255],
+// LDS-DMA double buffer, barrier before the last k-step).  gfx950 assembly GENERATED by scail_amd/asmgen/gemm4.py (csrc/gemm4.s),
+// embedded as a code object and loaded with hipModuleLoadData on first use.  Kernel argument block = asmgen/gemm4.py KERNARG_FMT.
+// ================================================================================================
+static const unsigned char k_gemm4_hsaco[] = {
+#include "gemm4_hsaco.inc"
+};
+struct Gemm4Args {
+    const void* x; const void* w; const void* bias; void* y; const void* resid; const void* gate; const void* table;
+    int64_t lda, ldc, ldr, gs;
+    int32_t M, N, K, rows_per_batch;
+    int32_t pad[2];
+};
+static_assert(sizeof(Gemm4Args) == 112, "Gemm4Args must match asmgen/gemm4.py KERNARG_SIZE");
+static hipModule_t g_gemm4_module = nullptr;
+static std::map<std::string, hipFunction_t> g_gemm4_fn;
+static std::map<std::pair<int, int>, std::pair<uint32_t*, int>> g_gemm4_tables;   // (m tiles, n tiles) -> device order table, entries
+static std::mutex g_gemm4_mutex;
+static int g_gemm4_mode = 1;               // 1 = use gemm4 where eligible (default), 0 = never
+static std::string g_gemm4_suffix;         // A/B variants of the ablation build ("gemm4_kernel:<suffix>")
+
+static int gemm4_function(const std::string& name, hipFunction_t* fn) {
+    std::lock_guard<std::mutex> lk(g_gemm4_mutex);
+    if (g_gemm4_module == nullptr) {
+        hipError_t e = hipModuleLoadData(&g_gemm4_module, k_gemm4_hsaco);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("gemm4: hipModuleLoadData failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+    }
+    auto it = g_gemm4_fn.find(name);
+    if (it == g_gemm4_fn.end()) {
+        hipFunction_t f;
+        hipError_t e = hipModuleGetFunction(&f, g_gemm4_module, name.c_str());
+        if (e != hipSuccess) {
+            scail_set_error("gemm4: kernel " + name + " is not in the embedded code object: " + hipGetErrorString(e));
+            return 2;
+        }
+        it = g_gemm4_fn.emplace(name, f).first;
+    }
+    *fn = it->second;
+    return 0;
+}
+
+// Tile order table (asmgen/gemm4.py tile_table): workgroup id b runs on XCD b % 8; every XCD walks a contiguous range of the
+// grouped order (group_m m-tiles x one n-tile at a time), so the 32 tiles in flight on an XCD share ~4 + 8 operand panels in L2.
+static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev, int* entries) {
+    std::lock_guard<std::mutex> lk(g_gemm4_mutex);
+    auto key = std::make_pair(tm * 8 + (group_m & 7), tn);
+    auto it = g_gemm4_tables.find(key);
+    if (it == g_gemm4_tables.end()) {
+        std::vector<uint32_t> order;
+        for (int g0 = 0; g0 < tm; g0 += group_m)
+            for (int n = 0; n < tn; ++n)
+                for (int m = g0; m < std::min(g0 + group_m, tm); ++m) order.push_back((uint32_t)m | ((uint32_t)n << 16));
+        const int T = (int)order.size(), per = (T + 7) / 8;
+        std::vector<uint32_t> table((size_t)per * 8);
+        for (int b = 0; b < per * 8; ++b) {
+            const int lin = (b & 7) * per + (b >> 3);
+            table[b] = lin < T ? order[lin] : 0xFFFFFFFFu;
+        }
+        uint32_t* d = nullptr;
+        if (hipMalloc(&d, table.size() * 4) != hipSuccess || hipMemcpy(d, table.data(), table.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            scail_set_error("gemm4: cannot allocate the tile order table");
+            return 2;
+        }
+        it = g_gemm4_tables.emplace(key, std::make_pair(d, per * 8)).first;
+    }
+    *dev = it->second.first;
+    *entries = it->second.second;
+    return 0;
+}
+
+static bool gemm4_eligible(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int64_t N, int64_t K, int epilogue) {
+    const int64_t lim = 1ll << 31;
+    const int64_t tail = M % 256;
+    return M >= 2048 && (tail == 0 || tail >= 8) && N % 256 == 0 && K % 64 == 0 && K >= 128 &&
+           (epilogue == SCAIL_EPI_BIAS || epilogue == SCAIL_EPI_GELU_TANH || epilogue == SCAIL_EPI_RESID) &&
+           M * ldc < lim && M * std::max<int64_t>(ldr, 1) < lim && 256 * lda < lim;
+}
+
+extern "C" int scail_gemm_kernel_for(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int64_t N, int64_t K, int epilogue) {
+    return (g_gemm4_mode && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) ? 4 : 8;
+}
+
+int scail_gemm4_knob(const char* knob, int value) {
+    std::string k(knob);
+    if (k == "gemm4") { g_gemm4_mode = value != 0; return 0; }
+    if (k.rfind("gemm4_kernel", 0) == 0) { g_gemm4_suffix = k.size() > 13 ? "_" + k.substr(13) : ""; return 0; }
+    return -1;
+}
+
 extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf16* w, const float* bias,
                                scail_bf16* y, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                                const scail_bf16* resid, int64_t ldr, const float* gate, int64_t gate_stride,
@@ -578,6 +675,33 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
                       (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0,
                   "pointer alignment");
     if (M == 0 || N == 0) return 0;
+    if (epilogue == SCAIL_EPI_RESID) {
+        SCAIL_REQUIRE(resid != nullptr && ldr % 4 == 0, "RESID epilogue needs resid with ldr % 4 == 0");
+        SCAIL_REQUIRE(gate == nullptr || (rows_per_batch > 0 && gate_stride % 4 == 0), "gate needs rows_per_batch > 0, gate_stride % 4 == 0");
+    }
+    if (g_gemm4_mode && g_gemm_tile == 0 && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) {
+        const int epi4 = epilogue == SCAIL_EPI_RESID ? (gate != nullptr ? 3 : 4) : epilogue;
+        std::string name = "scail_gemm4_e" + std::to_string(epi4);
+        if (epi4 == 0) name += g_gemm4_suffix;            // A/B variants exist for the bias epilogue only (ablation build)
+        hipFunction_t fn;
+        if (int rc = gemm4_function(name, &fn)) return rc;
+        uint32_t* table;
+        int entries;
+        if (int rc = gemm4_table((int)((M + 255) / 256), (int)(N / 256), g_group_m, &table, &entries)) return rc;
+        Gemm4Args a;
+        a.x = x; a.w = w; a.bias = bias; a.y = y; a.resid = resid; a.gate = gate; a.table = table;
+        a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.gs = gate_stride;
+        a.M = (int32_t)M; a.N = (int32_t)N; a.K = (int32_t)K; a.rows_per_batch = (int32_t)rows_per_batch;
+        a.pad[0] = a.pad[1] = 0;
+        size_t sz = sizeof(a);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)entries, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("gemm4: launch failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        return 0;
+    }
     GemmParams p;
     p.x = x; p.lda = lda; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;

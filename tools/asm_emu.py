@@ -470,6 +470,9 @@ class Emu:
             r = min(sgn(a), sgn(b)); self._wrs(w, d, r); w.scc = int(sgn(a) <= sgn(b))
         elif op == "s_cselect_b32":
             self._wrs(w, d, a if w.scc else b)
+        elif op in ("s_cmp_eq_u64", "s_cmp_lg_u64"):
+            x, y = self._rds64(w, s[0]), self._rds64(w, s[1])
+            w.scc = int((x == y) == op.startswith("s_cmp_eq"))
         elif op.startswith("s_cmp_"):
             u = op.endswith("u32")
             x, y = (a, b) if u else (sgn(a), sgn(b))
@@ -516,6 +519,11 @@ class Emu:
                 self._wrv(w, d, _u(np.exp2(F(0).astype(np.float64)).astype(np.float32)))
             elif op == "v_rcp_f32":
                 self._wrv(w, d, _u((1.0 / F(0).astype(np.float64)).astype(np.float32)))
+            elif op == "v_cvt_f32_u32":
+                self._wrv(w, d, _u(R(0).astype(np.float32)))
+            elif op == "v_cvt_u32_f32":
+                x = np.nan_to_num(F(0).astype(np.float64), nan=0.0, posinf=4294967295.0, neginf=0.0)
+                self._wrv(w, d, np.clip(np.trunc(x), 0, 4294967295).astype(np.uint64).astype(np.uint32))
             elif op == "v_cvt_pk_bf16_f32":
                 self._wrv(w, d, bf16_round(F(0)) | (bf16_round(F(1)) << 16))
             elif op == "v_permlane32_swap_b32":
