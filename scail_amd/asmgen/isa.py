@@ -251,6 +251,15 @@ def buffer_load_lds(voff: Reg, rsrc: Reg, soff, offset: int = 0, **kw) -> Instr:
                  extra_reads=[M0], offset=offset, **kw)
 
 
+def buffer_load(ndw: int, dst: Reg, voff: Reg, rsrc: Reg, soff, offset: int = 0, **kw) -> Instr:
+    """dst(ndw) = buffer[voff + soff + offset]  (raw buffer, offen)."""
+    op = {1: "buffer_load_dword", 2: "buffer_load_dwordx2", 4: "buffer_load_dwordx4"}[ndw]
+    assert dst.n == ndw and rsrc.n == 4 and 0 <= offset <= 4095
+    i = Instr(op, [dst], [voff, rsrc, soff], offset=offset, **kw)
+    i.text = f"{op} {dst}, {voff}, {rsrc}, {soff} offen" + (f" offset:{offset}" if offset else "")
+    return i
+
+
 def global_load(ndw: int, dst: Reg, vaddr: Reg, offset: int = 0, saddr: Optional[Reg] = None, **kw) -> Instr:
     """vaddr(2) + offset, or -- with ``saddr`` -- saddr(2 SGPRs) + zero-extended vaddr(1) + offset."""
     op = {1: "global_load_dword", 2: "global_load_dwordx2", 4: "global_load_dwordx4"}[ndw]

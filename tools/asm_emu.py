@@ -382,6 +382,21 @@ class Emu:
                     self.lds[lds_addr[l]:lds_addr[l] + 16] = self.mem.load(int(gaddr[l]), 16) if inrange[l] else 0
             self._queue(w, "vm", commit)
             return
+        if op.startswith("buffer_load"):
+            nb = d.n * 4
+            rs = self._regs_s(w, s[1])
+            base = rs[0] | ((rs[1] & 0xFFFF) << 32)
+            voff = self._rd(w, s[0]).astype(np.int64)
+            addr = base + voff + self._rds(w, s[2]) + ins.offset
+            def commit(addr=addr, d=d, nb=nb, mask=w.exec.copy()):
+                bank = w.v if d.kind == "v" else w.a
+                for l in range(64):
+                    if mask[l]:
+                        data = self.mem.load(int(addr[l]), nb).view(np.uint32)
+                        for i in range(d.n):
+                            bank[d.idx + i][l] = data[i]
+            self._queue(w, "vm", commit)
+            return
         if op.startswith("global_load"):
             nb = d.n * 4
             addr = self._gaddr(w, s[0], s[1] if len(s) > 1 else None) + ins.offset
