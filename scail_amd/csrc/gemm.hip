@@ -578,6 +578,10 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
 static const unsigned char k_gemm4_hsaco[] = {
 #include "gemm4_hsaco.inc"
 };
+// gemm8: the same kernels with TWO waves per SIMD (8 waves, wave tile 128 x 64, 128 accumulators in a[0:127]; asmgen/gemm8.py)
+static const unsigned char k_gemm8_hsaco[] = {
+#include "gemm8_hsaco.inc"
+};
 struct Gemm4Args {
     const void* x; const void* w; const void* bias; void* y; const void* resid; const void* gate; const void* table;
     int64_t lda, ldc, ldr, gs;
@@ -585,26 +589,28 @@ struct Gemm4Args {
     int32_t pad[2];
 };
 static_assert(sizeof(Gemm4Args) == 112, "Gemm4Args must match asmgen/gemm4.py KERNARG_SIZE");
-static hipModule_t g_gemm4_module = nullptr;
+static hipModule_t g_gemm4_module = nullptr, g_gemm8_module = nullptr;
 static std::map<std::string, hipFunction_t> g_gemm4_fn;
 static std::map<std::pair<int, int>, std::pair<uint32_t*, int>> g_gemm4_tables;   // (m tiles, n tiles) -> device order table, entries
 static std::mutex g_gemm4_mutex;
-static int g_gemm4_mode = 1;               // 1 = use gemm4 where eligible (default), 0 = never
+static int g_gemm4_mode = 8;               // generated kernels where eligible: 8 = gemm8 (default), 4 = gemm4, 0 = never (csrc/gemm.hip only)
 static std::string g_gemm4_suffix;         // A/B variants of the ablation build ("gemm4_kernel:<suffix>")
 
 static int gemm4_function(const std::string& name, hipFunction_t* fn) {
     std::lock_guard<std::mutex> lk(g_gemm4_mutex);
-    if (g_gemm4_module == nullptr) {
-        hipError_t e = hipModuleLoadData(&g_gemm4_module, k_gemm4_hsaco);
+    const bool is8 = name.rfind("scail_gemm8", 0) == 0;
+    hipModule_t& mod = is8 ? g_gemm8_module : g_gemm4_module;
+    if (mod == nullptr) {
+        hipError_t e = hipModuleLoadData(&mod, is8 ? k_gemm8_hsaco : k_gemm4_hsaco);
         if (e != hipSuccess) {
-            scail_set_error(std::string("gemm4: hipModuleLoadData failed: ") + hipGetErrorString(e));
+            scail_set_error(std::string("gemm4/8: hipModuleLoadData failed: ") + hipGetErrorString(e));
             return 2;
         }
     }
     auto it = g_gemm4_fn.find(name);
     if (it == g_gemm4_fn.end()) {
         hipFunction_t f;
-        hipError_t e = hipModuleGetFunction(&f, g_gemm4_module, name.c_str());
+        hipError_t e = hipModuleGetFunction(&f, mod, name.c_str());
         if (e != hipSuccess) {
             scail_set_error("gemm4: kernel " + name + " is not in the embedded code object: " + hipGetErrorString(e));
             return 2;
@@ -653,12 +659,12 @@ static bool gemm4_eligible(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int
 }
 
 extern "C" int scail_gemm_kernel_for(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int64_t N, int64_t K, int epilogue) {
-    return (g_gemm4_mode && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) ? 4 : 8;
+    return (g_gemm4_mode && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) ? (g_gemm4_mode == 4 ? 4 : 8) : 0;
 }
 
 int scail_gemm4_knob(const char* knob, int value) {
     std::string k(knob);
-    if (k == "gemm4") { g_gemm4_mode = value != 0; return 0; }
+    if (k == "gemm4") { g_gemm4_mode = (value == 4 || value == 8) ? value : (value ? 8 : 0); return 0; }
     if (k.rfind("gemm4_kernel", 0) == 0) { g_gemm4_suffix = k.size() > 13 ? "_" + k.substr(13) : ""; return 0; }
     return -1;
 }
@@ -681,7 +687,8 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
     }
     if (g_gemm4_mode && g_gemm_tile == 0 && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) {
         const int epi4 = epilogue == SCAIL_EPI_RESID ? (gate != nullptr ? 3 : 4) : epilogue;
-        std::string name = "scail_gemm4_e" + std::to_string(epi4);
+        const bool is8 = g_gemm4_mode != 4;
+        std::string name = std::string(is8 ? "scail_gemm8_e" : "scail_gemm4_e") + std::to_string(epi4);
         if (epi4 == 0) name += g_gemm4_suffix;            // A/B variants exist for the bias epilogue only (ablation build)
         hipFunction_t fn;
         if (int rc = gemm4_function(name, &fn)) return rc;
@@ -695,7 +702,7 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
         a.pad[0] = a.pad[1] = 0;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)entries, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)entries, 1, 1, is8 ? 512 : 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
         if (e != hipSuccess) {
             scail_set_error(std::string("gemm4: launch failed: ") + hipGetErrorString(e));
             return 2;

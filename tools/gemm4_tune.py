@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--variants", default=",c2,c4,dma2,dmalate")
     ap.add_argument("--ablations", default="abl_dma,abl_lds,abl_bar,abl_dma_lds")
+    ap.add_argument("--variants8", default=",c2,c5,wr1,ldlate,abl_dma,abl_lds,abl_bar,abl_dma_lds")
     ap.add_argument("--vendor", action="store_true")
     a = ap.parse_args()
     lib.load()
@@ -61,7 +62,7 @@ def main():
         for name, epi, kw in (("bias", L.EPI_BIAS, {}), ("nobias", L.EPI_BIAS, dict(nobias=True)), ("gelu", L.EPI_GELU_TANH, {}),
                               ("resid+gate", L.EPI_RESID, dict(resid=True, gate=True)), ("resid", L.EPI_RESID, dict(resid=True))):
             res = {}
-            for mode in (1, 0):
+            for mode in (8, 4, 0):
                 lib.tune_set("gemm4", mode)
                 y = resid.clone() if kw.get("resid") else torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
                 ops.gemm(x, w, None if kw.get("nobias") else b, out=y, epilogue=epi, resid=y if kw.get("resid") else None,
@@ -70,8 +71,9 @@ def main():
                                 gate if kw.get("gate") else None, rpb)
                 res[mode] = float((y[rows].float() - want).abs().max())
                 which = lib.load().scail_gemm_kernel_for(K, N, N if kw.get("resid") else 0, M, N, K, epi)
-            lib.tune_set("gemm4", 1)
-            print(json.dumps({"check": [M, N, K], "epi": name, "max_err_gemm4": res[1], "max_err_q8": res[0], "ok": res[1] < 6e-2}), flush=True)
+            lib.tune_set("gemm4", 8)
+            print(json.dumps({"check": [M, N, K], "epi": name, "max_err_gemm8": res[8], "max_err_gemm4": res[4], "max_err_q8": res[0],
+                              "ok": res[4] < 6e-2 and res[8] < 6e-2}), flush=True)
 
     # ---- timing on the step's shapes ----
     M = 97664
@@ -88,13 +90,20 @@ def main():
         lib.tune_set("gemm4", 0)
         ms = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=epi, **kw), a.iters)
         out["q8_TFLOPs"] = fl / ms / 1e9
-        lib.tune_set("gemm4", 1)
+        lib.tune_set("gemm4", 8)
+        for v in (a.variants8.split(",") if epi == L.EPI_BIAS else [""]):
+            setk(v)
+            ms = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=epi, **kw), a.iters)
+            out["gemm8" + ("_" + v if v else "") + "_TFLOPs"] = fl / ms / 1e9
+        setk("")
+        lib.tune_set("gemm4", 4)
         names = a.variants.split(",") + ([v for v in a.ablations.split(",") if v] if epi == L.EPI_BIAS else [])
         for v in (names if epi == L.EPI_BIAS else [""]):
             setk(v)
             ms = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=epi, **kw), a.iters)
             out["gemm4" + ("_" + v if v else "") + "_TFLOPs"] = fl / ms / 1e9
         setk("")
+        lib.tune_set("gemm4", 8)
         if a.vendor:
             ms = timeit(lambda: torch.nn.functional.linear(x, w), a.iters)
             out["vendor_TFLOPs"] = fl / ms / 1e9
