@@ -75,6 +75,9 @@ class Cfg:
     ld_step: float = 2.0
     rd_step: float = 1.5   # spacing (gaps) of the 8 fragment reads of a k-step
     stagger: float = 0.0   # > 0: one loop copy per wave, wave w issues its global loads `stagger * w` gaps later
+    ne: int = 4            # stage "spread": pieces written right after the barrier (the other 16 - ne spread over k-steps 0-2)
+    late_from: float = 1.0
+    late_step: float = 3.7
     name: str = "scail_gemm4_e0"
     abl: str = ""
 
@@ -163,12 +166,60 @@ class Gen:
                 k += 1
         return out
 
+    # ---- stage == "spread": every piece does  wait -> ds_write (tile T) -> global load (tile T + 2) into the same registers,
+    #      the 16 pieces evenly spread over the tile period (12 before the barrier into the OTHER slot, 4 after it into this slot):
+    #      no burst of LDS writes, two full iterations of flight per load, one counted `vmcnt(31)` per piece ----------------------
+    PIECES = [(op, i) for op in range(2) for i in range(8)]
+
+    def _piece(self, k: int, q: int, slot: int, gap: float, prev, with_wait=True, with_write=True):
+        op, i = self.PIECES[k]
+        out = []
+        w = isa.waitcnt(vmcnt=31, target_gap=gap)
+        w.after = list(prev)
+        wr = isa.ds_write(16, WRADDR[slot][i & 1], STG(q, op, i), op * 32768 + 1024 * i, target_gap=gap + 0.05)
+        wr.after = [w]
+        ld = isa.buffer_load(4, STG(q, op, i), (XDMA if op == 0 else WDMA)[i], S_XRSRC if op == 0 else S_WRSRC, S_KOFF, 0, target_gap=gap + 0.1)
+        ld.after = [wr]
+        return [w, wr, ld]
+
+    def body_spread(self, p: int, wave: int = 0) -> List[Instr]:
+        c = self.cfg
+        blk: List[Instr] = []
+        reads_p: List[Instr] = []
+        for ks in range(3):
+            r = self.frag_reads(p, ks + 1, 16.0 * ks + 1.0, c.rd_step)
+            reads_p += r
+            blk += r + self.mfmas(ks)
+        late: List[Instr] = []
+        prev: List[Instr] = []
+        for n, k in enumerate(range(c.ne, 16)):                     # tile t+1 (set p^1) -> slot p^1, then tile t+3 into the set
+            tr = self._piece(k, p ^ 1, p ^ 1, c.late_from + c.late_step * n + c.stagger * wave, prev)
+            late += tr
+            prev = [tr[-1]]
+        adv = [isa.sop("s_add_u32", S_KOFF, S_KOFF, I32(128), target_gap=47.1), isa.sop("s_min_u32", S_KOFF, S_KOFF, S_KMAX, target_gap=47.2)]
+        adv[0].after = list(prev)
+        w1, bar = isa.waitcnt(lgkmcnt=0, target_gap=47.3), isa.barrier(target_gap=47.5)
+        w1.after, bar.after = list(reads_p) + [x for x in late if x.cls == isa.DS_WRITE], [w1]
+        early: List[Instr] = []
+        prev = [bar, adv[1]]
+        for n, k in enumerate(range(c.ne)):                         # tile t+2 (set p) -> slot p, then tile t+4 into the set
+            tr = self._piece(k, p, p, 48.0 + (15.0 / max(c.ne, 1)) * n + 0.2 * wave, prev)
+            early += tr
+            prev = [tr[-1]]
+        nxt = self.frag_reads(p ^ 1, 0, 57.0, 0.8)
+        for i in nxt:
+            i.after = [bar] + [x for x in early if x.cls == isa.DS_WRITE]
+        blk += late + adv + [w1, bar] + early + nxt + self.mfmas(3)
+        return sched.schedule(blk, cap=c.cap, lookahead=1.0)
+
     def body(self, p: int, wave: int = 0) -> List[Instr]:
         """One k-tile (64 MFMAs) on slot p: k-steps 0-2, barrier, refill of slot p with tile t+2 || k-step 3 || first fragments
         of tile t+1 from slot p^1.  ``wave`` (with cfg.stagger): the loop exists once per wave, each copy issuing its 16 global
         loads in a different part of the tile period -- the four waves of a workgroup run in lock step (one barrier per tile), and
         with one wave per SIMD a load that finds the CU's memory pipeline busy stalls the wave's MFMA stream."""
         c = self.cfg
+        if c.stage == "spread":
+            return self.body_spread(p, wave)
         abl = c.abl.split(",")
         blk: List[Instr] = []
         reads_p: List[Instr] = []
@@ -283,6 +334,17 @@ class Gen:
         if dma:
             o += self.dma_tile(0, 0, 0) + self.dma_tile(1, 0, 0)
             o += [isa.waitcnt(vmcnt=0), isa.barrier()]
+        elif c.stage == "spread":
+            ld = lambda q, k: isa.buffer_load(4, STG(q, *self.PIECES[k]), (XDMA if self.PIECES[k][0] == 0 else WDMA)[self.PIECES[k][1]],
+                                              S_XRSRC if self.PIECES[k][0] == 0 else S_WRSRC, S_KOFF, 0)
+            wr = lambda q, slot, k: isa.ds_write(16, WRADDR[slot][self.PIECES[k][1] & 1], STG(q, *self.PIECES[k]),
+                                                 self.PIECES[k][0] * 32768 + 1024 * self.PIECES[k][1])
+            adv = lambda: [isa.sop("s_add_u32", S_KOFF, S_KOFF, I32(128)), isa.sop("s_min_u32", S_KOFF, S_KOFF, S_KMAX)]
+            o += [ld(0, k) for k in range(16)] + adv() + [isa.waitcnt(vmcnt=0)] + [wr(0, 0, k) for k in range(16)]          # tile 0 -> slot 0
+            o += [ld(1, k) for k in range(16)] + adv() + [isa.waitcnt(vmcnt=0)] + [wr(1, 1, k) for k in range(c.ne)]        # tile 1: early pieces
+            o += [ld(0, k) for k in range(16)] + adv()                                                                        # tile 2 -> set 0
+            o += [ld(1, k) for k in range(c.ne)]                                                                              # tile 3 early -> set 1
+            o += [isa.waitcnt(lgkmcnt=0), isa.barrier()]
         else:
             o += self.load_tile(0, 0, 0) + self.load_tile(1, 0, 0) + [isa.waitcnt(vmcnt=0)]
             o += self.write_tile(0, 0, 0, 0) + self.write_tile(1, 1, 0, 0) + self.load_tile(0, 0, 0)
@@ -536,6 +598,9 @@ def variant_cfgs():
     out.append(Cfg(epi=0, dma_step=0.5, name="scail_gemm4_e0_st05"))
     for abl in ("dma", "lds", "bar", "dma,lds", "nowait", "nold", "nost", "dma,nowait"):
         out.append(Cfg(epi=0, abl=abl, name="scail_gemm4_e0_abl_" + abl.replace(",", "_")))
+    out.append(Cfg(epi=0, stage="spread", name="scail_gemm4_e0_spread"))
+    out.append(Cfg(epi=0, stage="spread", stagger=0.9, name="scail_gemm4_e0_spreadstag"))
+    out.append(Cfg(epi=0, stage="spread", stagger=0.9, ne=2, late_step=3.2, name="scail_gemm4_e0_spread2"))
     out.append(Cfg(epi=0, stagger=16.0, ld_step=1.0, name="scail_gemm4_e0_stag16"))
     out.append(Cfg(epi=0, stagger=12.0, ld_step=0.75, name="scail_gemm4_e0_stag12"))
     out.append(Cfg(epi=0, stagger=0.5, ld_step=2.0, name="scail_gemm4_e0_stag05"))
