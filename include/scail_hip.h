@@ -56,14 +56,6 @@ int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf16* w, const
                     int64_t rows_per_batch, void* stream);
 
 /*
- * Which kernel scail_gemm_bf16 runs for a shape: 8 / 4 = the hand-scheduled kernels generated by scail_amd/asmgen/gemm8.py /
- * gemm4.py (csrc/gemm8.s, gemm4.s: 256 x 256 x 64 tile, accumulators in the AGPR file, two / one wave per SIMD; need M >= 2048,
- * N % 256 == 0, K % 64 == 0 and a bias / GELU-tanh / residual epilogue), 0 = the kernels of csrc/gemm.hip (ragged N, small M,
- * GELU-erf).  Host-only query.
- */
-int scail_gemm_kernel_for(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int64_t N, int64_t K, int epilogue);
-
-/*
  * LayerNorm (no affine, eps) + AdaLN modulate:  y = LN(x) * (1 + scale[b]) + shift[b]
  * (sat/ops/layernorm.py:16-24 + modulate dit...:760-761, used at :1031-1032, :1045-1046, :825).
  * Output row r in [0, n_batch*rows_out) reads source row
@@ -238,15 +230,18 @@ int scail_mul_bf16(const scail_bf16* a, const scail_bf16* b, scail_bf16* y, int6
 int scail_row_affine(const scail_bf16* x, scail_bf16* y, const float* rowscale, const scail_bf16* addrow, int64_t add_rows,
                      int64_t rows, int64_t D, void* stream);
 
-/* Tuning / A-B knob for kernel variants (same results, different schedules); used by tools/microbench.py.
- * knobs: "attn_variant" (bit 0: s_setprio around MFMA clusters, bit 1: skip no-op O rescales [default],
- *        bit 3: software-pipelined kernel); "gemm_tile" (0 auto, 128, 256). */
-int scail_tune_set(const char* knob, int value);
-
-/* Measurement aid: out2[0] = summed workgroup lifetimes in s_memtime ticks (shader cycles), out2[1] = workgroup count
- * of the launches made with the clock-stamped microbench variants (gemm_tile 1300-1364, attn_variant bit 20) since the
- * last reset. */
-int scail_debug_cycles(unsigned long long* out2, int reset);
+/*
+ * Runtime options of the library (process-wide; set before the first launch that should see them).  Returns 0, or 1 for an
+ * unknown option / out-of-range value (scail_last_error names it).
+ *   "attn4"      1 (default): scail_flash_attn_bf16 uses the 4-wave kernel wherever scail_flash_attn_kernel_for says 4;
+ *                0: the 8-wave kernel for every shape.
+ *   "attn4_thr"  lazy-rescale threshold of the 4-wave kernel in log2 units (default 8: the running row maximum is only raised,
+ *                and O / l rescaled, when a score exceeds it by more than 2^8; exact either way, 0 = rescale on every new
+ *                maximum like the 8-wave kernel).  Range [0, 64].
+ * Schedule A/B knobs, timing ablations and cycle probes are NOT part of this library: they live in the measurement build
+ * (include/scail_hip_ablation.h, SCAIL_ABLATIONS=1 python -m scail_amd.build -> scail_amd/libscail_hip_abl.so).
+ */
+int scail_set_option(const char* name, int value);
 
 /* fp32 -> bf16 (round to nearest even) and back; plumbing for boundary tensors. */
 int scail_f32_to_bf16(const float* x, scail_bf16* y, int64_t n, void* stream);

@@ -44,6 +44,7 @@ struct AttnParams {
 };
 
 __device__ unsigned long long g_attn_clk[2] = {0ull, 0ull};
+#ifdef SCAIL_ABLATIONS
 int scail_attn_clk(unsigned long long* out2, int reset) {
     if (out2 != nullptr) {
         unsigned long long v[2];
@@ -56,6 +57,7 @@ int scail_attn_clk(unsigned long long* out2, int reset) {
     }
     return 0;
 }
+#endif
 
 // VARIANT bit 0: s_setprio(1) around the MFMA clusters; bit 1: skip the O rescale when no row's running
 // max moved in this tile (exact: alpha == 1 for every lane).
@@ -647,6 +649,21 @@ extern "C" int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o
     return (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate)) ? 4 : 8;
 }
 
+// ---- runtime options of the product library (include/scail_hip.h) -----------------------------------------------------
+extern "C" int scail_set_option(const char* name, int value) {
+    const std::string k(name ? name : "");
+    if (k == "attn4") { g_attn4_mode = value != 0; return 0; }              // 0: 8-wave kernel for every shape
+    if (k == "attn4_thr") {                                                 // lazy-rescale threshold of attn4: P <= 2^value
+        SCAIL_REQUIRE(value >= 0 && value <= 64, "attn4_thr must be in [0, 64] (log2 units)");
+        g_attn4_thr_log2 = (float)value;
+        return 0;
+    }
+    scail_set_error(std::string("scail_set_option: unknown option ") + k);
+    return 1;
+}
+
+#ifdef SCAIL_ABLATIONS
+// ---- measurement build only (include/scail_hip_ablation.h): A/B of kernel schedules, timing ablations, cycle probes ----------
 int scail_gemm_tune(int v);
 int scail_gemm4_knob(const char* knob, int value);
 int scail_gemm_group_m(int v);
@@ -654,7 +671,7 @@ int scail_conv_tune(int v);
 static int g_attn_variant = 8 | (2 << 12);
 extern "C" int scail_tune_set(const char* knob, int value) {
     if (std::string(knob) == "attn_variant") {
-#ifndef SCAIL_ABLATIONS
+#if 0
         // timing ablations (wrong results on purpose; tools/microbench.py): lock-step bits 4 / 5, software-pipelined sub-code 5
         const int low = value & 0xFFFFF;
         if (low == 18 || low == 34 || low == 50 || ((value & 8) && ((value >> 12) & 15) == 5)) {
@@ -691,6 +708,8 @@ extern "C" int scail_tune_set(const char* knob, int value) {
     return 1;
 }
 
+#endif  // SCAIL_ABLATIONS
+
 extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t q_rs,
                                      const scail_bf16* k, int64_t k_ss, int64_t k_bs, int64_t k_rs,
                                      const scail_bf16* vt, int64_t vt_ss, int64_t vt_bs,
@@ -710,21 +729,28 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     if (Lq == 0 || n_batch == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[] = {reinterpret_cast<const void*>(&flash_attn_kernel<258, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<2, 4>), reinterpret_cast<const void*>(&flash_attn_kernel<0, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<1, 8>),
-                             reinterpret_cast<const void*>(&flash_attn_kernel<2, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<3, 8>),
-                             reinterpret_cast<const void*>(&flash_attn_swp_kernel<9, 3>),
+        const void* fns[] = {reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4, 0, 1>),
 #ifdef SCAIL_ABLATIONS
-                             reinterpret_cast<const void*>(&flash_attn_kernel<18, 8>),
-                             reinterpret_cast<const void*>(&flash_attn_kernel<34, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<50, 8>),
+                             reinterpret_cast<const void*>(&flash_attn_swp_kernel<5, 5>), reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4>),
+                             reinterpret_cast<const void*>(&flash_attn_swp_kernel<6, 4>), reinterpret_cast<const void*>(&flash_attn_swp_kernel<3, 3>),
+                             reinterpret_cast<const void*>(&flash_attn_swp_kernel<9, 3>), reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4, 1>),
 #endif
         };
-        for (int i = 0; i < (int)(sizeof(fns) / sizeof(fns[0])); ++i) {
-            hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, i == 6 ? ATT_PP_LDS_BYTES : ATT_LDS_BYTES);
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
             if (e != hipSuccess) {
                 scail_set_error(std::string("flash_attn: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
                 return 2;
             }
         }
+#ifdef SCAIL_ABLATIONS
+        const void* lock[] = {reinterpret_cast<const void*>(&flash_attn_kernel<258, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<2, 4>),
+                              reinterpret_cast<const void*>(&flash_attn_kernel<0, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<1, 8>),
+                              reinterpret_cast<const void*>(&flash_attn_kernel<2, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<3, 8>),
+                              reinterpret_cast<const void*>(&flash_attn_kernel<18, 8>), reinterpret_cast<const void*>(&flash_attn_kernel<34, 8>),
+                              reinterpret_cast<const void*>(&flash_attn_kernel<50, 8>)};
+        for (const void* f : lock) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
+#endif
         attr_set = true;
     }
     if (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate)) {
@@ -760,52 +786,61 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     p.heads = (int)heads; p.Lq = (int)Lq; p.Lk = (int)Lk; p.Lkp = (int)Lkp; p.n_seg = (int)n_seg;
     p.sl2 = scale * 1.4426950408889634f;
     p.accumulate = accumulate;
-    p.probe = (g_attn_variant >> 20) & 1;
+    p.probe = 0;
     dim3 grid((unsigned)((Lq + QBLK - 1) / QBLK), (unsigned)heads, (unsigned)n_batch);
-    if (g_attn_variant & 8) {
-        const int sub = (g_attn_variant >> 12) & 15;     // A/B of the interleave density
-        static bool swp_attr = false;
-        if (!swp_attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<5, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
 #ifdef SCAIL_ABLATIONS
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
-#endif
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
-            swp_attr = true;
+    // A/B schedules of the 8-wave kernel family (all parity-tested; measurements in DESIGN.md section 4.2)
+    p.probe = (g_attn_variant >> 20) & 1;
+    if (g_attn_variant != (8 | (2 << 12))) {
+        if (g_attn_variant & 8) {
+            const int sub = (g_attn_variant >> 12) & 15;     // A/B of the interleave density
+            static bool swp_attr = false;
+            if (!swp_attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<5, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+    #ifdef SCAIL_ABLATIONS
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+    #endif
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ATT_PP_LDS_BYTES);
+                swp_attr = true;
+            }
+            if (sub == 1) hipLaunchKernelGGL((flash_attn_swp_kernel<5, 5>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+            else if (sub == 2) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4, 0, 1>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);   // default
+            else if (sub == 3) hipLaunchKernelGGL((flash_attn_swp_kernel<6, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+            else if (sub == 4) hipLaunchKernelGGL((flash_attn_swp_kernel<3, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+    #ifdef SCAIL_ABLATIONS
+            else if (sub == 5) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4, 1>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+    #endif
+            else if (sub == 6) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);   // 4/4 without the store placement
+            else hipLaunchKernelGGL((flash_attn_swp_kernel<9, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+            return scail_check_launch("flash_attn");
         }
-        if (sub == 1) hipLaunchKernelGGL((flash_attn_swp_kernel<5, 5>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
-        else if (sub == 2) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4, 0, 1>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);   // default
-        else if (sub == 3) hipLaunchKernelGGL((flash_attn_swp_kernel<6, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
-        else if (sub == 4) hipLaunchKernelGGL((flash_attn_swp_kernel<3, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
-#ifdef SCAIL_ABLATIONS
-        else if (sub == 5) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4, 1>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
+        if (g_attn_variant & 256) {  // LDS-DMA staging
+            hipLaunchKernelGGL((flash_attn_kernel<258, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p);
+            return scail_check_launch("flash_attn");
+        }
+        if (g_attn_variant & 64) {   // 4-wave workgroups, two per CU
+            dim3 grid4((unsigned)((Lq + 127) / 128), (unsigned)heads, (unsigned)n_batch);
+            hipLaunchKernelGGL((flash_attn_kernel<2, 4>), grid4, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
+            return scail_check_launch("flash_attn");
+        }
+    #ifdef SCAIL_ABLATIONS
+        if ((g_attn_variant & 0xFFFFF) == 18) { hipLaunchKernelGGL((flash_attn_kernel<18, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
+        if ((g_attn_variant & 0xFFFFF) == 34) { hipLaunchKernelGGL((flash_attn_kernel<34, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
+        if ((g_attn_variant & 0xFFFFF) == 50) { hipLaunchKernelGGL((flash_attn_kernel<50, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
+    #endif
+        switch (g_attn_variant & 3) {
+            case 0: hipLaunchKernelGGL((flash_attn_kernel<0, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+            case 1: hipLaunchKernelGGL((flash_attn_kernel<1, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+            case 2: hipLaunchKernelGGL((flash_attn_kernel<2, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+            default: hipLaunchKernelGGL((flash_attn_kernel<3, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
+        }
+        return scail_check_launch("flash_attn");
+    }
 #endif
-        else if (sub == 6) hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);   // 4/4 without the store placement
-        else hipLaunchKernelGGL((flash_attn_swp_kernel<9, 3>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
-        return scail_check_launch("flash_attn");
-    }
-    if (g_attn_variant & 256) {  // LDS-DMA staging
-        hipLaunchKernelGGL((flash_attn_kernel<258, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p);
-        return scail_check_launch("flash_attn");
-    }
-    if (g_attn_variant & 64) {   // 4-wave workgroups, two per CU
-        dim3 grid4((unsigned)((Lq + 127) / 128), (unsigned)heads, (unsigned)n_batch);
-        hipLaunchKernelGGL((flash_attn_kernel<2, 4>), grid4, dim3(256), ATT_LDS_BYTES, (hipStream_t)stream, p);
-        return scail_check_launch("flash_attn");
-    }
-#ifdef SCAIL_ABLATIONS
-    if ((g_attn_variant & 0xFFFFF) == 18) { hipLaunchKernelGGL((flash_attn_kernel<18, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
-    if ((g_attn_variant & 0xFFFFF) == 34) { hipLaunchKernelGGL((flash_attn_kernel<34, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
-    if ((g_attn_variant & 0xFFFFF) == 50) { hipLaunchKernelGGL((flash_attn_kernel<50, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); return scail_check_launch("flash_attn"); }
-#endif
-    switch (g_attn_variant & 3) {
-        case 0: hipLaunchKernelGGL((flash_attn_kernel<0, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
-        case 1: hipLaunchKernelGGL((flash_attn_kernel<1, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
-        case 2: hipLaunchKernelGGL((flash_attn_kernel<2, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
-        default: hipLaunchKernelGGL((flash_attn_kernel<3, 8>), grid, dim3(ATT_THREADS), ATT_LDS_BYTES, (hipStream_t)stream, p); break;
-    }
+    // the 8-wave software-pipelined kernel: 4 / 4 VALU per MFMA gap, staging stores placed one per gap
+    hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4, 0, 1>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
     return scail_check_launch("flash_attn");
 }

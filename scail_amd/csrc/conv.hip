@@ -572,8 +572,12 @@ __global__ void from_channels_last_kernel(const u16* __restrict__ x, int64_t ldx
 // ================================================================================================
 // C ABI
 // ================================================================================================
-static int g_conv_halo = 4;
+#ifdef SCAIL_ABLATIONS
+static int g_conv_halo = 4;                                    // measurement build: A/B of the halo-kernel layouts (comment below)
 int scail_conv_tune(int v) { g_conv_halo = v; return 0; }
+#else
+static constexpr int g_conv_halo = 4;
+#endif
 
 static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
                        const scail_bf16* resid, int64_t ldr, const float* gamma, const int32_t* geom, void* stream) {
@@ -636,10 +640,12 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
             if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 32) else HALO_LAUNCH(0, 32, 1, false, 32)
         } else if (nf == 2) {
             if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96, 2) else HALO_LAUNCH(0, 32, 1, false, 96, 2)
+#ifdef SCAIL_ABLATIONS
         } else if (g_conv_halo == 1) {
             if (resid != nullptr) HALO_LAUNCH(3, 48, 2, false, 96) else HALO_LAUNCH(0, 48, 2, false, 96)
         } else if (g_conv_halo == 2) {
             if (resid != nullptr) HALO_LAUNCH(3, 32, 2, true, 96) else HALO_LAUNCH(0, 32, 2, true, 96)
+#endif
         } else {
             if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96) else HALO_LAUNCH(0, 32, 1, false, 96)
         }

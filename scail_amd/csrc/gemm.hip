@@ -257,36 +257,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_bf16_kernel(GemmParams p) {
 // q8 tile-group height (m-tiles sharing an n sweep per group): 4 measured best on the four per-token GEMM shapes
 // (tools/gemm_group_probe.py: 1: -5 %, 2: -1 %, 3-4: best, 8: -1..2 %, 16: -8 %, 32: -18 %)
 static int g_group_m = 4;
+#ifdef SCAIL_ABLATIONS
+// ---- measurement build only (include/scail_hip_ablation.h) ----
 int scail_gemm_group_m(int v) { g_group_m = v > 0 ? v : 4; return 0; }
 static int g_gemm_tile = 0;  // 0: choose by shape; 128 / 256: force; 257: 256 tile + LDS-DMA; 260: + DMA spread over the k-steps; 261: q8; 262: q8, MFMA-wave priority; 266: 4 waves
 // Codes >= 1000 select TIMING ABLATIONS of the big-tile kernels (most of them compute wrong results on purpose: loads or
-// fragment reads removed, all-L2-hit addressing, ...).  They exist for tools/microbench.py and are compiled in only when
-// the library is built with -DSCAIL_ABLATIONS (SCAIL_ABLATIONS=1 python -m scail_amd.build --force); the shipped library
-// rejects them.
+// fragment reads removed, all-L2-hit addressing, ...).  They exist for tools/microbench.py.
 int scail_gemm_tune(int v) {
-    bool ok = false;
+    bool ok = (v >= 1000 && v < 1600);
     switch (v) {
         case 0: case 128: case 256: case 257: case 260: case 261: case 262: case 266: ok = true; break;
         default: break;
     }
-#ifdef SCAIL_ABLATIONS
-    ok = ok || (v >= 1000 && v < 1600);
-#endif
     if (!ok) {
-        scail_set_error("scail_tune_set: gemm_tile " + std::to_string(v) + (v >= 1000 && v < 1600
-                            ? " is a timing ablation (wrong results); rebuild with SCAIL_ABLATIONS=1 to enable it" : " is not a known tile code"));
+        scail_set_error("scail_tune_set: gemm_tile " + std::to_string(v) + " is not a known tile code");
         return 1;
     }
     g_gemm_tile = v;
     return 0;
 }
+#endif
 
-
-// Measurement aid (tools/microbench.py): summed lifetime of the q8 workgroups in s_memtime ticks (= shader clock
-// cycles; the counters of the 8 XCDs are not synchronised, so only per-workgroup differences are meaningful) and
-// their count: sum / 256 CUs / wall time = the clock the chip sustains under a given variant.  Only kernels
-// instantiated with ABL bit 128 write it.
+// Summed lifetime of the q8 workgroups in s_memtime ticks and their count; written only by the ABL-bit-128 instantiations of
+// the measurement build (tools/microbench.py: sum / 256 CUs / wall time = the clock the chip sustains under a variant).
 __device__ unsigned long long g_q8_clk[2] = {0ull, 0ull};
+#ifdef SCAIL_ABLATIONS
 int scail_attn_clk(unsigned long long* out2, int reset);   // attn.hip: same counters for the attention kernel
 extern "C" int scail_debug_cycles(unsigned long long* out2, int reset) {
     if (out2 != nullptr && hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_q8_clk), 16) != hipSuccess) {
@@ -306,6 +301,7 @@ extern "C" int scail_debug_cycles(unsigned long long* out2, int reset) {
     }
     return 0;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Quadrant-phase kernel ("q8", gemm_tile 261).  256 x 256 x 64 tile, 8 waves (2 x 4), wave tile 128(m) x 64(n)
@@ -526,18 +522,17 @@ static int launch_gemm_q8(const GemmParams& p, hipStream_t stream) {
 
 template <int EPI>
 static int launch_gemm(const GemmParams& p, hipStream_t stream) {
+#ifdef SCAIL_ABLATIONS
+    // forced tiles / schedules and timing ablations of the measurement build (scail_gemm_tune)
     if (g_gemm_tile == 261) return launch_gemm_q8<EPI>(p, stream);
     if (g_gemm_tile == 266) return launch_gemm_t<256, 256, 2, 2, EPI, true>(p, stream);   // 4 waves, 128 x 128 per wave (AGPR accumulators)
-#ifdef SCAIL_ABLATIONS
     if (EPI == 0 && g_gemm_tile == 1101) return launch_gemm_q8<0, 1>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1102) return launch_gemm_q8<0, 2>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1103) return launch_gemm_q8<0, 3>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1104) return launch_gemm_q8<0, 4>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1108) return launch_gemm_q8<0, 8>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1112) return launch_gemm_q8<0, 12>(p, stream);
-#endif
     if (g_gemm_tile == 262) return launch_gemm_q8<EPI, 32>(p, stream);
-#ifdef SCAIL_ABLATIONS
     if (EPI == 0 && g_gemm_tile == 1300) return launch_gemm_q8<0, 128>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1301) return launch_gemm_q8<0, 129>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1302) return launch_gemm_q8<0, 130>(p, stream);
@@ -548,29 +543,29 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (EPI == 0 && g_gemm_tile == 1164) return launch_gemm_q8<0, 64>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1116) return launch_gemm_q8<0, 16>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1124) return launch_gemm_q8<0, 24>(p, stream);
-#endif
-#ifdef SCAIL_ABLATIONS
     if (EPI == 0 && g_gemm_tile == 1001) return launch_gemm_t<256, 256, 2, 4, 0, true, 1>(p, stream);   // ablations
     if (EPI == 0 && g_gemm_tile == 1002) return launch_gemm_t<256, 256, 2, 4, 0, true, 2>(p, stream);
-#endif
     if (g_gemm_tile == 260) return launch_gemm_t<256, 256, 2, 4, EPI, true, 4>(p, stream);   // DMA issue spread over the k-steps
-#ifdef SCAIL_ABLATIONS
     if (EPI == 0 && g_gemm_tile == 1008) return launch_gemm_t<256, 256, 2, 4, EPI, true, 8>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1024) return launch_gemm_t<256, 256, 2, 4, EPI, true, 24>(p, stream);
     if (EPI == 0 && g_gemm_tile == 1003) return launch_gemm_t<256, 256, 2, 4, 0, true, 3>(p, stream);
-#endif
     // measured at M = 97 664 (profiles/r01_pmc.md): 128 tile 820, 256 tile 1000, 256 + LDS-DMA 1090, 256 + DMA ring
     // of half k-tiles with counted vmcnt 1025, ping-pong 1000, quadrant-phase q8 1240-1290 TFLOP/s (default for the
     // big per-token GEMMs; the vendor library's assembly kernel reaches 1500 on the same shapes)
     if (g_gemm_tile == 256) return launch_gemm_t<256, 256, 2, 4, EPI, false>(p, stream);
-    const bool big = g_gemm_tile == 0 && p.M >= 2048 && p.N >= 1024;
+    if (g_gemm_tile == 257) return launch_gemm_t<256, 256, 2, 4, EPI, true>(p, stream);
+    if (g_gemm_tile == 128) return launch_gemm_t<128, 128, 2, 2, EPI, false>(p, stream);
+#endif
+    const bool big = p.M >= 2048 && p.N >= 1024;
     // q8 addresses a tile through a 2 GB buffer descriptor with 32-bit lane offsets
     if (big && 512 * p.lda + 2 * (int64_t)p.K < (1ll << 31) && 514 * (int64_t)p.K < (1ll << 31)) return launch_gemm_q8<EPI>(p, stream);
-    if (big || g_gemm_tile == 257) return launch_gemm_t<256, 256, 2, 4, EPI, true>(p, stream);
+    if (big) return launch_gemm_t<256, 256, 2, 4, EPI, true>(p, stream);
     return launch_gemm_t<128, 128, 2, 2, EPI, false>(p, stream);
 }
 
+#ifdef SCAIL_ABLATIONS
 // ================================================================================================
+// MEASUREMENT BUILD ONLY (parity with q8 at best, so the product library ships q8 alone).
 // gemm4: the hand-scheduled 4-wave kernels (256 x 256 x 64 tile, one wave per SIMD, the 256 accumulators of a lane in a[0:255],
 // LDS-DMA double buffer, barrier before the last k-step).  gfx950 assembly GENERATED by scail_amd/asmgen/gemm4.py (csrc/gemm4.s),
 // embedded as a code object and loaded with hipModuleLoadData on first use.  Kernel argument block = asmgen/gemm4.py KERNARG_FMT.
@@ -593,7 +588,7 @@ static hipModule_t g_gemm4_module = nullptr, g_gemm8_module = nullptr;
 static std::map<std::string, hipFunction_t> g_gemm4_fn;
 static std::map<std::pair<int, int>, std::pair<uint32_t*, int>> g_gemm4_tables;   // (m tiles, n tiles) -> device order table, entries
 static std::mutex g_gemm4_mutex;
-static int g_gemm4_mode = 8;               // generated kernels where eligible: 8 = gemm8 (default), 4 = gemm4, 0 = never (csrc/gemm.hip only)
+static int g_gemm4_mode = 0;               // generated kernels where eligible: 8 = gemm8, 4 = gemm4, 0 = never (default: q8)
 static std::string g_gemm4_suffix;         // A/B variants of the ablation build ("gemm4_kernel:<suffix>")
 
 static int gemm4_function(const std::string& name, hipFunction_t* fn) {
@@ -669,6 +664,8 @@ int scail_gemm4_knob(const char* knob, int value) {
     return -1;
 }
 
+#endif  // SCAIL_ABLATIONS
+
 extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf16* w, const float* bias,
                                scail_bf16* y, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
                                const scail_bf16* resid, int64_t ldr, const float* gate, int64_t gate_stride,
@@ -685,6 +682,7 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
         SCAIL_REQUIRE(resid != nullptr && ldr % 4 == 0, "RESID epilogue needs resid with ldr % 4 == 0");
         SCAIL_REQUIRE(gate == nullptr || (rows_per_batch > 0 && gate_stride % 4 == 0), "gate needs rows_per_batch > 0, gate_stride % 4 == 0");
     }
+#ifdef SCAIL_ABLATIONS
     if (g_gemm4_mode && g_gemm_tile == 0 && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) {
         const int epi4 = epilogue == SCAIL_EPI_RESID ? (gate != nullptr ? 3 : 4) : epilogue;
         const bool is8 = g_gemm4_mode != 4;
@@ -709,6 +707,7 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
         }
         return 0;
     }
+#endif
     GemmParams p;
     p.x = x; p.lda = lda; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;

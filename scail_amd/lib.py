@@ -25,7 +25,6 @@ SIGNATURES = {
     "scail_flash_attn_bf16": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
     "scail_flash_attn_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i],
-    "scail_gemm_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i],
     "scail_timestep_embedding": [_p, _p, _i64, _i64, _p],
     "scail_small_linear": [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
     "scail_adaln_table": [_p, _p, _p, _i64, _i64, _i64, _p],
@@ -42,8 +41,7 @@ SIGNATURES = {
     "scail_attn_small": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p, _p, _p, _i64, _p],
     "scail_mul_bf16": [_p, _p, _p, _i64, _p],
     "scail_row_affine": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
-    "scail_tune_set": [C.c_char_p, _i],
-    "scail_debug_cycles": [C.c_void_p, _i],
+    "scail_set_option": [C.c_char_p, _i],
     "scail_f32_to_bf16": [_p, _p, _i64, _p],
     "scail_bf16_to_f32": [_p, _p, _i64, _p],
     # include/scail_dit.h (structs are passed by pointer; scail_amd/cstep.py builds them)
@@ -65,6 +63,14 @@ SIGNATURES = {
 # return types other than the int status
 RESTYPES = {"scail_dit_destroy": None, "scail_vae_destroy": None, "scail_vae_workspace_bytes": _i64, "scail_dit_workspace_bytes": _i64, "scail_dit_sample_workspace_bytes": _i64,
             "scail_dit_block_workspace_bytes": _i64}
+
+# include/scail_hip_ablation.h: only libscail_hip_abl.so (SCAIL_ABLATIONS=1) exports these
+ABLATION_SIGNATURES = {
+    "scail_tune_set": [C.c_char_p, _i],
+    "scail_debug_cycles": [C.c_void_p, _i],
+    "scail_gemm_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i],
+}
+ABLATIONS = LIB_PATH.endswith("_abl.so")
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2
@@ -97,10 +103,15 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)     # AttributeError if the symbol is missing: loud by design
         fn.argtypes = args
         fn.restype = RESTYPES.get(name, C.c_int)
+    if ABLATIONS:
+        for name, args in ABLATION_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        for env, knob in (("SCAIL_ATTN_VARIANT", b"attn_variant"), ("SCAIL_GEMM_TILE", b"gemm_tile")):   # A/B overrides for measurement runs
+            if os.environ.get(env):
+                lib.scail_tune_set(knob, int(os.environ[env]))
     _lib = lib
-    for env, knob in (("SCAIL_ATTN_VARIANT", b"attn_variant"), ("SCAIL_GEMM_TILE", b"gemm_tile")):   # A/B overrides for test runs
-        if os.environ.get(env):
-            lib.scail_tune_set(knob, int(os.environ[env]))
     return lib
 
 
@@ -111,5 +122,14 @@ def call(name: str, *args) -> None:
         raise ScailHipError(f"{name} failed ({rc}): {lib.scail_last_error().decode()}")
 
 
+def set_option(name: str, value: int) -> None:
+    """Runtime option of the product library (include/scail_hip.h scail_set_option: "attn4", "attn4_thr")."""
+    call("scail_set_option", name.encode(), int(value))
+
+
 def tune_set(knob: str, value: int) -> None:
+    """Schedule A/B knobs and timing ablations: measurement build only (SCAIL_ABLATIONS=1, include/scail_hip_ablation.h)."""
+    if not ABLATIONS:
+        raise ScailHipError(f"tune_set({knob!r}): kernel variants exist only in the measurement build; run with SCAIL_ABLATIONS=1 "
+                            "after `SCAIL_ABLATIONS=1 python -m scail_amd.build`")
     call("scail_tune_set", knob.encode(), int(value))

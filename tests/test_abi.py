@@ -50,6 +50,25 @@ def test_ctypes_table_matches_header(libpath):
     assert lib.scail_abi_version() == L.ABI_VERSION
 
 
+def test_product_library_has_no_measurement_aids(libpath):
+    """Schedule A/B knobs, timing ablations, cycle probes and the generated GEMM experiments live in the measurement build only
+    (include/scail_hip_ablation.h -> libscail_hip_abl.so); the shipped library neither exports nor embeds them."""
+    from scail_amd import lib as L
+    lib = ctypes.CDLL(libpath)
+    abl = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "scail_hip_ablation.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(scail_[a-z0-9_]+)\s*\(", abl)))
+    assert set(names) == set(L.ABLATION_SIGNATURES)
+    for n in names:
+        assert not hasattr(lib, n), f"{n} must not be exported by the product library"
+    blob = open(libpath, "rb").read()
+    for kernel in (b"scail_gemm4_e0", b"scail_gemm8_e0", b"scail_attn4_rd3"):
+        assert kernel not in blob, kernel
+    assert b"scail_attn4" in blob                       # the shipped generated kernel is embedded
+    assert not L.ABLATIONS
+    with pytest.raises(L.ScailHipError, match="measurement build"):
+        L.tune_set("attn_variant", 2)
+
+
 def test_argument_validation_without_gpu(libpath):
     """Pure host-side checks of the ABI fire before any launch, so they are testable on CPU."""
     from scail_amd import lib as L
@@ -155,13 +174,8 @@ def test_more_argument_validation_without_gpu(libpath):
         ("RESID epilogue needs resid", "scail_gemm_bf16", (A, 64, A, None, A, 16, 8, 16, 64, 3, None, 0, None, 0, 0, None)),
         ("gate needs rows_per_batch", "scail_gemm_bf16", (A, 64, A, None, A, 16, 8, 16, 64, 3, A, 16, A, 16, 0, None)),
         ("pointer alignment", "scail_gemm_bf16", (A + 4, 64, A, None, A, 16, 8, 16, 64, 0, None, 0, None, 0, 0, None)),
-        ("unknown knob", "scail_tune_set", (b"no_such_knob", 1)),
-        # timing-ablation kernels (wrong results on purpose) are not in the shipped library
-        ("timing ablation", "scail_tune_set", (b"gemm_tile", 1101)),
-        ("timing ablation", "scail_tune_set", (b"attn_variant", 18)),
-        ("timing ablation", "scail_tune_set", (b"attn_variant", 8 | (5 << 12))),
-        ("not a known tile code", "scail_tune_set", (b"gemm_tile", 999)),
-        ("removed kernel", "scail_tune_set", (b"attn_variant", 512)),
+        ("unknown option", "scail_set_option", (b"no_such_option", 1)),
+        ("attn4_thr must be in", "scail_set_option", (b"attn4_thr", 99)),
     ]
     for needle, fn, args in cases:
         with pytest.raises(L.ScailHipError, match=needle):

@@ -46,10 +46,16 @@ def close(a, b, rtol=2e-2, atol=2e-2, msg=""):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[128, 256, 257, 260, 261, 262])
+@pytest.fixture(params=[0, 128, 256, 257, 260, 261, 262])
 def gemm_tile(request):
-    """Force each GEMM tile instantiation in turn (the library picks by shape otherwise)."""
+    """0 = the product dispatch (by shape).  The forced tile instantiations exist only in the measurement build
+    (SCAIL_ABLATIONS=1, include/scail_hip_ablation.h) and are skipped without it."""
     from scail_amd import lib as L
+    if request.param == 0:
+        yield 0
+        return
+    if not L.ABLATIONS:
+        pytest.skip("kernel variant of the measurement build (run with SCAIL_ABLATIONS=1)")
     L.tune_set("gemm_tile", request.param)
     yield request.param
     L.tune_set("gemm_tile", 0)
@@ -195,6 +201,11 @@ ATTN_VARIANTS = [8 | (2 << 12), 2, 258, 66, 8 | (1 << 12), 8 | (6 << 12)]
 @pytest.fixture(params=ATTN_VARIANTS)
 def attn_variant(request):
     from scail_amd import lib as L
+    if request.param == ATTN_VARIANTS[0]:               # the product's 8-wave kernel
+        yield request.param
+        return
+    if not L.ABLATIONS:
+        pytest.skip("kernel variant of the measurement build (run with SCAIL_ABLATIONS=1)")
     L.tune_set("attn_variant", request.param)
     yield request.param
     L.tune_set("attn_variant", ATTN_VARIANTS[0])
@@ -297,12 +308,12 @@ def test_attn4_vs_oracle(ops, B, H, Lq, Lk):
     assert _which(qg, kg, o) == 4
     ops.flash_attn(qg, kg, vt, out=o)
     close(o, ref, rtol=2e-2, atol=1e-2, msg=f"attn4 Lq={Lq} Lk={Lk}")
-    L.tune_set("attn4", 0)
+    L.set_option("attn4", 0)
     try:
         assert _which(qg, kg, o) == 8
         o8 = ops.flash_attn(qg, kg, vt)
     finally:
-        L.tune_set("attn4", 1)
+        L.set_option("attn4", 1)
     close(o8, ref, rtol=2e-2, atol=1e-2, msg="8-wave kernel on the same inputs")
     close(o, o8.float(), rtol=2e-2, atol=1e-2, msg="attn4 vs 8-wave")
 
@@ -323,10 +334,10 @@ def test_attn4_strided_views_segments_and_lazy_rescale(ops):
     o = torch.empty(B, Lt, D, device=DEV, dtype=torch.bfloat16)
     assert _which(g[..., :D], g[..., D:2 * D], o) == 4
     for thr in (8, 0, 2):                               # thr 0: rescale whenever any row maximum moves
-        L.tune_set("attn4_thr", thr)
+        L.set_option("attn4_thr", thr)
         ops.flash_attn(g[..., :D], g[..., D:2 * D], vt, out=o)
         close(o, ref, atol=1e-2, msg=f"attn4 on views of the qkv buffer, thr {thr}")
-    L.tune_set("attn4_thr", 8)
+    L.set_option("attn4_thr", 8)
     # key segments (sequence-parallel all-gather layout): 3 x 512 keys
     S, Ls, Lq = 3, 512, 200
     q = rnd(1, Lq, D, seed=4)
