@@ -227,6 +227,9 @@ def main():
     lib.load()
     sp = parallel.init_from_env(backend) if world > 1 else None
     import torch.distributed as dist
+    # N > 1: verify every collective of the layer exchange on rank-stamped data before anything is timed; the result
+    # (ranks, backend, RCCL version) goes into the JSON line so a scaling run can be validated from its output alone
+    sp_check = sp.self_check(dev) if sp is not None else None
 
     p, (T, H, W), Lt, Lc = CONFIGS[args.config]
     p = dict(p)
@@ -307,7 +310,14 @@ def main():
     # when the kernel source (the generated csrc/attn4.s, or attn.hip for shapes the 8-wave kernel serves) has changed since
     # or the launch shape differs, so the field cannot go stale silently
     traffic = None
-    which = lib.load().scail_flash_attn_kernel_for(3 * p["hidden_size"], 3 * p["hidden_size"], p["hidden_size"], attn_Lq, L, 0)
+    Dm = p["hidden_size"]
+    if sp_mode == "ulysses":                 # (L, Dn) matrices of this rank's head group (parallel.py)
+        strides = (Dm // world, Dm // world, Dm // world)
+    elif sp_mode == "allgather":             # local q rows of the fused qkv buffer, gathered K rows
+        strides = (3 * Dm, Dm, Dm)
+    else:
+        strides = (3 * Dm, 3 * Dm, Dm)
+    which = lib.load().scail_flash_attn_kernel_for(*strides, attn_Lq, L, 0)
     ksrc = "attn4.s" if which == 4 else "attn.hip"
     kname = "scail_attn4 (hand-scheduled 4-wave flash attention, csrc/attn4.s)" if which == 4 else "flash_attn_swp_kernel<4, 4, 0, 1>"
     try:
@@ -326,7 +336,7 @@ def main():
                                f"{p['num_layers']} layers, random-init bf16 weights",
                    "parallelism": f"sp{world}" + (f"-{sp_mode}" if sp is not None else ""), "cond_cache": False, "noise_tokens": Lnoise, "all_tokens_x_batch": 2 * L,
                    "step_tflop": fl / 1e12, "step_mfma_frac": fl / t_step / (world * PEAK_BF16_TFLOPS * 1e12),
-                   "finite": finite, "x_abs_mean": x_abs_mean},
+                   "finite": finite, "x_abs_mean": x_abs_mean, "sp_check": sp_check},
         "roofline": {"bound": "mfma", "kernel": kname + " (self-attention)", "achieved": ach,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
                      "traffic": traffic, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,

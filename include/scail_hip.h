@@ -123,6 +123,22 @@ int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t q_rs,
  */
 int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate);
 
+/*
+ * Cross attention over TWO key sets in one launch:
+ *     o = bf16( bf16(softmax(scale q k1^T) v1) + softmax(scale q k2^T) v2 )
+ * Replaces the text + CLIP-image cross attention of CrossAttentionLayer (dit_video_crossattn_sc_xc.py:1107-1203: two
+ * attention_fn calls over the same queries, outputs added in bf16) -- independent softmax states per set, Q read once, O written
+ * once (no read-modify-write).  Layouts as scail_flash_attn_bf16 with n_seg = 1: q / o row-strided token-major views with
+ * heads * 128 columns, k1 / k2 (batch stride 0 = shared by the batch) with Lk1 / Lk2 >= 1 valid keys each, vt1 / vt2 =
+ * scail_transpose_v images (heads, 128, ceil64(Lk)) per batch element (batch stride 0 = shared).  Meant for short key sets
+ * (hundreds of keys): 128-row query blocks, two workgroups per CU.
+ */
+int scail_cross_attn2_bf16(const scail_bf16* q, int64_t q_bs, int64_t q_rs,
+                           const scail_bf16* k1, int64_t k1_bs, int64_t k1_rs, const scail_bf16* vt1, int64_t vt1_bs, int64_t Lk1,
+                           const scail_bf16* k2, int64_t k2_bs, int64_t k2_rs, const scail_bf16* vt2, int64_t vt2_bs, int64_t Lk2,
+                           scail_bf16* o, int64_t o_bs, int64_t o_rs,
+                           int64_t n_batch, int64_t heads, int64_t Lq, float scale, void* stream);
+
 /* Sinusoidal timestep embedding in fp64 like sgm/modules/diffusionmodules/util.py:207-231:
  * out[b, :dim/2] = cos(t*f), out[b, dim/2:] = sin(t*f), f_j = exp(-ln(1e4) j/(dim/2)). fp32 out. */
 int scail_timestep_embedding(const float* t, float* out, int64_t n, int64_t dim, void* stream);

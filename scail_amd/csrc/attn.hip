@@ -318,6 +318,216 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_attn_kernel(AttnParams p) {
 
 
 // ================================================================================================
+// Cross attention over TWO short key sets in one launch: O = softmax(q K1^T) V1 + softmax(q K2^T) V2 (text + CLIP image
+// tokens, dit_video_crossattn_sc_xc.py:1107-1203: two scaled-dot-product attentions over the same queries whose bf16
+// outputs are added).  The two sets keep independent softmax states: when the tile sequence crosses from set 1 to set 2 the
+// normalised O1 is packed to bf16 (32 registers; the reference rounds each attention output to bf16 before the add as well),
+// the state is reset, and the epilogue writes bf16(O1) + O2 -- Q is read once, O written once, nothing is read back.
+// Launch shape for SHORT key sets (13 tiles at 512 + 257 keys): 4 waves x 32 query rows, 64 KB of LDS -> two workgroups per
+// CU, so one workgroup's prologue (Q + first tile: ~2 us of latency against ~20 us of work), softmax and barriers overlap
+// the other's MFMAs; the K / V^T tiles of a (batch, head) are shared by its 382 workgroups and stay in L2.
+// ================================================================================================
+struct Cross2Params {
+    const u16* q; int64_t q_bs, q_rs;
+    const u16* k0; int64_t k0_bs, k0_rs; const u16* vt0; int64_t vt0_bs; int Lk0, Lkp0;
+    const u16* k1; int64_t k1_bs, k1_rs; const u16* vt1; int64_t vt1_bs; int Lk1, Lkp1;
+    u16* o; int64_t o_bs, o_rs;
+    int heads, Lq;
+    float sl2;  // scale * log2(e)
+};
+
+#define X2_THREADS 256
+#define X2_LDS_BYTES (2 * (KVBLK * HD + HD * KVBLK) * 2)   // 64 KiB: two workgroups per CU
+__global__ __launch_bounds__(X2_THREADS, 2) void cross_attn2_kernel(Cross2Params p) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Ks = smem;                      // [2][KVBLK][HD]
+    u16* Vs = smem + 2 * KVBLK * HD;     // [2][HD][KVBLK]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, g = lane >> 5;
+    const int h = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): Q[q][16 ks + 8 g .. +7] ----
+    bf16x8 qf[HD / 16];
+    {
+        const int qrow = min(q0 + ql, p.Lq - 1);
+        const u16* qp = p.q + b * p.q_bs + (int64_t)qrow * p.q_rs + (int64_t)h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    }
+
+    // ---- staging by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, lane-linear in LDS, no registers): per tile
+    // 16 K pieces of 4 rows + 16 V^T pieces of 8 rows, 4 + 4 per wave.  Rows are unpadded; the 16-byte chunk index is XOR-swizzled
+    // on the per-lane SOURCE address and in the fragment reads (same involution), which keeps the reads conflict-free.
+    const int dk_row = lane >> 4, dk_c = lane & 15, dv_row = lane >> 3, dv_c = lane & 7;
+    const u16* kb0 = p.k0 + b * p.k0_bs + (int64_t)h * HD;
+    const u16* kb1 = p.k1 + b * p.k1_bs + (int64_t)h * HD;
+    const u16* vb0 = p.vt0 + b * p.vt0_bs + (int64_t)h * HD * p.Lkp0;
+    const u16* vb1 = p.vt1 + b * p.vt1_bs + (int64_t)h * HD * p.Lkp1;
+    const int n0 = p.Lkp0 / KVBLK, n1 = p.Lkp1 / KVBLK, ntiles = n0 + n1;
+#define X2_ISSUE(tt_, buf_)                                                                                 \
+    {                                                                                                       \
+        const bool s1_ = (tt_) >= n0;                                                                       \
+        const int key0_ = ((tt_) - (s1_ ? n0 : 0)) * KVBLK;                                                 \
+        const u16* kp_ = s1_ ? kb1 : kb0;                                                                   \
+        const int64_t krs_ = s1_ ? p.k1_rs : p.k0_rs;                                                       \
+        const int last_ = (s1_ ? p.Lk1 : p.Lk0) - 1;                                                        \
+        const int lkp_ = s1_ ? p.Lkp1 : p.Lkp0;                                                             \
+        const u16* vp_ = (s1_ ? vb1 : vb0) + key0_;                                                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                  \
+            const int j_ = wave * 4 + i_;                                                                   \
+            const int kr_ = 4 * j_ + dk_row;                                                                \
+            const u16* ks_src = kp_ + (int64_t)min(key0_ + kr_, last_) * krs_ + ((dk_c ^ (kr_ & 15)) << 3); \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks_src,          \
+                (__attribute__((address_space(3))) void*)(Ks + ((buf_) * KVBLK + 4 * j_) * HD), 16, 0, 0);   \
+            const int vr_ = 8 * j_ + dv_row;                                                                \
+            const u16* vs_src = vp_ + (int64_t)vr_ * lkp_ + ((dv_c ^ ((vr_ >> 1) & 7)) << 3);               \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs_src,          \
+                (__attribute__((address_space(3))) void*)(Vs + ((buf_) * HD + 8 * j_) * KVBLK), 16, 0, 0);   \
+        }                                                                                                   \
+    }
+    // swizzled fragment-read offsets (elements): chunk (2 ks + g) of row ql
+    int koff[HD / 16], voff[4];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) koff[ks] = ((2 * ks + g) ^ (ql & 15)) << 3;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) voff[ks] = ((2 * ks + g) ^ ((ql >> 1) & 7)) << 3;
+
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    uint2 o1[HD / 32][4];                     // bf16(O1) of key set 1, in the epilogue's store layout
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl2 = p.sl2;
+
+    X2_ISSUE(0, 0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): tile 0 has landed in LDS, Q fragments in registers
+    __syncthreads();
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int cur = tt & 1;
+        if (tt + 1 < ntiles) X2_ISSUE(tt + 1, cur ^ 1)
+        if (tt == n0) {
+            // ---- key set 1 is complete: O1 = acc / l, rounded to bf16; fresh softmax state for set 2 ----
+            const float inv1 = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+#pragma unroll
+            for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    o1[d][rr].x = pack_bf16x2(o[d][4 * rr + 0] * inv1, o[d][4 * rr + 1] * inv1);
+                    o1[d][rr].y = pack_bf16x2(o[d][4 * rr + 2] * inv1, o[d][4 * rr + 3] * inv1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[d][4 * rr + e] = 0.f;
+                }
+            m_run = -INFINITY;
+            l_run = 0.f;
+        }
+        // ---- S^T = K Q^T ----
+        f32x16 s[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[f][e] = 0.f;
+        const u16* ks_ = Ks + (cur * KVBLK + ql) * HD;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + f * 32 * HD + koff[ks]);
+                s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[f], 0, 0, 0);
+            }
+        }
+        // ---- mask the padded keys of each set's last tile ----
+        {
+            const bool s1 = tt >= n0;
+            const int t = tt - (s1 ? n0 : 0), ns = s1 ? n1 : n0;
+            const int tail = (s1 ? p.Lk1 : p.Lk0) - (ns - 1) * KVBLK;   // valid keys in the set's last tile (1..64)
+            if (t == ns - 1 && tail < KVBLK) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+                        if (key >= tail) s[f][r] = -INFINITY;
+                    }
+            }
+        }
+        // ---- online softmax ----
+        float mx = s[0][0];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[f][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sl2);
+        const float msc = m_new * sl2;
+        float rs = 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[f][r] * sl2 - msc);
+                s[f][r] = pv;
+                rs += pv;
+            }
+        l_run = l_run * alpha + rs;
+        if (!__all(m_new == m_run)) {        // exact skip: alpha == 1 for every lane
+#pragma unroll
+            for (int d = 0; d < HD / 32; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        }
+        m_run = m_new;
+        // ---- P^T fragments: k-slot group ks <-> score registers s[ks>>1][8 (ks&1) .. +7] ----
+        bf16x8 pf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 u;
+            const int f = ks >> 1, r0 = (ks & 1) * 8;
+            u.x = pack_bf16x2(s[f][r0 + 0], s[f][r0 + 1]);
+            u.y = pack_bf16x2(s[f][r0 + 2], s[f][r0 + 3]);
+            u.z = pack_bf16x2(s[f][r0 + 4], s[f][r0 + 5]);
+            u.w = pack_bf16x2(s[f][r0 + 6], s[f][r0 + 7]);
+            pf[ks] = __builtin_bit_cast(bf16x8, u);
+        }
+        // ---- O^T += V^T P^T ----
+        const u16* vs_ = Vs + (cur * HD + ql) * KVBLK;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int d = 0; d < HD / 32; ++d) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * KVBLK + voff[ks]);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[d], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tt + 1 are in LDS before the barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: O[q][32 d + 8 rr + 4 g + e] = bf16(O1) + O2 ----
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    const int qrow = q0 + ql;
+    if (qrow < p.Lq) {
+        u16* op = p.o + b * p.o_bs + (int64_t)qrow * p.o_rs + (int64_t)h * HD + 4 * g;
+#pragma unroll
+        for (int d = 0; d < HD / 32; ++d) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                uint2 w;
+                w.x = pack_bf16x2(o[d][4 * rr + 0] * inv + bf_lo(o1[d][rr].x), o[d][4 * rr + 1] * inv + bf_hi(o1[d][rr].x));
+                w.y = pack_bf16x2(o[d][4 * rr + 2] * inv + bf_lo(o1[d][rr].y), o[d][4 * rr + 3] * inv + bf_hi(o1[d][rr].y));
+                *reinterpret_cast<uint2*>(op + d * 32 + rr * 8) = w;
+            }
+        }
+    }
+}
+
+// ================================================================================================
 // Building blocks shared with the software-pipelined kernel below (Q fragments are read from LDS there).
 // A "ping-pong" variant (the two wave groups half a tile apart: one on the matrix pipe while its SIMD
 // partner runs the softmax, two barriers per tile) was measured at 584 TFLOP/s against 1035-1078 for the
@@ -843,4 +1053,39 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     // the 8-wave software-pipelined kernel: 4 / 4 VALU per MFMA gap, staging stores placed one per gap
     hipLaunchKernelGGL((flash_attn_swp_kernel<4, 4, 0, 1>), grid, dim3(ATT_THREADS), ATT_PP_LDS_BYTES, (hipStream_t)stream, p);
     return scail_check_launch("flash_attn");
+}
+
+extern "C" int scail_cross_attn2_bf16(const scail_bf16* q, int64_t q_bs, int64_t q_rs,
+                                      const scail_bf16* k1, int64_t k1_bs, int64_t k1_rs, const scail_bf16* vt1, int64_t vt1_bs, int64_t Lk1,
+                                      const scail_bf16* k2, int64_t k2_bs, int64_t k2_rs, const scail_bf16* vt2, int64_t vt2_bs, int64_t Lk2,
+                                      scail_bf16* o, int64_t o_bs, int64_t o_rs,
+                                      int64_t n_batch, int64_t heads, int64_t Lq, float scale, void* stream) {
+    SCAIL_REQUIRE(Lk1 >= 1 && Lk2 >= 1 && Lk1 < (1ll << 30) && Lk2 < (1ll << 30), "cross_attn2: each key set needs at least one key");
+    SCAIL_REQUIRE(heads >= 1 && heads < 65536 && n_batch < 65536 && Lq < (1ll << 31) - 256, "cross_attn2: grid limits");
+    SCAIL_REQUIRE(q_rs % 8 == 0 && k1_rs % 8 == 0 && k2_rs % 8 == 0 && o_rs % 4 == 0 && q_bs % 8 == 0 && k1_bs % 8 == 0 && k2_bs % 8 == 0 &&
+                      vt1_bs % 8 == 0 && vt2_bs % 8 == 0 && o_bs % 4 == 0,
+                  "cross_attn2: strides must keep 16-byte (q, k, vt) / 8-byte (o) alignment");
+    SCAIL_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(k1) & 15) == 0 && (reinterpret_cast<uintptr_t>(k2) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(vt1) & 15) == 0 && (reinterpret_cast<uintptr_t>(vt2) & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 7) == 0,
+                  "cross_attn2: pointer alignment");
+    if (n_batch == 0 || Lq == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X2_LDS_BYTES);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("cross_attn2: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    Cross2Params p;
+    p.q = q; p.q_bs = q_bs; p.q_rs = q_rs;
+    p.k0 = k1; p.k0_bs = k1_bs; p.k0_rs = k1_rs; p.vt0 = vt1; p.vt0_bs = vt1_bs; p.Lk0 = (int)Lk1; p.Lkp0 = (int)((Lk1 + KVBLK - 1) / KVBLK * KVBLK);
+    p.k1 = k2; p.k1_bs = k2_bs; p.k1_rs = k2_rs; p.vt1 = vt2; p.vt1_bs = vt2_bs; p.Lk1 = (int)Lk2; p.Lkp1 = (int)((Lk2 + KVBLK - 1) / KVBLK * KVBLK);
+    p.o = o; p.o_bs = o_bs; p.o_rs = o_rs;
+    p.heads = (int)heads; p.Lq = (int)Lq;
+    p.sl2 = scale * 1.44269504088896340736f;
+    dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)heads, (unsigned)n_batch);
+    hipLaunchKernelGGL(cross_attn2_kernel, grid, dim3(X2_THREADS), X2_LDS_BYTES, (hipStream_t)stream, p);
+    return scail_check_launch("cross_attn2");
 }

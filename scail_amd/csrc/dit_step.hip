@@ -100,12 +100,11 @@ static int dit_block(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, c
     DIT_TRY(scail_rmsnorm_rope(q, 3 * D, q, 3 * D, lw.cqn, nullptr, nullptr, M, M, D, 128, eps, stream));
     const scail_bf16* kt = cond->k_text + i * B * cond->Lt * D;
     const scail_bf16* vtt = cond->vt_text + i * B * nh * 128 * Ltp;
-    DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, kt, 0, cond->Lt * D, D, vtt, 0, nh * 128 * Ltp, att, Ltok * D, D,
-                                  B, nh, Ltok, cond->Lt, 1, scale, 0, stream));
     const scail_bf16* kc = cond->k_clip + i * cond->Bc * cond->Lc * D;
     const scail_bf16* vtc = cond->vt_clip + i * cond->Bc * nh * 128 * Lcp;
-    DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, kc, 0, cond->Bc == 1 ? 0 : cond->Lc * D, D, vtc, 0,
-                                  cond->Bc == 1 ? 0 : nh * 128 * Lcp, att, Ltok * D, D, B, nh, Ltok, cond->Lc, 1, scale, 1, stream));
+    DIT_TRY(scail_cross_attn2_bf16(q, Ltok * 3 * D, 3 * D, kt, cond->Lt * D, D, vtt, nh * 128 * Ltp, cond->Lt,
+                                   kc, cond->Bc == 1 ? 0 : cond->Lc * D, D, vtc, cond->Bc == 1 ? 0 : nh * 128 * Lcp, cond->Lc,
+                                   att, Ltok * D, D, B, nh, Ltok, scale, stream));
     DIT_TRY(scail_gemm_bf16(att, D, lw.co_w, lw.co_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, nullptr, 0, 0, stream));
     // -- MLP (dit...:1045-1050; sat/transformer_defaults.py:163-176) --
     DIT_TRY(scail_ln_modulate(hid, D, xn, D, m + 3 * D, m + 4 * D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));

@@ -516,8 +516,7 @@ class DiffusionTransformer(nn.Module):
             cq = qkv[..., :D]
             ops.gemm(xn, lw["cq_w"], lw["cq_b"], out=cq)
             ops.rmsnorm_rope(cq, lw["cqn"], eps=eps)
-            ops.flash_attn(cq, cond["k_text"][i], cond["vt_text"][i], out=att)
-            ops.flash_attn(cq, cond["k_clip"][i], cond["vt_clip"][i], out=att, accumulate=True)
+            ops.cross_attn2(cq, cond["k_text"][i], cond["vt_text"][i], cond["k_clip"][i], cond["vt_clip"][i], out=att)
             ops.gemm(att, lw["co_w"], lw["co_b"], out=h, epilogue=L.EPI_RESID, resid=h)
             # -- MLP (:1045-1050; sat/transformer_defaults.py:163-176) --
             ops.ln_modulate(h, sh_m, sc_m, out=xn, eps=eps)

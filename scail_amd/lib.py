@@ -25,6 +25,8 @@ SIGNATURES = {
     "scail_flash_attn_bf16": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
     "scail_flash_attn_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i],
+    "scail_cross_attn2_bf16": [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
+                               _i64, _i64, _i64, _f, _p],
     "scail_timestep_embedding": [_p, _p, _i64, _i64, _p],
     "scail_small_linear": [_p, _p, _p, _p, _i64, _i64, _i64, _i, _i, _p],
     "scail_adaln_table": [_p, _p, _p, _i64, _i64, _i64, _p],

@@ -166,6 +166,31 @@ def flash_attn(q, k, vt, out=None, scale=None, accumulate=False, n_seg=1, k_seg_
     return out
 
 
+def cross_attn2(q, k1, vt1, k2, vt2, out=None, scale=None):
+    """softmax(q k1^T) v1 + softmax(q k2^T) v2 in one launch (text + CLIP cross attention, dit_video_crossattn_sc_xc.py:1107-1203).
+    q (B, Lq, H*128) view; k1 / k2 (B|1, Lk, H*128) views; vt1 / vt2 (B|1, H, 128, ceil64(Lk)) transpose_v images."""
+    _chk(q, bf16, "cross_attn2.q")
+    B, Lq, D = q.shape
+    H = D // 128
+    assert D == H * 128 and q.stride(2) == 1
+    if out is None:
+        out = torch.empty(B, Lq, D, device=q.device, dtype=bf16)
+    _chk(out, bf16, "cross_attn2.out")
+    assert out.stride(2) == 1 and out.shape == (B, Lq, D)
+    sets = []
+    for k, vt in ((k1, vt1), (k2, vt2)):
+        _chk(k, bf16, "cross_attn2.k"); _chk(vt, bf16, "cross_attn2.vt")
+        Lk = k.shape[1]
+        assert k.shape[0] in (1, B) and vt.shape[0] == k.shape[0] and k.shape[2] == D and k.stride(2) == 1
+        assert vt.shape[1:] == (H, 128, (Lk + 63) // 64 * 64) and vt[0].is_contiguous(), (vt.shape, Lk)
+        sets += [k.data_ptr(), 0 if k.shape[0] == 1 else k.stride(0), k.stride(1), vt.data_ptr(), 0 if vt.shape[0] == 1 else vt.stride(0), Lk]
+    if scale is None:
+        scale = 1.0 / math.sqrt(128)
+    L.call("scail_cross_attn2_bf16", q.data_ptr(), q.stride(0), q.stride(1), *sets, out.data_ptr(), out.stride(0), out.stride(1),
+           B, H, Lq, scale, _stream())
+    return out
+
+
 def timestep_embedding(t, dim):
     _chk(t, f32, "timestep_embedding.t")
     out = torch.empty(t.shape[0], dim, device=t.device, dtype=f32)

@@ -8,10 +8,10 @@ SP rank 0 (diffusion_video.py:571-585).
 MI355X design: the same latent split and rank-shifted RoPE (so a rank's tokens are an aligned slab
 of ref, noise and pose tokens), but instead of 4 all-to-alls per attention (12 per layer, also for
 the two cross-attentions whose K/V are replicated anyway) each layer does ONE exchange: an
-all-gather of the post-norm, post-RoPE K and of the V^T staging buffer over xGMI (RCCL; direct
-peer links, no ring dependence), after which every rank runs full attention of its local queries
-against the n_seg gathered key segments (``scail_flash_attn_bf16`` n_seg > 1).  Softmax is
-permutation invariant over keys, so rank-major key order is harmless.  Everything else in the
+all-gather of the post-norm, post-RoPE K rows and of the V rows over xGMI (RCCL; direct peer links, no
+ring dependence), after which every rank runs full attention of its local queries against the gathered
+keys -- one contiguous (L, D) matrix in rank-major token order, so the launch is the ordinary
+single-segment one.  Softmax is permutation invariant over keys, so rank-major key order is harmless.  Everything else in the
 block is per-token and needs no communication; weights are replicated (32 GB << 288 GB HBM).
 The K/V projection is issued first so the all-gather overlaps the Q projection + Q norm/RoPE; the two CFG batch
 elements are independent sequences, so the exchange of one runs under the attention of the other (both modes).
@@ -200,6 +200,36 @@ class SequenceParallel:
     def gather_to_rank0(self, t, dim):
         return self.backend.gather_cat(t.contiguous(), dim)
 
+    def self_check(self, device) -> dict:
+        """First contact with the fabric: run each collective the layer exchange uses on rank-stamped data and verify the
+        result on every rank BEFORE any timed or production work (a wrong-but-silent exchange would only show up as a bad
+        video).  Returns what a log line needs to validate a scaling run: group size, backend, RCCL version, mode.
+        Raises RuntimeError naming the collective that failed."""
+        N, r = self.size, self.rank
+        bf = torch.bfloat16
+        inp = (torch.arange(N * 8, device=device, dtype=torch.float32).reshape(N, 8) + 1000 * r).to(bf)
+        got = torch.empty_like(inp)
+        self.backend.all_to_all(got, inp, async_op=True).wait()
+        want = torch.stack([(torch.arange(8, device=device, dtype=torch.float32) + 8 * r + 1000 * s).to(bf) for s in range(N)])
+        if not torch.equal(got, want):
+            raise RuntimeError(f"sequence-parallel self-check: all_to_all returned wrong data on rank {r} of {N}")
+        loc = torch.full((4, 8), float(r + 1), device=device, dtype=bf)
+        allg = torch.empty(N, 4, 8, device=device, dtype=bf)
+        self.backend.all_gather_into(allg, loc).wait()
+        if not torch.equal(allg, torch.arange(1, N + 1, device=device, dtype=torch.float32).to(bf).view(N, 1, 1).expand(N, 4, 8)):
+            raise RuntimeError(f"sequence-parallel self-check: all_gather returned wrong data on rank {r} of {N}")
+        t = torch.full((4,), float(r == 0) * 7.0, device=device, dtype=torch.float32)
+        self.backend.broadcast(t)
+        if not bool((t == 7.0).all()):
+            raise RuntimeError(f"sequence-parallel self-check: broadcast returned wrong data on rank {r} of {N}")
+        info = {"ranks": N, "collectives_verified": ["all_to_all", "all_gather", "broadcast"]}
+        d = getattr(self.backend, "dist", None)
+        if d is not None:
+            info["backend"] = d.get_backend(self.backend.group)
+            if info["backend"] == "nccl":
+                info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        return info
+
     # ---- the one per-layer exchange ----
     def self_attention(self, net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps):
         if self.resolve_mode(net.num_attention_heads) == "ulysses":
@@ -207,77 +237,84 @@ class SequenceParallel:
         return self.self_attention_allgather(net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps)
 
     def self_attention_ulysses(self, net, lw, xn, qkv, cos, sin, att, Ltok, eps):
-        """The reference's exchange (sat/mpu/ulysses_attn_layer.py:65-107): scatter heads / gather sequence for
-        q, k, v in ONE all-to-all, attention over the full sequence for heads/size heads, all-to-all back.
-        Norm + RoPE are applied before the exchange (the q/k RMSNorm spans all heads of a token).
-        The CFG batch elements are independent sequences, so they are pipelined: the exchange of element b+1
-        runs (on RCCL's stream) under the attention of element b, and the way back of b under the attention of b+1."""
+        """The reference's exchange (sat/mpu/ulysses_attn_layer.py:65-107): scatter heads / gather sequence for q, k, v,
+        attention over the full sequence for heads/size heads, all-to-all back.  Norm + RoPE are applied before the
+        exchange (the q/k RMSNorm spans all heads of a token).
+        Layout: q, k and v travel in THREE all-to-alls of (dst rank, Ltok, Dn) slabs, so what a rank receives for each is
+        (src rank, Ltok, Dn) = one CONTIGUOUS (size * Ltok, Dn) matrix in rank-major token order.  The attention is then the
+        ordinary single-segment full-length launch on heads/size heads -- size * Ltok is a multiple of 64 whenever the
+        unsharded length is, so the 4-wave kernel (scail_flash_attn_kernel_for == 4) serves it although the per-rank slabs
+        are ragged (6 104 tokens at 8 ranks).  Key order is rank-major, not raster order: softmax is permutation invariant
+        over keys, and q / o use the same order, undone by the way back.
+        The CFG batch elements are independent sequences, so they are pipelined: the exchange of element b+1 runs (on
+        RCCL's stream) under the attention of element b, and the way back of b under the attention of b+1."""
         D, nh, N = net.hidden_size, net.num_attention_heads, self.size
         B = xn.shape[0]
         Hn = nh // N
         Dn = Hn * 128
+        Lf = N * Ltok
         key = ("u", B, Ltok)
         if key not in self._buf:
             dev = xn.device
-            Lp = (Ltok + 63) // 64 * 64
             e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.bfloat16)
-            self._buf = {key: dict(send=e(B, N, 3, Ltok, Dn), recv=e(B, N, 3, Ltok, Dn), vtg=e(B, N, 1, Hn, 128, Lp),
-                                   oseg=e(B, N, Ltok, Dn), back=e(B, N, Ltok, Dn))}
+            self._buf = {key: dict(send=e(B, 3, N, Ltok, Dn), recv=e(B, 3, N, Ltok, Dn), vt=e(B, 1, Hn, 128, (Lf + 63) // 64 * 64),
+                                   ofull=e(B, N, Ltok, Dn), back=e(B, N, Ltok, Dn))}
         bf = self._buf[key]
-        send, recv, vtg, oseg, back = bf["send"], bf["recv"], bf["vtg"], bf["oseg"], bf["back"]
+        send, recv, vt, ofull, back = bf["send"], bf["recv"], bf["vt"], bf["ofull"], bf["back"]
         fwd = []
-        for b in range(B):                                                  # (dst rank, q|k|v, L, Dn) per batch element
+        for b in range(B):
             # projection + norm + RoPE per element: the exchange of element b runs under the projection of element b+1
             ops.gemm(xn[b], lw["qkv_w"], lw["qkv_b"], out=qkv[b])
             ops.rmsnorm_rope(qkv[b:b + 1, :, D:2 * D], lw["kn"], cos, sin, rows_per_batch=Ltok, eps=eps)
             ops.rmsnorm_rope(qkv[b:b + 1, :, :D], lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
-            send[b].copy_(qkv[b].view(Ltok, 3, N, Dn).permute(2, 1, 0, 3))
-            fwd.append(self.backend.all_to_all(recv[b], send[b], async_op=True))   # recv[b][src] = its tokens, my heads
+            send[b].copy_(qkv[b].view(Ltok, 3, N, Dn).permute(1, 2, 0, 3))           # (q|k|v, dst rank, Ltok, Dn)
+            fwd.append([self.backend.all_to_all(recv[b, j], send[b, j], async_op=True) for j in range(3)])
         bwd = []
         for b in range(B):
-            fwd[b].wait()
-            ops.transpose_v(recv[b, :, 2], Hn, out=vtg[b].view(N, Hn, 128, -1))   # all source ranks' V in one launch
-            # ONE launch: the source rank is the kernel's batch index for q / o (N x Ltok query rows), K / V^T are the N
-            # gathered segments broadcast over it -- N * Ltok / 256 x heads/N workgroups instead of N launches that
-            # each fill less than the chip
-            net._timed("self_attn", ops.flash_attn, recv[b, :, 0], recv[b, 0:1, 1], vtg[b, 0], out=oseg[b],
-                       n_seg=N, k_seg_stride=recv.stride(1), vt_seg_stride=vtg.stride(1))
-            bwd.append(self.backend.all_to_all(back[b], oseg[b], async_op=True))    # back[b][g] = my tokens, head group g
+            for h in fwd[b]:
+                h.wait()
+            qf, kf, vf = (recv[b, j].view(1, Lf, Dn) for j in range(3))              # all ranks' tokens, my heads
+            ops.transpose_v(vf, Hn, out=vt[b])
+            net._timed("self_attn", ops.flash_attn, qf, kf, vt[b], out=ofull[b].view(1, Lf, Dn))
+            bwd.append(self.backend.all_to_all(back[b], ofull[b], async_op=True))    # back[b][g] = my tokens, head group g
         for b in range(B):
             bwd[b].wait()
             att[b].view(Ltok, N, Dn).copy_(back[b].permute(1, 0, 2))
         return att
 
     def self_attention_allgather(self, net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps):
-        """xn (B, Lloc, D) -> att (B, Lloc, D): per CFG batch element K/V projection, K norm+RoPE, V^T staging and the
-        all-gather of both (so the gather of element b runs under the projection of element b+1), Q projection + norm +
-        RoPE under the last gather, then attention over all ranks' keys element by element."""
-        D, nh = net.hidden_size, net.num_attention_heads
+        """xn (B, Lloc, D) -> att (B, Lloc, D): per CFG batch element K / V projection, K norm + RoPE and the all-gather of
+        both (so the gather of element b runs under the projection of element b+1), Q projection + norm + RoPE under the
+        last gather, then attention of the local queries over all ranks' keys element by element.
+        Layout: K and V ROWS are gathered (not per-rank V^T images), so each arrives as one contiguous (size * Ltok, D)
+        matrix in rank-major token order and the attention is the ordinary single-segment launch (4-wave kernel whenever
+        the unsharded length is a multiple of 64, however ragged the per-rank slabs are); V^T is staged from the gathered
+        rows (one pass over 2 L D bytes per element: 0.1 % of the attention it feeds)."""
+        D, nh, N = net.hidden_size, net.num_attention_heads, self.size
         B = xn.shape[0]
-        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        Lf = N * Ltok
+        q = qkv[..., :D]
         key = (B, Ltok)
         if key not in self._buf:
-            Lp = vt_loc.shape[-1]
             dev = xn.device
-            self._buf = {key: dict(
-                kloc=torch.empty(B, Ltok, D, device=dev, dtype=torch.bfloat16),
-                kg=torch.empty(B, self.size, 1, Ltok, D, device=dev, dtype=torch.bfloat16),
-                vtg=torch.empty(B, self.size, 1, nh, 128, Lp, device=dev, dtype=torch.bfloat16))}
+            e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.bfloat16)
+            self._buf = {key: dict(kloc=e(B, Ltok, D), vloc=e(B, Ltok, D), kg=e(B, N, Ltok, D), vg=e(B, N, Ltok, D),
+                                   vt=e(B, 1, nh, 128, (Lf + 63) // 64 * 64))}
         bufs = self._buf[key]
-        kloc, kg, vtg = bufs["kloc"], bufs["kg"], bufs["vtg"]
+        kloc, vloc, kg, vg, vt = bufs["kloc"], bufs["vloc"], bufs["kg"], bufs["vg"], bufs["vt"]
         hs = []
         for b in range(B):      # K / V projection per element: the gather of element b runs under the projection of element b+1
-            ops.gemm(xn[b], lw["qkv_w"][D:], lw["qkv_b"][D:], out=qkv[b, :, D:])    # K and V columns
-            ops.rmsnorm_rope(k[b:b + 1], lw["kn"], cos, sin, out=kloc[b:b + 1], rows_per_batch=Ltok, eps=eps)
-            ops.transpose_v(v[b:b + 1], nh, out=vt_loc[b:b + 1])
-            hs.append((self.backend.all_gather_into(kg[b], kloc[b:b + 1]), self.backend.all_gather_into(vtg[b], vt_loc[b:b + 1])))
+            ops.gemm(xn[b], lw["qkv_w"][D:2 * D], lw["qkv_b"][D:2 * D], out=qkv[b, :, D:2 * D])
+            ops.gemm(xn[b], lw["qkv_w"][2 * D:], lw["qkv_b"][2 * D:], out=vloc[b])
+            ops.rmsnorm_rope(qkv[b:b + 1, :, D:2 * D], lw["kn"], cos, sin, out=kloc[b:b + 1], rows_per_batch=Ltok, eps=eps)
+            hs.append((self.backend.all_gather_into(kg[b], kloc[b]), self.backend.all_gather_into(vg[b], vloc[b])))
         ops.gemm(xn, lw["qkv_w"][:D], lw["qkv_b"][:D], out=q)                       # overlaps the exchange
         ops.rmsnorm_rope(q, lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
         for b in range(B):
             hs[b][0].wait()
             hs[b][1].wait()
-            net._timed("self_attn", ops.flash_attn, q[b:b + 1], kg[b, 0], vtg[b, 0], out=att[b:b + 1], n_seg=self.size,
-                       k_seg_stride=kg.stride(1), vt_seg_stride=vtg.stride(1))
+            ops.transpose_v(vg[b].view(1, Lf, D), nh, out=vt[b])
+            net._timed("self_attn", ops.flash_attn, q[b:b + 1], kg[b].view(1, Lf, D), vt[b], out=att[b:b + 1])
         return att
 
 

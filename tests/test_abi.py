@@ -174,6 +174,8 @@ def test_more_argument_validation_without_gpu(libpath):
         ("RESID epilogue needs resid", "scail_gemm_bf16", (A, 64, A, None, A, 16, 8, 16, 64, 3, None, 0, None, 0, 0, None)),
         ("gate needs rows_per_batch", "scail_gemm_bf16", (A, 64, A, None, A, 16, 8, 16, 64, 3, A, 16, A, 16, 0, None)),
         ("pointer alignment", "scail_gemm_bf16", (A + 4, 64, A, None, A, 16, 8, 16, 64, 0, None, 0, None, 0, 0, None)),
+        ("each key set needs at least one key", "scail_cross_attn2_bf16", (A, 0, 128, A, 0, 128, A, 0, 0, A, 0, 128, A, 0, 8, A, 0, 128, 1, 1, 8, 0.1, None)),
+        ("cross_attn2: strides", "scail_cross_attn2_bf16", (A, 0, 132, A, 0, 128, A, 0, 8, A, 0, 128, A, 0, 8, A, 0, 128, 1, 1, 8, 0.1, None)),
         ("unknown option", "scail_set_option", (b"no_such_option", 1)),
         ("attn4_thr must be in", "scail_set_option", (b"attn4_thr", 99)),
     ]

@@ -396,3 +396,32 @@ def test_patchify_embed_and_unpatchify(ops):
     tokout = rnd(B, T * (H // 2) * (W // 2), 64, seed=9)
     wantu = tokout.reshape(B, T, H // 2, W // 2, 1, 2, 2, 16).permute(0, 1, 4, 7, 2, 5, 3, 6).reshape(B, T, 16, H, W)
     close(ops.unpatchify(gpu_bf16(tokout), T, H, W), wantu, rtol=0, atol=0, msg="unpatchify")
+
+
+# ------------------------------------------------------------------------------------------------
+# fused two-key-set cross attention (text + CLIP, dit_video_crossattn_sc_xc.py:1107-1203)
+@pytest.mark.parametrize("B,H,Lq,Lk1,Lk2,shared2", [(2, 2, 300, 512, 257, True), (1, 3, 128, 77, 1, False), (2, 1, 515, 64, 320, False),
+                                                     (1, 2, 40, 130, 257, True), (2, 2, 1000, 512, 257, False)])
+def test_cross_attn2_vs_oracle(ops, B, H, Lq, Lk1, Lk2, shared2):
+    """one launch over two key sets = the oracle's two attentions, each rounded to bf16, added (the reference adds the bf16
+    outputs of two attention_fn calls); ragged last tiles in both sets, one-key set, query rows not a multiple of 128, the
+    second set shared by the batch (CLIP of an unbatched reference image) or per batch element, strided q view."""
+    D = H * 128
+    B2 = 1 if shared2 else B
+    qkv = rnd(B, Lq, 3 * D, seed=1)
+    q = qkv[..., :D]
+    k1, v1 = rnd(B, Lk1, D, seed=2), rnd(B, Lk1, D, seed=3)
+    k2, v2 = rnd(B2, Lk2, D, seed=4), rnd(B2, Lk2, D, seed=5, scale=2.0)
+    k2[0, Lk2 - 1, :128] = bfr(q[0, 3, :128] * 2.0)            # a dominant key in the masked last tile of set 2
+    ref = bfr(_attn_ref(q, k1, v1, H)) + _attn_ref(q, k2.expand(B, -1, -1), v2.expand(B, -1, -1), H)
+    g = gpu_bf16(qkv)
+    vt1 = ops.transpose_v(gpu_bf16(v1), H)
+    vt2 = ops.transpose_v(gpu_bf16(v2), H)
+    o = torch.full((B, Lq + 1, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.cross_attn2(g[..., :D], gpu_bf16(k1), vt1, gpu_bf16(k2), vt2, out=o[:, :Lq])
+    close(o[:, :Lq], ref, rtol=2e-2, atol=1e-2, msg=f"cross_attn2 {B, H, Lq, Lk1, Lk2}")
+    assert (o[:, Lq] == 7.0).all(), "rows past Lq must not be written"
+    # and against the two-launch path it replaces (same rounding points: bit-close, not just tolerance-close)
+    o2 = ops.flash_attn(g[..., :D], gpu_bf16(k1), vt1)
+    ops.flash_attn(g[..., :D], gpu_bf16(k2), vt2, out=o2, accumulate=True)
+    close(o[:, :Lq], o2.float(), rtol=1e-2, atol=4e-3, msg="cross_attn2 vs flash_attn + accumulate")

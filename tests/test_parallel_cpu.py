@@ -25,6 +25,8 @@ def _worker(rank, world, port, golden, q):
     cfg = O.DiTConfig(**O.TINY)
     sd = O.make_state_dict(cfg, seed=int(g["seed"]))
     sp = SequenceParallel(TorchDistBackend(None))
+    info = sp.self_check(torch.device("cpu"))              # every collective of the layer exchange, on rank-stamped data
+    assert info["ranks"] == world and info["backend"] == "gloo", info
     x = g["x"].clone()
     if rank != 0:
         x.zero_()
