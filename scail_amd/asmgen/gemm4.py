@@ -68,7 +68,11 @@ def tile_table(M: int, N: int, group_m: int = 4):
 class Cfg:
     epi: int = 0           # 0 bias, 1 bias + GELU-tanh, 3 resid + gate * (acc + bias), 4 resid + (acc + bias)
     cap: int = 3           # fillers per MFMA gap
-    stage: str = "reg"     # "reg": global -> VGPR -> ds_write (default); "dma": LDS-DMA (buffer_load ... lds), kept for the A/B
+    stage: str = "reg"     # "reg": global -> VGPR -> ds_write (default); "dma": LDS-DMA (buffer_load ... lds), kept for the A/B;
+                           # "dma2": LDS-DMA, whole-tile fragment registers read half a tile ahead, two barriers (body_dma2)
+    b1_at: float = 9.5     # dma2: gap of the barrier that releases the slot (after the reads of k-steps 2, 3)
+    b2_at: float = 31.5    # dma2: gap of the barrier that publishes tile t+1
+    rd2_step: float = 0.5  # dma2: spacing of the 16 fragment reads of a half tile
     dma_from: float = 48.0  # first gap of the 16 LDS-DMA pieces / LDS writes of tile t+2 (after the barrier at 47.5)
     dma_step: float = 1.0
     ld_from: float = 1.0   # first gap of the 16 global loads of tile t+3 (register staging)
@@ -85,6 +89,10 @@ class Cfg:
 def ACC(nb, mb): return A((nb * 4 + mb) * 16, 16)
 def FW(buf, nb): return V(buf * 32 + nb * 4, 4)            # W fragments (MFMA A operand)
 def FX(buf, mb): return V(buf * 32 + 16 + mb * 4, 4)       # x fragments (MFMA B operand)
+# stage "dma2": the fragments of a WHOLE k-tile stay in registers (4 k-steps x 32): sets 0, 1 = v0..63, sets 2, 3 = v96..159
+# (the staging registers of the register path, unused by the LDS-DMA paths)
+def FW4(ks, nb): return V((ks * 32 if ks < 2 else 96 + (ks - 2) * 32) + nb * 4, 4)
+def FX4(ks, mb): return V((ks * 32 if ks < 2 else 96 + (ks - 2) * 32) + 16 + mb * 4, 4)
 
 
 XADDR = [[V(64 + s * 4 + ks) for ks in range(4)] for s in range(2)]
@@ -117,16 +125,17 @@ class Gen:
         self.cfg = cfg
 
     # ---------------------------------------------------------------------------------------------
+    def fw(self, ks, nb): return FW4(ks, nb) if self.cfg.stage == "dma2" else FW(ks & 1, nb)
+    def fx(self, ks, mb): return FX4(ks, mb) if self.cfg.stage == "dma2" else FX(ks & 1, mb)
+
     def mfmas(self, ks: int) -> List[Instr]:
-        buf = ks & 1
-        return [isa.mfma(ACC(nb, mb), FW(buf, nb), FX(buf, mb), ACC(nb, mb), tag=f"k{ks}") for nb in range(4) for mb in range(4)]
+        return [isa.mfma(ACC(nb, mb), self.fw(ks, nb), self.fx(ks, mb), ACC(nb, mb), tag=f"k{ks}") for nb in range(4) for mb in range(4)]
 
     def frag_reads(self, slot: int, ks: int, t0: float, step: float) -> List[Instr]:
-        buf = ks & 1
         out = []
         for i in range(4):
-            out.append(isa.ds_read_b128(FW(buf, i), WADDR[slot][ks], 4096 * i, target_gap=t0 + step * (2 * i)))
-            out.append(isa.ds_read_b128(FX(buf, i), XADDR[slot][ks], 4096 * i, target_gap=t0 + step * (2 * i + 1)))
+            out.append(isa.ds_read_b128(self.fw(ks, i), WADDR[slot][ks], 4096 * i, target_gap=t0 + step * (2 * i)))
+            out.append(isa.ds_read_b128(self.fx(ks, i), XADDR[slot][ks], 4096 * i, target_gap=t0 + step * (2 * i + 1)))
         return out
 
     def dma_tile(self, slot: int, t0: float, step: float, advance: bool = True) -> List[Instr]:
@@ -212,6 +221,38 @@ class Gen:
         blk += late + adv + [w1, bar] + early + nxt + self.mfmas(3)
         return sched.schedule(blk, cap=c.cap, lookahead=1.0)
 
+    # ---- stage == "dma2": LDS-DMA staging two tiles deep inside the two 64 KB slots ---------------------------------------------
+    #   registers hold the fragments of a whole k-tile (4 sets); they are read HALF A TILE ahead of their MFMAs:
+    #     gaps  0-31  MFMA k-steps 0, 1 of tile t   ||  read fragments of k-steps 2, 3 of tile t (slot p)
+    #     barrier B1 (every wave has read the last fragments of tile t: slot p is free)
+    #     gaps ~10-42 the 16 LDS-DMA pieces of tile t+2 -> slot p, one per two gaps
+    #     barrier B2 (each wave: vmcnt(pieces of THIS iteration issued so far) -> its pieces of tile t+1, issued one iteration
+    #                 ago, have landed; after the barrier everybody's have)
+    #     gaps 32-63  MFMA k-steps 2, 3 of tile t   ||  read fragments of k-steps 0, 1 of tile t+1 (slot p^1)
+    #   -> a DMA piece has 0.8-1.3 tile periods of flight, a fragment read half a tile, and no LDS write instruction exists.
+    def body_dma2(self, p: int) -> List[Instr]:
+        c = self.cfg
+        abl = c.abl.split(",")
+        rd_a = [] if "lds" in abl else self.frag_reads(p, 2, 0.0, c.rd2_step) + self.frag_reads(p, 3, 8 * c.rd2_step, c.rd2_step)
+        w1, b1 = isa.waitcnt(lgkmcnt=0, target_gap=c.b1_at - 0.2), isa.barrier(target_gap=c.b1_at)
+        w1.after, b1.after = list(rd_a), list(rd_a) + [w1]
+        dma = [] if "dma" in abl else self.dma_tile(p, c.b1_at + 0.5, c.dma_step * 2.0)
+        for i in dma:
+            i.after = [b1]
+        w2, b2 = isa.waitcnt(vmcnt=0, target_gap=c.b2_at - 0.2), isa.barrier(target_gap=c.b2_at)
+        b2.after = [w2, b1]
+        w2.after = [b1]
+        rd_b = [] if "lds" in abl else self.frag_reads(p ^ 1, 0, c.b2_at + 0.5, c.rd2_step) + self.frag_reads(p ^ 1, 1, c.b2_at + 0.5 + 8 * c.rd2_step, c.rd2_step)
+        for i in rd_b:
+            i.after = [b2]
+        sync1 = [w1] + ([b1] if "bar" not in abl else [])
+        sync2 = [w2] + ([b2] if "bar" not in abl else [])
+        blk = rd_a + self.mfmas(0) + sync1 + dma + self.mfmas(1) + sync2 + rd_b + self.mfmas(2) + self.mfmas(3)
+        seq = sched.schedule(blk, cap=c.cap, lookahead=1.0)
+        n_before = sum(1 for i in seq[:seq.index(w2)] if getattr(i, "tag", "") == "dma")
+        w2.vmcnt, w2.mods = n_before, f"vmcnt({n_before})"
+        return seq
+
     def body(self, p: int, wave: int = 0) -> List[Instr]:
         """One k-tile (64 MFMAs) on slot p: k-steps 0-2, barrier, refill of slot p with tile t+2 || k-step 3 || first fragments
         of tile t+1 from slot p^1.  ``wave`` (with cfg.stagger): the loop exists once per wave, each copy issuing its 16 global
@@ -220,6 +261,8 @@ class Gen:
         c = self.cfg
         if c.stage == "spread":
             return self.body_spread(p, wave)
+        if c.stage == "dma2":
+            return self.body_dma2(p)
         abl = c.abl.split(",")
         blk: List[Instr] = []
         reads_p: List[Instr] = []
@@ -310,7 +353,7 @@ class Gen:
         o += [isa.sop("s_sub_u32", mlast, S_M, S_M0T), isa.sop("s_sub_u32", mlast, mlast, I32(1)),         # last valid x row of the tile
               isa.vop("v_lshrrev_b32", t[3], I32(3), LANE), isa.vop("v_and_b32", t[4], I32(7), LANE),
               isa.vop("v_lshlrev_b32", t[5], I32(6), S_WAVE)]
-        dma = c.stage == "dma"
+        dma = c.stage in ("dma", "dma2")
         for i in range(8):
             o += [isa.vop("v_add_u32", t[6], I32(8 * i), t[3]), isa.vop("v_add_u32", t[6], t[6], t[5])]           # row in tile
             if dma:
@@ -359,10 +402,17 @@ class Gen:
             return []
         tail: List[Instr] = []
         sched.insert_lgkm_waits(self.body(1), carry_in=[], carry_out=tail)
-        order = [tuple(i.writes()) for i in tail[-8:]]
-        reads = {tuple(i.writes()): i for i in self.frag_reads(0, 0, 0, 0)}
-        assert sorted(order) == sorted(reads), "the last 8 LDS operations of a body must be the next tile's first fragment reads"
+        n = self.n_carry
+        order = [tuple(i.writes()) for i in tail[-n:]]
+        first = self.frag_reads(0, 0, 0, 0) + (self.frag_reads(0, 1, 0, 0) if n == 16 else [])
+        reads = {tuple(i.writes()): i for i in first}
+        assert sorted(order) == sorted(reads), "the last LDS operations of a body must be the next tile's first fragment reads"
         return [reads[k] for k in order]
+
+    @property
+    def n_carry(self) -> int:
+        """fragment reads a body leaves in flight for its successor"""
+        return 16 if self.cfg.stage == "dma2" else 8
 
     def loop(self) -> List[Instr]:
         """The k-loop, two bodies (slot 0 / slot 1).  The first fragments of tile t+1 are read at the end of body t and consumed
@@ -379,7 +429,8 @@ class Gen:
             b0 = [i for i in b0 if not (i.op == "s_waitcnt" and getattr(i, "lgkmcnt", None) not in (None, 0))]
             b1 = [i for i in b1 if not (i.op == "s_waitcnt" and getattr(i, "lgkmcnt", None) not in (None, 0))]
         if "lds" not in self.cfg.abl.split(",") and "nost" not in self.cfg.abl.split(","):
-            assert sig(c0[-8:]) == sig(first) and sig(c1[-8:]) == sig(first), "a body must end with the next tile's first fragment reads in flight"
+            n = self.n_carry
+            assert sig(c0[-n:]) == sig(first) and sig(c1[-n:]) == sig(first), "a body must end with the next tile's first fragment reads in flight"
         o: List[Instr] = []
         waves = range(4) if self.cfg.stagger else range(1)
         if self.cfg.stagger:
@@ -593,6 +644,13 @@ def variant_cfgs():
     for cap in (2, 4):
         out.append(Cfg(epi=0, cap=cap, name=f"scail_gemm4_e0_c{cap}"))
     out.append(Cfg(epi=0, stage="dma", name="scail_gemm4_e0_lds_dma"))
+    out.append(Cfg(epi=0, stage="dma2", name="scail_gemm4_e0_dma2"))
+    out.append(Cfg(epi=0, stage="dma2", cap=2, name="scail_gemm4_e0_dma2_c2"))
+    out.append(Cfg(epi=0, stage="dma2", rd2_step=1.0, b1_at=17.5, name="scail_gemm4_e0_dma2_rd1"))
+    out.append(Cfg(epi=0, stage="dma2", dma_step=0.5, name="scail_gemm4_e0_dma2_d05"))
+    out.append(Cfg(epi=0, stage="dma2", abl="dma", name="scail_gemm4_e0_dma2_abl_dma"))
+    out.append(Cfg(epi=0, stage="dma2", abl="lds", name="scail_gemm4_e0_dma2_abl_lds"))
+    out.append(Cfg(epi=0, stage="dma2", abl="dma,lds", name="scail_gemm4_e0_dma2_abl_dma_lds"))
     out.append(Cfg(epi=0, ld_from=1.0, ld_step=1.0, name="scail_gemm4_e0_ld1"))
     out.append(Cfg(epi=0, ld_from=16.0, ld_step=1.5, name="scail_gemm4_e0_ldmid"))
     out.append(Cfg(epi=0, dma_step=0.5, name="scail_gemm4_e0_st05"))

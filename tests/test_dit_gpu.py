@@ -256,10 +256,22 @@ def test_engine_sample_from_reference_yaml_shapes():
                   image_clip_features=torch.randn(1, 5, 1280, generator=g).to(DEV).to(torch.bfloat16))
     c = dict(crossattn=torch.randn(1, 12, 64, generator=g).to(DEV), **shared)
     uc = dict(crossattn=torch.zeros(1, 12, 64, device=DEV), **shared)
+    # seeded reference-format weights into the engine's network, so the whole sampler can be checked against the oracle's
+    cfg = O.DiTConfig(**O.CONFIG1)
+    sd = O.make_state_dict(cfg, seed=77)
+    missing, unexpected = eng.network.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
     z = eng.sample(c, uc=uc, batch_size=1, shape=(T, 16, H, W), generator=torch.Generator().manual_seed(1))
     assert z.shape == (1, T, 16, H, W) and z.dtype == torch.bfloat16 and torch.isfinite(z.float()).all()
     z2 = eng.sample(c, uc=uc, batch_size=1, shape=(T, 16, H, W), generator=torch.Generator().manual_seed(1), fused=False)
     torch.testing.assert_close(z2.float(), z.float(), rtol=2e-2, atol=2e-2)
+    # the oracle's RFSampler + Denoiser + VanillaCFG loop (oracle sample(): sampling.py:950-982) on the same noise and conditions
+    x0 = torch.randn(1, T, 16, H, W, generator=torch.Generator().manual_seed(1))
+    cpu = lambda t: t.float().cpu()
+    want, _ = O.sample(cfg, sd, x0, cpu(c["crossattn"]), cpu(uc["crossattn"]), cpu(shared["ref_concat"]), cpu(shared["concat_smpl_render"]),
+                       cpu(shared["image_clip_features"]), num_steps=2, cfg_scale=4.0, shift_scale=5.0)
+    assert _cos(z.float().cpu(), want) >= 0.999
+    torch.testing.assert_close(z.float().cpu(), want, rtol=3e-2, atol=3e-2)
 
 
 @pytest.mark.parametrize("world,mode", [(2, "allgather"), (2, "ulysses")])

@@ -1,0 +1,41 @@
+"""CPU emulation (tools/asm_emu.py) of the generated GEMM kernels of the MEASUREMENT build (scail_amd/asmgen/gemm4.py, gemm8.py:
+experiments that reached parity with the shipped q8 kernel): the generator keeps producing hazard-free code whose
+results equal the fp64 product of the bf16-rounded operands, under the emulator's lazy (latest-allowed) completion of LDS / memory
+operations -- the mode that exposes a missing or too-weak s_waitcnt."""
+import math
+
+import numpy as np
+import pytest
+
+from scail_amd.asmgen import gemm4
+from tools import gemm4_emu_run as R
+
+
+def _case(cfg, M, N, K, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    kw = dict(bias=rng.standard_normal(N).astype(np.float32))
+    if cfg.epi in (3, 4):
+        kw["resid"] = rng.standard_normal((M, N)).astype(np.float32)
+    if cfg.epi == 3:
+        kw.update(gate=rng.standard_normal((2, N)).astype(np.float32), rows_per_batch=(M + 1) // 2)
+    return x, w, kw
+
+
+def _variant(name):
+    return [c for c in gemm4.DEFAULTS + gemm4.variant_cfgs() if c.name == name][0]
+
+
+@pytest.mark.parametrize("name,shape", [("scail_gemm4_e0", (300, 256, 192)),              # register staging, ragged last m-tile
+                                        ("scail_gemm4_e3", (264, 256, 128)),              # gate * (acc + bias) + residual epilogue
+                                        ("scail_gemm4_e0_dma2", (300, 256, 320)),         # LDS-DMA two tiles deep, odd tile count
+                                        ("scail_gemm4_e0_spread", (256, 256, 256))])
+def test_gemm4_emulated(name, shape):
+    cfg = _variant(name)
+    assert R.check_static(cfg) == [], "hazard distances of the generated loop / prologue"
+    x, w, kw = _case(cfg, *shape)
+    y, _ = R.run(cfg, x, w, lazy=True, **kw)
+    ref = R.reference(cfg, x, w, **kw)
+    err = np.abs(y - ref)
+    assert err.max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max()), float(err.max())     # one bf16 rounding of the output

@@ -40,10 +40,11 @@ def ref_rows(x, w, b, rows, epi, resid=None, gate=None, rpb=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--variants", default=",c2,c4,dma2,dmalate")
-    ap.add_argument("--ablations", default="abl_dma,abl_lds,abl_bar,abl_dma_lds")
-    ap.add_argument("--variants8", default=",c2,c5,wr1,ldlate,abl_dma,abl_lds,abl_bar,abl_dma_lds")
+    ap.add_argument("--variants", default=",spread,lds_dma,dma2,dma2_c2,dma2_rd1,dma2_d05")
+    ap.add_argument("--ablations", default="dma2_abl_dma,dma2_abl_lds,dma2_abl_dma_lds")
+    ap.add_argument("--variants8", default="-", help="gemm8 variants (\"-\" = skip gemm8)")
     ap.add_argument("--vendor", action="store_true")
+    ap.add_argument("--skip-check", action="store_true")
     a = ap.parse_args()
     lib.load()
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -63,6 +64,9 @@ def main():
                               ("resid+gate", L.EPI_RESID, dict(resid=True, gate=True)), ("resid", L.EPI_RESID, dict(resid=True))):
             res = {}
             for mode in (8, 4, 0):
+                if a.skip_check:
+                    res[mode] = 0.0
+                    continue
                 lib.tune_set("gemm4", mode)
                 y = resid.clone() if kw.get("resid") else torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
                 ops.gemm(x, w, None if kw.get("nobias") else b, out=y, epilogue=epi, resid=y if kw.get("resid") else None,
@@ -90,8 +94,10 @@ def main():
         lib.tune_set("gemm4", 0)
         ms = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=epi, **kw), a.iters)
         out["q8_TFLOPs"] = fl / ms / 1e9
+        rows = torch.randint(0, M, (256,), device=DEV)
+        y_q8 = y[rows].float().clone() if epi == L.EPI_BIAS else None
         lib.tune_set("gemm4", 8)
-        for v in (a.variants8.split(",") if epi == L.EPI_BIAS else [""]):
+        for v in ([t for t in a.variants8.split(",") if t or not a.variants8 == "-"] if epi == L.EPI_BIAS and a.variants8 != "-" else ([""] if a.variants8 != "-" else [])):
             setk(v)
             ms = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=epi, **kw), a.iters)
             out["gemm8" + ("_" + v if v else "") + "_TFLOPs"] = fl / ms / 1e9
@@ -102,6 +108,8 @@ def main():
             setk(v)
             ms = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=epi, **kw), a.iters)
             out["gemm4" + ("_" + v if v else "") + "_TFLOPs"] = fl / ms / 1e9
+            if y_q8 is not None and "abl" not in v:
+                out["gemm4" + ("_" + v if v else "") + "_maxdiff_vs_q8"] = float((y[rows].float() - y_q8).abs().max())
         setk("")
         lib.tune_set("gemm4", 0)
         if a.vendor:
