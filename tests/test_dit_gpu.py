@@ -270,8 +270,11 @@ def test_engine_sample_from_reference_yaml_shapes():
     cpu = lambda t: t.float().cpu()
     want, _ = O.sample(cfg, sd, x0, cpu(c["crossattn"]), cpu(uc["crossattn"]), cpu(shared["ref_concat"]), cpu(shared["concat_smpl_render"]),
                        cpu(shared["image_clip_features"]), num_steps=2, cfg_scale=4.0, shift_scale=5.0)
+    # tolerance of the 2-step CFG sampler as in test_sampler_*: the guidance combine v_u + 4 (v_c - v_u) carries (2 * 4 - 1) x the
+    # forward error of the bf16 network into every step -> atol 0.14, plus cosine and mean-error bounds
     assert _cos(z.float().cpu(), want) >= 0.999
-    torch.testing.assert_close(z.float().cpu(), want, rtol=3e-2, atol=3e-2)
+    assert float((z.float().cpu() - want).abs().mean()) < 2e-2
+    torch.testing.assert_close(z.float().cpu(), want, rtol=3e-2, atol=0.14)
 
 
 @pytest.mark.parametrize("world,mode", [(2, "allgather"), (2, "ulysses")])
