@@ -21,7 +21,8 @@ extern "C" {
  *                          threshold, XCD-aware workgroup ids on/off, variant of asmgen/attn4.py variant_cfgs()
  *   "gemm_tile"            0 auto, 128, 256, 257, 260, 261 (q8), 262, 266; 1000-1599 = timing ablations (wrong results)
  *   "gemm_group_m"         q8 tile-group height
- *   "gemm4" (0 / 4 / 8), "gemm4_kernel[:suffix]"   generated GEMM kernels (asmgen/gemm4.py, gemm8.py) where eligible
+ *   "gemm4" (0 / 4 / 8), "gemm4_kernel[:suffix]"   generated GEMM kernels: off / gemm4 (the product default) / gemm8 (two waves per
+ *                          SIMD, this build only); variant of asmgen/gemm4.py, gemm8.py variant_cfgs() for the bias epilogue
  *   "conv_halo"            halo-convolution layout 0-4
  */
 int scail_tune_set(const char* knob, int value);
@@ -29,9 +30,6 @@ int scail_tune_set(const char* knob, int value);
 /* out2[0] = summed workgroup lifetimes in s_memtime ticks (shader cycles), out2[1] = workgroup count of the launches made with
  * the clock-stamped variants (gemm_tile 1300-1364, attn_variant bit 20) since the last reset. */
 int scail_debug_cycles(unsigned long long* out2, int reset);
-
-/* Which kernel scail_gemm_bf16 runs for a shape in this build: 8 / 4 = generated gemm8 / gemm4, 0 = csrc/gemm.hip. */
-int scail_gemm_kernel_for(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int64_t N, int64_t K, int epilogue);
 
 #ifdef __cplusplus
 }

@@ -68,11 +68,14 @@ def tile_table(M: int, N: int, group_m: int = 4):
 class Cfg:
     epi: int = 0           # 0 bias, 1 bias + GELU-tanh, 3 resid + gate * (acc + bias), 4 resid + (acc + bias)
     cap: int = 3           # fillers per MFMA gap
+    lookahead: float = 1.0 # scheduler: how far before its target gap a filler may be placed
     stage: str = "reg"     # "reg": global -> VGPR -> ds_write (default); "dma": LDS-DMA (buffer_load ... lds), kept for the A/B;
                            # "dma2": LDS-DMA, whole-tile fragment registers read half a tile ahead, two barriers (body_dma2)
     b1_at: float = 9.5     # dma2: gap of the barrier that releases the slot (after the reads of k-steps 2, 3)
     b2_at: float = 31.5    # dma2: gap of the barrier that publishes tile t+1
     rd2_step: float = 0.5  # dma2: spacing of the 16 fragment reads of a half tile
+    nt_store: bool = False # epilogue stores with the non-temporal hint (y is written once and read by a later kernel)
+    mi: int = 32           # MFMA shape: 32 = v_mfma_f32_32x32x16_bf16 (64 per tile), 16 = v_mfma_f32_16x16x32_bf16 (128 per tile; dma2 only)
     dma_from: float = 48.0  # first gap of the 16 LDS-DMA pieces / LDS writes of tile t+2 (after the barrier at 47.5)
     dma_step: float = 1.0
     ld_from: float = 1.0   # first gap of the 16 global loads of tile t+3 (register staging)
@@ -93,6 +96,12 @@ def FX(buf, mb): return V(buf * 32 + 16 + mb * 4, 4)       # x fragments (MFMA B
 # (the staging registers of the register path, unused by the LDS-DMA paths)
 def FW4(ks, nb): return V((ks * 32 if ks < 2 else 96 + (ks - 2) * 32) + nb * 4, 4)
 def FX4(ks, mb): return V((ks * 32 if ks < 2 else 96 + (ks - 2) * 32) + 16 + mb * 4, 4)
+
+
+# mi = 16: 8 x 8 blocks of 16 x 16 per wave (4 accumulators each), fragments of a k32-step = 8 + 8 quads: set 0 = v0..63, set 1 = v96..159
+def ACC16(nb, mb): return A((nb * 8 + mb) * 4, 4)
+def FW16(s, nb): return V((0 if s == 0 else 96) + nb * 4, 4)
+def FX16(s, mb): return V((0 if s == 0 else 96) + 32 + mb * 4, 4)
 
 
 XADDR = [[V(64 + s * 4 + ks) for ks in range(4)] for s in range(2)]
@@ -127,6 +136,16 @@ class Gen:
     # ---------------------------------------------------------------------------------------------
     def fw(self, ks, nb): return FW4(ks, nb) if self.cfg.stage == "dma2" else FW(ks & 1, nb)
     def fx(self, ks, mb): return FX4(ks, mb) if self.cfg.stage == "dma2" else FX(ks & 1, mb)
+
+    def mfmas16(self, s: int) -> List[Instr]:
+        return [isa.mfma16(ACC16(nb, mb), FW16(s, nb), FX16(s, mb), ACC16(nb, mb), tag=f"k{s}") for nb in range(8) for mb in range(8)]
+
+    def frag_reads16(self, slot: int, s: int, t0: float, step: float) -> List[Instr]:
+        out = []
+        for i in range(8):
+            out.append(isa.ds_read_b128(FW16(s, i), WADDR[slot][s], 2048 * i, target_gap=t0 + step * (2 * i)))
+            out.append(isa.ds_read_b128(FX16(s, i), XADDR[slot][s], 2048 * i, target_gap=t0 + step * (2 * i + 1)))
+        return out
 
     def mfmas(self, ks: int) -> List[Instr]:
         return [isa.mfma(ACC(nb, mb), self.fw(ks, nb), self.fx(ks, mb), ACC(nb, mb), tag=f"k{ks}") for nb in range(4) for mb in range(4)]
@@ -233,22 +252,33 @@ class Gen:
     def body_dma2(self, p: int) -> List[Instr]:
         c = self.cfg
         abl = c.abl.split(",")
-        rd_a = [] if "lds" in abl else self.frag_reads(p, 2, 0.0, c.rd2_step) + self.frag_reads(p, 3, 8 * c.rd2_step, c.rd2_step)
-        w1, b1 = isa.waitcnt(lgkmcnt=0, target_gap=c.b1_at - 0.2), isa.barrier(target_gap=c.b1_at)
+        gs = 2.0 if c.mi == 16 else 1.0           # gaps per 32 matrix-pipe cycles
+        b1_at, b2_at = c.b1_at * gs, c.b2_at * gs + (0.5 if c.mi == 16 else 0.0)
+        if c.mi == 16:
+            rd_a = [] if "lds" in abl else self.frag_reads16(p, 1, 0.0, c.rd2_step * gs)
+        else:
+            rd_a = [] if "lds" in abl else self.frag_reads(p, 2, 0.0, c.rd2_step) + self.frag_reads(p, 3, 8 * c.rd2_step, c.rd2_step)
+        w1, b1 = isa.waitcnt(lgkmcnt=0, target_gap=b1_at - 0.2), isa.barrier(target_gap=b1_at)
         w1.after, b1.after = list(rd_a), list(rd_a) + [w1]
-        dma = [] if "dma" in abl else self.dma_tile(p, c.b1_at + 0.5, c.dma_step * 2.0)
+        dma = [] if "dma" in abl else self.dma_tile(p, b1_at + 0.5, c.dma_step * 2.0 * gs)
         for i in dma:
             i.after = [b1]
-        w2, b2 = isa.waitcnt(vmcnt=0, target_gap=c.b2_at - 0.2), isa.barrier(target_gap=c.b2_at)
+        w2, b2 = isa.waitcnt(vmcnt=0, target_gap=b2_at - 0.2), isa.barrier(target_gap=b2_at)
         b2.after = [w2, b1]
         w2.after = [b1]
-        rd_b = [] if "lds" in abl else self.frag_reads(p ^ 1, 0, c.b2_at + 0.5, c.rd2_step) + self.frag_reads(p ^ 1, 1, c.b2_at + 0.5 + 8 * c.rd2_step, c.rd2_step)
+        if c.mi == 16:
+            rd_b = [] if "lds" in abl else self.frag_reads16(p ^ 1, 0, b2_at + 0.5, c.rd2_step * gs)
+        else:
+            rd_b = [] if "lds" in abl else self.frag_reads(p ^ 1, 0, b2_at + 0.5, c.rd2_step) + self.frag_reads(p ^ 1, 1, b2_at + 0.5 + 8 * c.rd2_step, c.rd2_step)
         for i in rd_b:
             i.after = [b2]
         sync1 = [w1] + ([b1] if "bar" not in abl else [])
         sync2 = [w2] + ([b2] if "bar" not in abl else [])
-        blk = rd_a + self.mfmas(0) + sync1 + dma + self.mfmas(1) + sync2 + rd_b + self.mfmas(2) + self.mfmas(3)
-        seq = sched.schedule(blk, cap=c.cap, lookahead=1.0)
+        if c.mi == 16:
+            blk = rd_a + sync1 + dma + self.mfmas16(0) + sync2 + rd_b + self.mfmas16(1)
+        else:
+            blk = rd_a + self.mfmas(0) + sync1 + dma + self.mfmas(1) + sync2 + rd_b + self.mfmas(2) + self.mfmas(3)
+        seq = sched.schedule(blk, cap=c.cap, lookahead=c.lookahead)
         n_before = sum(1 for i in seq[:seq.index(w2)] if getattr(i, "tag", "") == "dma")
         w2.vmcnt, w2.mods = n_before, f"vmcnt({n_before})"
         return seq
@@ -336,14 +366,18 @@ class Gen:
               isa.sop("s_mov_b32", S_KOFF, I32(0)), isa.sop("s_mov_b32", S_T, I32(0)),
               isa.sop("s_lshl_b32", S_XLDS, S_WAVE, I32(13)), isa.sop("s_add_u32", S_WLDS, S_XLDS, I32(32768))]
         ql, g, t = T_[1], T_[2], T_
-        o += [isa.vop("v_and_b32", ql, I32(31), LANE), isa.vop("v_lshrrev_b32", g, I32(5), LANE)]
+        if c.mi == 16:
+            # 16 x 16 x 32 fragments: lane -> row l % 16, 16-byte chunk 4 s + (l / 16) of the 128-byte k-row (s = k32-step)
+            o += [isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
+        else:
+            o += [isa.vop("v_and_b32", ql, I32(31), LANE), isa.vop("v_lshrrev_b32", g, I32(5), LANE)]
         # fragment read addresses: row r (128 B), chunk (2 ks + g) ^ ((r >> 1) & 7); x rows 128 wm + 32 mb + ql, W rows 128 wn + ...
         o += [isa.vop("v_lshrrev_b32", t[3], I32(1), ql), isa.vop("v_and_b32", t[3], I32(7), t[3]), isa.vop("v_lshlrev_b32", t[4], I32(7), ql),
               isa.vop("v_lshlrev_b32", t[5], I32(14), S_WM), isa.vop("v_add_u32", t[5], t[5], t[4]),                     # x: wm * 128 rows * 128 B
               isa.vop("v_lshlrev_b32", t[6], I32(14), S_WN), isa.vop("v_add_u32", t[6], t[6], t[4]),
               isa.vop("v_add_u32", t[6], I32(32768), t[6])]
-        for ks in range(4):
-            o += [isa.vop("v_or_b32", t[7], I32(2 * ks), g), isa.vop("v_xor_b32", t[7], t[7], t[3]),
+        for ks in range(2 if c.mi == 16 else 4):
+            o += [isa.vop("v_or_b32", t[7], I32((4 if c.mi == 16 else 2) * ks), g), isa.vop("v_xor_b32", t[7], t[7], t[3]),
                   isa.vop("v_lshl_add_u32", XADDR[0][ks], t[7], I32(4), t[5]), isa.vop("v_lshl_add_u32", WADDR[0][ks], t[7], I32(4), t[6]),
                   isa.vop("v_add_u32", XADDR[1][ks], I32(65536), XADDR[0][ks]), isa.vop("v_add_u32", WADDR[1][ks], I32(65536), WADDR[0][ks])]
         # source offsets: piece i of this wave = tile rows 64 w + 8 i + (lane >> 3), 16-byte chunk lane & 7 of the 128-byte k-row.
@@ -404,7 +438,10 @@ class Gen:
         sched.insert_lgkm_waits(self.body(1), carry_in=[], carry_out=tail)
         n = self.n_carry
         order = [tuple(i.writes()) for i in tail[-n:]]
-        first = self.frag_reads(0, 0, 0, 0) + (self.frag_reads(0, 1, 0, 0) if n == 16 else [])
+        if self.cfg.mi == 16:
+            first = self.frag_reads16(0, 0, 0, 0)
+        else:
+            first = self.frag_reads(0, 0, 0, 0) + (self.frag_reads(0, 1, 0, 0) if n == 16 else [])
         reads = {tuple(i.writes()): i for i in first}
         assert sorted(order) == sorted(reads), "the last LDS operations of a body must be the next tile's first fragment reads"
         return [reads[k] for k in order]
@@ -452,30 +489,37 @@ class Gen:
 
     # ---------------------------------------------------------------------------------------------
     def epilogue(self) -> List[Instr]:
-        """y[m][n .. n+3] for the lane's rows m = m0 + 128 wm + 32 mb + (lane & 31), n = n0 + 128 wn + 32 nb + 8 rr + 4 g."""
+        """mi = 32: y[m][n .. n+3] for the lane's rows m = m0 + 128 wm + 32 mb + (lane & 31), n = n0 + 128 wn + 32 nb + 8 rr + 4 g;
+        mi = 16: rows m = m0 + 128 wm + 16 mb + (lane & 15), n = n0 + 128 wn + 16 nb + 4 (lane >> 4) -- in both layouts a lane owns
+        quads of 4 consecutive n, `quads` below lists them as (n offset, accumulator quad of row block mb, bias quad)."""
         c = self.cfg
         e: List[Instr] = []
         ql, g, t = T_[1], T_[2], T_
+        if c.mi == 16:
+            n_mb, rows_mb = 8, 16
+            quads = [(16 * nb, (lambda mb, nb=nb: ACC16(nb, mb)), V(nb * 4, 4)) for nb in range(8)]
+        else:
+            n_mb, rows_mb = 4, 32
+            quads = [(32 * nb + 8 * rr, (lambda mb, nb=nb, rr=rr: A((nb * 4 + mb) * 16 + 4 * rr, 4)), V(nb * 16 + rr * 4, 4))
+                     for nb in range(4) for rr in range(4)]
         nw = ST[4]            # n0 + 128 wn (first column of the wave)
         e += [isa.sop("s_lshl_b32", nw, S_WN, I32(7)), isa.sop("s_add_u32", nw, nw, S_N0T)]
         e += self.addr64_madd(S_Y, nw, I32(1), 1)
-        # bias quads: BQ[nb][rr] = bias[nw + 32 nb + 8 rr + 4 g .. +3]  (zeros when bias == NULL)
-        BQ = [[V(nb * 16 + rr * 4, 4) for rr in range(4)] for nb in range(4)]           # v0..v63 (fragment registers are dead)
+        # bias quads (fragment registers are dead): zeros when bias == NULL
         for i in range(64):
             e.append(isa.vop("v_mov_b32", V(i), I32(0)))
         e += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias")]
         e += self.addr64_madd(S_BIAS, nw, I32(1), 2)
         e += [isa.vop("v_lshlrev_b32", t[3], I32(4), g)]                       # 4 g floats = 16 g bytes
-        for nb in range(4):
-            for rr in range(4):
-                e.append(isa.global_load(4, BQ[nb][rr], t[3], (32 * nb + 8 * rr) * 4, saddr=S_BIAS))
+        for noff, _, bq_ in quads:
+            e.append(isa.global_load(4, bq_, t[3], noff * 4, saddr=S_BIAS))
         e += [isa.waitcnt(vmcnt=0), isa.label("L_nobias")]
         # rows
         mw = ST[5]
         e += [isa.sop("s_lshl_b32", mw, S_WM, I32(7)), isa.sop("s_add_u32", mw, mw, S_M0T)]
         ldcb = ST[6]
         e += [isa.sop("s_lshl_b32", ldcb, S_LDC.sub(0), I32(1))]
-        RCP, KC0, KC1 = V(129), V(132), V(133)
+        RCP, KC0, KC1 = V(161), V(162), V(163)
         if c.epi in (3, 4):
             e += self.addr64_madd(S_RES, nw, I32(1), 1)
             e += [isa.sop("s_lshl_b32", ST[7], S_LDR.sub(0), I32(1))]
@@ -488,11 +532,11 @@ class Gen:
             K0, K1 = 0.7978845608028654, 0.044715
             sc = 2.0 * 1.4426950408889634
             e += [isa.vop("v_mov_b32", KC0, F32(K0 * sc)), isa.vop("v_mov_b32", KC1, F32(K0 * K1 * sc))]
-        for mb in range(4):
-            row, yoff, roff, goff, bq = V(134), V(135), V(136), V(137), V(138)
+        for mb in range(n_mb):
+            row, yoff, roff, goff, bq = V(164), V(165), V(166), V(167), V(168)
             e += [isa.vop("v_add_u32", row, mw, ql)]
             if mb:
-                e += [isa.vop("v_add_u32", row, I32(32 * mb), row)]
+                e += [isa.vop("v_add_u32", row, I32(rows_mb * mb), row)]
             e += [isa.vop("v_mul_lo_u32", yoff, row, ldcb), isa.vop("v_lshl_add_u32", yoff, g, I32(3), yoff)]
             if c.epi in (3, 4):
                 e += [isa.vop("v_mul_lo_u32", roff, row, ST[7]), isa.vop("v_lshl_add_u32", roff, g, I32(3), roff)]
@@ -503,38 +547,37 @@ class Gen:
                       isa.vop("v_mul_lo_u32", goff, bq, ST[12]), isa.vop("v_lshl_add_u32", goff, g, I32(4), goff)]
             e += [isa.v_cmp("v_cmp_lt_u32", row, S_M),
                   Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
-            k = 0
-            for nb in range(4):
-                for rr in range(4):
-                    base = 140 + 16 * (k % 2)         # two rotating register groups
-                    k += 1
-                    f = [V(base + i) for i in range(4)]
-                    w, rp, r_, u2, gq = V(base + 4, 2), V(base + 6, 2), V(base + 8), [V(base + 9), V(base + 10)], V(base + 12, 4)
-                    noff = (32 * nb + 8 * rr)
-                    if c.epi in (3, 4):
-                        e.append(isa.global_load(2, rp, roff, noff * 2, saddr=S_RES, extra_reads=[EXEC]))
+            for k, (noff, accq, bq_) in enumerate(quads):
+                base = 170 + 16 * (k % 2)         # two rotating register groups
+                f = [V(base + i) for i in range(4)]
+                w, rp, r_, u2, gq = V(base + 4, 2), V(base + 6, 2), V(base + 8), [V(base + 9), V(base + 10)], V(base + 12, 4)
+                acc = accq(mb)
+                if c.epi in (3, 4):
+                    e.append(isa.global_load(2, rp, roff, noff * 2, saddr=S_RES, extra_reads=[EXEC]))
+                if c.epi == 3:
+                    e.append(isa.global_load(4, gq, goff, noff * 4, saddr=S_GATE, extra_reads=[EXEC]))
+                for i in range(4):
+                    e += [isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)),
+                          isa.vop("v_add_f32", f[i], f[i], bq_.sub(i))]
+                if c.epi == 1:
+                    for i in range(4):           # gelu_tanh(v) = v - v / (exp2(2 log2e k0 (v + k1 v^3)) + 1)
+                        u = u2[i & 1]
+                        e += [isa.vop("v_mul_f32", u, f[i], f[i]), isa.vop("v_fma_f32", u, u, KC1, KC0),
+                              isa.vop("v_mul_f32", u, u, f[i]), isa.vop("v_exp_f32", u, u), isa.vop("v_add_f32", u, F32(1.0), u),
+                              isa.vop("v_rcp_f32", u, u), isa.vop("v_fma_f32", f[i], Neg(f[i]), u, f[i])]
+                if c.epi in (3, 4):
+                    e.append(isa.waitcnt(vmcnt=0))
                     if c.epi == 3:
-                        e.append(isa.global_load(4, gq, goff, noff * 4, saddr=S_GATE, extra_reads=[EXEC]))
-                    for i in range(4):
-                        e += [isa.vop("v_accvgpr_read_b32", f[i], ACC(nb, mb).sub(4 * rr + i)),
-                              isa.vop("v_add_f32", f[i], f[i], BQ[nb][rr].sub(i))]
-                    if c.epi == 1:
-                        for i in range(4):           # gelu_tanh(v) = v - v / (exp2(2 log2e k0 (v + k1 v^3)) + 1)
-                            u = u2[i & 1]
-                            e += [isa.vop("v_mul_f32", u, f[i], f[i]), isa.vop("v_fma_f32", u, u, KC1, KC0),
-                                  isa.vop("v_mul_f32", u, u, f[i]), isa.vop("v_exp_f32", u, u), isa.vop("v_add_f32", u, F32(1.0), u),
-                                  isa.vop("v_rcp_f32", u, u), isa.vop("v_fma_f32", f[i], Neg(f[i]), u, f[i])]
-                    if c.epi in (3, 4):
-                        e.append(isa.waitcnt(vmcnt=0))
-                        if c.epi == 3:
-                            for i in range(4):
-                                e.append(isa.vop("v_mul_f32", f[i], f[i], gq.sub(i)))
-                        for i in range(4):           # + residual (bf16 pairs: low half << 16, high half & 0xffff0000)
-                            src = rp.sub(i >> 1)
-                            e += [isa.vop("v_lshlrev_b32", r_, I32(16), src) if (i & 1) == 0 else isa.vop("v_and_b32", r_, I32(0xFFFF0000), src),
-                                  isa.vop("v_add_f32", f[i], f[i], r_)]
-                    e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
-                          isa.global_store(2, yoff, w, noff * 2, saddr=S_Y, extra_reads=[EXEC])]
+                        for i in range(4):
+                            e.append(isa.vop("v_mul_f32", f[i], f[i], gq.sub(i)))
+                    for i in range(4):           # + residual (bf16 pairs: low half << 16, high half & 0xffff0000)
+                        src = rp.sub(i >> 1)
+                        e += [isa.vop("v_lshlrev_b32", r_, I32(16), src) if (i & 1) == 0 else isa.vop("v_and_b32", r_, I32(0xFFFF0000), src),
+                              isa.vop("v_add_f32", f[i], f[i], r_)]
+                st = isa.global_store(2, yoff, w, noff * 2, saddr=S_Y, extra_reads=[EXEC])
+                if c.nt_store:
+                    st.text += " nt"
+                e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]), st]
             e += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
         e += [isa.label("L_exit"), isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
         return self._pad_between_labels(e)
@@ -635,12 +678,14 @@ def assembly(cfgs) -> str:
     return HEAD + "".join(kernel_text(c) for c in cfgs) + metadata(cfgs)
 
 
-DEFAULTS = [Cfg(epi=0, name="scail_gemm4_e0"), Cfg(epi=1, name="scail_gemm4_e1"), Cfg(epi=3, name="scail_gemm4_e3"),
-            Cfg(epi=4, name="scail_gemm4_e4")]
+# the shipped kernels: LDS-DMA two tiles deep, v_mfma_f32_16x16x32_bf16, <= 1 filler per 16-cycle MFMA gap, slot released at gap 11,
+# one DMA piece per 7 gaps (measured best of the sweep in profiles/r02_gemm4_mi16.log: 1467 TFLOP/s where q8 does 1309, the vendor 1495)
+SHIPPED = dict(stage="dma2", mi=16, cap=1, rd2_step=0.25, b1_at=5.5, dma_step=1.75)
+DEFAULTS = [Cfg(epi=e, name=f"scail_gemm4_e{e}", **SHIPPED) for e in (0, 1, 3, 4)]
 
 
 def variant_cfgs():
-    out = []
+    out = [Cfg(epi=e, name=f"scail_gemm4_e{e}_reg") for e in (0, 1, 3, 4)]       # round-2 first version: register staging, 32x32x16
     for cap in (2, 4):
         out.append(Cfg(epi=0, cap=cap, name=f"scail_gemm4_e0_c{cap}"))
     out.append(Cfg(epi=0, stage="dma", name="scail_gemm4_e0_lds_dma"))
@@ -648,6 +693,27 @@ def variant_cfgs():
     out.append(Cfg(epi=0, stage="dma2", cap=2, name="scail_gemm4_e0_dma2_c2"))
     out.append(Cfg(epi=0, stage="dma2", rd2_step=1.0, b1_at=17.5, name="scail_gemm4_e0_dma2_rd1"))
     out.append(Cfg(epi=0, stage="dma2", dma_step=0.5, name="scail_gemm4_e0_dma2_d05"))
+    out.append(Cfg(epi=0, stage="dma2", mi=16, cap=2, name="scail_gemm4_e0_mi16"))
+    out.append(Cfg(epi=0, stage="dma2", mi=16, cap=1, name="scail_gemm4_e0_mi16_c1"))
+    out.append(Cfg(epi=0, stage="dma2", mi=16, cap=3, name="scail_gemm4_e0_mi16_c3"))
+    M16 = dict(epi=0, stage="dma2", mi=16, cap=1)
+    out.append(Cfg(**M16, rd2_step=1.0, b1_at=17.5, name="scail_gemm4_e0_mi16_rd1"))
+    out.append(Cfg(**M16, rd2_step=0.25, b1_at=5.5, name="scail_gemm4_e0_mi16_rd025"))
+    out.append(Cfg(**M16, dma_step=0.75, name="scail_gemm4_e0_mi16_d075"))
+    out.append(Cfg(**M16, dma_step=1.25, name="scail_gemm4_e0_mi16_d125"))
+    out.append(Cfg(**M16, rd2_step=0.25, b1_at=5.5, dma_step=1.4, name="scail_gemm4_e0_mi16_early"))
+    out.append(Cfg(**M16, dma_step=1.5, name="scail_gemm4_e0_mi16_d15"))
+    out.append(Cfg(**M16, rd2_step=0.25, b1_at=5.5, dma_step=1.75, name="scail_gemm4_e0_mi16_early175"))
+    out.append(Cfg(**M16, rd2_step=0.25, b1_at=5.5, dma_step=1.9, name="scail_gemm4_e0_mi16_early19"))
+    out.append(Cfg(**M16, rd2_step=0.25, b1_at=4.5, dma_step=1.85, name="scail_gemm4_e0_mi16_early185"))
+    out.append(Cfg(epi=0, stage="dma2", mi=16, cap=2, rd2_step=0.25, b1_at=5.5, dma_step=1.75, name="scail_gemm4_e0_mi16_early175c2"))
+    out.append(Cfg(**M16, dma_step=1.25, nt_store=True, name="scail_gemm4_e0_mi16_d125nt"))
+    out.append(Cfg(**M16, dma_step=1.25, lookahead=2.0, name="scail_gemm4_e0_mi16_d125la2"))
+    out.append(Cfg(**M16, b2_at=27.5, name="scail_gemm4_e0_mi16_b2e"))
+    out.append(Cfg(**M16, b2_at=39.5, name="scail_gemm4_e0_mi16_b2l"))
+    out.append(Cfg(epi=0, stage="dma2", mi=16, cap=2, abl="dma", name="scail_gemm4_e0_mi16_abl_dma"))
+    out.append(Cfg(epi=0, stage="dma2", mi=16, cap=2, abl="lds", name="scail_gemm4_e0_mi16_abl_lds"))
+    out.append(Cfg(epi=0, stage="dma2", mi=16, cap=2, abl="dma,lds", name="scail_gemm4_e0_mi16_abl_dma_lds"))
     out.append(Cfg(epi=0, stage="dma2", abl="dma", name="scail_gemm4_e0_dma2_abl_dma"))
     out.append(Cfg(epi=0, stage="dma2", abl="lds", name="scail_gemm4_e0_dma2_abl_lds"))
     out.append(Cfg(epi=0, stage="dma2", abl="dma,lds", name="scail_gemm4_e0_dma2_abl_dma_lds"))

@@ -193,6 +193,13 @@ def mfma(D: Reg, a: Reg, b: Reg, c, **kw) -> Instr:
     return Instr("v_mfma_f32_32x32x16_bf16", [D], [a, b, c], **kw)
 
 
+def mfma16(D: Reg, a: Reg, b: Reg, c, **kw) -> Instr:
+    """D(4) = A(4: 16 rows x 32 k, bf16) x B(4: 32 k x 16 cols) + C(4 | 0)  -- v_mfma_f32_16x16x32_bf16 (4 passes = 16 cycles).
+    Lane l holds A[l % 16][8 (l / 16) .. +7], B[8 (l / 16) .. +7][l % 16] and D[4 (l / 16) + e][l % 16], e = 0..3."""
+    assert D.n == 4 and a.n == 4 and b.n == 4
+    return Instr("v_mfma_f32_16x16x32_bf16", [D], [a, b, c], **kw)
+
+
 def vop(op: str, dst, *srcs, **kw) -> Instr:
     d = [dst] if isinstance(dst, Reg) else list(dst)
     return Instr(op, d, list(srcs), **kw)

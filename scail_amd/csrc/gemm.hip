@@ -563,20 +563,23 @@ static int launch_gemm(const GemmParams& p, hipStream_t stream) {
     return launch_gemm_t<128, 128, 2, 2, EPI, false>(p, stream);
 }
 
-#ifdef SCAIL_ABLATIONS
 // ================================================================================================
-// MEASUREMENT BUILD ONLY (parity with q8 at best, so the product library ships q8 alone).
-// gemm4: the hand-scheduled 4-wave kernels (256 x 256 x 64 tile, one wave per SIMD, the 256 accumulators of a lane in a[0:255],
-// LDS-DMA double buffer, barrier before the last k-step).  gfx950 assembly GENERATED by scail_amd/asmgen/gemm4.py (csrc/gemm4.s),
-// embedded as a code object and loaded with hipModuleLoadData on first use.  Kernel argument block = asmgen/gemm4.py KERNARG_FMT.
+// gemm4: the hand-scheduled 4-wave kernels (256 x 256 x 64 tile, one wave per SIMD, wave tile 128 x 128 as 8 x 8 blocks of
+// v_mfma_f32_16x16x32_bf16, the 256 accumulators of a lane in a[0:255], LDS-DMA staging two tiles deep inside two 64 KB slots, the
+// fragments of a whole k-tile in registers and read half a tile ahead).  gfx950 assembly GENERATED by scail_amd/asmgen/gemm4.py
+// (csrc/gemm4.s), embedded as a code object and loaded with hipModuleLoadData on first use.  Kernel argument block =
+// asmgen/gemm4.py KERNARG_FMT.  Default for the big per-token GEMMs (1467 TFLOP/s where the hipcc q8
+// kernel does 1309 and the vendor's assembly kernel 1495).
 // ================================================================================================
 static const unsigned char k_gemm4_hsaco[] = {
 #include "gemm4_hsaco.inc"
 };
-// gemm8: the same kernels with TWO waves per SIMD (8 waves, wave tile 128 x 64, 128 accumulators in a[0:127]; asmgen/gemm8.py)
+#ifdef SCAIL_ABLATIONS
+// gemm8 (measurement build): two waves per SIMD (8 waves, wave tile 128 x 64, 128 accumulators in a[0:127]; asmgen/gemm8.py)
 static const unsigned char k_gemm8_hsaco[] = {
 #include "gemm8_hsaco.inc"
 };
+#endif
 struct Gemm4Args {
     const void* x; const void* w; const void* bias; void* y; const void* resid; const void* gate; const void* table;
     int64_t lda, ldc, ldr, gs;
@@ -588,17 +591,22 @@ static hipModule_t g_gemm4_module = nullptr, g_gemm8_module = nullptr;
 static std::map<std::string, hipFunction_t> g_gemm4_fn;
 static std::map<std::pair<int, int>, std::pair<uint32_t*, int>> g_gemm4_tables;   // (m tiles, n tiles) -> device order table, entries
 static std::mutex g_gemm4_mutex;
-static int g_gemm4_mode = 0;               // generated kernels where eligible: 8 = gemm8, 4 = gemm4, 0 = never (default: q8)
-static std::string g_gemm4_suffix;         // A/B variants of the ablation build ("gemm4_kernel:<suffix>")
+static int g_gemm4_mode = 4;               // generated kernels where eligible: 4 = gemm4 (default), 0 = never (csrc/gemm.hip only), 8 = gemm8 (measurement build)
+static std::string g_gemm4_suffix;         // A/B variants of the measurement build ("gemm4_kernel:<suffix>")
 
 static int gemm4_function(const std::string& name, hipFunction_t* fn) {
     std::lock_guard<std::mutex> lk(g_gemm4_mutex);
     const bool is8 = name.rfind("scail_gemm8", 0) == 0;
     hipModule_t& mod = is8 ? g_gemm8_module : g_gemm4_module;
     if (mod == nullptr) {
-        hipError_t e = hipModuleLoadData(&mod, is8 ? k_gemm8_hsaco : k_gemm4_hsaco);
+#ifdef SCAIL_ABLATIONS
+        const void* image = is8 ? (const void*)k_gemm8_hsaco : (const void*)k_gemm4_hsaco;
+#else
+        const void* image = k_gemm4_hsaco;
+#endif
+        hipError_t e = hipModuleLoadData(&mod, image);
         if (e != hipSuccess) {
-            scail_set_error(std::string("gemm4/8: hipModuleLoadData failed: ") + hipGetErrorString(e));
+            scail_set_error(std::string("gemm4: hipModuleLoadData failed: ") + hipGetErrorString(e));
             return 2;
         }
     }
@@ -635,7 +643,7 @@ static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev, int* entries
         }
         uint32_t* d = nullptr;
         if (hipMalloc(&d, table.size() * 4) != hipSuccess || hipMemcpy(d, table.data(), table.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            scail_set_error("gemm4: cannot allocate the tile order table");
+            scail_set_error("gemm4: cannot allocate the tile order table (the first call for a tile grid allocates; do it outside stream capture)");
             return 2;
         }
         it = g_gemm4_tables.emplace(key, std::make_pair(d, per * 8)).first;
@@ -654,17 +662,20 @@ static bool gemm4_eligible(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int
 }
 
 extern "C" int scail_gemm_kernel_for(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int64_t N, int64_t K, int epilogue) {
-    return (g_gemm4_mode && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) ? (g_gemm4_mode == 4 ? 4 : 8) : 0;
+    return (g_gemm4_mode && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) ? g_gemm4_mode : 0;
 }
 
+// runtime option of the product library (scail_set_option "gemm4"): 1 = generated kernels where eligible, 0 = csrc/gemm.hip only
+int scail_gemm4_enable(int on) { g_gemm4_mode = on ? 4 : 0; return 0; }
+
+#ifdef SCAIL_ABLATIONS
 int scail_gemm4_knob(const char* knob, int value) {
     std::string k(knob);
-    if (k == "gemm4") { g_gemm4_mode = (value == 4 || value == 8) ? value : (value ? 8 : 0); return 0; }
+    if (k == "gemm4") { g_gemm4_mode = (value == 4 || value == 8) ? value : (value ? 4 : 0); return 0; }
     if (k.rfind("gemm4_kernel", 0) == 0) { g_gemm4_suffix = k.size() > 13 ? "_" + k.substr(13) : ""; return 0; }
     return -1;
 }
-
-#endif  // SCAIL_ABLATIONS
+#endif
 
 extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf16* w, const float* bias,
                                scail_bf16* y, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
@@ -683,9 +694,13 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
         SCAIL_REQUIRE(gate == nullptr || (rows_per_batch > 0 && gate_stride % 4 == 0), "gate needs rows_per_batch > 0, gate_stride % 4 == 0");
     }
 #ifdef SCAIL_ABLATIONS
-    if (g_gemm4_mode && g_gemm_tile == 0 && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) {
+    const bool forced_tile = g_gemm_tile != 0;
+#else
+    const bool forced_tile = false;
+#endif
+    if (g_gemm4_mode && !forced_tile && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) {
         const int epi4 = epilogue == SCAIL_EPI_RESID ? (gate != nullptr ? 3 : 4) : epilogue;
-        const bool is8 = g_gemm4_mode != 4;
+        const bool is8 = g_gemm4_mode == 8;
         std::string name = std::string(is8 ? "scail_gemm8_e" : "scail_gemm4_e") + std::to_string(epi4);
         if (epi4 == 0) name += g_gemm4_suffix;            // A/B variants exist for the bias epilogue only (ablation build)
         hipFunction_t fn;
@@ -707,7 +722,6 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
         }
         return 0;
     }
-#endif
     GemmParams p;
     p.x = x; p.lda = lda; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc;
     p.M = (int)M; p.N = (int)N; p.K = (int)K;

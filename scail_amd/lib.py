@@ -25,6 +25,7 @@ SIGNATURES = {
     "scail_flash_attn_bf16": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
     "scail_flash_attn_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i],
+    "scail_gemm_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i],
     "scail_cross_attn2_bf16": [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                                _i64, _i64, _i64, _f, _p],
     "scail_timestep_embedding": [_p, _p, _i64, _i64, _p],
@@ -70,7 +71,6 @@ RESTYPES = {"scail_dit_destroy": None, "scail_vae_destroy": None, "scail_vae_wor
 ABLATION_SIGNATURES = {
     "scail_tune_set": [C.c_char_p, _i],
     "scail_debug_cycles": [C.c_void_p, _i],
-    "scail_gemm_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i],
 }
 ABLATIONS = LIB_PATH.endswith("_abl.so")
 

@@ -61,9 +61,9 @@ def test_product_library_has_no_measurement_aids(libpath):
     for n in names:
         assert not hasattr(lib, n), f"{n} must not be exported by the product library"
     blob = open(libpath, "rb").read()
-    for kernel in (b"scail_gemm4_e0", b"scail_gemm8_e0", b"scail_attn4_rd3"):
+    for kernel in (b"scail_gemm4_e0_reg", b"scail_gemm8_e0", b"scail_attn4_rd3"):
         assert kernel not in blob, kernel
-    assert b"scail_attn4" in blob                       # the shipped generated kernel is embedded
+    assert b"scail_attn4" in blob and b"scail_gemm4_e3" in blob       # the shipped generated kernels are embedded
     assert not L.ABLATIONS
     with pytest.raises(L.ScailHipError, match="measurement build"):
         L.tune_set("attn_variant", 2)

@@ -1,5 +1,5 @@
-"""CPU emulation (tools/asm_emu.py) of the generated GEMM kernels of the MEASUREMENT build (scail_amd/asmgen/gemm4.py, gemm8.py:
-experiments that reached parity with the shipped q8 kernel): the generator keeps producing hazard-free code whose
+"""CPU emulation (tools/asm_emu.py) of the generated GEMM kernels (scail_amd/asmgen/gemm4.py): the four shipped kernels
+(scail_gemm4_e0/1/3/4, csrc/gemm4.s) and variants of the measurement build: the generator produces hazard-free code whose
 results equal the fp64 product of the bf16-rounded operands, under the emulator's lazy (latest-allowed) completion of LDS / memory
 operations -- the mode that exposes a missing or too-weak s_waitcnt."""
 import math
@@ -27,9 +27,12 @@ def _variant(name):
     return [c for c in gemm4.DEFAULTS + gemm4.variant_cfgs() if c.name == name][0]
 
 
-@pytest.mark.parametrize("name,shape", [("scail_gemm4_e0", (300, 256, 192)),              # register staging, ragged last m-tile
-                                        ("scail_gemm4_e3", (264, 256, 128)),              # gate * (acc + bias) + residual epilogue
-                                        ("scail_gemm4_e0_dma2", (300, 256, 320)),         # LDS-DMA two tiles deep, odd tile count
+@pytest.mark.parametrize("name,shape", [("scail_gemm4_e0", (300, 256, 192)),              # SHIPPED: LDS-DMA two tiles deep, 16x16x32 MFMAs; ragged last m-tile
+                                        ("scail_gemm4_e1", (256, 256, 128)),              # + GELU-tanh
+                                        ("scail_gemm4_e3", (264, 256, 320)),              # gate * (acc + bias) + residual, odd tile count
+                                        ("scail_gemm4_e4", (520, 512, 128)),              # residual, two m-tiles and n-tiles + ragged third
+                                        ("scail_gemm4_e0_reg", (300, 256, 192)),          # measurement build: register staging, 32x32x16
+                                        ("scail_gemm4_e0_dma2", (300, 256, 320)),         # ... LDS-DMA two tiles deep, 32x32x16
                                         ("scail_gemm4_e0_spread", (256, 256, 256))])
 def test_gemm4_emulated(name, shape):
     cfg = _variant(name)

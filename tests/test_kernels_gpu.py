@@ -104,6 +104,51 @@ def test_gemm_strided_and_residual(ops, gemm_tile):
     close(h2, resid + (x @ w.t() + b), msg="gemm ungated residual")
 
 
+@pytest.mark.parametrize("M,N,K", [(2048 + 136, 512, 192), (4096, 768, 320), (2600 + 8, 256, 128), (2 * 1100, 256, 448)])
+@pytest.mark.parametrize("epi", ["bias", "nobias", "gelu_tanh", "resid+gate", "resid"])
+def test_gemm4_vs_oracle(ops, M, N, K, epi):
+    """the generated 4-wave kernels (csrc/gemm4.s; scail_gemm_kernel_for == 4): ragged last m-tile (136 / 8 valid rows), 1-3 n-tiles,
+    odd and even k-tile counts (3, 5, 2, 7), all four epilogues + NULL bias, strided x / y views, gate rows per batch not a multiple of
+    the tile; against fp32 and against the kernels of csrc/gemm.hip on the same inputs (same accumulation order: equal to the last bit
+    up to the epilogue's rounding)."""
+    from scail_amd import lib as L
+    xbig = rnd(M, K + 64, seed=1)
+    x = xbig[:, 64:]                                                  # lda = K + 64
+    w, b = rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
+    resid, gate = rnd(M, N, seed=4), rnd(2, N, seed=5)
+    rpb = M // 2
+    bias = None if epi == "nobias" else b
+    ref = x @ w.t() + (0 if bias is None else bias)
+    code = L.EPI_BIAS
+    kw = {}
+    if epi == "gelu_tanh":
+        ref, code = O.gelu_tanh(ref), L.EPI_GELU_TANH
+    if epi.startswith("resid"):
+        code = L.EPI_RESID
+        if epi == "resid+gate":
+            ref = ref * gate.repeat_interleave(rpb, 0)
+        ref = resid + ref
+    xg, wg = gpu_bf16(xbig)[:, 64:], gpu_bf16(w)
+    outs = []
+    for on in (1, 0):
+        L.set_option("gemm4", on)
+        try:
+            ybig = torch.full((M + 1, N + 8), 3.0, device=DEV, dtype=torch.bfloat16)
+            y = ybig[:M, :N]                                           # ldc = N + 8; one guard row, 8 guard columns
+            if epi.startswith("resid"):
+                y.copy_(gpu_bf16(resid))
+                kw = dict(resid=y, gate=gate.to(DEV) if epi == "resid+gate" else None, rows_per_batch=rpb if epi == "resid+gate" else 0)
+            which = L.load().scail_gemm_kernel_for(xg.stride(0), y.stride(0), y.stride(0) if kw else 0, M, N, K, code)
+            assert which == (4 if on else 0)
+            ops.gemm(xg, wg, None if bias is None else bias.to(DEV), out=y, epilogue=code, **kw)
+        finally:
+            L.set_option("gemm4", 1)
+        close(y, ref, rtol=1e-2, atol=1e-2, msg=f"gemm4={on} {M}x{N}x{K} {epi}")
+        assert (ybig[M] == 3.0).all() and (ybig[:, N:] == 3.0).all(), "writes outside the M x N result"
+        outs.append(y.float().clone())
+    close(outs[0], outs[1], rtol=8e-3, atol=1e-3, msg="gemm4 vs csrc/gemm.hip")
+
+
 def test_gemm_errors_are_loud(ops):
     from scail_amd import lib as L
     x, w = gpu_bf16(rnd(8, 72)), gpu_bf16(rnd(16, 72))

@@ -290,6 +290,28 @@ class Emu:
             w.mfma_pending.append([MFMA_LATENCY, d, out.view(np.uint32).copy()])
             w.stats["mfma"] += 1
             return
+        if op == "v_mfma_f32_16x16x32_bf16":
+            self._retire_mfma(w, 1)
+            if isinstance(s[2], isa.Reg):
+                self._flush_mfma_for(w, s[2])
+            A = self._regs(w, s[0])       # (4, 64) uint32
+            B = self._regs(w, s[1])
+            lane = np.arange(64)
+            Am = np.zeros((16, 32), dtype=np.float32)
+            Bm = np.zeros((32, 16), dtype=np.float32)
+            for j in range(8):
+                av = (A[j >> 1] >> (16 * (j & 1))) & 0xFFFF
+                bv = (B[j >> 1] >> (16 * (j & 1))) & 0xFFFF
+                Am[lane & 15, 8 * (lane >> 4) + j] = bf16_to_f32(av)
+                Bm[8 * (lane >> 4) + j, lane & 15] = bf16_to_f32(bv)
+            P = Am.astype(np.float64) @ Bm.astype(np.float64)
+            C = _f(self._regs(w, s[2]).copy()) if isinstance(s[2], isa.Reg) else np.zeros((4, 64), dtype=np.float32)
+            out = np.zeros((4, 64), dtype=np.float32)
+            for r in range(4):
+                out[r] = (C[r].astype(np.float64) + P[4 * (lane >> 4) + r, lane & 15]).astype(np.float32)
+            w.mfma_pending.append([MFMA_LATENCY // 2, d, out.view(np.uint32).copy()])
+            w.stats["mfma"] += 1
+            return
         self._retire_mfma(w, slots)
 
         # ---- waits / control ----------------------------------------------------------------------
