@@ -79,6 +79,9 @@ class Cfg:
     sm_group: int = 1      # 1: element by element (dependent neighbours); 8 / 16: stage by stage over 8 / 16 elements
     max_chains: int = 1    # independent partial-maximum chains per row block in the row max
     abl: str = ""          # TIMING ABLATIONS (wrong results; ablation build only): "dma" / "lds" / "valu" / "bar" / "max" removed
+    mi: int = 32           # MFMA shape: 32 = v_mfma_f32_32x32x16_bf16 (64 per tile), 16 = v_mfma_f32_16x16x32_bf16 (128 per tile)
+    fold: bool = False     # (mi = 16) q arrives multiplied by scale * log2(e): the running maximum is folded into the accumulator
+                           # init of the first QK^T MFMA (S' = S - M), so p = exp2(S') needs no scale / shift instruction
 
     @property
     def unroll(self): return max(2, self.rd)
@@ -99,6 +102,32 @@ def Kf(kb, ks): return A(192 + (kb * 8 + ks) * 4, 4)
 def Sb(i, kb, rb): return V(i * 64 + (kb * 2 + rb) * 16, 16)
 def Vtf(db, ks): return V(128 + (db * 4 + ks) * 4, 4)
 
+
+# mi = 16 (16 x 16 x 32 MFMAs): 16-query blocks qb 0..3, 16-key blocks kb 0..3, 16-d blocks db 0..7, 32-wide k-steps
+def O16(db, qb): return A((db * 4 + qb) * 4, 4)
+def Qf16(qb, ks): return A(128 + (qb * 4 + ks) * 4, 4)
+def Kf16(kb, ks): return A(192 + (kb * 4 + ks) * 4, 4)
+# the two key blocks of a 32-key step sit in 8 consecutive registers, so their packed bf16 P quad (the B operand of P.V) is built in place
+def Sb16(i, kb, qb): return V(i * 64 + ((kb >> 1) * 4 + qb) * 8 + (kb & 1) * 4, 4)
+def Pq16(i, ks, qb): return V(i * 64 + (ks * 4 + qb) * 8, 4)
+def Vtf16(db, ks): return V(128 + (db * 2 + ks) * 4, 4)
+
+
+KADDR16 = [[V(192 + ks * 2 + par) for par in range(2)] for ks in range(4)]       # [k-step][parity of the key block]
+VADDR16 = [V(200), V(201)]
+M16 = [V(212 + i) for i in range(4)]
+MC16 = [V(216 + i) for i in range(4)]
+L16 = [[V(220 + qb * 2 + j) for j in range(2)] for qb in range(4)]
+MX16 = [V(228 + i) for i in range(4)]
+ALPHA16 = [V(232 + i) for i in range(4)]
+OOFF16 = [V(236 + i) for i in range(4)]
+ROW16 = [V(240 + i) for i in range(4)]
+TMP16 = [V(244 + i) for i in range(8)] + [V(202), V(203)]      # 10 temporaries inside the loop (the epilogue uses the dead S registers)
+
+# fold: -M of query block qb as an accumulator-init quad, row-sum partials; M16 / MC16 / MX16 / ALPHA16 do not exist
+NEGM = [V(212 + 4 * qb, 4) for qb in range(4)]
+L16F = [[V(228 + qb * 2 + j) for j in range(2)] for qb in range(4)]
+S_CLAMP, S_FIRST = S(87), S(88)       # rescale subroutine: lower bound of the maximum step (0, -inf at the very first tile), first-call flag
 
 KADDR = [V(192 + i) for i in range(8)]
 VADDR = [V(200 + i) for i in range(4)]
@@ -256,6 +285,114 @@ class Gen:
             ins.target_gap = t_fin + 0.5 * k
         return out + fin
 
+    # ---- mi = 16 --------------------------------------------------------------------------------------------------------------
+    def qk_mfmas16(self, nxt: int) -> List[Instr]:
+        """S_next[kb][qb] = sum_ks K[kb][ks] x Q[qb][ks], key-block major (S[0][*] completes after 16 MFMAs); the A fragment stays
+        for 4 consecutive MFMAs."""
+        out = []
+        for kb in range(4):
+            for ks in range(4):
+                for qb in range(4):
+                    d = Sb16(nxt, kb, qb)
+                    c0 = NEGM[qb] if self.cfg.fold else I32(0)
+                    out.append(isa.mfma16(d, Kf16(kb, ks), Qf16(qb, ks), c0 if ks == 0 else d, tag="qk"))
+        return out
+
+    def pv_mfmas16(self, cur: int) -> List[Instr]:
+        """O[db][qb] += V^T[db][ks] x P[qb][ks]; P[qb][ks] = the packed quad built in place from S[2 ks][qb], S[2 ks + 1][qb]."""
+        out = []
+        for ks in range(2):
+            for db in range(8):
+                for qb in range(4):
+                    out.append(isa.mfma16(O16(db, qb), Vtf16(db, ks), Pq16(cur, ks, qb), O16(db, qb), tag="pv"))
+        return out
+
+    def softmax_finish16(self, cur: int, t0: float, t1: float) -> List[Instr]:
+        out = []
+        nofma = "fma" in self.cfg.abl.split(",")
+        for ks in range(2):
+            for qb in range(4):
+                base = Pq16(cur, ks, qb).idx
+                regs = [V(base + j) for j in range(8)]
+                lsum = L16F if self.cfg.fold else L16
+                for j, r in enumerate(regs):
+                    if not nofma and not self.cfg.fold:
+                        out.append(isa.vop("v_fma_f32", r, r, S_C, Neg(MC16[qb])))
+                    out.append(isa.vop("v_exp_f32", r, r))
+                    out.append(isa.vop("v_add_f32", lsum[qb][j & 1], lsum[qb][j & 1], r))
+                for i in range(4):
+                    out.append(isa.vop("v_cvt_pk_bf16_f32", regs[i], regs[2 * i], regs[2 * i + 1]))
+        n = len(out)
+        for k, ins in enumerate(out):
+            ins.target_gap = t0 + (t1 - t0) * k / n
+        return out
+
+    def rowmax16(self, nxt: int, t_kb, t_fin: float) -> List[Instr]:
+        """MX16[qb] = max over the 64 keys of S_next (the 4 lanes l % 16 == q of a query), then VCC = any(MX - M > thr)."""
+        out = []
+        for kb in range(4):
+            grp = []
+            for qb in range(4):
+                s = Sb16(nxt, kb, qb)
+                acc = TMP16[qb]
+                if kb == 0:
+                    grp.append(isa.vop("v_max3_f32", acc, s.sub(0), s.sub(1), s.sub(2)))
+                    grp.append(isa.vop("v_max_f32", acc, acc, s.sub(3)))
+                else:
+                    grp.append(isa.vop("v_max3_f32", acc, acc, s.sub(0), s.sub(1)))
+                    grp.append(isa.vop("v_max3_f32", acc, acc, s.sub(2), s.sub(3)))
+            grp = grp[0::2] + grp[1::2]                     # the four rows' chains interleaved
+            span = 12.0 / len(grp)
+            for k, ins in enumerate(grp):
+                ins.target_gap = t_kb[kb] + k * span
+            out.extend(grp)
+        if self.cfg.fold:
+            # S' is already relative to the running maximum: any lane's partial maximum above thr triggers the (rare) subroutine,
+            # which does the cross-lane part
+            fin = [isa.vop("v_max3_f32", TMP16[4], TMP16[0], TMP16[1], TMP16[2]), isa.vop("v_max_f32", TMP16[4], TMP16[4], TMP16[3]),
+                   isa.v_cmp("v_cmp_gt_f32", TMP16[4], S_THR)]
+            for k, ins in enumerate(fin):
+                ins.target_gap = t_fin + 0.5 * k
+            return out + fin
+        fin = []
+        for qb in range(4):
+            acc, cp = TMP16[qb], TMP16[4 + (qb & 1)]
+            fin.append(isa.vop("v_mov_b32", cp, acc))
+            fin.append(isa.permlane32_swap(acc, cp))                                  # acc = {lo, lo}, cp = {hi, hi}
+            fin.append(isa.vop("v_max_f32", acc, acc, cp))
+            fin.append(isa.vop("v_mov_b32", cp, acc))
+            fin.append(isa.permlane16_swap(acc, cp))                                  # acc = even rows twice, cp = odd rows twice
+            fin.append(isa.vop("v_max_f32", MX16[qb], acc, cp))
+            fin.append(isa.vop("v_sub_f32", TMP16[6 + (qb & 1)], MX16[qb], M16[qb]))
+            if qb & 1:
+                fin.append(isa.vop("v_max_f32", TMP16[6], TMP16[6], TMP16[7]))
+                if qb == 3:
+                    fin.append(isa.vop("v_max_f32", TMP16[8], TMP16[8], TMP16[6]))
+                else:
+                    fin.append(isa.vop("v_mov_b32", TMP16[8], TMP16[6]))
+        fin.append(isa.v_cmp("v_cmp_gt_f32", TMP16[8], S_THR))
+        for k, ins in enumerate(fin):
+            ins.target_gap = t_fin + 0.5 * k
+        return out + fin
+
+    def v_frag_reads16(self, slot: int, t0: float, step: float) -> List[Instr]:
+        out = []
+        k = 0
+        for ks in range(2):
+            for db in range(8):
+                out.append(isa.ds_read_b128(Vtf16(db, ks), VADDR16[ks], slot * 16384 + db * 2048, target_gap=t0 + step * k))
+                k += 1
+        return out
+
+    def k_frag_reads16(self, slot: int, t0: float, step: float) -> List[Instr]:
+        out = []
+        k = 0
+        for kb in range(4):
+            for ks in range(4):
+                out.append(isa.ds_read_b128(Kf16(kb, ks), KADDR16[ks][kb & 1], slot * 16384 + (kb >> 1) * 8192, target_gap=t0 + step * k))
+                k += 1
+        return out
+
     def v_frag_reads(self, slot: int, t0: float, step: float) -> List[Instr]:
         out = []
         k = 0
@@ -287,27 +424,30 @@ class Gen:
 
     # ---------------------------------------------------------------------------------------------
     def iter_block(self, p: int, tail: bool) -> List[Instr]:
-        """One pipelined tile iteration at unroll position p (tile t = p mod unroll), scheduled."""
+        """One pipelined tile iteration at unroll position p (tile t = p mod unroll), scheduled.  Gap numbers below are in units
+        of 32 matrix-pipe cycles; mi = 16 has two MFMA gaps per unit (gs = 2)."""
         c = self.cfg
         cur, nxt = p & 1, (p + 1) & 1
         rd = c.rd
+        m16 = c.mi == 16
+        gs = 2.0 if m16 else 1.0
         blk: List[Instr] = []
         abl = c.abl.split(",")
         if not tail and "dma" not in abl:
-            blk += self.dma_tile("k", (p + c.pk) % rd, c.dma_k_at, c.dma_step)
-            blk += self.dma_tile("v", (p + c.pv) % rd, c.dma_v_at, c.dma_step)
+            blk += self.dma_tile("k", (p + c.pk) % rd, c.dma_k_at * gs, c.dma_step * gs)
+            blk += self.dma_tile("v", (p + c.pv) % rd, c.dma_v_at * gs, c.dma_step * gs)
         if "lds" not in abl:
-            blk += self.v_frag_reads(p % rd, 2.0 if not tail else 0.0, 1.5 if not tail else 1.0)
+            blk += (self.v_frag_reads16 if m16 else self.v_frag_reads)(p % rd, (2.0 if not tail else 0.0) * gs, (1.5 if not tail else 1.0) * gs)
         if not tail:
-            blk += self.qk_mfmas(nxt)
+            blk += self.qk_mfmas16(nxt) if m16 else self.qk_mfmas(nxt)
         if "valu" not in abl:
-            blk += self.softmax_finish(cur, 0.0, c.sm_end if not tail else 20.0)
-        blk += self.pv_mfmas(cur)
+            blk += (self.softmax_finish16 if m16 else self.softmax_finish)(cur, 0.0, (c.sm_end if not tail else 20.0) * gs)
+        blk += self.pv_mfmas16(cur) if m16 else self.pv_mfmas(cur)
         if not tail:
             if "lds" not in abl:
-                blk += self.k_frag_reads((p + 2) % rd, 18.0, 2.0)
+                blk += (self.k_frag_reads16 if m16 else self.k_frag_reads)((p + 2) % rd, 18.0 * gs, 2.0 * gs)
             if "valu" not in abl and "max" not in abl:
-                blk += self.rowmax(nxt, 21.0, 38.0, 52.0)
+                blk += self.rowmax16(nxt, (20.0, 36.0, 52.0, 68.0), 84.0) if m16 else self.rowmax(nxt, 21.0, 38.0, 52.0)
         seq = sched.schedule(blk, cap=c.cap, lookahead=c.lookahead)
         seq = sched.insert_lgkm_waits(seq)
         return seq
@@ -321,11 +461,78 @@ class Gen:
             return [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep)]
         if "valu" in c.abl.split(",") or "max" in c.abl.split(","):
             return [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep), isa.barrier()]
+        sub = f"L_rescale{(p + 1) & 1}" if c.fold else "L_rescale"
         return [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep), isa.barrier(),
-                isa.branch("s_cbranch_vccz", skip), isa.s_call(S_RET, "L_rescale"), isa.label(skip)]
+                isa.branch("s_cbranch_vccz", skip), isa.s_call(S_RET, sub), isa.label(skip)]
 
     # =============================================================================================
+    def rescale_sub16(self) -> List[Instr]:
+        out = [isa.label("L_rescale"), isa.nop(15), isa.nop(15)]
+        for qb in range(4):
+            mn, d = TMP16[0 + (qb & 1)], TMP16[2 + (qb & 1)]
+            out += [isa.vop("v_max_f32", mn, M16[qb], MX16[qb]),
+                    isa.vop("v_sub_f32", d, M16[qb], mn),
+                    isa.vop("v_mul_f32", d, d, S_C),
+                    isa.vop("v_exp_f32", ALPHA16[qb], d),
+                    isa.vop("v_mov_b32", M16[qb], mn),
+                    isa.vop("v_mul_f32", MC16[qb], mn, S_C)]
+            for j in range(2):
+                out.append(isa.vop("v_mul_f32", L16[qb][j], L16[qb][j], ALPHA16[qb]))
+        k = 0
+        for db in range(8):
+            for qb in range(4):
+                for r in range(4):
+                    t = TMP16[4 + (k % 6)]
+                    k += 1
+                    o = O16(db, qb).sub(r)
+                    out += [isa.vop("v_accvgpr_read_b32", t, o), isa.vop("v_mul_f32", t, t, ALPHA16[qb]),
+                            isa.vop("v_accvgpr_write_b32", o, t)]
+        out.append(isa.nop(3))
+        out.append(Instr("s_setpc_b64", [], [S_RET], cls=isa.BRANCH))
+        return sched.pad_hazards(out[:1]) + sched.pad_hazards(out[1:])
+
+    def rescale_sub16f(self, nxt: int) -> List[Instr]:
+        """fold: raise the running maxima by the (cross-lane) maximum of the pending score tile S'(t+1) in buffer ``nxt``:
+        mx = max(rowmax, CLAMP);  S' -= mx, -M -= mx, and -- unless this is the first call of the kernel (O = l = 0, mx may be a huge
+        negative number) -- l, O *= 2^-mx."""
+        out = [isa.label(f"L_rescale{nxt}"), isa.nop(15), isa.nop(15)]
+        mx = [TMP16[qb] for qb in range(4)]
+        cp, al = TMP16[4], [TMP16[5 + qb] for qb in range(4)]
+        for qb in range(4):
+            out += [isa.vop("v_mov_b32", cp, mx[qb]), isa.permlane32_swap(mx[qb], cp), isa.vop("v_max_f32", mx[qb], mx[qb], cp),
+                    isa.vop("v_mov_b32", cp, mx[qb]), isa.permlane16_swap(mx[qb], cp), isa.vop("v_max_f32", mx[qb], mx[qb], cp),
+                    isa.vop("v_max_f32", mx[qb], mx[qb], S_CLAMP)]
+            for i in range(4):
+                out.append(isa.vop("v_sub_f32", NEGM[qb].sub(i), NEGM[qb].sub(i), mx[qb]))
+            for kb in range(4):
+                for i in range(4):
+                    r = Sb16(nxt, kb, qb).sub(i)
+                    out.append(isa.vop("v_sub_f32", r, r, mx[qb]))
+        out += [isa.sop("s_cmp_lg_u32", None, S_FIRST, I32(0)), isa.sop("s_mov_b32", S_FIRST, I32(0)), isa.sop("s_mov_b32", S_CLAMP, I32(0)),
+                isa.branch("s_cbranch_scc1", f"L_rescale{nxt}_ret")]
+        for qb in range(4):
+            out += [isa.vop("v_exp_f32", al[qb], Neg(mx[qb]))]
+        for qb in range(4):
+            for j in range(2):
+                out.append(isa.vop("v_mul_f32", L16F[qb][j], L16F[qb][j], al[qb]))
+        k = 0
+        for db in range(8):
+            for qb in range(4):
+                for r in range(4):
+                    t = [cp, TMP16[9]][k % 2]
+                    k += 1
+                    o = O16(db, qb).sub(r)
+                    out += [isa.vop("v_accvgpr_read_b32", t, o), isa.vop("v_mul_f32", t, t, al[qb]),
+                            isa.vop("v_accvgpr_write_b32", o, t)]
+        out += [isa.label(f"L_rescale{nxt}_ret"), isa.nop(3), Instr("s_setpc_b64", [], [S_RET], cls=isa.BRANCH)]
+        i0 = next(k for k, x in enumerate(out) if x.label == f"L_rescale{nxt}_ret")
+        return sched.pad_hazards(out[:1]) + sched.pad_hazards(out[1:i0]) + sched.pad_hazards(out[i0:])
+
     def rescale_sub(self) -> List[Instr]:
+        if self.cfg.fold:
+            return self.rescale_sub16f(0) + self.rescale_sub16f(1)
+        if self.cfg.mi == 16:
+            return self.rescale_sub16()
         out = [isa.label("L_rescale"), isa.nop(15), isa.nop(15)]
         for rb in range(2):
             mn, d = TMP[6 + rb], TMP[8 + rb]
@@ -402,21 +609,45 @@ class Gen:
               isa.sop("s_mul_i32", S_KMAX, ST[12], S_KSTEP), isa.sop("s_lshl_b32", S_VMAX, ST[12], I32(7)),
               isa.sop("s_lshl_b32", S_KLDS, S_WAVE, I32(12)), isa.sop("s_add_u32", S_VLDS, S_KLDS, I32(c.rd * 16384)),
               isa.sop("s_mov_b32", S_SEG, I32(0))]
-        # ---- lane geometry ----
-        ql, g = VT1, VT2
-        o += [isa.vop("v_and_b32", ql, I32(31), LANE), isa.vop("v_lshrrev_b32", g, I32(5), LANE)]
-        t = TMP
-        # K fragment addresses: row ql (256 B), 16-byte chunk (2 ks + g) ^ (ql & 15)
-        o += [isa.vop("v_and_b32", t[0], I32(15), ql), isa.vop("v_lshlrev_b32", t[1], I32(8), ql)]
-        for ks in range(8):
-            o += [isa.vop("v_or_b32", t[2], I32(2 * ks), g), isa.vop("v_xor_b32", t[2], t[2], t[0]),
-                  isa.vop("v_lshl_add_u32", KADDR[ks], t[2], I32(4), t[1])]
-        # V^T fragment addresses: row ql (128 B), chunk (2 ks + g) ^ ((ql >> 1) & 7), in the V ring
-        o += [isa.vop("v_lshrrev_b32", t[0], I32(1), ql), isa.vop("v_and_b32", t[0], I32(7), t[0]),
-              isa.vop("v_lshlrev_b32", t[1], I32(7), ql), isa.vop("v_add_u32", t[1], I32(c.rd * 16384), t[1])]
-        for ks in range(4):
-            o += [isa.vop("v_or_b32", t[2], I32(2 * ks), g), isa.vop("v_xor_b32", t[2], t[2], t[0]),
-                  isa.vop("v_lshl_add_u32", VADDR[ks], t[2], I32(4), t[1])]
+        if c.mi == 16:
+            # ---- lane geometry (mi = 16): ql = lane % 16 (fragment row / query column), g = lane / 16 (16-byte chunk inside a 32-wide k-step) ----
+            ql, g = VT1, VT2
+            o += [isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
+            t = TMP16
+            # K fragment addresses.  A-row r = ql of key block kb reads key  32 (kb >> 1) + 8 (kb & 1) + 16 (r >> 3) + (r & 7)  of the tile:
+            # with this row order a lane's score registers of blocks 2 ks, 2 ks + 1 are exactly the 8 keys its P.V k-slots hold in the V^T
+            # image of scail_transpose_v (key bits 2 <-> 3 swapped inside 16-key groups) -- no cross-lane movement between the two GEMMs.
+            # LDS row = key (256 B), 16-byte chunk (4 ks + g) ^ (key & 15);  parity = kb & 1, kb >> 1 goes into the immediate offset
+            o += [isa.vop("v_and_b32", t[0], I32(7), ql), isa.vop("v_lshrrev_b32", t[1], I32(3), ql), isa.vop("v_lshl_add_u32", t[1], t[1], I32(4), t[0])]   # 16 (r >> 3) + (r & 7)
+            for par in range(2):
+                o += [isa.vop("v_add_u32", t[2], I32(8 * par), t[1]),                    # key row inside the 32-key half
+                      isa.vop("v_add_u32", t[3], I32(8 * par), t[0]),                    # key & 15
+                      isa.vop("v_lshlrev_b32", t[2], I32(8), t[2])]
+                for ks in range(4):
+                    o += [isa.vop("v_or_b32", t[4], I32(4 * ks), g), isa.vop("v_xor_b32", t[4], t[4], t[3]),
+                          isa.vop("v_lshl_add_u32", KADDR16[ks][par], t[4], I32(4), t[2])]
+            # V^T fragment addresses: row 16 db + ql (128 B), chunk (4 ks + g) ^ ((ql >> 1) & 7), in the V ring; db goes into the offset
+            o += [isa.vop("v_lshrrev_b32", t[0], I32(1), ql), isa.vop("v_and_b32", t[0], I32(7), t[0]),
+                  isa.vop("v_lshlrev_b32", t[1], I32(7), ql), isa.vop("v_add_u32", t[1], I32(c.rd * 16384), t[1])]
+            for ks in range(2):
+                o += [isa.vop("v_or_b32", t[2], I32(4 * ks), g), isa.vop("v_xor_b32", t[2], t[2], t[0]),
+                      isa.vop("v_lshl_add_u32", VADDR16[ks], t[2], I32(4), t[1])]
+        else:
+            # ---- lane geometry ----
+            ql, g = VT1, VT2
+            o += [isa.vop("v_and_b32", ql, I32(31), LANE), isa.vop("v_lshrrev_b32", g, I32(5), LANE)]
+            t = TMP
+            # K fragment addresses: row ql (256 B), 16-byte chunk (2 ks + g) ^ (ql & 15)
+            o += [isa.vop("v_and_b32", t[0], I32(15), ql), isa.vop("v_lshlrev_b32", t[1], I32(8), ql)]
+            for ks in range(8):
+                o += [isa.vop("v_or_b32", t[2], I32(2 * ks), g), isa.vop("v_xor_b32", t[2], t[2], t[0]),
+                      isa.vop("v_lshl_add_u32", KADDR[ks], t[2], I32(4), t[1])]
+            # V^T fragment addresses: row ql (128 B), chunk (2 ks + g) ^ ((ql >> 1) & 7), in the V ring
+            o += [isa.vop("v_lshrrev_b32", t[0], I32(1), ql), isa.vop("v_and_b32", t[0], I32(7), t[0]),
+                  isa.vop("v_lshlrev_b32", t[1], I32(7), ql), isa.vop("v_add_u32", t[1], I32(c.rd * 16384), t[1])]
+            for ks in range(4):
+                o += [isa.vop("v_or_b32", t[2], I32(2 * ks), g), isa.vop("v_xor_b32", t[2], t[2], t[0]),
+                      isa.vop("v_lshl_add_u32", VADDR[ks], t[2], I32(4), t[1])]
         # LDS-DMA source offsets.  K piece i of this wave: tile rows 16 w + 4 i + (lane >> 4), chunk (lane & 15) ^ (row & 15)
         o += [isa.vop("v_lshrrev_b32", t[0], I32(4), LANE), isa.vop("v_and_b32", t[1], I32(15), LANE),
               isa.vop("v_lshlrev_b32", t[3], I32(4), S_WAVE)]       # 16 w
@@ -434,29 +665,65 @@ class Gen:
                   isa.vop("v_xor_b32", t[5], t[1], t[5]),
                   isa.vop("v_mul_lo_u32", t[6], t[6], lkpb), isa.vop("v_lshl_add_u32", t[6], t[5], I32(4), t[6]),
                   isa.vop("v_subrev_u32", VDMA[i], I32(1024 * i), t[6])]
-        # query rows of this lane: row = 256 qb + 64 w + 32 rb + ql ; Q loads straight into the accumulator file
-        qrsb, orsb, lqm1 = ST[12], ST[13], ST[9]
-        o += [isa.sop("s_lshl_b32", qrsb, S_QRS.sub(0), I32(1)), isa.sop("s_lshl_b32", orsb, S_ORS.sub(0), I32(1)),
-              isa.sop("s_sub_u32", lqm1, S_LQ, I32(1)),
-              isa.sop("s_lshl_b32", ST[8], S_QB, I32(8)), isa.sop("s_lshl_b32", ST[7], S_WAVE, I32(6)),
-              isa.sop("s_add_u32", ST[8], ST[8], ST[7])]
-        for rb in range(2):
-            o += [isa.vop("v_add_u32", ROW[rb], ST[8], ql)]
-            if rb:
-                o += [isa.vop("v_add_u32", ROW[rb], I32(32), ROW[rb])]
-            o += [isa.vop("v_min_u32", t[0], ROW[rb], lqm1), isa.vop("v_mul_lo_u32", t[0], t[0], qrsb),
-                  isa.vop("v_lshl_add_u32", t[1 + rb], g, I32(4), t[0]),
-                  isa.vop("v_mul_lo_u32", t[3], ROW[rb], orsb), isa.vop("v_lshl_add_u32", OOFF[rb], g, I32(3), t[3])]
-        for rb in range(2):
-            for ks in range(8):
-                o.append(isa.global_load(4, Qf(rb, ks), t[1 + rb], 32 * ks, saddr=S_Q))
-        # softmax state
-        for i in range(128):
-            o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
-        for rb in range(2):
-            o += [isa.vop("v_mov_b32", M_[rb], F32(-1e30)), isa.vop("v_mul_f32", MC[rb], M_[rb], S_C)]
-            for j in range(4):
-                o.append(isa.vop("v_mov_b32", L_[rb][j], I32(0)))
+        if c.mi == 16:
+            # query rows of this lane: row = 256 qb_wg + 64 w + 16 qb + ql ; Q loads straight into the accumulator file:
+            # B operand of S^T = K Q^T: lane holds Q[row][32 ks + 8 g .. +7]
+            qrsb, orsb, lqm1 = ST[12], ST[13], ST[9]
+            o += [isa.sop("s_lshl_b32", qrsb, S_QRS.sub(0), I32(1)), isa.sop("s_lshl_b32", orsb, S_ORS.sub(0), I32(1)),
+                  isa.sop("s_sub_u32", lqm1, S_LQ, I32(1)),
+                  isa.sop("s_lshl_b32", ST[8], S_QB, I32(8)), isa.sop("s_lshl_b32", ST[7], S_WAVE, I32(6)),
+                  isa.sop("s_add_u32", ST[8], ST[8], ST[7])]
+            qa = [TMP16[4 + qb] for qb in range(4)]
+            for qb in range(4):
+                o += [isa.vop("v_add_u32", ROW16[qb], ST[8], ql)]
+                if qb:
+                    o += [isa.vop("v_add_u32", ROW16[qb], I32(16 * qb), ROW16[qb])]
+                o += [isa.vop("v_min_u32", t[0], ROW16[qb], lqm1), isa.vop("v_mul_lo_u32", t[0], t[0], qrsb),
+                      isa.vop("v_lshl_add_u32", qa[qb], g, I32(4), t[0]),
+                      isa.vop("v_mul_lo_u32", t[3], ROW16[qb], orsb), isa.vop("v_lshl_add_u32", OOFF16[qb], g, I32(3), t[3])]
+            for qb in range(4):
+                for ks in range(4):
+                    o.append(isa.global_load(4, Qf16(qb, ks), qa[qb], 64 * ks, saddr=S_Q))
+            # softmax state
+            for i in range(128):
+                o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
+            if c.fold:
+                # running maximum starts at 0; the first tile's subroutine call (unconditional, CLAMP = -inf) sets it to the tile's maximum
+                for qb in range(4):
+                    for i in range(4):
+                        o.append(isa.vop("v_mov_b32", NEGM[qb].sub(i), I32(0)))
+                    for j in range(2):
+                        o.append(isa.vop("v_mov_b32", L16F[qb][j], I32(0)))
+                o += [isa.sop("s_mov_b32", S_CLAMP, I32(0xFF800000)), isa.sop("s_mov_b32", S_FIRST, I32(1))]
+            else:
+                for qb in range(4):
+                    o += [isa.vop("v_mov_b32", M16[qb], F32(-1e30)), isa.vop("v_mul_f32", MC16[qb], M16[qb], S_C)]
+                    for j in range(2):
+                        o.append(isa.vop("v_mov_b32", L16[qb][j], I32(0)))
+        else:
+            # query rows of this lane: row = 256 qb + 64 w + 32 rb + ql ; Q loads straight into the accumulator file
+            qrsb, orsb, lqm1 = ST[12], ST[13], ST[9]
+            o += [isa.sop("s_lshl_b32", qrsb, S_QRS.sub(0), I32(1)), isa.sop("s_lshl_b32", orsb, S_ORS.sub(0), I32(1)),
+                  isa.sop("s_sub_u32", lqm1, S_LQ, I32(1)),
+                  isa.sop("s_lshl_b32", ST[8], S_QB, I32(8)), isa.sop("s_lshl_b32", ST[7], S_WAVE, I32(6)),
+                  isa.sop("s_add_u32", ST[8], ST[8], ST[7])]
+            for rb in range(2):
+                o += [isa.vop("v_add_u32", ROW[rb], ST[8], ql)]
+                if rb:
+                    o += [isa.vop("v_add_u32", ROW[rb], I32(32), ROW[rb])]
+                o += [isa.vop("v_min_u32", t[0], ROW[rb], lqm1), isa.vop("v_mul_lo_u32", t[0], t[0], qrsb),
+                      isa.vop("v_lshl_add_u32", t[1 + rb], g, I32(4), t[0]),
+                      isa.vop("v_mul_lo_u32", t[3], ROW[rb], orsb), isa.vop("v_lshl_add_u32", OOFF[rb], g, I32(3), t[3])]
+            for rb in range(2):
+                for ks in range(8):
+                    o.append(isa.global_load(4, Qf(rb, ks), t[1 + rb], 32 * ks, saddr=S_Q))
+            # softmax state
+            for i in range(128):
+                o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
+            for rb in range(2):
+                o += [isa.vop("v_mov_b32", M_[rb], F32(-1e30)), isa.vop("v_mul_f32", MC[rb], M_[rb], S_C)]
+                for j in range(4):
+                    o.append(isa.vop("v_mov_b32", L_[rb][j], I32(0)))
         return sched.pad_hazards(o)
 
     def segment_start(self) -> List[Instr]:
@@ -468,16 +735,24 @@ class Gen:
             o += self.dma_tile("k", j % c.rd, 0, 0)
         for j in range(c.pv):
             o += self.dma_tile("v", j % c.rd, 0, 0)
+        m16 = c.mi == 16
+        kfr = self.k_frag_reads16 if m16 else self.k_frag_reads
         o += [isa.waitcnt(vmcnt=0), isa.barrier()]
-        o += self.k_frag_reads(0, 0, 0)
+        o += kfr(0, 0, 0)
         o += [isa.waitcnt(lgkmcnt=0), isa.barrier()]
         o += self.dma_tile("k", c.rd % c.rd, 0, 0)                 # K(rd) into slot 0, whose fragments are in registers now
-        o += self.qk_mfmas(0)
-        o += self.k_frag_reads(1 % c.rd, 0, 0)
+        o += self.qk_mfmas16(0) if m16 else self.qk_mfmas(0)
+        o += kfr(1 % c.rd, 0, 0)
         o += [isa.nop(15)]
-        o += self.rowmax(0, 0, 0, 0)
-        o += [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep if c.rd > 2 else 0), isa.barrier(),
-              isa.branch("s_cbranch_vccz", "L_seg_norescale"), isa.s_call(S_RET, "L_rescale"), isa.label("L_seg_norescale")]
+        o += self.rowmax16(0, (0, 0, 0, 0), 0) if m16 else self.rowmax(0, 0, 0, 0)
+        o += [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=c.vm_keep if c.rd > 2 else 0), isa.barrier()]
+        if c.fold:
+            # the very first tile of the kernel always goes through the subroutine (it establishes the maxima, whatever their sign)
+            o += [isa.sop("s_cmp_lg_u32", None, S_FIRST, I32(0)), isa.branch("s_cbranch_scc1", "L_seg_rescale"),
+                  isa.branch("s_cbranch_vccz", "L_seg_norescale"), isa.label("L_seg_rescale"), isa.s_call(S_RET, "L_rescale0"),
+                  isa.label("L_seg_norescale")]
+        else:
+            o += [isa.branch("s_cbranch_vccz", "L_seg_norescale"), isa.s_call(S_RET, "L_rescale"), isa.label("L_seg_norescale")]
         return sched.pad_hazards(sched.insert_lgkm_waits(o))
 
     def loops(self) -> List[Instr]:
@@ -513,6 +788,30 @@ class Gen:
             o += [isa.sop("s_lshl_b64", st, ss, I32(1)), isa.sop("s_add_u32", rs.sub(0), rs.sub(0), st.sub(0)),
                   isa.sop("s_addc_u32", rs.sub(1), rs.sub(1), st.sub(1))]
         o += [isa.branch("s_branch", "L_seg_start")]
+        if self.cfg.mi == 16:
+            # ---- epilogue (mi = 16): O / l -> bf16; the lane owns query rows 16 qb + ql and columns d = 16 db + 4 g + e.  The S registers
+            #      are dead here and serve as temporaries ----
+            e = [isa.label("L_epilogue")]
+            inv = [V(qb) for qb in range(4)]
+            for qb in range(4):
+                a, b = V(4), V(5)
+                lsum = L16F if self.cfg.fold else L16
+                e += [isa.vop("v_add_f32", a, lsum[qb][0], lsum[qb][1]), isa.vop("v_mov_b32", b, a),
+                      isa.permlane32_swap(a, b), isa.vop("v_add_f32", a, a, b), isa.vop("v_mov_b32", b, a),
+                      isa.permlane16_swap(a, b), isa.vop("v_add_f32", a, a, b), isa.vop("v_rcp_f32", inv[qb], a)]
+            for qb in range(4):
+                e += [isa.v_cmp("v_cmp_lt_u32", ROW16[qb], S_LQ), Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+                for db in range(8):
+                    base = 8 + 6 * (db % 2)
+                    f = [V(base + i) for i in range(4)]
+                    w = V(base + 4, 2)
+                    for i in range(4):
+                        e += [isa.vop("v_accvgpr_read_b32", f[i], O16(db, qb).sub(i)), isa.vop("v_mul_f32", f[i], f[i], inv[qb])]
+                    e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
+                          isa.global_store(2, OOFF16[qb], w, 32 * db, saddr=S_O, extra_reads=[EXEC])]
+                e += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+            e += [isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
+            return o + sched.pad_hazards(e)
         # ---- epilogue: O / l -> bf16, rows of this lane: d = 32 db + 8 rr + 4 g + e ----
         e: List[Instr] = [isa.label("L_epilogue")]
         inv = [TMP[0], TMP[1]]
@@ -635,6 +934,12 @@ def assembly(cfgs) -> str:
 DEFAULT = Cfg(rd=4, cap=5, name="scail_attn4")
 
 
+# the two shipped kernels: DEFAULT (any scale, 32x32x16 MFMAs) and M16F (q pre-multiplied by scale * log2 e, 16x16x32 MFMAs, running
+# maximum folded into the accumulator init; scail_flash_attn_bf16 with scale == 0)
+M16F = Cfg(name="scail_attn4_m16f", mi=16, fold=True, cap=2, lookahead=2.0)
+SHIPPED = [DEFAULT, M16F]
+
+
 def variant_cfgs():
     """A/B variants for GPU tuning runs (ablation build only); the kernel name encodes the knobs, tools/attn4_tune.py lists them."""
     out = []
@@ -654,6 +959,18 @@ def variant_cfgs():
     # timing ablations (WRONG RESULTS): what each instruction class costs beside the 64 MFMAs of a tile
     for abl in ("dma", "lds", "valu", "bar", "max", "dma,lds", "dma,lds,valu", "dma,lds,valu,bar", "fma"):
         out.append(Cfg(name="scail_attn4_abl_" + abl.replace(",", "_"), abl=abl))
+    # 16 x 16 x 32 MFMAs (128 per tile, 16-cycle gaps)
+    for cap in (2, 3):
+        out.append(Cfg(name=f"scail_attn4_m16c{cap}", cap=cap, mi=16))
+    out.append(Cfg(name="scail_attn4_m16c2la2", cap=2, mi=16, lookahead=2.0))
+    for abl in ("dma", "lds", "valu", "dma,lds,valu"):
+        out.append(Cfg(name="scail_attn4_m16_abl_" + abl.replace(",", "_"), abl=abl, mi=16, cap=2))
+    out.append(Cfg(name="scail_attn4_m16f_c3", mi=16, fold=True, cap=3))
+    out.append(Cfg(name="scail_attn4_m16f_sm44", mi=16, fold=True, cap=2, lookahead=2.0, sm_end=44.0))
+    out.append(Cfg(name="scail_attn4_m16_abl_fma", abl="fma", mi=16, cap=2, lookahead=2.0))
+    out.append(Cfg(name="scail_attn4_m16_abl_fma_c3", abl="fma", mi=16, cap=3))
+    out.append(Cfg(name="scail_attn4_m16_abl_fma_sm44", abl="fma", mi=16, cap=2, sm_end=44.0, lookahead=2.0))
+    out.append(Cfg(name="scail_attn4_m16_abl_fma_max", abl="fma,max", mi=16, cap=2, lookahead=2.0))
     out.append(Cfg(name="scail_attn4_abl_fma_c4", abl="fma", cap=4))
     out.append(Cfg(name="scail_attn4_abl_fma_sm44", abl="fma", sm_end=44.0))
     return out
@@ -669,7 +986,7 @@ def main():
         open(dst, "w").write(assembly([DEFAULT] + variant_cfgs()))
         print(dst)
         return
-    text = assembly([DEFAULT])
+    text = assembly(SHIPPED)
     if "--check" in sys.argv:
         sys.exit(0 if open(out).read() == text else 1)
     if not os.path.exists(out) or open(out).read() != text:

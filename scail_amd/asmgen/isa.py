@@ -205,6 +205,14 @@ def vop(op: str, dst, *srcs, **kw) -> Instr:
     return Instr(op, d, list(srcs), **kw)
 
 
+def permlane16_swap(a: Reg, b: Reg, **kw) -> Instr:
+    """v_permlane16_swap_b32 a, b: the odd 16-lane rows of ``a`` (lanes 16-31, 48-63) are exchanged with the even rows of ``b``
+    (lanes 0-15, 32-47); both read and written."""
+    i = Instr("v_permlane16_swap_b32", [a, b], [a, b], **kw)
+    i.text = f"v_permlane16_swap_b32 {a}, {b}"
+    return i
+
+
 def permlane32_swap(a: Reg, b: Reg, **kw) -> Instr:
     """v_permlane32_swap_b32 a, b: lanes 32-63 of ``a`` are exchanged with lanes 0-31 of ``b`` (both read and written)."""
     i = Instr("v_permlane32_swap_b32", [a, b], [a, b], **kw)

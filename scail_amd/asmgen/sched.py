@@ -48,7 +48,7 @@ def min_distance(p: Instr, c: Instr, kind: str, unit: Tuple[str, int]) -> int:
                 return VALU_TO_MFMA_DIST
             if p.cls == isa.TRANS and c.cls in (isa.VALU, isa.DS_WRITE, isa.VMEM_STORE):
                 return TRANS_DIST
-            if c.op == "v_permlane32_swap_b32" and p.cls in (isa.VALU, isa.TRANS):
+            if c.op in ("v_permlane32_swap_b32", "v_permlane16_swap_b32") and p.cls in (isa.VALU, isa.TRANS):
                 return PERMLANE_DIST
             if unit[0] == "m0" and c.cls == isa.LDS_DMA:
                 return M0_DIST

@@ -21,6 +21,8 @@
 // in); a row's two lanes (g = 0, 1) keep the same m and separate partial l that are added once at
 // the end.  LDS rows are padded (K: 272 B, V^T: 144 B) so every ds_read_b128 service group touches
 // 16 distinct 16-byte slots.
+#include <map>
+#include <mutex>
 #include "common.h"
 
 #define HD 128
@@ -823,12 +825,14 @@ struct Attn4Args {
 };
 static_assert(sizeof(Attn4Args) == 152, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
 static hipModule_t g_attn4_module = nullptr;
-static std::string g_attn4_name = "scail_attn4";
-static hipFunction_t g_attn4_fn = nullptr;
+static std::string g_attn4_name = "scail_attn4";                 // general kernel (A/B variants of the measurement build replace it)
+static std::map<std::string, hipFunction_t> g_attn4_fns;
+static std::mutex g_attn4_mutex;
 static float g_attn4_thr_log2 = 8.0f;      // lazy-rescale threshold: P <= 2^thr
 static int g_attn4_xcd = 1;                // XCD-aware workgroup-id decode (A/B knob "attn4_xcd")
 
-static int attn4_function(hipFunction_t* fn) {
+static int attn4_function(const std::string& name, hipFunction_t* fn) {
+    std::lock_guard<std::mutex> lk(g_attn4_mutex);
     if (g_attn4_module == nullptr) {
         hipError_t e = hipModuleLoadData(&g_attn4_module, k_attn4_hsaco);
         if (e != hipSuccess) {
@@ -836,19 +840,20 @@ static int attn4_function(hipFunction_t* fn) {
             return 2;
         }
     }
-    if (g_attn4_fn == nullptr) {
-        hipError_t e = hipModuleGetFunction(&g_attn4_fn, g_attn4_module, g_attn4_name.c_str());
+    auto it = g_attn4_fns.find(name);
+    if (it == g_attn4_fns.end()) {
+        hipFunction_t f;
+        hipError_t e = hipModuleGetFunction(&f, g_attn4_module, name.c_str());
         if (e != hipSuccess) {
-            scail_set_error("attn4: kernel " + g_attn4_name + " is not in the embedded code object: " + hipGetErrorString(e));
+            scail_set_error("attn4: kernel " + name + " is not in the embedded code object: " + hipGetErrorString(e));
             return 2;
         }
+        it = g_attn4_fns.emplace(name, f).first;
     }
-    *fn = g_attn4_fn;
+    *fn = it->second;
     return 0;
 }
 
-// Shapes the 4-wave kernel covers (the 8-wave kernels above serve everything else): whole 64-key tiles, no accumulate, at least
-// a few tiles of keys, and every byte offset inside one (batch, head) slice below 2^31.
 static bool attn4_eligible(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate) {
     const int64_t lim = (1ll << 30);     // elements -> 2^31 bytes
     return Lk % 64 == 0 && Lk >= 512 && accumulate == 0 && Lq * q_rs < lim && Lk * k_rs < lim && Lq * o_rs < lim && 128 * Lk < lim;
@@ -908,9 +913,8 @@ extern "C" int scail_tune_set(const char* knob, int value) {
         std::string k(knob), name = "scail_attn4";
         if (k.size() > 13) name += "_" + k.substr(13);
         g_attn4_name = name;
-        g_attn4_fn = nullptr;
         hipFunction_t fn;
-        return attn4_function(&fn);
+        return attn4_function(name, &fn);
     }
     if (std::string(knob).rfind("gemm4", 0) == 0) return scail_gemm4_knob(knob, value);     // "gemm4" on / off, "gemm4_kernel:<suffix>"
     if (std::string(knob) == "gemm_tile") return scail_gemm_tune(value);
@@ -935,6 +939,8 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     SCAIL_REQUIRE((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(k) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(vt) & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 7) == 0,
                   "pointer alignment");
+    const bool prescaled = scale == SCAIL_ATTN_Q_PRESCALED;        // q already carries scale * log2(e)
+    const float sl2 = prescaled ? 1.0f : scale * 1.4426950408889634f;
     const int64_t Lkp = (Lk + 63) / 64 * 64;
     SCAIL_REQUIRE(vt_bs == 0 || vt_bs == heads * HD * Lkp, "vt batch stride must be 0 or heads*128*ceil64(Lk)");
     SCAIL_REQUIRE(Lq < (1ll << 31) && Lkp * n_seg < (1ll << 31), "sequence too long");
@@ -966,14 +972,17 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         attr_set = true;
     }
     if (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate)) {
+        // q in log2 units -> the 16x16x32 kernel with the maximum folded into the accumulator init; any other scale -> the general one
+        // (a variant chosen with the measurement build's "attn4_kernel" knob replaces both)
         hipFunction_t fn;
-        if (int rc = attn4_function(&fn)) return rc;
+        const bool fold = prescaled && g_attn4_name == "scail_attn4";
+        if (int rc = attn4_function(fold ? std::string("scail_attn4_m16f") : g_attn4_name, &fn)) return rc;
         Attn4Args a;
         a.q = q; a.k = k; a.vt = vt; a.o = o;
         a.q_bs = q_bs; a.q_rs = q_rs; a.k_ss = k_ss; a.k_bs = k_bs; a.k_rs = k_rs; a.vt_ss = vt_ss; a.vt_bs = vt_bs;
         a.o_bs = o_bs; a.o_rs = o_rs;
         a.heads = (int32_t)heads; a.Lq = (int32_t)Lq; a.Lk = (int32_t)Lk; a.Lkp = (int32_t)Lkp; a.n_seg = (int32_t)n_seg;
-        a.sl2 = scale * 1.4426950408889634f;
+        a.sl2 = sl2;
         a.thr = g_attn4_thr_log2 / a.sl2;
         a.nqb = (int32_t)((Lq + 255) / 256);
         a.magic_nqb = (uint32_t)(((1ull << 31) + a.nqb - 1) / a.nqb);
@@ -996,7 +1005,7 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     p.vt = vt; p.vt_ss = vt_ss; p.vt_bs = vt_bs;
     p.o = o; p.o_bs = o_bs; p.o_rs = o_rs;
     p.heads = (int)heads; p.Lq = (int)Lq; p.Lk = (int)Lk; p.Lkp = (int)Lkp; p.n_seg = (int)n_seg;
-    p.sl2 = scale * 1.4426950408889634f;
+    p.sl2 = sl2;
     p.accumulate = accumulate;
     p.probe = 0;
     dim3 grid((unsigned)((Lq + QBLK - 1) / QBLK), (unsigned)heads, (unsigned)n_batch);

@@ -90,9 +90,10 @@ static int dit_block(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, c
     DIT_TRY(scail_gemm_bf16(xn, D, lw.qkv_w, lw.qkv_b, qkv, 3 * D, M, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
     DIT_TRY(scail_rmsnorm_rope(k, 3 * D, k, 3 * D, lw.kn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
     DIT_TRY(scail_transpose_v(v, 3 * D, Ltok * 3 * D, vt, B, nh, 128, Ltok, stream));
-    DIT_TRY(scail_rmsnorm_rope(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
+    // the queries go to the attention in log2 units (q * scale * log2 e, one rounding): its exp2 then needs no scale / shift per score
+    DIT_TRY(scail_rmsnorm_rope_scaled(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, M, Ltok, D, 128, eps, scale * 1.4426950408889634f, stream));
     DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, k, 0, Ltok * 3 * D, 3 * D, vt, 0, nh * 128 * Lp, att, Ltok * D, D,
-                                  B, nh, Ltok, Ltok, 1, scale, 0, stream));
+                                  B, nh, Ltok, Ltok, 1, SCAIL_ATTN_Q_PRESCALED, 0, stream));
     DIT_TRY(scail_gemm_bf16(att, D, lw.o_w, lw.o_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, m + 2 * D, 6 * D, Ltok, stream));
     // -- cross attention: text + CLIP, ungated residual (dit...:1039-1042, :1107-1203) --
     DIT_TRY(scail_layernorm_affine(hid, D, xn, D, lw.ln_w, lw.ln_b, M, D, eps, stream));

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_kernel(
 __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
     const u16* __restrict__ x, int64_t ldx, u16* __restrict__ y, int64_t ldy,
     const float* __restrict__ w, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
-    int64_t rows_per_batch, int D, int head_dim, float eps) {
+    int64_t rows_per_batch, int D, int head_dim, float eps, float out_scale) {
     __shared__ float red[4];
     const int64_t r = blockIdx.x;
     const u16* xr = x + r * ldx;
@@ -127,6 +127,8 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = n[e];
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= out_scale;       // 1.0f (exact) unless the caller folds a scale into the row
             *reinterpret_cast<uint4*>(yr + (int64_t)c * 8) = pack8(o);
         }
     }
@@ -356,6 +358,13 @@ extern "C" int scail_rmsnorm_rope(const scail_bf16* x, int64_t ldx, scail_bf16* 
                                   const float* w, const float* cos_tab, const float* sin_tab,
                                   int64_t rows, int64_t rows_per_batch, int64_t D, int64_t head_dim,
                                   float eps, void* stream) {
+    return scail_rmsnorm_rope_scaled(x, ldx, y, ldy, w, cos_tab, sin_tab, rows, rows_per_batch, D, head_dim, eps, 1.0f, stream);
+}
+
+extern "C" int scail_rmsnorm_rope_scaled(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t ldy,
+                                         const float* w, const float* cos_tab, const float* sin_tab,
+                                         int64_t rows, int64_t rows_per_batch, int64_t D, int64_t head_dim,
+                                         float eps, float out_scale, void* stream) {
     SCAIL_REQUIRE(D % 8 == 0 && D <= ROW_THREADS * 8 * ROW_MAXV, "D must be a multiple of 8 and <= 6144");
     SCAIL_REQUIRE(head_dim % 8 == 0 && D % head_dim == 0, "head_dim must be a multiple of 8 dividing D");
     SCAIL_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "strides must keep 16-byte alignment");
@@ -365,7 +374,7 @@ extern "C" int scail_rmsnorm_rope(const scail_bf16* x, int64_t ldx, scail_bf16* 
     SCAIL_REQUIRE(rows_per_batch > 0, "rows_per_batch must be positive");
     if (rows == 0) return 0;
     hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                       x, ldx, y, ldy, w, cos_tab, sin_tab, rows_per_batch, (int)D, (int)head_dim, eps);
+                       x, ldx, y, ldy, w, cos_tab, sin_tab, rows_per_batch, (int)D, (int)head_dim, eps, out_scale);
     return scail_check_launch("rmsnorm_rope");
 }
 

@@ -506,8 +506,8 @@ class DiffusionTransformer(nn.Module):
                 ops.gemm(xn, lw["qkv_w"], lw["qkv_b"], out=qkv)
                 ops.rmsnorm_rope(k, lw["kn"], cos, sin, rows_per_batch=Ltok, eps=eps)
                 ops.transpose_v(v, nh, out=vt)
-                ops.rmsnorm_rope(q, lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
-                self._timed("self_attn", ops.flash_attn, q, k, vt, out=att)
+                ops.rmsnorm_rope(q, lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps, out_scale=ops.ATTN_LOG2_SCALE)   # q in log2 units
+                self._timed("self_attn", ops.flash_attn, q, k, vt, out=att, q_prescaled=True)
             else:
                 sp.self_attention(self, lw, xn, qkv, vt, cos, sin, att, Ltok, eps)
             ops.gemm(att, lw["o_w"], lw["o_b"], out=h, epilogue=L.EPI_RESID, resid=h, gate=g_a, rows_per_batch=Ltok)

@@ -108,8 +108,12 @@ def layernorm_affine(x, w, b, out=None, eps=1e-6):
     return out
 
 
-def rmsnorm_rope(x, w, cos=None, sin=None, out=None, rows_per_batch=None, head_dim=128, eps=1e-6):
-    """RMSNorm over the last dim (+RoPE with (L, head_dim/2) fp32 tables).  In place when out is None."""
+ATTN_LOG2_SCALE = 1.4426950408889634 / math.sqrt(128.0)     # q * this = queries in log2 units (flash_attn(..., q_prescaled=True))
+
+
+def rmsnorm_rope(x, w, cos=None, sin=None, out=None, rows_per_batch=None, head_dim=128, eps=1e-6, out_scale=1.0):
+    """RMSNorm over the last dim (+RoPE with (L, head_dim/2) fp32 tables), times ``out_scale`` before the rounding to bf16.
+    In place when out is None."""
     _chk(x, bf16, "rmsnorm_rope.x"); _chk(w, f32, "w")
     rows, D, ldx = _rowmajor2d(x, "rmsnorm_rope.x")
     out = x if out is None else out
@@ -121,8 +125,8 @@ def rmsnorm_rope(x, w, cos=None, sin=None, out=None, rows_per_batch=None, head_d
         assert rows_per_batch <= cos.shape[0]
     else:
         rows_per_batch = rows if rows_per_batch is None else rows_per_batch
-    L.call("scail_rmsnorm_rope", x.data_ptr(), ldx, out.data_ptr(), ldy, w.data_ptr(), _ptr(cos), _ptr(sin), rows,
-           rows_per_batch, D, head_dim, eps, _stream())
+    L.call("scail_rmsnorm_rope_scaled", x.data_ptr(), ldx, out.data_ptr(), ldy, w.data_ptr(), _ptr(cos), _ptr(sin), rows,
+           rows_per_batch, D, head_dim, eps, float(out_scale), _stream())
     return out
 
 
@@ -141,9 +145,10 @@ def transpose_v(v, heads, head_dim=128, out=None):
 
 
 def flash_attn(q, k, vt, out=None, scale=None, accumulate=False, n_seg=1, k_seg_stride=0, vt_seg_stride=0,
-               k_broadcast=False):
+               k_broadcast=False, q_prescaled=False):
     """q (B, Lq, H*128) view; k (B|1, Lk, H*128) view [per segment]; vt (B|1, H, 128, Lkp) [per segment].
-    Output (B, Lq, H*128) view.  ``k_broadcast``: K/V have batch 1 and are shared by all B queries."""
+    Output (B, Lq, H*128) view.  ``k_broadcast``: K/V have batch 1 and are shared by all B queries.
+    ``q_prescaled``: q already carries scale * log2(e) (rmsnorm_rope(..., out_scale=ATTN_LOG2_SCALE)); include/scail_hip.h scale == 0."""
     _chk(q, bf16, "flash_attn.q"); _chk(k, bf16, "k"); _chk(vt, bf16, "vt")
     B, Lq, D = q.shape
     H = D // 128
@@ -160,6 +165,8 @@ def flash_attn(q, k, vt, out=None, scale=None, accumulate=False, n_seg=1, k_seg_
     vt_bs = 0 if (k_broadcast or vt.shape[0] == 1) else vt.stride(0)
     if scale is None:
         scale = 1.0 / math.sqrt(128)
+    if q_prescaled:
+        scale = 0.0
     L.call("scail_flash_attn_bf16", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride, k_bs,
            k.stride(1), vt.data_ptr(), vt_seg_stride, vt_bs, out.data_ptr(), out.stride(0), out.stride(1), B, H, Lq,
            Lk, n_seg, scale, 1 if accumulate else 0, _stream())

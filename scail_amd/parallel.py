@@ -266,7 +266,7 @@ class SequenceParallel:
             # projection + norm + RoPE per element: the exchange of element b runs under the projection of element b+1
             ops.gemm(xn[b], lw["qkv_w"], lw["qkv_b"], out=qkv[b])
             ops.rmsnorm_rope(qkv[b:b + 1, :, D:2 * D], lw["kn"], cos, sin, rows_per_batch=Ltok, eps=eps)
-            ops.rmsnorm_rope(qkv[b:b + 1, :, :D], lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
+            ops.rmsnorm_rope(qkv[b:b + 1, :, :D], lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps, out_scale=ops.ATTN_LOG2_SCALE)
             send[b].copy_(qkv[b].view(Ltok, 3, N, Dn).permute(1, 2, 0, 3))           # (q|k|v, dst rank, Ltok, Dn)
             fwd.append([self.backend.all_to_all(recv[b, j], send[b, j], async_op=True) for j in range(3)])
         bwd = []
@@ -275,7 +275,7 @@ class SequenceParallel:
                 h.wait()
             qf, kf, vf = (recv[b, j].view(1, Lf, Dn) for j in range(3))              # all ranks' tokens, my heads
             ops.transpose_v(vf, Hn, out=vt[b])
-            net._timed("self_attn", ops.flash_attn, qf, kf, vt[b], out=ofull[b].view(1, Lf, Dn))
+            net._timed("self_attn", ops.flash_attn, qf, kf, vt[b], out=ofull[b].view(1, Lf, Dn), q_prescaled=True)
             bwd.append(self.backend.all_to_all(back[b], ofull[b], async_op=True))    # back[b][g] = my tokens, head group g
         for b in range(B):
             bwd[b].wait()
@@ -309,12 +309,12 @@ class SequenceParallel:
             ops.rmsnorm_rope(qkv[b:b + 1, :, D:2 * D], lw["kn"], cos, sin, out=kloc[b:b + 1], rows_per_batch=Ltok, eps=eps)
             hs.append((self.backend.all_gather_into(kg[b], kloc[b]), self.backend.all_gather_into(vg[b], vloc[b])))
         ops.gemm(xn, lw["qkv_w"][:D], lw["qkv_b"][:D], out=q)                       # overlaps the exchange
-        ops.rmsnorm_rope(q, lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps)
+        ops.rmsnorm_rope(q, lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps, out_scale=ops.ATTN_LOG2_SCALE)        # q in log2 units
         for b in range(B):
             hs[b][0].wait()
             hs[b][1].wait()
             ops.transpose_v(vg[b].view(1, Lf, D), nh, out=vt[b])
-            net._timed("self_attn", ops.flash_attn, q[b:b + 1], kg[b].view(1, Lf, D), vt[b], out=att[b:b + 1])
+            net._timed("self_attn", ops.flash_attn, q[b:b + 1], kg[b].view(1, Lf, D), vt[b], out=att[b:b + 1], q_prescaled=True)
         return att
 
 

@@ -22,22 +22,25 @@ def _rt(x):
     return R.from_bf16_bits(R.to_bf16_bits(x))
 
 
-def _case(cfg, B, H, Lq, Lk, nseg=1, lazy=True, spike=False, thr=8.0, seed=0, mode=None):
+def _case(cfg, B, H, Lq, Lk, nseg=1, lazy=True, spike=False, thr=8.0, seed=0, mode=None, qscale=1.0, qshift=0.0):
     rng = np.random.default_rng(seed)
-    q = rng.standard_normal((B, Lq, H * 128)).astype(np.float32)
+    q = (rng.standard_normal((B, Lq, H * 128)) * qscale + qshift).astype(np.float32)
     ks = [rng.standard_normal((B, Lk, H * 128)).astype(np.float32) for _ in range(nseg)]
     vs = [rng.standard_normal((B, Lk, H * 128)).astype(np.float32) for _ in range(nseg)]
     if spike:                                     # keys that dominate late: the running max must jump (guide rule 26)
         ks[-1][0, Lk - 3, :128] = q[0, 7, :128] * 3.0
         ks[0][0, 70 % Lk, :128] = q[0, 9, :128] * 2.0
     o, st = R.run(cfg, q, ks, vs, H, lazy=lazy, thr_log2=thr, mode=mode)
+    if cfg.fold:                                  # the kernel sees q * scale * log2(e) rounded to bf16 (scail_rmsnorm_rope_scaled)
+        c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
+        q = _rt(q * c) / c
     ref = R.reference(_rt(q), np.concatenate([_rt(x) for x in ks], 1), np.concatenate([_rt(x) for x in vs], 1), H)
     np.testing.assert_allclose(o, ref, rtol=2e-2, atol=6e-3)
     return st
 
 
 def test_generated_file_is_current():
-    text = attn4.assembly([attn4.DEFAULT])
+    text = attn4.assembly(attn4.SHIPPED)
     assert open(os.path.join(ROOT, "scail_amd", "csrc", "attn4.s")).read() == text, "run `python -m scail_amd.asmgen.attn4`"
 
 
@@ -68,3 +71,37 @@ def test_segments_and_lazy_rescale():
     _case(attn4.DEFAULT, 1, 2, 100, 192, nseg=3, spike=True, seed=4)
     _case(attn4.DEFAULT, 1, 1, 256, 640, lazy=False, spike=True, thr=0.0, seed=5)       # rescale whenever a row max moves
     _case(attn4.DEFAULT, 1, 1, 256, 640, lazy=True, spike=True, thr=2.0, seed=6)
+
+
+# ---- the second shipped kernel: 16x16x32 MFMAs, q in log2 units, running maximum folded into the accumulator init (M16F) ----
+def test_m16f_static_hazards_clean():
+    assert R.check_static(attn4.M16F) == []
+
+
+@pytest.mark.parametrize("tiles", [1, 2, 3, 4, 5, 6, 7, 9, 11])
+def test_m16f_every_remainder_path(tiles):
+    _case(attn4.M16F, 1, 1, 256, 64 * tiles, lazy=bool(tiles & 1), seed=tiles)
+
+
+def test_m16f_heads_batch_ragged_queries_segments_and_rescale():
+    _case(attn4.M16F, 2, 4, 300, 128, seed=1)
+    _case(attn4.M16F, 1, 3, 520, 64, seed=2)
+    _case(attn4.M16F, 1, 2, 100, 192, nseg=3, spike=True, seed=4)
+    _case(attn4.M16F, 1, 1, 256, 640, lazy=False, spike=True, thr=0.0, seed=5)
+    _case(attn4.M16F, 1, 1, 256, 640, lazy=True, spike=True, thr=2.0, seed=6)
+
+
+def test_m16f_first_tile_sets_the_maximum_whatever_its_sign():
+    """the running maximum starts at 0 and the first tile's (unconditional) subroutine call moves it to the tile's maximum: scores far
+    below 0 must not underflow the whole row (q . k = -300 in log2 units here), scores far above must not overflow"""
+    rng = np.random.default_rng(7)
+    B, H, Lq, Lk = 1, 1, 64, 192
+    k = rng.standard_normal((B, Lk, 128)).astype(np.float32) * 0.05 + 1.0           # all keys ~ +1 per component
+    v = rng.standard_normal((B, Lk, 128)).astype(np.float32)
+    for sign in (-1.0, 1.0):
+        q = (sign * 18.0 + rng.standard_normal((B, Lq, 128)) * 0.05).astype(np.float32)     # q . k / sqrt(128) * log2 e ~ sign * 300
+        o, _ = R.run(attn4.M16F, q, [k], [v], H)
+        c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
+        ref = R.reference(_rt(q * c) / c, _rt(k), _rt(v), H)
+        assert np.isfinite(o).all()
+        np.testing.assert_allclose(o, ref, rtol=2e-2, atol=6e-3)

@@ -196,6 +196,14 @@ def test_rmsnorm_rope(ops, heads):
     ops.rmsnorm_rope(xg[..., D:2 * D], w.to(DEV), cos[:, 0::2].contiguous().to(DEV), sin[:, 0::2].contiguous().to(DEV))
     close(xg[..., D:2 * D], ref_rope, msg="rmsnorm+rope in place")
     close(xg[..., :D], x[..., :D], rtol=0, atol=0, msg="neighbour columns untouched")
+    # out_scale (queries in log2 units for the attention): one rounding of scale * result; 1.0 is bit-identical to the plain entry
+    o1 = torch.empty_like(out)
+    ops.rmsnorm_rope(gpu_bf16(x)[..., D:2 * D], w.to(DEV), cos[:, 0::2].contiguous().to(DEV), sin[:, 0::2].contiguous().to(DEV), out=o1,
+                     out_scale=ops.ATTN_LOG2_SCALE)
+    close(o1, ref_rope * ops.ATTN_LOG2_SCALE, rtol=1e-2, atol=2e-3, msg="rmsnorm+rope, scaled output")
+    o2 = torch.empty_like(out)
+    ops.rmsnorm_rope(gpu_bf16(x)[..., D:2 * D], w.to(DEV), cos[:, 0::2].contiguous().to(DEV), sin[:, 0::2].contiguous().to(DEV), out=o2, out_scale=1.0)
+    assert torch.equal(o2, xg[..., D:2 * D])
 
 
 def test_rope_tables_match_oracle():
@@ -470,3 +478,45 @@ def test_cross_attn2_vs_oracle(ops, B, H, Lq, Lk1, Lk2, shared2):
     o2 = ops.flash_attn(g[..., :D], gpu_bf16(k1), vt1)
     ops.flash_attn(g[..., :D], gpu_bf16(k2), vt2, out=o2, accumulate=True)
     close(o[:, :Lq], o2.float(), rtol=1e-2, atol=4e-3, msg="cross_attn2 vs flash_attn + accumulate")
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,which", [(1, 1, 256, 512, 4), (2, 2, 300, 576, 4), (1, 2, 700, 1024, 4), (1, 3, 130, 832, 4), (1, 2, 520, 1088, 4),
+                                             (2, 1, 200, 300, 8), (1, 2, 64, 448, 8)])
+def test_flash_attn_prescaled_queries(ops, B, H, Lq, Lk, which):
+    """scale == SCAIL_ATTN_Q_PRESCALED: q arrives multiplied by scale * log2(e) (one rounding, as scail_rmsnorm_rope_scaled leaves
+    it).  Shapes the 4-wave kernel takes run scail_attn4_m16f (16x16x32 MFMAs, maximum folded into the accumulator init: every
+    remainder path of its tile loop, ragged query blocks, XCD-aware and plain id decode); the others the 8-wave kernel with a unit
+    scale.  Reference: fp32 attention of the queries the kernel effectively sees (q' / (scale log2 e))."""
+    from scail_amd import lib as L
+    D = H * 128
+    c = ops.ATTN_LOG2_SCALE
+    q, k, v = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3)
+    k[0, Lk - 3, :128] = bfr(q[0, 7, :128] * 3.0)                   # late dominant key: the running maximum must jump
+    qp = bfr(q * c)
+    ref = _attn_ref(qp / c, k, v, H)
+    qg, kg = gpu_bf16(qp), gpu_bf16(k)
+    vt = ops.transpose_v(gpu_bf16(v), H)
+    o = torch.empty(B, Lq, D, device=DEV, dtype=torch.bfloat16)
+    assert _which(qg, kg, o) == which
+    for thr in ((8, 0) if which == 4 else (8,)):
+        L.set_option("attn4_thr", thr)
+        try:
+            ops.flash_attn(qg, kg, vt, out=o, q_prescaled=True)
+        finally:
+            L.set_option("attn4_thr", 8)
+        close(o, ref, rtol=2e-2, atol=1e-2, msg=f"prescaled q, kernel {which}, thr {thr}")
+
+
+def test_flash_attn_prescaled_extreme_first_tile(ops):
+    """scail_attn4_m16f starts its running maximum at 0 and lets the first tile set it: rows whose scores all lie ~300 log2 units below
+    (above) zero must neither underflow to 0 / 0 nor overflow"""
+    H, Lq, Lk = 1, 256, 512
+    c = ops.ATTN_LOG2_SCALE
+    k = bfr(rnd(1, Lk, 128, seed=2) * 0.05 + 1.0)
+    v = rnd(1, Lk, 128, seed=3)
+    vt = ops.transpose_v(gpu_bf16(v), H)
+    for sign in (-1.0, 1.0):
+        qp = bfr((sign * 18.0 + rnd(1, Lq, 128, seed=1) * 0.05) * c)
+        o = ops.flash_attn(gpu_bf16(qp), gpu_bf16(k), vt, q_prescaled=True)
+        assert torch.isfinite(o.float()).all()
+        close(o, _attn_ref(qp / c, k, v, H), rtol=2e-2, atol=1e-2, msg=f"sign {sign}")

@@ -569,6 +569,13 @@ class Emu:
                 na, nb = a.copy(), b.copy()
                 na[32:], nb[:32] = b[:32], a[32:]
                 w.v[ra.idx], w.v[rb_.idx] = na, nb
+            elif op == "v_permlane16_swap_b32":
+                ra, rb_ = ins.dst[0], ins.dst[1]                     # vdst odd rows <-> vsrc even rows (rows of 16 lanes)
+                a, b = w.v[ra.idx].copy(), w.v[rb_.idx].copy()
+                na, nb = a.copy(), b.copy()
+                na[16:32], nb[0:16] = b[0:16], a[16:32]
+                na[48:64], nb[32:48] = b[32:48], a[48:64]
+                w.v[ra.idx], w.v[rb_.idx] = na, nb
             elif op == "v_add_u32":
                 self._wrv(w, d, (R(0).astype(np.uint64) + R(1)).astype(np.uint32))
             elif op == "v_subrev_u32":

@@ -60,7 +60,10 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     assert Lk % 64 == 0
     Lkp = Lk
     mem = E.Memory(size=1 << 26)
-    qb = to_bf16_bits(q)
+    sl2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+    fold = getattr(cfg, "fold", False)
+    # fold: the caller hands over q already multiplied by scale * log2(e) (one rounding to bf16, as scail_rmsnorm_rope_scaled does)
+    qb = to_bf16_bits(q * np.float32(sl2)) if fold else to_bf16_bits(q)
     kb = np.stack([to_bf16_bits(x) for x in ksegs])                       # (S, B, Lk, D)
     vt = np.stack([transpose_v(to_bf16_bits(x), heads) for x in vsegs])    # (S, B, H, 128, Lkp)
     pq = mem.alloc("q", qb)
@@ -68,7 +71,8 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     pvt = mem.alloc("vt", vt)
     po = mem.alloc("o", np.zeros((B, Lq, D), dtype=np.uint16))
     prog = program if program is not None else attn4.Gen(cfg).program()
-    sl2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+    if fold:
+        sl2 = 1.0
     args = attn4.pack_args(pq, pk, pvt, po, Lq * D, D, B * Lk * D, Lk * D, D, B * heads * 128 * Lkp, heads * 128 * Lkp, Lq * D, D,
                            heads, Lq, Lk, Lkp, n_seg, sl2, thr_log2 / sl2, n_batch=B, mode=mode)
     stats = None
