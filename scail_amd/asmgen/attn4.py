@@ -80,6 +80,8 @@ class Cfg:
     max_chains: int = 1    # independent partial-maximum chains per row block in the row max
     abl: str = ""          # TIMING ABLATIONS (wrong results; ablation build only): "dma" / "lds" / "valu" / "bar" / "max" removed
     mi: int = 32           # MFMA shape: 32 = v_mfma_f32_32x32x16_bf16 (64 per tile), 16 = v_mfma_f32_16x16x32_bf16 (128 per tile)
+    lsum: bool = False     # (fold) row sums on the matrix pipe: a 9th "d block" whose V^T fragment is a constant row of ones accumulates
+                           # sum_k P[k][q] beside O (8 extra MFMAs per tile replace 64 v_add_f32)
     fold: bool = False     # (mi = 16) q arrives multiplied by scale * log2(e): the running maximum is folded into the accumulator
                            # init of the first QK^T MFMA (S' = S - M), so p = exp2(S') needs no scale / shift instruction
 
@@ -127,6 +129,10 @@ TMP16 = [V(244 + i) for i in range(8)] + [V(202), V(203)]      # 10 temporaries 
 # fold: -M of query block qb as an accumulator-init quad, row-sum partials; M16 / MC16 / MX16 / ALPHA16 do not exist
 NEGM = [V(212 + 4 * qb, 4) for qb in range(4)]
 L16F = [[V(228 + qb * 2 + j) for j in range(2)] for qb in range(4)]
+# lsum: accumulator quads of the ones-row product (row 0 = lanes 0-15, register 0 holds the row sums) and the constant A fragment
+LACC = [V(228, 4), V(232, 4), V(236, 4), V(240, 4)]           # = L16F + OOFF16 + ROW16 (recomputed in the epilogue)
+ONES = V(248, 4)
+TMPL = [V(244 + i) for i in range(4)] + [V(202), V(203)]      # the 6 temporaries left inside the loop
 S_CLAMP, S_FIRST = S(87), S(88)       # rescale subroutine: lower bound of the maximum step (0, -inf at the very first tile), first-call flag
 
 KADDR = [V(192 + i) for i in range(8)]
@@ -305,6 +311,9 @@ class Gen:
             for db in range(8):
                 for qb in range(4):
                     out.append(isa.mfma16(O16(db, qb), Vtf16(db, ks), Pq16(cur, ks, qb), O16(db, qb), tag="pv"))
+            if self.cfg.lsum:
+                for qb in range(4):
+                    out.append(isa.mfma16(LACC[qb], ONES, Pq16(cur, ks, qb), LACC[qb], tag="pv"))
         return out
 
     def softmax_finish16(self, cur: int, t0: float, t1: float) -> List[Instr]:
@@ -319,7 +328,8 @@ class Gen:
                     if not nofma and not self.cfg.fold:
                         out.append(isa.vop("v_fma_f32", r, r, S_C, Neg(MC16[qb])))
                     out.append(isa.vop("v_exp_f32", r, r))
-                    out.append(isa.vop("v_add_f32", lsum[qb][j & 1], lsum[qb][j & 1], r))
+                    if not self.cfg.lsum:
+                        out.append(isa.vop("v_add_f32", lsum[qb][j & 1], lsum[qb][j & 1], r))
                 for i in range(4):
                     out.append(isa.vop("v_cvt_pk_bf16_f32", regs[i], regs[2 * i], regs[2 * i + 1]))
         n = len(out)
@@ -332,9 +342,10 @@ class Gen:
         out = []
         for kb in range(4):
             grp = []
+            T = TMPL if self.cfg.lsum else TMP16
             for qb in range(4):
                 s = Sb16(nxt, kb, qb)
-                acc = TMP16[qb]
+                acc = T[qb]
                 if kb == 0:
                     grp.append(isa.vop("v_max3_f32", acc, s.sub(0), s.sub(1), s.sub(2)))
                     grp.append(isa.vop("v_max_f32", acc, acc, s.sub(3)))
@@ -349,8 +360,9 @@ class Gen:
         if self.cfg.fold:
             # S' is already relative to the running maximum: any lane's partial maximum above thr triggers the (rare) subroutine,
             # which does the cross-lane part
-            fin = [isa.vop("v_max3_f32", TMP16[4], TMP16[0], TMP16[1], TMP16[2]), isa.vop("v_max_f32", TMP16[4], TMP16[4], TMP16[3]),
-                   isa.v_cmp("v_cmp_gt_f32", TMP16[4], S_THR)]
+            T = TMPL if self.cfg.lsum else TMP16
+            fin = [isa.vop("v_max3_f32", T[4], T[0], T[1], T[2]), isa.vop("v_max_f32", T[4], T[4], T[3]),
+                   isa.v_cmp("v_cmp_gt_f32", T[4], S_THR)]
             for k, ins in enumerate(fin):
                 ins.target_gap = t_fin + 0.5 * k
             return out + fin
@@ -496,8 +508,11 @@ class Gen:
         mx = max(rowmax, CLAMP);  S' -= mx, -M -= mx, and -- unless this is the first call of the kernel (O = l = 0, mx may be a huge
         negative number) -- l, O *= 2^-mx."""
         out = [isa.label(f"L_rescale{nxt}"), isa.nop(15), isa.nop(15)]
-        mx = [TMP16[qb] for qb in range(4)]
-        cp, al = TMP16[4], [TMP16[5 + qb] for qb in range(4)]
+        lsum = self.cfg.lsum
+        if lsum:      # the V^T fragments of the finished tile are dead at the call sites: v128.. serve as temporaries
+            mx, cp, al, t2 = [TMPL[qb] for qb in range(4)], V(128), [V(129 + qb) for qb in range(4)], V(133)
+        else:
+            mx, cp, al, t2 = [TMP16[qb] for qb in range(4)], TMP16[4], [TMP16[5 + qb] for qb in range(4)], TMP16[9]
         for qb in range(4):
             out += [isa.vop("v_mov_b32", cp, mx[qb]), isa.permlane32_swap(mx[qb], cp), isa.vop("v_max_f32", mx[qb], mx[qb], cp),
                     isa.vop("v_mov_b32", cp, mx[qb]), isa.permlane16_swap(mx[qb], cp), isa.vop("v_max_f32", mx[qb], mx[qb], cp),
@@ -513,13 +528,17 @@ class Gen:
         for qb in range(4):
             out += [isa.vop("v_exp_f32", al[qb], Neg(mx[qb]))]
         for qb in range(4):
-            for j in range(2):
-                out.append(isa.vop("v_mul_f32", L16F[qb][j], L16F[qb][j], al[qb]))
+            if lsum:
+                for j in range(4):
+                    out.append(isa.vop("v_mul_f32", LACC[qb].sub(j), LACC[qb].sub(j), al[qb]))
+            else:
+                for j in range(2):
+                    out.append(isa.vop("v_mul_f32", L16F[qb][j], L16F[qb][j], al[qb]))
         k = 0
         for db in range(8):
             for qb in range(4):
                 for r in range(4):
-                    t = [cp, TMP16[9]][k % 2]
+                    t = [cp, t2][k % 2]
                     k += 1
                     o = O16(db, qb).sub(r)
                     out += [isa.vop("v_accvgpr_read_b32", t, o), isa.vop("v_mul_f32", t, t, al[qb]),
@@ -617,14 +636,15 @@ class Gen:
             # K fragment addresses.  A-row r = ql of key block kb reads key  32 (kb >> 1) + 8 (kb & 1) + 16 (r >> 3) + (r & 7)  of the tile:
             # with this row order a lane's score registers of blocks 2 ks, 2 ks + 1 are exactly the 8 keys its P.V k-slots hold in the V^T
             # image of scail_transpose_v (key bits 2 <-> 3 swapped inside 16-key groups) -- no cross-lane movement between the two GEMMs.
-            # LDS row = key (256 B), 16-byte chunk (4 ks + g) ^ (key & 15);  parity = kb & 1, kb >> 1 goes into the immediate offset
+            # LDS row = key (256 B), 16-byte chunk (4 ks + g) ^ f(key) with f(key) = key bits 0-2 | key bit 4 << 3 -- for the keys of a
+            # fragment f = r, which makes the 16 lanes of every ds_read_b128 lane group hit 16 different 4-bank sets (with the 32x32
+            # kernel's f = key & 15 half of the K fragment reads were 2-way conflicts here);  parity = kb & 1, kb >> 1 -> immediate offset
             o += [isa.vop("v_and_b32", t[0], I32(7), ql), isa.vop("v_lshrrev_b32", t[1], I32(3), ql), isa.vop("v_lshl_add_u32", t[1], t[1], I32(4), t[0])]   # 16 (r >> 3) + (r & 7)
             for par in range(2):
                 o += [isa.vop("v_add_u32", t[2], I32(8 * par), t[1]),                    # key row inside the 32-key half
-                      isa.vop("v_add_u32", t[3], I32(8 * par), t[0]),                    # key & 15
                       isa.vop("v_lshlrev_b32", t[2], I32(8), t[2])]
                 for ks in range(4):
-                    o += [isa.vop("v_or_b32", t[4], I32(4 * ks), g), isa.vop("v_xor_b32", t[4], t[4], t[3]),
+                    o += [isa.vop("v_or_b32", t[4], I32(4 * ks), g), isa.vop("v_xor_b32", t[4], t[4], ql),
                           isa.vop("v_lshl_add_u32", KADDR16[ks][par], t[4], I32(4), t[2])]
             # V^T fragment addresses: row 16 db + ql (128 B), chunk (4 ks + g) ^ ((ql >> 1) & 7), in the V ring; db goes into the offset
             o += [isa.vop("v_lshrrev_b32", t[0], I32(1), ql), isa.vop("v_and_b32", t[0], I32(7), t[0]),
@@ -652,8 +672,13 @@ class Gen:
         o += [isa.vop("v_lshrrev_b32", t[0], I32(4), LANE), isa.vop("v_and_b32", t[1], I32(15), LANE),
               isa.vop("v_lshlrev_b32", t[3], I32(4), S_WAVE)]       # 16 w
         for i in range(4):
-            o += [isa.vop("v_add_u32", t[4], I32(4 * i), t[0]),                     # row & 15
-                  isa.vop("v_xor_b32", t[5], t[1], t[4]), isa.vop("v_add_u32", t[6], t[4], t[3]),
+            o += [isa.vop("v_add_u32", t[4], I32(4 * i), t[0])]                     # row & 15
+            if c.mi == 16:        # swizzle key f(row) = row bits 0-2 | row bit 4 << 3 (bit 4 of the tile row = wave & 1)
+                o += [isa.vop("v_and_b32", t[5], I32(7), t[4]), isa.sop("s_and_b32", ST[0], S_WAVE, I32(1)),
+                      isa.vop("v_lshl_or_b32", t[5], ST[0], I32(3), t[5]), isa.vop("v_xor_b32", t[5], t[1], t[5])]
+            else:
+                o += [isa.vop("v_xor_b32", t[5], t[1], t[4])]
+            o += [isa.vop("v_add_u32", t[6], t[4], t[3]),
                   isa.vop("v_mul_lo_u32", t[6], t[6], krsb), isa.vop("v_lshl_add_u32", t[6], t[5], I32(4), t[6]),
                   isa.vop("v_subrev_u32", KDMA[i], I32(1024 * i), t[6])]
         # V^T piece i: rows 32 w + 8 i + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)
@@ -695,6 +720,15 @@ class Gen:
                     for j in range(2):
                         o.append(isa.vop("v_mov_b32", L16F[qb][j], I32(0)))
                 o += [isa.sop("s_mov_b32", S_CLAMP, I32(0xFF800000)), isa.sop("s_mov_b32", S_FIRST, I32(1))]
+                if c.lsum:
+                    # row sums on the matrix pipe: A fragment = a row of ones in row 0 (lanes with lane % 16 == 0), zeros elsewhere
+                    for qb in range(4):
+                        for i in range(4):
+                            o.append(isa.vop("v_mov_b32", LACC[qb].sub(i), I32(0)))
+                    o += [isa.v_cmp("v_cmp_eq_u32", ql, I32(0)), isa.vop("v_mov_b32", ONES.sub(0), I32(0x3F803F80))]
+                    o += [isa.v_cndmask(ONES.sub(0), I32(0), ONES.sub(0))]
+                    for i in range(1, 4):
+                        o.append(isa.vop("v_mov_b32", ONES.sub(i), ONES.sub(0)))
             else:
                 for qb in range(4):
                     o += [isa.vop("v_mov_b32", M16[qb], F32(-1e30)), isa.vop("v_mul_f32", MC16[qb], M16[qb], S_C)]
@@ -793,22 +827,37 @@ class Gen:
             #      are dead here and serve as temporaries ----
             e = [isa.label("L_epilogue")]
             inv = [V(qb) for qb in range(4)]
+            row16, ooff16 = ROW16, OOFF16
+            if self.cfg.lsum:
+                # the row / offset registers were given to the row-sum accumulators: rebuild them (row = 256 qb_wg + 64 w + 16 qb + lane % 16)
+                row16, ooff16 = [V(16 + qb) for qb in range(4)], [V(20 + qb) for qb in range(4)]
+                ql, g, t3, orsb = V(24), V(25), V(26), ST[13]
+                e += [isa.sop("s_lshl_b32", orsb, S_ORS.sub(0), I32(1)), isa.sop("s_lshl_b32", ST[8], S_QB, I32(8)),
+                      isa.sop("s_lshl_b32", ST[7], S_WAVE, I32(6)), isa.sop("s_add_u32", ST[8], ST[8], ST[7]),
+                      isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
+                for qb in range(4):
+                    e += [isa.vop("v_add_u32", row16[qb], ST[8], ql)]
+                    if qb:
+                        e += [isa.vop("v_add_u32", row16[qb], I32(16 * qb), row16[qb])]
+                    e += [isa.vop("v_mul_lo_u32", t3, row16[qb], orsb), isa.vop("v_lshl_add_u32", ooff16[qb], g, I32(3), t3)]
             for qb in range(4):
                 a, b = V(4), V(5)
                 lsum = L16F if self.cfg.fold else L16
-                e += [isa.vop("v_add_f32", a, lsum[qb][0], lsum[qb][1]), isa.vop("v_mov_b32", b, a),
+                first = ([isa.vop("v_mov_b32", a, LACC[qb].sub(0))] if self.cfg.lsum        # lanes 0-15 hold the sums, the other rows of the block are 0
+                         else [isa.vop("v_add_f32", a, lsum[qb][0], lsum[qb][1])])
+                e += first + [isa.vop("v_mov_b32", b, a),
                       isa.permlane32_swap(a, b), isa.vop("v_add_f32", a, a, b), isa.vop("v_mov_b32", b, a),
                       isa.permlane16_swap(a, b), isa.vop("v_add_f32", a, a, b), isa.vop("v_rcp_f32", inv[qb], a)]
             for qb in range(4):
-                e += [isa.v_cmp("v_cmp_lt_u32", ROW16[qb], S_LQ), Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+                e += [isa.v_cmp("v_cmp_lt_u32", row16[qb], S_LQ), Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
                 for db in range(8):
-                    base = 8 + 6 * (db % 2)
+                    base = 32 + 6 * (db % 2)
                     f = [V(base + i) for i in range(4)]
                     w = V(base + 4, 2)
                     for i in range(4):
                         e += [isa.vop("v_accvgpr_read_b32", f[i], O16(db, qb).sub(i)), isa.vop("v_mul_f32", f[i], f[i], inv[qb])]
                     e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
-                          isa.global_store(2, OOFF16[qb], w, 32 * db, saddr=S_O, extra_reads=[EXEC])]
+                          isa.global_store(2, ooff16[qb], w, 32 * db, saddr=S_O, extra_reads=[EXEC])]
                 e += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
             e += [isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
             return o + sched.pad_hazards(e)
@@ -936,7 +985,7 @@ DEFAULT = Cfg(rd=4, cap=5, name="scail_attn4")
 
 # the two shipped kernels: DEFAULT (any scale, 32x32x16 MFMAs) and M16F (q pre-multiplied by scale * log2 e, 16x16x32 MFMAs, running
 # maximum folded into the accumulator init; scail_flash_attn_bf16 with scale == 0)
-M16F = Cfg(name="scail_attn4_m16f", mi=16, fold=True, cap=2, lookahead=2.0)
+M16F = Cfg(name="scail_attn4_m16f", mi=16, fold=True, lsum=True, cap=1, sm_end=44.0, lookahead=2.0)
 SHIPPED = [DEFAULT, M16F]
 
 
@@ -965,8 +1014,30 @@ def variant_cfgs():
     out.append(Cfg(name="scail_attn4_m16c2la2", cap=2, mi=16, lookahead=2.0))
     for abl in ("dma", "lds", "valu", "dma,lds,valu"):
         out.append(Cfg(name="scail_attn4_m16_abl_" + abl.replace(",", "_"), abl=abl, mi=16, cap=2))
+    F = dict(mi=16, fold=True, cap=2, lookahead=2.0)
+    out.append(Cfg(name="scail_attn4_m16g", lsum=True, **F))
+    out.append(Cfg(name="scail_attn4_m16g_sm44", lsum=True, sm_end=44.0, **F))
+    out.append(Cfg(name="scail_attn4_m16g_sm36", lsum=True, sm_end=36.0, **F))
+    out.append(Cfg(name="scail_attn4_m16g_c1", lsum=True, **{**F, "cap": 1}))
+    G1 = dict(mi=16, fold=True, lsum=True, cap=1)
+    out.append(Cfg(name="scail_attn4_m16g_c1sm44", sm_end=44.0, lookahead=2.0, **G1))
+    out.append(Cfg(name="scail_attn4_m16g_c1sm60", sm_end=60.0, lookahead=2.0, **G1))
+    out.append(Cfg(name="scail_attn4_m16g_c1la1", lookahead=1.0, **G1))
+    out.append(Cfg(name="scail_attn4_m16g_c1la4", lookahead=4.0, **G1))
+    out.append(Cfg(name="scail_attn4_m16g_c1dmamid", dma_k_at=26.0, dma_v_at=42.0, dma_step=4.0, lookahead=2.0, **G1))
+    out.append(Cfg(name="scail_attn4_m16g_c1dmaspread", dma_k_at=2.0, dma_v_at=34.0, dma_step=8.0, lookahead=2.0, **G1))
+    out.append(Cfg(name="scail_attn4_m16f_c1", mi=16, fold=True, cap=1, lookahead=2.0))
+    out.append(Cfg(name="scail_attn4_m16f_nolsum", mi=16, fold=True, cap=2, lookahead=2.0))      # round-2 first fold version (row sums on the VALU)
     out.append(Cfg(name="scail_attn4_m16f_c3", mi=16, fold=True, cap=3))
-    out.append(Cfg(name="scail_attn4_m16f_sm44", mi=16, fold=True, cap=2, lookahead=2.0, sm_end=44.0))
+    out.append(Cfg(name="scail_attn4_m16f_c3la2", mi=16, fold=True, cap=3, lookahead=2.0))
+    out.append(Cfg(name="scail_attn4_m16f_la1", mi=16, fold=True, cap=2, lookahead=1.0))
+    out.append(Cfg(name="scail_attn4_m16f_la4", mi=16, fold=True, cap=2, lookahead=4.0))
+    for sm in (40.0, 44.0, 48.0, 60.0):
+        out.append(Cfg(name=f"scail_attn4_m16f_sm{int(sm)}", sm_end=sm, **F))
+    out.append(Cfg(name="scail_attn4_m16f_dmaspread", dma_k_at=2.0, dma_v_at=34.0, dma_step=8.0, **F))
+    out.append(Cfg(name="scail_attn4_m16f_dmamid", dma_k_at=26.0, dma_v_at=42.0, dma_step=4.0, **F))
+    for abl in ("dma", "lds", "valu", "max", "bar", "dma,lds,valu"):
+        out.append(Cfg(name="scail_attn4_m16f_abl_" + abl.replace(",", "_"), abl=abl, **F))
     out.append(Cfg(name="scail_attn4_m16_abl_fma", abl="fma", mi=16, cap=2, lookahead=2.0))
     out.append(Cfg(name="scail_attn4_m16_abl_fma_c3", abl="fma", mi=16, cap=3))
     out.append(Cfg(name="scail_attn4_m16_abl_fma_sm44", abl="fma", mi=16, cap=2, sm_end=44.0, lookahead=2.0))

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--variants", default=",dmamid,sm48")
     ap.add_argument("--ablations", default="abl_fma,abl_fma_c4,abl_fma_sm44")
     ap.add_argument("--skip-check", action="store_true")
+    ap.add_argument("--prescaled", action="store_true", help="hand q over in log2 units (scale == 0 path: the fold variants need it)")
     ap.add_argument("--full", action="store_true", help="also time the 40-head launch of the best variant")
     a = ap.parse_args()
     lib.load()
@@ -71,8 +72,13 @@ def main():
             vts = torch.stack([ops.transpose_v(vs[s], H) for s in range(nseg)])
             rows = torch.arange(Lq, device=DEV)
             kcat, vcat = torch.cat(list(ks), 1), torch.cat(list(vs), 1)
-            ref = ref_rows(q, kcat, vcat, rows, range(H))
             kw = dict(n_seg=nseg, k_seg_stride=ks.stride(0), vt_seg_stride=vts.stride(0))
+            if a.prescaled:
+                q = (q.float() * ops.ATTN_LOG2_SCALE).to(torch.bfloat16)
+                ref = ref_rows(q.float() / ops.ATTN_LOG2_SCALE, kcat, vcat, rows, range(H))
+                kw["q_prescaled"] = True
+            else:
+                ref = ref_rows(q, kcat, vcat, rows, range(H))
             lib.tune_set("attn4", 0)
             o_old = ops.flash_attn(q, ks[0], vts[0], **kw)
             e_old = check("old", o_old, ref, rows)
@@ -96,9 +102,16 @@ def main():
     out = torch.empty(2, a.L, D, device=DEV, dtype=torch.bfloat16)
     fl = 4.0 * a.L * a.L * 128 * a.heads * 2
     rows = torch.cat([torch.arange(0, 64), torch.arange(a.L - 64, a.L), torch.randint(0, a.L, (64,))]).to(DEV)
-    ref = ref_rows(q, k, v, rows, (0, a.heads - 1))
+    akw = {}
+    if a.prescaled:
+        qs = (q.float() * ops.ATTN_LOG2_SCALE).to(torch.bfloat16)
+        ref = ref_rows((qs.float() / ops.ATTN_LOG2_SCALE), k, v, rows, (0, a.heads - 1))
+        q = qs
+        akw = dict(q_prescaled=True)
+    else:
+        ref = ref_rows(q, k, v, rows, (0, a.heads - 1))
     lib.tune_set("attn4", 0)
-    med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), a.iters)
+    med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out, **akw), a.iters)
     print(json.dumps({"kernel": "8-wave swp (round 1)", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9,
                       "max_err": check("old", out, ref, rows)}), flush=True)
     lib.tune_set("attn4", 1)
@@ -106,7 +119,7 @@ def main():
     for var in variants + [x for x in a.ablations.split(",") if x]:
         setk(var)
         out.zero_()
-        med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), a.iters)
+        med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out, **akw), a.iters)
         err = check("new", out, ref, rows)
         results.append((med, var))
         print(json.dumps({"kernel": f"attn4 variant {var}", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9, "max_err": err}), flush=True)
