@@ -74,6 +74,10 @@ class Cfg:
     b1_at: float = 9.5     # dma2: gap of the barrier that releases the slot (after the reads of k-steps 2, 3)
     b2_at: float = 31.5    # dma2: gap of the barrier that publishes tile t+1
     rd2_step: float = 0.5  # dma2: spacing of the 16 fragment reads of a half tile
+    wpacked: bool = False  # EXPERIMENT (measured: no gain, 1425 vs 1435 TFLOP/s): W arrives TILE-MAJOR (pack_w below): block (n tile,
+                           # k tile) = the 32 KB LDS image of that tile, so each LDS-DMA piece of W reads 1 KB of contiguous memory.  The
+                           # "wpack" / "xpack" TIMING ablations that suggested +6 % re-read the same 32 KB every k-tile: they measure L2
+                           # hits, not contiguity.  Kept as an emulator-tested variant of the measurement build only
     nt_store: bool = False # epilogue stores with the non-temporal hint (y is written once and read by a later kernel)
     mi: int = 32           # MFMA shape: 32 = v_mfma_f32_32x32x16_bf16 (64 per tile), 16 = v_mfma_f32_16x16x32_bf16 (128 per tile; dma2 only)
     dma_from: float = 48.0  # first gap of the 16 LDS-DMA pieces / LDS writes of tile t+2 (after the barrier at 47.5)
@@ -127,6 +131,7 @@ S_M0T, S_N0T = S(51), S(52)                  # tile origin (rows / columns)
 S_XLDS, S_WLDS = S(53), S(54)                # LDS byte offset of this wave's DMA region inside a slot
 ST = [S(56 + i) for i in range(16)]          # s56..s71 temporaries
 S_SAVE = S(72, 2)
+S_WOFF, S_WMAX = S(74), S(75)                # wpacked: byte offset of the current k-tile block inside the packed W panel, its last value
 
 
 class Gen:
@@ -161,15 +166,19 @@ class Gen:
         """16 LDS-DMA pieces of this wave (8 x rows, 8 W rows: 64 rows of each operand tile) for the k-tile at S_KOFF."""
         out = []
         k = 0
-        for lds, offs, rsrc in ((S_XLDS, XDMA, S_XRSRC), (S_WLDS, WDMA, S_WRSRC)):
+        wp = self.cfg.wpacked
+        for lds, offs, rsrc, koff in ((S_XLDS, XDMA, S_XRSRC, S_KOFF), (S_WLDS, WDMA, S_WRSRC, S_WOFF if wp else S_KOFF)):
             for half in range(2):
                 out.append(isa.sop("s_add_u32", M0, lds, I32(slot * 65536 + half * 4096), target_gap=t0 + step * k - 0.5))
                 for i in range(4):
-                    out.append(isa.buffer_load_lds(offs[half * 4 + i], rsrc, S_KOFF, 1024 * i, target_gap=t0 + step * k, tag="dma"))
+                    out.append(isa.buffer_load_lds(offs[half * 4 + i], rsrc, koff, 1024 * i, target_gap=t0 + step * k, tag="dma"))
                     k += 1
         if advance:
             out.append(isa.sop("s_add_u32", S_KOFF, S_KOFF, I32(128), target_gap=t0 + step * k))
             out.append(isa.sop("s_min_u32", S_KOFF, S_KOFF, S_KMAX, target_gap=t0 + step * k + 0.1))
+            if wp:
+                out.append(isa.sop("s_add_u32", S_WOFF, S_WOFF, I32(32768), target_gap=t0 + step * k + 0.2))
+                out.append(isa.sop("s_min_u32", S_WOFF, S_WOFF, S_WMAX, target_gap=t0 + step * k + 0.3))
         return out
 
     def load_tile(self, q: int, t0: float, step: float) -> List[Instr]:
@@ -364,6 +373,7 @@ class Gen:
         o += [isa.sop("s_lshl_b32", ldab, S_LDA.sub(0), I32(1)), isa.sop("s_lshl_b32", kb2, S_K, I32(1)),
               isa.sop("s_lshr_b32", S_KT, S_K, I32(6)), isa.sop("s_sub_u32", ST[8], S_KT, I32(1)), isa.sop("s_lshl_b32", S_KMAX, ST[8], I32(7)),
               isa.sop("s_mov_b32", S_KOFF, I32(0)), isa.sop("s_mov_b32", S_T, I32(0)),
+              isa.sop("s_mov_b32", S_WOFF, I32(0)), isa.sop("s_lshl_b32", S_WMAX, ST[8], I32(15)),          # (KT - 1) * 32 KB
               isa.sop("s_lshl_b32", S_XLDS, S_WAVE, I32(13)), isa.sop("s_add_u32", S_WLDS, S_XLDS, I32(32768))]
         ql, g, t = T_[1], T_[2], T_
         if c.mi == 16:
@@ -398,6 +408,17 @@ class Gen:
                   isa.vop("v_lshl_add_u32", t[8], t[7], I32(4), t[8]), isa.vop("v_subrev_u32", XDMA[i], I32(1024 * (i & 3) if dma else 0), t[8]),
                   isa.vop("v_mul_lo_u32", t[9], t[6], kb2), isa.vop("v_lshl_add_u32", t[9], t[7], I32(4), t[9]),
                   isa.vop("v_subrev_u32", WDMA[i], I32(1024 * (i & 3) if dma else 0), t[9])]
+            # TIMING ABLATIONS "wpack" / "xpack": every LDS-DMA piece reads 1 KB of CONTIGUOUS memory, as a tile-major pre-packed
+            # operand would allow (wrong results: the addresses are not the operand's)
+            if c.wpacked:
+                # packed W: piece i of this wave = bytes [(8 wave + i) KB, +1 KB) of the tile's 32 KB block, lane-linear (the block is the
+                # LDS image: the source swizzle was applied by scail_gemm_pack_w)
+                o += [isa.vop("v_lshlrev_b32", t[8], I32(13), S_WAVE), isa.vop("v_lshl_add_u32", t[8], LANE, I32(4), t[8]),
+                      isa.vop("v_add_u32", WDMA[i], I32(1024 * i - (1024 * (i & 3) if dma else 0)), t[8])]
+            for tag, reg in (("wpack", WDMA[i]), ("xpack", XDMA[i])):
+                if tag in c.abl.split(","):
+                    o += [isa.vop("v_lshlrev_b32", t[8], I32(13), S_WAVE), isa.vop("v_lshl_add_u32", t[8], LANE, I32(4), t[8]),
+                          isa.vop("v_add_u32", reg, I32(1024 * i - (1024 * (i & 3) if dma else 0)), t[8])]
         if not dma:
             # LDS write address of the lane inside a piece: (lane >> 3) * 128 + ((lane & 7) ^ (4 * parity + (lane >> 4))) * 16
             o += [isa.vop("v_lshrrev_b32", t[6], I32(4), LANE), isa.vop("v_lshlrev_b32", t[7], I32(7), t[3]),
@@ -684,6 +705,24 @@ SHIPPED = dict(stage="dma2", mi=16, cap=1, rd2_step=0.25, b1_at=5.5, dma_step=1.
 DEFAULTS = [Cfg(epi=e, name=f"scail_gemm4_e{e}", **SHIPPED) for e in (0, 1, 3, 4)]
 
 
+def pack_w(w_bits, N: int, K: int):
+    """the tile-major weight layout of the ``wpacked`` experiment (test infrastructure for the emulator): (N, K) uint16 -> packed.
+    Block (n tile, k tile) = 32 pieces x 64 lanes x 8 elements; lane l of piece p holds row 8 p + (l >> 3) of the tile, source
+    chunk (l & 7) ^ ((row >> 1) & 7) -- the LDS image the kernels' fragment reads expect."""
+    import numpy as np
+    tn, tk = N // 256, K // 64
+    w4 = w_bits.reshape(tn, 256, tk, 64)                                  # [n tile][row][k tile][k]
+    out = np.zeros((tn, tk, 32, 64, 8), dtype=w_bits.dtype)
+    lane = np.arange(64)
+    for p in range(32):
+        row = 8 * p + (lane >> 3)
+        ch = (lane & 7) ^ ((row >> 1) & 7)
+        cols = ch[:, None] * 8 + np.arange(8)[None, :]
+        blk = w4[:, row[:, None], :, cols]                                # advanced indices first: (64, 8, tn, tk)
+        out[:, :, p] = np.transpose(blk, (2, 3, 0, 1))
+    return out.reshape(-1)
+
+
 def variant_cfgs():
     out = [Cfg(epi=e, name=f"scail_gemm4_e{e}_reg") for e in (0, 1, 3, 4)]       # round-2 first version: register staging, 32x32x16
     for cap in (2, 4):
@@ -703,6 +742,10 @@ def variant_cfgs():
     out.append(Cfg(**M16, dma_step=1.25, name="scail_gemm4_e0_mi16_d125"))
     out.append(Cfg(**M16, rd2_step=0.25, b1_at=5.5, dma_step=1.4, name="scail_gemm4_e0_mi16_early"))
     out.append(Cfg(**M16, dma_step=1.5, name="scail_gemm4_e0_mi16_d15"))
+    out.append(Cfg(epi=0, name="scail_gemm4p_e0", wpacked=True, **SHIPPED))
+    out.append(Cfg(epi=3, name="scail_gemm4p_e3", wpacked=True, **SHIPPED))
+    for abl in ("wpack", "xpack", "wpack,xpack"):
+        out.append(Cfg(epi=0, abl=abl, name="scail_gemm4_e0_abl_" + abl.replace(",", "_"), **SHIPPED))
     out.append(Cfg(**M16, rd2_step=0.25, b1_at=5.5, dma_step=1.75, name="scail_gemm4_e0_mi16_early175"))
     out.append(Cfg(**M16, rd2_step=0.25, b1_at=5.5, dma_step=1.9, name="scail_gemm4_e0_mi16_early19"))
     out.append(Cfg(**M16, rd2_step=0.25, b1_at=4.5, dma_step=1.85, name="scail_gemm4_e0_mi16_early185"))

@@ -31,6 +31,8 @@ def _variant(name):
                                         ("scail_gemm4_e1", (256, 256, 128)),              # + GELU-tanh
                                         ("scail_gemm4_e3", (264, 256, 320)),              # gate * (acc + bias) + residual, odd tile count
                                         ("scail_gemm4_e4", (520, 512, 128)),              # residual, two m-tiles and n-tiles + ragged third
+                                        ("scail_gemm4p_e0", (300, 512, 192)),             # measurement build: tile-major packed W experiment, 2 n-tiles
+                                        ("scail_gemm4p_e3", (264, 256, 448)),             # ... 7 k-tiles
                                         ("scail_gemm4_e0_reg", (300, 256, 192)),          # measurement build: register staging, 32x32x16
                                         ("scail_gemm4_e0_dma2", (300, 256, 320)),         # ... LDS-DMA two tiles deep, 32x32x16
                                         ("scail_gemm4_e0_spread", (256, 256, 256))])

@@ -29,7 +29,8 @@ def run(cfg: gemm4.Cfg, x, w, bias=None, resid=None, gate=None, rows_per_batch=0
     xs = np.zeros((M, lda), dtype=np.uint16)
     xs[:, :K] = to_bf16_bits(x)
     px = mem.alloc("x", xs)
-    pw = mem.alloc("w", to_bf16_bits(w))
+    wb = to_bf16_bits(w)
+    pw = mem.alloc("w", gemm4.pack_w(wb, N, K) if getattr(cfg, "wpacked", False) else wb)
     pb = mem.alloc("bias", bias.astype(np.float32)) if bias is not None else 0
     py = mem.alloc("y", np.zeros((M, N), dtype=np.uint16))
     pr = mem.alloc("resid", to_bf16_bits(resid)) if resid is not None else 0
