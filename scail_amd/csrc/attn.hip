@@ -854,6 +854,14 @@ static int attn4_function(const std::string& name, hipFunction_t* fn) {
     return 0;
 }
 
+// load the embedded code object and resolve the shipped kernels now (scail_dit_create calls this: a first launch inside
+// hipStreamBeginCapture must not have to load a module)
+int scail_attn4_preload() {
+    hipFunction_t fn;
+    if (int rc = attn4_function("scail_attn4", &fn)) return rc;
+    return attn4_function("scail_attn4_m16f", &fn);
+}
+
 static bool attn4_eligible(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate) {
     const int64_t lim = (1ll << 30);     // elements -> 2^31 bytes
     return Lk % 64 == 0 && Lk >= 512 && accumulate == 0 && Lq * q_rs < lim && Lk * k_rs < lim && Lq * o_rs < lim && 128 * Lk < lim;

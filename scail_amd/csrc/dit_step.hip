@@ -6,6 +6,8 @@
 #include <vector>
 
 #include "common.h"
+int scail_attn4_preload();   // attn.hip
+int scail_gemm4_preload();   // gemm.hip
 #include "../../include/scail_dit.h"
 
 struct scail_dit {
@@ -151,6 +153,10 @@ extern "C" int scail_dit_create(const scail_dit_config* cfg, const scail_dit_wei
     scail_dit* h = new scail_dit;
     h->cfg = *cfg;
     h->w = *w;
+    // the generated kernels live in embedded code objects loaded on first use: do it here, not inside a stream capture of the first
+    // step (the per-shape tile-order table of the GEMM is still allocated by the first launch of a shape: warm up once before capturing)
+    if (int rc = scail_attn4_preload()) { delete h; return rc; }
+    if (int rc = scail_gemm4_preload()) { delete h; return rc; }
     h->layers.assign(w->layers, w->layers + cfg->num_layers);
     h->w.layers = h->layers.data();
     *out = h;

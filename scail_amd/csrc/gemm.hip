@@ -665,6 +665,14 @@ extern "C" int scail_gemm_kernel_for(int64_t lda, int64_t ldc, int64_t ldr, int6
     return (g_gemm4_mode && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) ? g_gemm4_mode : 0;
 }
 
+// load the embedded code object and resolve the four shipped kernels now (see scail_attn4_preload)
+int scail_gemm4_preload() {
+    hipFunction_t fn;
+    for (int e : {0, 1, 3, 4})
+        if (int rc = gemm4_function("scail_gemm4_e" + std::to_string(e), &fn)) return rc;
+    return 0;
+}
+
 // runtime option of the product library (scail_set_option "gemm4"): 1 = generated kernels where eligible, 0 = csrc/gemm.hip only
 int scail_gemm4_enable(int on) { g_gemm4_mode = on ? 4 : 0; return 0; }
 
