@@ -317,7 +317,7 @@ def main():
         strides = (3 * Dm, Dm, Dm)
     else:
         strides = (3 * Dm, 3 * Dm, Dm)
-    which = lib.load().scail_flash_attn_kernel_for(*strides, attn_Lq, L, 0)
+    which = lib.load().scail_flash_attn_kernel_for(*strides, attn_Lq, L, 0, 1)
     ksrc = "attn4.s" if which == 4 else "attn.hip"
     kname = ("scail_attn4_m16f (hand-scheduled 4-wave flash attention, 16x16x32 MFMAs, queries in log2 units; csrc/attn4.s)"
              if which == 4 else "flash_attn_swp_kernel<4, 4, 0, 1>")

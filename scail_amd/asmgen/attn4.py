@@ -80,6 +80,9 @@ class Cfg:
     max_chains: int = 1    # independent partial-maximum chains per row block in the row max
     abl: str = ""          # TIMING ABLATIONS (wrong results; ablation build only): "dma" / "lds" / "valu" / "bar" / "max" removed
     mi: int = 32           # MFMA shape: 32 = v_mfma_f32_32x32x16_bf16 (64 per tile), 16 = v_mfma_f32_16x16x32_bf16 (128 per tile)
+    ragged: bool = False   # (mi = 16) any key count: the last tile of a segment may hold 1..64 valid keys.  Its out-of-range K rows are
+                           # fetched from 64 rows earlier (in bounds), their scores are set to -FLT_MAX before the row maximum; both only in
+                           # the remainder iterations of a segment (the hot loop never touches the last tile)
     lsum: bool = False     # (fold) row sums on the matrix pipe: a 9th "d block" whose V^T fragment is a constant row of ones accumulates
                            # sum_k P[k][q] beside O (8 extra MFMAs per tile replace 64 v_add_f32)
     fold: bool = False     # (mi = 16) q arrives multiplied by scale * log2(e): the running maximum is folded into the accumulator
@@ -133,7 +136,9 @@ L16F = [[V(228 + qb * 2 + j) for j in range(2)] for qb in range(4)]
 LACC = [V(228, 4), V(232, 4), V(236, 4), V(240, 4)]           # = L16F + OOFF16 + ROW16 (recomputed in the epilogue)
 ONES = V(248, 4)
 TMPL = [V(244 + i) for i in range(4)] + [V(202), V(203)]      # the 6 temporaries left inside the loop
-S_CLAMP, S_FIRST = S(87), S(88)       # rescale subroutine: lower bound of the maximum step (0, -inf at the very first tile), first-call flag
+S_CLAMP, S_FIRST = S(87), S(88)
+S_TAILREL = [S(89 + i) for i in range(4)]     # ragged: valid keys of the last tile - first tile row of this wave's K piece i
+S_TAIL = S(93)       # rescale subroutine: lower bound of the maximum step (0, -inf at the very first tile), first-call flag
 
 KADDR = [V(192 + i) for i in range(8)]
 VADDR = [V(200 + i) for i in range(4)]
@@ -387,6 +392,28 @@ class Gen:
             ins.target_gap = t_fin + 0.5 * k
         return out + fin
 
+    def mask_scores16(self, nxt: int, tile_ahead: int, t_kb) -> List[Instr]:
+        """ragged: scores of keys >= the valid count of tile S_T + tile_ahead are set to -FLT_MAX (exp2 -> 0, ignored by the row
+        maximum).  Key of register e of block kb in lane group g: 32 (kb >> 1) + 8 (kb & 1) + e + G, G = 16 (g >> 1) + 4 (g & 1).
+        VT1 holds -FLT_MAX (a literal beside VCC would exceed the constant-bus limit of v_cndmask_b32)."""
+        valid, lim = ST[1], ST[2]
+        G, g = TMPL[5], VT2
+        t0 = t_kb[0] - 3.0
+        out = [isa.sop("s_add_u32", valid, S_T, I32(tile_ahead), target_gap=t0),
+               isa.sop("s_lshl_b32", valid, valid, I32(6), target_gap=t0 + 0.1),
+               isa.sop("s_sub_u32", valid, S_LK, valid, target_gap=t0 + 0.2),
+               isa.vop("v_and_b32", G, I32(1), g, target_gap=t0 + 0.3), isa.vop("v_lshlrev_b32", G, I32(2), G, target_gap=t0 + 0.4),
+               isa.vop("v_lshrrev_b32", VT0, I32(1), g, target_gap=t0 + 0.5), isa.vop("v_lshl_add_u32", G, VT0, I32(4), G, target_gap=t0 + 0.6)]
+        for kb in range(4):
+            for e in range(4):
+                tg = t_kb[kb] - 1.5 + 0.3 * e
+                out += [isa.sop("s_sub_u32", lim, valid, I32(32 * (kb >> 1) + 8 * (kb & 1) + e), target_gap=tg),
+                        isa.v_cmp("v_cmp_gt_i32", lim, G, target_gap=tg + 0.05)]                        # vcc = key is valid
+                for qb in range(4):
+                    r = Sb16(nxt, kb, qb).sub(e)
+                    out.append(isa.v_cndmask(r, VT1, r, target_gap=tg + 0.1))
+        return out
+
     def v_frag_reads16(self, slot: int, t0: float, step: float) -> List[Instr]:
         out = []
         k = 0
@@ -423,11 +450,26 @@ class Gen:
                 k += 1
         return out
 
-    def dma_tile(self, which: str, slot: int, t0: float, step: float) -> List[Instr]:
-        """4 LDS-DMA pieces of this wave for one K or V^T tile, then advance (and clamp) the stream offset."""
+    def dma_tile(self, which: str, slot: int, t0: float, step: float, careful: bool = False) -> List[Instr]:
+        """4 LDS-DMA pieces of this wave for one K or V^T tile, then advance (and clamp) the stream offset.
+        careful (ragged K tiles): if this is the segment's last tile, lanes whose tile row lies beyond the valid keys read the row
+        64 rows earlier (in bounds; the scores of those keys are masked)."""
         lds, offs, rsrc, off, stp, mx = ((S_KLDS, KDMA, S_KRSRC, S_KOFF, S_KSTEP, S_KMAX) if which == "k" else
                                          (S_VLDS, VDMA, S_VRSRC, S_VOFF, S_VSTEP, S_VMAX))
         out = [isa.sop("s_add_u32", M0, lds, I32(slot * 16384), target_gap=t0 - 0.6)]
+        if careful and which == "k":
+            tmp, g, lim = VT0, VT2, ST[4]
+            out.append(isa.sop("s_cmp_eq_u32", None, off, mx, target_gap=t0 - 0.5))
+            for i in range(4):
+                tg = t0 + step * i
+                out += [isa.sop("s_cselect_b32", lim, S_TAILREL[i], I32(64), target_gap=tg - 0.4),
+                        isa.v_cmp("v_cmp_le_i32", lim, g, target_gap=tg - 0.3),                      # vcc = row beyond the valid keys
+                        isa.vop("v_subrev_u32", tmp, stp, offs[i], target_gap=tg - 0.2),              # offset of the row 64 rows earlier
+                        isa.v_cndmask(tmp, offs[i], tmp, target_gap=tg - 0.1),
+                        isa.buffer_load_lds(tmp, rsrc, off, 1024 * i, target_gap=tg, tag="dma")]
+            out.append(isa.sop("s_add_u32", off, off, stp, target_gap=t0 + step * 3 + 0.3))
+            out.append(isa.sop("s_min_u32", off, off, mx, target_gap=t0 + step * 3 + 0.6))
+            return out
         for i in range(4):
             out.append(isa.buffer_load_lds(offs[i], rsrc, off, 1024 * i, target_gap=t0 + step * i, tag="dma"))
         out.append(isa.sop("s_add_u32", off, off, stp, target_gap=t0 + step * 3 + 0.3))
@@ -435,7 +477,7 @@ class Gen:
         return out
 
     # ---------------------------------------------------------------------------------------------
-    def iter_block(self, p: int, tail: bool) -> List[Instr]:
+    def iter_block(self, p: int, tail: bool, careful: bool = False) -> List[Instr]:
         """One pipelined tile iteration at unroll position p (tile t = p mod unroll), scheduled.  Gap numbers below are in units
         of 32 matrix-pipe cycles; mi = 16 has two MFMA gaps per unit (gs = 2)."""
         c = self.cfg
@@ -445,13 +487,16 @@ class Gen:
         gs = 2.0 if m16 else 1.0
         blk: List[Instr] = []
         abl = c.abl.split(",")
+        careful = careful and c.ragged
         if not tail and "dma" not in abl:
-            blk += self.dma_tile("k", (p + c.pk) % rd, c.dma_k_at * gs, c.dma_step * gs)
+            blk += self.dma_tile("k", (p + c.pk) % rd, c.dma_k_at * gs, c.dma_step * gs, careful=careful)
             blk += self.dma_tile("v", (p + c.pv) % rd, c.dma_v_at * gs, c.dma_step * gs)
         if "lds" not in abl:
             blk += (self.v_frag_reads16 if m16 else self.v_frag_reads)(p % rd, (2.0 if not tail else 0.0) * gs, (1.5 if not tail else 1.0) * gs)
         if not tail:
             blk += self.qk_mfmas16(nxt) if m16 else self.qk_mfmas(nxt)
+            if careful:
+                blk += self.mask_scores16(nxt, 1, (20.0, 36.0, 52.0, 68.0))
         if "valu" not in abl:
             blk += (self.softmax_finish16 if m16 else self.softmax_finish)(cur, 0.0, (c.sm_end if not tail else 20.0) * gs)
         blk += self.pv_mfmas16(cur) if m16 else self.pv_mfmas(cur)
@@ -720,6 +765,13 @@ class Gen:
                     for j in range(2):
                         o.append(isa.vop("v_mov_b32", L16F[qb][j], I32(0)))
                 o += [isa.sop("s_mov_b32", S_CLAMP, I32(0xFF800000)), isa.sop("s_mov_b32", S_FIRST, I32(1))]
+                if c.ragged:
+                    # valid keys of a segment's last tile (1..64), relative to the first tile row of this wave's K piece i; lane term of
+                    # the key index of a score register (mask_scores16) in VT1 -- ql is not needed past this point
+                    o += [isa.sop("s_lshr_b32", ST[0], S_LKP, I32(6)), isa.sop("s_sub_u32", ST[0], ST[0], I32(1)), isa.sop("s_lshl_b32", ST[0], ST[0], I32(6)),
+                          isa.sop("s_sub_u32", S_TAIL, S_LK, ST[0]), isa.sop("s_lshl_b32", ST[1], S_WAVE, I32(4)), isa.sop("s_sub_u32", ST[1], S_TAIL, ST[1])]
+                    for i in range(4):
+                        o.append(isa.sop("s_sub_u32", S_TAILREL[i], ST[1], I32(4 * i)))
                 if c.lsum:
                     # row sums on the matrix pipe: A fragment = a row of ones in row 0 (lanes with lane % 16 == 0), zeros elsewhere
                     for qb in range(4):
@@ -729,6 +781,9 @@ class Gen:
                     o += [isa.v_cndmask(ONES.sub(0), I32(0), ONES.sub(0))]
                     for i in range(1, 4):
                         o.append(isa.vop("v_mov_b32", ONES.sub(i), ONES.sub(0)))
+                if c.ragged:
+                    assert c.lsum, "ragged reuses VT0 / VT1, which only the lsum epilogue leaves free"
+                    o.append(isa.vop("v_mov_b32", VT1, F32(-3.0e38)))             # the masked score (ql is not needed past this point)
             else:
                 for qb in range(4):
                     o += [isa.vop("v_mov_b32", M16[qb], F32(-1e30)), isa.vop("v_mul_f32", MC16[qb], M16[qb], S_C)]
@@ -766,7 +821,7 @@ class Gen:
         o: List[Instr] = [isa.label("L_seg_start"), isa.sop("s_mov_b32", S_KOFF, I32(0)), isa.sop("s_mov_b32", S_VOFF, I32(0)),
                           isa.sop("s_mov_b32", S_T, I32(0))]
         for j in range(c.rd):
-            o += self.dma_tile("k", j % c.rd, 0, 0)
+            o += self.dma_tile("k", j % c.rd, 0, 0, careful=c.ragged)
         for j in range(c.pv):
             o += self.dma_tile("v", j % c.rd, 0, 0)
         m16 = c.mi == 16
@@ -774,8 +829,10 @@ class Gen:
         o += [isa.waitcnt(vmcnt=0), isa.barrier()]
         o += kfr(0, 0, 0)
         o += [isa.waitcnt(lgkmcnt=0), isa.barrier()]
-        o += self.dma_tile("k", c.rd % c.rd, 0, 0)                 # K(rd) into slot 0, whose fragments are in registers now
+        o += self.dma_tile("k", c.rd % c.rd, 0, 0, careful=c.ragged)   # K(rd) into slot 0, whose fragments are in registers now
         o += self.qk_mfmas16(0) if m16 else self.qk_mfmas(0)
+        if c.ragged:
+            o += [isa.nop(15)] + self.mask_scores16(0, 0, (0, 0, 0, 0))
         o += kfr(1 % c.rd, 0, 0)
         o += [isa.nop(15)]
         o += self.rowmax16(0, (0, 0, 0, 0), 0) if m16 else self.rowmax(0, 0, 0, 0)
@@ -795,7 +852,8 @@ class Gen:
         o: List[Instr] = []
         r = ST[0]
         # dispatch: R = T - t remaining tiles (t multiple of U);  R >= U + 2 -> U full iterations in the hot loop
-        o += [isa.label("L_dispatch"), isa.sop("s_sub_u32", r, S_NT, S_T), isa.sop("s_cmp_ge_u32", None, r, I32(U + 2)),
+        # (ragged: R >= U + pk + 1, so that neither a K DMA nor a QK^T of the hot loop touches the segment's last tile)
+        o += [isa.label("L_dispatch"), isa.sop("s_sub_u32", r, S_NT, S_T), isa.sop("s_cmp_ge_u32", None, r, I32(U + c.pk + 1 if c.ragged else U + 2)),
               isa.branch("s_cbranch_scc0", "L_rem0")]
         o += [isa.label("L_hot")]
         for p in range(U):
@@ -805,9 +863,9 @@ class Gen:
         for p in range(U):
             o += [isa.label(f"L_rem{p}"), isa.sop("s_sub_u32", r, S_NT, S_T), isa.sop("s_cmp_eq_u32", None, r, I32(1)),
                   isa.branch("s_cbranch_scc1", f"L_tail{p}")]
-            o += self.iter_block(p, tail=False) + self.iter_end(p, "rem")
+            o += self.iter_block(p, tail=False, careful=True) + self.iter_end(p, "rem")
             o += [isa.sop("s_add_u32", S_T, S_T, I32(1))]
-        o += [isa.branch("s_branch", "L_tail0")]
+        o += [isa.branch("s_branch", "L_rem0" if c.ragged else "L_tail0")]      # ragged: up to U + pk remainder iterations -> the chain cycles
         for p in range(U):
             o += [isa.label(f"L_tail{p}")] + self.iter_block(p, tail=True)
             o += [isa.nop(15), isa.nop(15), isa.waitcnt(vmcnt=0), isa.waitcnt(lgkmcnt=0), isa.barrier(), isa.branch("s_branch", "L_seg_end")]
@@ -985,7 +1043,7 @@ DEFAULT = Cfg(rd=4, cap=5, name="scail_attn4")
 
 # the two shipped kernels: DEFAULT (any scale, 32x32x16 MFMAs) and M16F (q pre-multiplied by scale * log2 e, 16x16x32 MFMAs, running
 # maximum folded into the accumulator init; scail_flash_attn_bf16 with scale == 0)
-M16F = Cfg(name="scail_attn4_m16f", mi=16, fold=True, lsum=True, cap=1, sm_end=44.0, lookahead=2.0)
+M16F = Cfg(name="scail_attn4_m16f", mi=16, fold=True, lsum=True, ragged=True, cap=1, sm_end=44.0, lookahead=2.0)
 SHIPPED = [DEFAULT, M16F]
 
 

@@ -862,14 +862,17 @@ int scail_attn4_preload() {
     return attn4_function("scail_attn4_m16f", &fn);
 }
 
-static bool attn4_eligible(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate) {
+static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
+// prescaled (scale == SCAIL_ATTN_Q_PRESCALED) selects scail_attn4_m16f, which takes ANY key count >= 512 (ragged last tile: K rows
+// fetched from 64 rows earlier, scores masked); the general kernel needs whole 64-key tiles
+static bool attn4_eligible(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate, bool prescaled) {
     const int64_t lim = (1ll << 30);     // elements -> 2^31 bytes
-    return Lk % 64 == 0 && Lk >= 512 && accumulate == 0 && Lq * q_rs < lim && Lk * k_rs < lim && Lq * o_rs < lim && 128 * Lk < lim;
+    const bool ragged_ok = prescaled && g_attn4_name == "scail_attn4";
+    return (Lk % 64 == 0 || ragged_ok) && Lk >= 512 && accumulate == 0 && Lq * q_rs < lim && Lk * k_rs < lim && Lq * o_rs < lim && 128 * (Lk + 63) < lim;
 }
 
-static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
-extern "C" int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate) {
-    return (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate)) ? 4 : 8;
+extern "C" int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate, int prescaled) {
+    return (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate, prescaled != 0)) ? 4 : 8;
 }
 
 int scail_gemm4_enable(int on);   // gemm.hip
@@ -979,7 +982,7 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
 #endif
         attr_set = true;
     }
-    if (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate)) {
+    if (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate, prescaled)) {
         // q in log2 units -> the 16x16x32 kernel with the maximum folded into the accumulator init; any other scale -> the general one
         // (a variant chosen with the measurement build's "attn4_kernel" knob replaces both)
         hipFunction_t fn;

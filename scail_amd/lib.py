@@ -25,7 +25,7 @@ SIGNATURES = {
     "scail_transpose_v": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "scail_flash_attn_bf16": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
-    "scail_flash_attn_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i],
+    "scail_flash_attn_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i, _i],
     "scail_gemm_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i],
     "scail_cross_attn2_bf16": [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                                _i64, _i64, _i64, _f, _p],

@@ -105,3 +105,11 @@ def test_m16f_first_tile_sets_the_maximum_whatever_its_sign():
         ref = R.reference(_rt(q * c) / c, _rt(k), _rt(v), H)
         assert np.isfinite(o).all()
         np.testing.assert_allclose(o, ref, rtol=2e-2, atol=6e-3)
+
+
+@pytest.mark.parametrize("Lk,nseg", [(513, 1), (575, 1), (64 * 9 + 1, 1), (64 * 12 + 63, 1), (100, 2), (64 * 6 + 32, 1), (129, 3)])
+def test_m16f_ragged_key_counts(Lk, nseg):
+    """any key count: the last tile of a segment holds 1..63 valid keys (513: a single one).  Their K rows are fetched from 64 rows
+    earlier and their scores masked; the emulator's memory refuses any read outside an allocated buffer, so a fetch past the end
+    of K would fail here even though its scores are masked."""
+    _case(attn4.M16F, 1, 2 if Lk < 200 else 1, 70, Lk, nseg=nseg, spike=(Lk > 200), seed=Lk)

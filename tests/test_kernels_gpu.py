@@ -342,9 +342,10 @@ def test_flash_attn_properties_long(ops):
 
 # ------------------------------------------------------------------------------------------------
 # attn4: the hand-scheduled 4-wave kernel (csrc/attn4.s) that scail_flash_attn_bf16 selects for Lk % 64 == 0, Lk >= 512
-def _which(q, k, o, accumulate=False):
+def _which(q, k, o, accumulate=False, prescaled=False):
     from scail_amd import lib as L
-    return L.load().scail_flash_attn_kernel_for(q.stride(1), k.stride(1), o.stride(1), q.shape[1], k.shape[1], 1 if accumulate else 0)
+    return L.load().scail_flash_attn_kernel_for(q.stride(1), k.stride(1), o.stride(1), q.shape[1], k.shape[1], 1 if accumulate else 0,
+                                                1 if prescaled else 0)
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk", [(1, 1, 256, 512), (2, 2, 300, 576), (1, 2, 700, 1024), (1, 3, 130, 832), (1, 2, 520, 1088)])
@@ -481,6 +482,7 @@ def test_cross_attn2_vs_oracle(ops, B, H, Lq, Lk1, Lk2, shared2):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,which", [(1, 1, 256, 512, 4), (2, 2, 300, 576, 4), (1, 2, 700, 1024, 4), (1, 3, 130, 832, 4), (1, 2, 520, 1088, 4),
+                                             (1, 2, 300, 513, 4), (2, 1, 130, 64 * 9 + 63, 4), (1, 1, 700, 64 * 13 + 17, 4), (1, 2, 64, 1000, 4),   # ragged key counts
                                              (2, 1, 200, 300, 8), (1, 2, 64, 448, 8)])
 def test_flash_attn_prescaled_queries(ops, B, H, Lq, Lk, which):
     """scale == SCAIL_ATTN_Q_PRESCALED: q arrives multiplied by scale * log2(e) (one rounding, as scail_rmsnorm_rope_scaled leaves
@@ -497,7 +499,9 @@ def test_flash_attn_prescaled_queries(ops, B, H, Lq, Lk, which):
     qg, kg = gpu_bf16(qp), gpu_bf16(k)
     vt = ops.transpose_v(gpu_bf16(v), H)
     o = torch.empty(B, Lq, D, device=DEV, dtype=torch.bfloat16)
-    assert _which(qg, kg, o) == which
+    assert _which(qg, kg, o, prescaled=True) == which
+    if Lk % 64:
+        assert _which(qg, kg, o) == 8                            # a raw scale keeps the 8-wave kernel for ragged key counts
     for thr in ((8, 0) if which == 4 else (8,)):
         L.set_option("attn4_thr", thr)
         try:

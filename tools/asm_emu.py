@@ -72,7 +72,12 @@ class Memory:
         off = addr - ARENA_BASE
         if off < 0 or off + n > self.top:
             raise RuntimeError(f"global access out of the arena: 0x{addr:x} (+{n})")
-        return off
+        # every access must lie inside ONE allocated buffer: a kernel that reads past the end of an operand (into the alignment gap
+        # or into its neighbour) is caught here even when the values are masked later
+        for lo, size, _, _ in self.bufs.values():
+            if lo <= off and off + n <= lo + size:
+                return off
+        raise RuntimeError(f"global access outside every allocated buffer: arena offset {off} (+{n})")
 
     def load(self, addr: int, n: int) -> np.ndarray:
         off = self._chk(addr, n)

@@ -57,8 +57,8 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     B, Lq, D = q.shape
     n_seg = len(ksegs)
     Lk = ksegs[0].shape[1]
-    assert Lk % 64 == 0
-    Lkp = Lk
+    assert Lk % 64 == 0 or getattr(cfg, "ragged", False)
+    Lkp = (Lk + 63) // 64 * 64
     mem = E.Memory(size=1 << 26)
     sl2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
     fold = getattr(cfg, "fold", False)
