@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("SCAIL_BENCH_CONFIG", "14b"), choices=list(CONFIGS))
     ap.add_argument("--layers", type=int, default=None, help="DEBUG ONLY: fewer layers (result flagged invalid)")
+    ap.add_argument("--latent-hw", type=int, nargs=2, default=None, metavar=("H", "W"),
+                    help="OTHER RESOLUTION (result flagged invalid for the headline metric): latent height / width, e.g. 60 104 = 480x832")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the config-4 VAE leg after the timed region")
     ap.add_argument("--cfg-scale", type=float, default=4.0)
@@ -232,6 +234,8 @@ def main():
     sp_check = sp.self_check(dev) if sp is not None else None
 
     p, (T, H, W), Lt, Lc = CONFIGS[args.config]
+    if args.latent_hw is not None:
+        H, W = args.latent_hw
     p = dict(p)
     if args.layers is not None:
         p["num_layers"] = args.layers
@@ -332,7 +336,7 @@ def main():
         "metric": "denoising-step latent tokens/sec", "value": Lnoise / t_step, "unit": "latent tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_step * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"SCAIL-{args.config} DiT sampler step (batch-2 CFG forward + Euler), 512x896x81f latent "
+        "config": {"workload": f"SCAIL-{args.config} DiT sampler step (batch-2 CFG forward + Euler), {8 * H}x{8 * W}x81f latent "
                                f"({T},16,{H},{W}), L={L} tokens (ref+noise+pose), text {Lt}, clip {Lc}, "
                                f"{p['num_layers']} layers, random-init bf16 weights",
                    "parallelism": f"sp{world}" + (f"-{sp_mode}" if sp is not None else ""), "cond_cache": False, "noise_tokens": Lnoise, "all_tokens_x_batch": 2 * L,
@@ -345,6 +349,8 @@ def main():
     }
     if args.layers is not None:
         out["config"]["INVALID_debug_layers"] = args.layers
+    if args.latent_hw is not None:
+        out["config"]["INVALID_other_resolution"] = list(args.latent_hw)
     if rank == 0 and world == 1 and not args.no_vae:
         out["config"]["vae"] = vae_leg(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
