@@ -96,6 +96,20 @@ int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, const float
                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * Timing of the executor's own launches with HIP events recorded on the launch stream (what bench.py's `roofline` objects are computed
+ * from: the timed thing is the product path itself, not an instrumented copy).  scail_dit_profile(h, 1): every following scail_dit_step
+ * / scail_dit_block / scail_dit_sample brackets each launch of the categories below with an event pair (events are pooled in the
+ * handle; counters restart); scail_dit_profile(h, 0) stops.  scail_dit_profile_read waits for the recorded events and returns the summed
+ * kernel time in ms and the number of launches of one category since the last enable.  Off by default; do not enable inside a stream
+ * capture (event records are not capturable into a replayable graph with readable timings).
+ */
+#define SCAIL_DIT_PROF_SELF_ATTN 0   /* scail_flash_attn_bf16 of the self-attention (dit...:1058-1105) */
+#define SCAIL_DIT_PROF_GEMM 1        /* the six per-token GEMMs of a block: qkv, attention out, cross q, cross out, MLP up, MLP down */
+#define SCAIL_DIT_PROF_CROSS_ATTN 2  /* scail_cross_attn2_bf16 (dit...:1107-1203) */
+int scail_dit_profile(scail_dit* h, int enable);
+int scail_dit_profile_read(scail_dit* h, int category, double* ms_total, int64_t* launches);
+
+/*
  * The whole Euler sampling loop of RFSampler (sampling.py:920-982) with VanillaCFG (guiders.py:41-57) for one request:
  *   for i < n_steps:  v = DiT([x; x], timesteps[i], cond [uncond | cond], ref, pose);  x += dsigma[i] (v_u + cfg (v_c - v_u))
  * x fp32 [1,T,16,H,W] in / out (device); timesteps DEVICE fp32 [n_steps][2] (= 1000 sigma_i, twice); dsigma HOST fp32

@@ -148,6 +148,8 @@ class Instr:
     # ---- text ------------------------------------------------------------------------------------
     def render(self) -> str:
         if self.op == "label":
+            if self.label is None:                       # an assembler directive riding as a pseudo-label (".p2align 6")
+                return "\t" + self.text
             return f"{self.label}:"
         if getattr(self, "text", None):
             body = self.text

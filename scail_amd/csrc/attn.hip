@@ -824,51 +824,73 @@ struct Attn4Args {
     int32_t pad;
 };
 static_assert(sizeof(Attn4Args) == 152, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
-static hipModule_t g_attn4_module = nullptr;
-static std::string g_attn4_name = "scail_attn4";                 // general kernel (A/B variants of the measurement build replace it)
-static std::map<std::string, hipFunction_t> g_attn4_fns;
+// Code objects, kernel handles (and the GEMM's tile-order tables, gemm.hip) belong to ONE device: they are cached per HIP device
+// id, so a process that drives several GPUs (a DiT on cuda:0 and another engine on cuda:1, a threaded multi-GPU host) launches the
+// module loaded on the device that is current at the call.
+static std::map<int, hipModule_t> g_attn4_modules;                // device -> loaded code object
+static const char* const k_attn4_default = "scail_attn4_m16f";   // the shipped kernel
+static std::string g_attn4_name = k_attn4_default;               // A/B variants of the measurement build replace it ("attn4_kernel:<suffix>")
+static std::map<std::pair<int, std::string>, hipFunction_t> g_attn4_fns;
 static std::mutex g_attn4_mutex;
 static float g_attn4_thr_log2 = 8.0f;      // lazy-rescale threshold: P <= 2^thr
 static int g_attn4_xcd = 1;                // XCD-aware workgroup-id decode (A/B knob "attn4_xcd")
 
 static int attn4_function(const std::string& name, hipFunction_t* fn) {
     std::lock_guard<std::mutex> lk(g_attn4_mutex);
-    if (g_attn4_module == nullptr) {
-        hipError_t e = hipModuleLoadData(&g_attn4_module, k_attn4_hsaco);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        scail_set_error("attn4: hipGetDevice failed");
+        return 2;
+    }
+    auto mit = g_attn4_modules.find(dev);
+    if (mit == g_attn4_modules.end()) {
+        hipModule_t mod = nullptr;
+        hipError_t e = hipModuleLoadData(&mod, k_attn4_hsaco);
         if (e != hipSuccess) {
             scail_set_error(std::string("attn4: hipModuleLoadData failed: ") + hipGetErrorString(e));
             return 2;
         }
+        mit = g_attn4_modules.emplace(dev, mod).first;
     }
-    auto it = g_attn4_fns.find(name);
+    auto it = g_attn4_fns.find(std::make_pair(dev, name));
     if (it == g_attn4_fns.end()) {
         hipFunction_t f;
-        hipError_t e = hipModuleGetFunction(&f, g_attn4_module, name.c_str());
+        hipError_t e = hipModuleGetFunction(&f, mit->second, name.c_str());
         if (e != hipSuccess) {
             scail_set_error("attn4: kernel " + name + " is not in the embedded code object: " + hipGetErrorString(e));
             return 2;
         }
-        it = g_attn4_fns.emplace(name, f).first;
+        it = g_attn4_fns.emplace(std::make_pair(dev, name), f).first;
     }
     *fn = it->second;
     return 0;
 }
 
-// load the embedded code object and resolve the shipped kernels now (scail_dit_create calls this: a first launch inside
+// load the embedded code object and resolve the shipped kernel now (scail_dit_create calls this: a first launch inside
 // hipStreamBeginCapture must not have to load a module)
 int scail_attn4_preload() {
     hipFunction_t fn;
-    if (int rc = attn4_function("scail_attn4", &fn)) return rc;
-    return attn4_function("scail_attn4_m16f", &fn);
+    return attn4_function(k_attn4_default, &fn);
 }
 
 static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
-// prescaled (scale == SCAIL_ATTN_Q_PRESCALED) selects scail_attn4_m16f, which takes ANY key count >= 512 (ragged last tile: K rows
-// fetched from 64 rows earlier, scores masked); the general kernel needs whole 64-key tiles
+// scail_attn4_m16f takes ANY key count >= 512 (ragged last tile: K rows fetched from 64 rows earlier, scores masked) and any scale (q in
+// log2 units as it is, a raw scale through a one-time multiplication of the Q fragments in its prologue); what is left to the 8-wave
+// kernel: short key sets, accumulate, slices beyond 32-bit byte offsets.  (A non-ragged A/B variant of the measurement build needs
+// whole 64-key tiles.)
+static bool attn4_variant_is(const char* what) { return g_attn4_name.find(what) != std::string::npos; }
 static bool attn4_eligible(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate, bool prescaled) {
     const int64_t lim = (1ll << 30);     // elements -> 2^31 bytes
-    const bool ragged_ok = prescaled && g_attn4_name == "scail_attn4";
-    return (Lk % 64 == 0 || ragged_ok) && Lk >= 512 && accumulate == 0 && Lq * q_rs < lim && Lk * k_rs < lim && Lq * o_rs < lim && 128 * (Lk + 63) < lim;
+    const bool is_default = g_attn4_name == k_attn4_default;
+    const bool ragged_ok = is_default, raw_ok = is_default || !(attn4_variant_is("m16f") || attn4_variant_is("m16g"));
+    return (Lk % 64 == 0 || ragged_ok) && (prescaled || raw_ok) && Lk >= 512 && accumulate == 0 && Lq * q_rs < lim && Lk * k_rs < lim &&
+           Lq * o_rs < lim && 128 * (Lk + 63) < lim;
+}
+// The kernel decodes its 1-D workgroup id with reciprocal multiplications that are exact while id * divisor < 2^31
+// (asmgen/attn4.py magic31): query blocks^2 * heads * batch and heads^2 * batch must stay below that; larger grids run the 8-wave kernel.
+static bool attn4_grid_ok(int64_t n_batch, int64_t heads, int64_t Lq) {
+    const int64_t nqb = (Lq + 255) / 256, lim = 1ll << 31;
+    return heads < (1 << 15) && n_batch < (1 << 15) && nqb * heads * n_batch < lim / nqb && heads * n_batch < lim / heads;
 }
 
 extern "C" int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate, int prescaled) {
@@ -921,8 +943,9 @@ extern "C" int scail_tune_set(const char* knob, int value) {
     if (std::string(knob).rfind("attn4_kernel", 0) == 0) {
         // A/B of the generated schedules: knob = "attn4_kernel" (default kernel) or "attn4_kernel:<suffix>" -> kernel
         // scail_attn4_<suffix> of the embedded code object (the variants exist only in the ablation build, SCAIL_ABLATIONS=1)
-        std::string k(knob), name = "scail_attn4";
-        if (k.size() > 13) name += "_" + k.substr(13);
+        std::string k(knob), name = k_attn4_default;
+        if (k.size() > 13) name = "scail_attn4_" + k.substr(13);
+        if (name == "scail_attn4_general") name = "scail_attn4";      // the 32x32x16 kernel (round 2's raw-scale path)
         g_attn4_name = name;
         hipFunction_t fn;
         return attn4_function(name, &fn);
@@ -951,6 +974,7 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
                       (reinterpret_cast<uintptr_t>(vt) & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 7) == 0,
                   "pointer alignment");
     const bool prescaled = scale == SCAIL_ATTN_Q_PRESCALED;        // q already carries scale * log2(e)
+    SCAIL_REQUIRE(prescaled || (scale > 0.0f && scale < 3.0e38f), "scale must be a positive finite number or SCAIL_ATTN_Q_PRESCALED");
     const float sl2 = prescaled ? 1.0f : scale * 1.4426950408889634f;
     const int64_t Lkp = (Lk + 63) / 64 * 64;
     SCAIL_REQUIRE(vt_bs == 0 || vt_bs == heads * HD * Lkp, "vt batch stride must be 0 or heads*128*ceil64(Lk)");
@@ -982,19 +1006,21 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
 #endif
         attr_set = true;
     }
-    if (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate, prescaled)) {
-        // q in log2 units -> the 16x16x32 kernel with the maximum folded into the accumulator init; any other scale -> the general one
-        // (a variant chosen with the measurement build's "attn4_kernel" knob replaces both)
+    if (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate, prescaled) && attn4_grid_ok(n_batch, heads, Lq)) {
+        // scail_attn4_m16f (or the variant chosen with the measurement build's "attn4_kernel" knob).  The 16x16x32 "fold" kernels
+        // work on scores in log2 units: sl2 = 0 says q carries scale * log2(e) already, any other value is multiplied into the Q
+        // fragments once in the prologue; their lazy-rescale threshold is in log2 units.  The 32x32x16 variants of the
+        // measurement build take sl2 per score and the threshold in raw-score units.
         hipFunction_t fn;
-        const bool fold = prescaled && g_attn4_name == "scail_attn4";
-        if (int rc = attn4_function(fold ? std::string("scail_attn4_m16f") : g_attn4_name, &fn)) return rc;
+        const bool fold = attn4_variant_is("m16f") || attn4_variant_is("m16g");
+        if (int rc = attn4_function(g_attn4_name, &fn)) return rc;
         Attn4Args a;
         a.q = q; a.k = k; a.vt = vt; a.o = o;
         a.q_bs = q_bs; a.q_rs = q_rs; a.k_ss = k_ss; a.k_bs = k_bs; a.k_rs = k_rs; a.vt_ss = vt_ss; a.vt_bs = vt_bs;
         a.o_bs = o_bs; a.o_rs = o_rs;
         a.heads = (int32_t)heads; a.Lq = (int32_t)Lq; a.Lk = (int32_t)Lk; a.Lkp = (int32_t)Lkp; a.n_seg = (int32_t)n_seg;
-        a.sl2 = sl2;
-        a.thr = g_attn4_thr_log2 / a.sl2;
+        a.sl2 = fold ? (prescaled ? 0.0f : sl2) : sl2;
+        a.thr = fold ? g_attn4_thr_log2 : g_attn4_thr_log2 / sl2;
         a.nqb = (int32_t)((Lq + 255) / 256);
         a.magic_nqb = (uint32_t)(((1ull << 31) + a.nqb - 1) / a.nqb);
         a.magic_heads = (uint32_t)(((1ull << 31) + heads - 1) / heads);

@@ -10,10 +10,20 @@ int scail_attn4_preload();   // attn.hip
 int scail_gemm4_preload();   // gemm.hip
 #include "../../include/scail_dit.h"
 
+// Optional HIP-event timing of the executor's own launches (scail_dit_profile, include/scail_dit.h): event pairs recorded on the
+// launch stream around every launch of a category; the events are pooled in the handle and reused by the next enable.
+constexpr int PROF_CATS = 3;     // SCAIL_DIT_PROF_SELF_ATTN / _GEMM / _CROSS_ATTN
+struct ProfPool {
+    std::vector<hipEvent_t> ev;  // start / stop alternating
+    size_t used = 0;
+};
+
 struct scail_dit {
     scail_dit_config cfg;
     scail_dit_weights w;
     std::vector<scail_dit_layer> layers;
+    bool prof = false;
+    ProfPool pool[PROF_CATS];
 };
 
 namespace {
@@ -73,6 +83,30 @@ __global__ void dup_rows_kernel(const float* __restrict__ in, float* __restrict_
         if (rc_ != 0) return rc_;       \
     }
 
+static int prof_mark(scail_dit* h, int cat, void* stream) {
+    ProfPool& p = h->pool[cat];
+    if (p.used == p.ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+            scail_set_error("scail_dit_profile: hipEventCreate failed");
+            return 2;
+        }
+        p.ev.push_back(e);
+    }
+    if (hipEventRecord(p.ev[p.used++], (hipStream_t)stream) != hipSuccess) {
+        scail_set_error("scail_dit_profile: hipEventRecord failed (profiling cannot run inside a stream capture)");
+        return 2;
+    }
+    return 0;
+}
+// one launch of category cat_, bracketed by an event pair when profiling is on
+#define DIT_PROF(cat_, call_)                                   \
+    {                                                           \
+        if (h->prof) DIT_TRY(prof_mark(h, cat_, stream));       \
+        DIT_TRY(call_);                                         \
+        if (h->prof) DIT_TRY(prof_mark(h, cat_, stream));       \
+    }
+
 // One transformer block in place on hid (B, Ltok, D): AdaLNMixin.layer_forward, dit...:1009-1051.
 //   m (B, 6D) fp32 = shift_a | scale_a | gate_a | shift_m | scale_m | gate_m of THIS layer (adaLN emb + table)
 static int dit_block(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, const scail_dit_cond* cond,
@@ -89,30 +123,30 @@ static int dit_block(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, c
     const scail_dit_layer& lw = h->layers[i];
     // -- self attention (dit...:1031-1036, :1058-1105) --
     DIT_TRY(scail_ln_modulate(hid, D, xn, D, m, m + D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
-    DIT_TRY(scail_gemm_bf16(xn, D, lw.qkv_w, lw.qkv_b, qkv, 3 * D, M, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xn, D, lw.qkv_w, lw.qkv_b, qkv, 3 * D, M, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
     DIT_TRY(scail_rmsnorm_rope(k, 3 * D, k, 3 * D, lw.kn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
     DIT_TRY(scail_transpose_v(v, 3 * D, Ltok * 3 * D, vt, B, nh, 128, Ltok, stream));
     // the queries go to the attention in log2 units (q * scale * log2 e, one rounding): its exp2 then needs no scale / shift per score
     DIT_TRY(scail_rmsnorm_rope_scaled(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, M, Ltok, D, 128, eps, scale * 1.4426950408889634f, stream));
-    DIT_TRY(scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, k, 0, Ltok * 3 * D, 3 * D, vt, 0, nh * 128 * Lp, att, Ltok * D, D,
-                                  B, nh, Ltok, Ltok, 1, SCAIL_ATTN_Q_PRESCALED, 0, stream));
-    DIT_TRY(scail_gemm_bf16(att, D, lw.o_w, lw.o_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, m + 2 * D, 6 * D, Ltok, stream));
+    DIT_PROF(SCAIL_DIT_PROF_SELF_ATTN, scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, k, 0, Ltok * 3 * D, 3 * D, vt, 0, nh * 128 * Lp, att, Ltok * D, D,
+                                                             B, nh, Ltok, Ltok, 1, SCAIL_ATTN_Q_PRESCALED, 0, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(att, D, lw.o_w, lw.o_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, m + 2 * D, 6 * D, Ltok, stream));
     // -- cross attention: text + CLIP, ungated residual (dit...:1039-1042, :1107-1203) --
     DIT_TRY(scail_layernorm_affine(hid, D, xn, D, lw.ln_w, lw.ln_b, M, D, eps, stream));
-    DIT_TRY(scail_gemm_bf16(xn, D, lw.cq_w, lw.cq_b, q, 3 * D, M, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xn, D, lw.cq_w, lw.cq_b, q, 3 * D, M, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
     DIT_TRY(scail_rmsnorm_rope(q, 3 * D, q, 3 * D, lw.cqn, nullptr, nullptr, M, M, D, 128, eps, stream));
     const scail_bf16* kt = cond->k_text + i * B * cond->Lt * D;
     const scail_bf16* vtt = cond->vt_text + i * B * nh * 128 * Ltp;
     const scail_bf16* kc = cond->k_clip + i * cond->Bc * cond->Lc * D;
     const scail_bf16* vtc = cond->vt_clip + i * cond->Bc * nh * 128 * Lcp;
-    DIT_TRY(scail_cross_attn2_bf16(q, Ltok * 3 * D, 3 * D, kt, cond->Lt * D, D, vtt, nh * 128 * Ltp, cond->Lt,
-                                   kc, cond->Bc == 1 ? 0 : cond->Lc * D, D, vtc, cond->Bc == 1 ? 0 : nh * 128 * Lcp, cond->Lc,
-                                   att, Ltok * D, D, B, nh, Ltok, scale, stream));
-    DIT_TRY(scail_gemm_bf16(att, D, lw.co_w, lw.co_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, nullptr, 0, 0, stream));
+    DIT_PROF(SCAIL_DIT_PROF_CROSS_ATTN, scail_cross_attn2_bf16(q, Ltok * 3 * D, 3 * D, kt, cond->Lt * D, D, vtt, nh * 128 * Ltp, cond->Lt,
+                                                               kc, cond->Bc == 1 ? 0 : cond->Lc * D, D, vtc, cond->Bc == 1 ? 0 : nh * 128 * Lcp, cond->Lc,
+                                                               att, Ltok * D, D, B, nh, Ltok, scale, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(att, D, lw.co_w, lw.co_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, nullptr, 0, 0, stream));
     // -- MLP (dit...:1045-1050; sat/transformer_defaults.py:163-176) --
     DIT_TRY(scail_ln_modulate(hid, D, xn, D, m + 3 * D, m + 4 * D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
-    DIT_TRY(scail_gemm_bf16(xn, D, lw.w1, lw.b1, ff, FF, M, FF, D, SCAIL_EPI_GELU_TANH, nullptr, 0, nullptr, 0, 0, stream));
-    DIT_TRY(scail_gemm_bf16(ff, FF, lw.w2, lw.b2, hid, D, M, D, FF, SCAIL_EPI_RESID, hid, D, m + 5 * D, 6 * D, Ltok, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xn, D, lw.w1, lw.b1, ff, FF, M, FF, D, SCAIL_EPI_GELU_TANH, nullptr, 0, nullptr, 0, 0, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(ff, FF, lw.w2, lw.b2, hid, D, M, D, FF, SCAIL_EPI_RESID, hid, D, m + 5 * D, 6 * D, Ltok, stream));
     return 0;
 }
 
@@ -163,7 +197,43 @@ extern "C" int scail_dit_create(const scail_dit_config* cfg, const scail_dit_wei
     return 0;
 }
 
-extern "C" void scail_dit_destroy(scail_dit* h) { delete h; }
+extern "C" void scail_dit_destroy(scail_dit* h) {
+    if (h != nullptr)
+        for (ProfPool& p : h->pool)
+            for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+extern "C" int scail_dit_profile(scail_dit* h, int enable) {
+    SCAIL_REQUIRE(h != nullptr, "null handle");
+    h->prof = enable != 0;
+    if (h->prof)
+        for (ProfPool& p : h->pool) p.used = 0;       // a new measurement: reuse the pooled events
+    return 0;
+}
+
+extern "C" int scail_dit_profile_read(scail_dit* h, int category, double* ms_total, int64_t* launches) {
+    SCAIL_REQUIRE(h != nullptr && ms_total != nullptr && launches != nullptr, "null argument");
+    SCAIL_REQUIRE(category >= 0 && category < PROF_CATS, "unknown category");
+    ProfPool& p = h->pool[category];
+    SCAIL_REQUIRE(p.used % 2 == 0, "unbalanced event pairs (a step failed between the marks)");
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        if (hipEventSynchronize(p.ev[i + 1]) != hipSuccess) {
+            scail_set_error("scail_dit_profile_read: hipEventSynchronize failed");
+            return 2;
+        }
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) != hipSuccess) {
+            scail_set_error("scail_dit_profile_read: hipEventElapsedTime failed");
+            return 2;
+        }
+        sum += ms;
+    }
+    *ms_total = sum;
+    *launches = (int64_t)(p.used / 2);
+    return 0;
+}
 
 extern "C" int64_t scail_dit_workspace_bytes(const scail_dit* h, int64_t B, int64_t T, int64_t H, int64_t W) {
     if (h == nullptr || B <= 0 || T <= 0 || H <= 0 || W <= 0 || H % 4 != 0 || W % 4 != 0) return -1;

@@ -17,6 +17,7 @@
 #include "common.h"
 #include <algorithm>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <vector>
 
@@ -587,38 +588,46 @@ struct Gemm4Args {
     int32_t pad[2];
 };
 static_assert(sizeof(Gemm4Args) == 112, "Gemm4Args must match asmgen/gemm4.py KERNARG_SIZE");
-static hipModule_t g_gemm4_module = nullptr, g_gemm8_module = nullptr;
-static std::map<std::string, hipFunction_t> g_gemm4_fn;
-static std::map<std::pair<int, int>, std::pair<uint32_t*, int>> g_gemm4_tables;   // (m tiles, n tiles) -> device order table, entries
+// per-device caches (a code object / a hipMalloc'd table belongs to the device that was current when it was created)
+static std::map<std::pair<int, int>, hipModule_t> g_gemm4_modules;          // (device, 4 | 8) -> loaded code object
+static std::map<std::pair<int, std::string>, hipFunction_t> g_gemm4_fn;     // (device, kernel name)
+static std::map<std::tuple<int, int, int>, std::pair<uint32_t*, int>> g_gemm4_tables;   // (device, m tiles * 8 + group, n tiles) -> device order table, entries
 static std::mutex g_gemm4_mutex;
 static int g_gemm4_mode = 4;               // generated kernels where eligible: 4 = gemm4 (default), 0 = never (csrc/gemm.hip only), 8 = gemm8 (measurement build)
 static std::string g_gemm4_suffix;         // A/B variants of the measurement build ("gemm4_kernel:<suffix>")
 
 static int gemm4_function(const std::string& name, hipFunction_t* fn) {
     std::lock_guard<std::mutex> lk(g_gemm4_mutex);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        scail_set_error("gemm4: hipGetDevice failed");
+        return 2;
+    }
     const bool is8 = name.rfind("scail_gemm8", 0) == 0;
-    hipModule_t& mod = is8 ? g_gemm8_module : g_gemm4_module;
-    if (mod == nullptr) {
+    auto mit = g_gemm4_modules.find(std::make_pair(dev, is8 ? 8 : 4));
+    if (mit == g_gemm4_modules.end()) {
 #ifdef SCAIL_ABLATIONS
         const void* image = is8 ? (const void*)k_gemm8_hsaco : (const void*)k_gemm4_hsaco;
 #else
         const void* image = k_gemm4_hsaco;
 #endif
+        hipModule_t mod = nullptr;
         hipError_t e = hipModuleLoadData(&mod, image);
         if (e != hipSuccess) {
             scail_set_error(std::string("gemm4: hipModuleLoadData failed: ") + hipGetErrorString(e));
             return 2;
         }
+        mit = g_gemm4_modules.emplace(std::make_pair(dev, is8 ? 8 : 4), mod).first;
     }
-    auto it = g_gemm4_fn.find(name);
+    auto it = g_gemm4_fn.find(std::make_pair(dev, name));
     if (it == g_gemm4_fn.end()) {
         hipFunction_t f;
-        hipError_t e = hipModuleGetFunction(&f, mod, name.c_str());
+        hipError_t e = hipModuleGetFunction(&f, mit->second, name.c_str());
         if (e != hipSuccess) {
             scail_set_error("gemm4: kernel " + name + " is not in the embedded code object: " + hipGetErrorString(e));
             return 2;
         }
-        it = g_gemm4_fn.emplace(name, f).first;
+        it = g_gemm4_fn.emplace(std::make_pair(dev, name), f).first;
     }
     *fn = it->second;
     return 0;
@@ -626,9 +635,14 @@ static int gemm4_function(const std::string& name, hipFunction_t* fn) {
 
 // Tile order table (asmgen/gemm4.py tile_table): workgroup id b runs on XCD b % 8; every XCD walks a contiguous range of the
 // grouped order (group_m m-tiles x one n-tile at a time), so the 32 tiles in flight on an XCD share ~4 + 8 operand panels in L2.
-static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev, int* entries) {
+static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev_table, int* entries) {
     std::lock_guard<std::mutex> lk(g_gemm4_mutex);
-    auto key = std::make_pair(tm * 8 + (group_m & 7), tn);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        scail_set_error("gemm4: hipGetDevice failed");
+        return 2;
+    }
+    auto key = std::make_tuple(dev, tm * 8 + (group_m & 7), tn);
     auto it = g_gemm4_tables.find(key);
     if (it == g_gemm4_tables.end()) {
         std::vector<uint32_t> order;
@@ -648,8 +662,22 @@ static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev, int* entries
         }
         it = g_gemm4_tables.emplace(key, std::make_pair(d, per * 8)).first;
     }
-    *dev = it->second.first;
+    *dev_table = it->second.first;
     *entries = it->second.second;
+    return 0;
+}
+
+// Frees the tile-order tables of EVERY device (scail_release_caches, include/scail_hip.h): call with no launch in flight.
+int scail_gemm4_release_tables() {
+    std::lock_guard<std::mutex> lk(g_gemm4_mutex);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : g_gemm4_tables) {
+        (void)hipSetDevice(std::get<0>(kv.first));
+        (void)hipFree(kv.second.first);
+    }
+    g_gemm4_tables.clear();
+    (void)hipSetDevice(cur);
     return 0;
 }
 

@@ -73,6 +73,18 @@ class CStep:
         except Exception:
             pass
 
+    PROF_SELF_ATTN, PROF_GEMM, PROF_CROSS_ATTN = 0, 1, 2          # include/scail_dit.h SCAIL_DIT_PROF_*
+
+    def profile(self, enable: bool) -> None:
+        """HIP-event timing of the executor's own launches (scail_dit_profile): on = restart the counters."""
+        L.call("scail_dit_profile", self._h, 1 if enable else 0)
+
+    def profile_read(self, category: int):
+        """(summed kernel ms, launches) of one category since profile(True); waits for the recorded events."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        L.call("scail_dit_profile_read", self._h, category, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
     def workspace_bytes(self, B, T, H, W) -> int:
         n = L.load().scail_dit_workspace_bytes(self._h, B, T, H, W)
         if n < 0:

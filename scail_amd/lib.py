@@ -46,6 +46,7 @@ SIGNATURES = {
     "scail_mul_bf16": [_p, _p, _p, _i64, _p],
     "scail_row_affine": [_p, _p, _p, _p, _i64, _i64, _i64, _p],
     "scail_set_option": [C.c_char_p, _i],
+    "scail_release_caches": [],
     "scail_f32_to_bf16": [_p, _p, _i64, _p],
     "scail_bf16_to_f32": [_p, _p, _i64, _p],
     # include/scail_dit.h (structs are passed by pointer; scail_amd/cstep.py builds them)
@@ -53,6 +54,8 @@ SIGNATURES = {
     "scail_dit_destroy": [_p],
     "scail_dit_workspace_bytes": [_p, _i64, _i64, _i64, _i64],
     "scail_dit_step": [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p],
+    "scail_dit_profile": [_p, _i],
+    "scail_dit_profile_read": [_p, _i, _p, _p],
     "scail_dit_block_workspace_bytes": [_p, _i64, _i64],
     "scail_dit_block": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _i64, _p],
     "scail_dit_sample_workspace_bytes": [_p, _i64, _i64, _i64],

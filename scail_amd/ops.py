@@ -108,6 +108,7 @@ def layernorm_affine(x, w, b, out=None, eps=1e-6):
     return out
 
 
+ATTN_Q_PRESCALED = -1.0        # include/scail_hip.h SCAIL_ATTN_Q_PRESCALED
 ATTN_LOG2_SCALE = 1.4426950408889634 / math.sqrt(128.0)     # q * this = queries in log2 units (flash_attn(..., q_prescaled=True))
 
 
@@ -148,7 +149,7 @@ def flash_attn(q, k, vt, out=None, scale=None, accumulate=False, n_seg=1, k_seg_
                k_broadcast=False, q_prescaled=False):
     """q (B, Lq, H*128) view; k (B|1, Lk, H*128) view [per segment]; vt (B|1, H, 128, Lkp) [per segment].
     Output (B, Lq, H*128) view.  ``k_broadcast``: K/V have batch 1 and are shared by all B queries.
-    ``q_prescaled``: q already carries scale * log2(e) (rmsnorm_rope(..., out_scale=ATTN_LOG2_SCALE)); include/scail_hip.h scale == 0."""
+    ``q_prescaled``: q already carries scale * log2(e) (rmsnorm_rope(..., out_scale=ATTN_LOG2_SCALE)); include/scail_hip.h SCAIL_ATTN_Q_PRESCALED."""
     _chk(q, bf16, "flash_attn.q"); _chk(k, bf16, "k"); _chk(vt, bf16, "vt")
     B, Lq, D = q.shape
     H = D // 128
@@ -166,7 +167,7 @@ def flash_attn(q, k, vt, out=None, scale=None, accumulate=False, n_seg=1, k_seg_
     if scale is None:
         scale = 1.0 / math.sqrt(128)
     if q_prescaled:
-        scale = 0.0
+        scale = ATTN_Q_PRESCALED
     L.call("scail_flash_attn_bf16", q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k_seg_stride, k_bs,
            k.stride(1), vt.data_ptr(), vt_seg_stride, vt_bs, out.data_ptr(), out.stride(0), out.stride(1), B, H, Lq,
            Lk, n_seg, scale, 1 if accumulate else 0, _stream())

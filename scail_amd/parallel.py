@@ -209,16 +209,23 @@ class SequenceParallel:
         Raises RuntimeError naming the collective that failed."""
         N, r = self.size, self.rank
         bf = torch.bfloat16
-        inp = (torch.arange(N * 8, device=device, dtype=torch.float32).reshape(N, 8) + 1000 * r).to(bf)
+        # stamps are 16-bit INTEGER patterns carried in the bf16 payload (viewed, not converted): every (source, destination,
+        # element) triple is a distinct value, so a chunk routed to the wrong rank or rows permuted inside a chunk cannot compare
+        # equal (bf16-rounded float stamps above 256 collapse neighbouring ranks / elements onto the same value)
+        assert N * N * 8 < 32768
+        stamp = lambda src, dst: ((src * N + dst) * 8 + torch.arange(8, device=device, dtype=torch.int32) + 1).to(torch.int16)
+        inp = torch.stack([stamp(r, d) for d in range(N)]).view(bf)
         got = torch.empty_like(inp)
         self.backend.all_to_all(got, inp, async_op=True).wait()
-        want = torch.stack([(torch.arange(8, device=device, dtype=torch.float32) + 8 * r + 1000 * s).to(bf) for s in range(N)])
-        if not torch.equal(got, want):
+        want = torch.stack([stamp(s, r) for s in range(N)])
+        if not torch.equal(got.view(torch.int16), want):
             raise RuntimeError(f"sequence-parallel self-check: all_to_all returned wrong data on rank {r} of {N}")
-        loc = torch.full((4, 8), float(r + 1), device=device, dtype=bf)
+        loc = (torch.arange(32, device=device, dtype=torch.int32).view(4, 8) + 64 * r + 1).to(torch.int16).view(bf)
         allg = torch.empty(N, 4, 8, device=device, dtype=bf)
         self.backend.all_gather_into(allg, loc).wait()
-        if not torch.equal(allg, torch.arange(1, N + 1, device=device, dtype=torch.float32).to(bf).view(N, 1, 1).expand(N, 4, 8)):
+        want = (torch.arange(32, device=device, dtype=torch.int32).view(1, 4, 8)
+                + 64 * torch.arange(N, device=device, dtype=torch.int32).view(N, 1, 1) + 1).to(torch.int16)
+        if not torch.equal(allg.view(torch.int16), want):
             raise RuntimeError(f"sequence-parallel self-check: all_gather returned wrong data on rank {r} of {N}")
         t = torch.full((4,), float(r == 0) * 7.0, device=device, dtype=torch.float32)
         self.backend.broadcast(t)

@@ -24,8 +24,8 @@ registers ``ulysse``, ``pos_embed`` and ``adaln_layer`` in its constructor, dit.
 ``attention_fn`` that applies the 3-segment RoPE to q / k and then calls its ``old_impl`` (dit...:653-757), the innermost
 link being ``UlyessAttentionMixin.attention_fn``.  A mixin added later lands OUTSIDE that chain, so the HIP hook re-links
 it: every non_conflict wrapper stays, only the innermost link (the SDPA / Ulysses call) is replaced by the HIP kernel.
-Unsupported situations (CPU tensors, dropout in training, masks, head_dim != 128, sequence-parallel world > 1 in the
-attention seam) raise ``ScailHipError``: there is no fallback to the torch path.
+Unsupported situations (CPU tensors, dropout in training, masks, head_dim != 128, a SAT sequence-parallel world > 1 in
+EITHER seam -- both replace code that exchanges between ranks) raise ``ScailHipError``: there is no fallback to the torch path.
 
 The compute itself sits behind a small backend object (``HipBackend``: the ctypes bindings of scail_amd.ops / cstep) so a
 CPU test can hook the mixins into the real reference network and check the hook table and the argument contract with a
@@ -63,6 +63,32 @@ def _sat_bases():
     return BaseMixin, non_conflict
 
 
+def _sequence_parallel_world_size() -> int:
+    """SAT's sequence-parallel world size when the host program has SAT's mpu loaded and initialised (sat/mpu/initialize.py), else
+    1.  Queried through sys.modules: scail_amd never imports SAT itself."""
+    for name in ("sat.mpu", "sat.mpu.initialize"):
+        m = sys.modules.get(name)
+        f = getattr(m, "get_sequence_parallel_world_size", None) if m is not None else None
+        if f is not None:
+            try:
+                return int(f())
+            except Exception:            # mpu not initialised (single process): SAT itself asserts here
+                return 1
+    return 1
+
+
+def _require_single_sp_rank(where: str):
+    """Both seams replace code that EXCHANGES under sequence parallelism (the Ulysses all-to-alls of
+    UlyessAttentionMixin.attention_fn, dit...:351-379 / sat/mpu/ulysses_attn_layer.py:41-110): with world > 1 each rank would
+    silently attend to its own token shard only.  The multi-rank path of this repo is scail_amd.parallel.SequenceParallel behind
+    the network seam (B1), not the hook seams."""
+    n = _sequence_parallel_world_size()
+    if n > 1:
+        raise L.ScailHipError(f"{where}: sequence-parallel world size is {n}; the SAT hook seams (B2 / B3) are single-rank -- use the "
+                              f"network seam (network_config.target: scail_amd.dit.DiffusionTransformer) with "
+                              f"scail_amd.parallel.SequenceParallel for sequence parallelism")
+
+
 def _splice_innermost(chain, inner):
     """collect_hooks_ (sat/model/base_model.py:151-163) nests non_conflict hooks as partial(hook, old_impl=<older chain>).
     Returns the same chain with its innermost callable replaced by ``inner``."""
@@ -81,7 +107,7 @@ class HipBackend:
     def __init__(self, engine=None):
         self.engine = engine
         self._cstep = None
-        self._cond_src = None
+        self._cond_src = None          # the (text, clip) tensors the cached K / V were projected from (strong references)
         self._cond = None
 
     # -- seam B3 -------------------------------------------------------------------------------
@@ -96,15 +122,23 @@ class HipBackend:
         return o.view(b, lq, h, d).permute(0, 2, 1, 3)
 
     # -- seam B2 -------------------------------------------------------------------------------
-    def block(self, layer_id: int, hidden, mod, text, clip, rope):
+    def block(self, layer_id: int, hidden, mod, text, clip, rope, cond_key=None):
         """hidden (B, L, D) bf16 contiguous (updated in place and returned); mod (B, 6D) fp32; text (B, Lt, D), clip
-        (Bc, Lc, D) bf16 = the EMBEDDED conditioning; rope = (T, Hp, Wp, H_shift, W_shift)."""
+        (Bc, Lc, D) bf16 = the EMBEDDED conditioning; rope = (T, Hp, Wp, H_shift, W_shift).  ``cond_key``: the (text, clip)
+        OBJECTS the host network hands every layer of this forward (they differ from ``text`` / ``clip`` when the hook had to
+        convert the dtype); default: the tensors themselves."""
         from .cstep import CStep
         eng = self.engine
-        src = (text.data_ptr(), clip.data_ptr(), tuple(text.shape), tuple(clip.shape), text._version, clip._version)
-        if self._cond_src != src:             # same tensors for every layer of one forward: project K / V once
+        # The reference hands every layer of ONE forward the same encoder_outputs / image_clip_features and builds fresh ones per
+        # forward (dit...:1505-1515).  Project K / V once per forward: always at layer 0 (every forward starts there), and whenever
+        # the tensors are not the very objects the cache was built from.  The cache holds strong references, so the allocator
+        # cannot hand the same address to a later forward's conditioning while the entry is alive (address + _version alone would
+        # match a freed-and-reallocated tensor of another prompt).
+        kt, kc = cond_key if cond_key is not None else (text, clip)
+        src = self._cond_src
+        if layer_id == 0 or src is None or src[0] is not kt or src[1] is not kc or src[2] != (kt._version, kc._version):
             self._cond = eng.kv_conditioning(text, clip)
-            self._cond_src = src
+            self._cond_src = (kt, kc, (kt._version, kc._version))
         if self._cstep is None:
             self._cstep = CStep(eng, eng.prepare())
         cos, sin = eng._rope(*rope, hidden.device)
@@ -133,6 +167,7 @@ def _build():
                            log_attention_weights=None, scaling_attention_score=True, **kwargs):
             """The innermost link: what attention_fn_default / UlyessAttentionMixin.attention_fn compute (unmasked SDPA)."""
             q, k, v = query_layer, key_layer, value_layer
+            _require_single_sp_rank("attention_fn")
             if q.dim() != 4 or k.shape != v.shape or q.shape[:2] != k.shape[:2] or q.shape[3] != k.shape[3]:
                 raise L.ScailHipError(f"attention_fn: expected q (B, heads, Lq, hd) and k, v (B, heads, Lk, hd), got "
                                       f"{tuple(q.shape)} {tuple(k.shape)} {tuple(v.shape)}")
@@ -159,6 +194,7 @@ def _build():
         @non_conflict
         def layer_forward(self, hidden_states, mask, *args, old_impl=None, **kwargs):
             layer_id = int(kwargs["layer_id"])
+            _require_single_sp_rank("layer_forward")
             emb = kwargs["emb"]                                   # adaln_projection(emb): (B, 6D)   dit...:1555, 1562
             text = kwargs["encoder_outputs"]                      # text_embedding(context): (B, Lt, D)   dit...:1505, 1563
             clip = kwargs["image_clip_features"]                  # clip_proj(...) repeated to B: (B, 257, D)  dit...:1507-1515
@@ -177,7 +213,7 @@ def _build():
             if h.data_ptr() == hidden_states.data_ptr():
                 h = h.clone()                                      # hooks return a new tensor; the kernel works in place
             as_bf16 = lambda t: t.to(torch.bfloat16).contiguous()
-            out = self.backend.block(layer_id, h, mod, as_bf16(text), as_bf16(clip), rope)
+            out = self.backend.block(layer_id, h, mod, as_bf16(text), as_bf16(clip), rope, cond_key=(text, clip))
             return out.to(dt)
 
         def backend_table(self, layer_id, device):

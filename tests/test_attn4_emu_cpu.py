@@ -113,3 +113,65 @@ def test_m16f_ragged_key_counts(Lk, nseg):
     earlier and their scores masked; the emulator's memory refuses any read outside an allocated buffer, so a fetch past the end
     of K would fail here even though its scores are masked."""
     _case(attn4.M16F, 1, 2 if Lk < 200 else 1, 70, Lk, nseg=nseg, spike=(Lk > 200), seed=Lk)
+
+
+# ---- round 3: optimistic hot loop (fixed reference point, verified on the row sums, workgroup restart) and raw-scale callers ----
+def _m16f_spiked(factor, row, key, tiles=11, seed=21, lazy=True):
+    """One key, far from tile 0, aligned with query ``row``: its score exceeds the row's first-tile maximum by about
+    factor * 128 / sqrt(128) * log2(e) = 16.3 * factor log2 units."""
+    rng = np.random.default_rng(seed)
+    Lq, Lk = 256, 64 * tiles
+    q = rng.standard_normal((1, Lq, 128)).astype(np.float32)
+    k = rng.standard_normal((1, Lk, 128)).astype(np.float32)
+    v = rng.standard_normal((1, Lk, 128)).astype(np.float32)
+    k[0, key] = q[0, row] * factor
+    o, st = R.run(attn4.M16F, q, [k], [v], 1, lazy=lazy)
+    c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
+    ref = R.reference(_rt(q * c) / c, _rt(k), _rt(v), 1)
+    assert np.isfinite(o).all()
+    np.testing.assert_allclose(o, ref, rtol=2e-2, atol=6e-3)
+    return st, tiles
+
+
+def test_m16f_optimistic_pass_needs_no_restart_inside_the_headroom():
+    """a key 80 log2 units above the first tile's maximum (P up to 2^40 with 40 units of headroom): one pass, exact"""
+    st, tiles = _m16f_spiked(5.0, row=7, key=64 * 2 + 5)
+    assert st["mfma"] == 136 * tiles                     # 128 + 8 (row sums) MFMAs per tile and wave, nothing recomputed
+
+
+@pytest.mark.parametrize("row,key", [(7, 64 * 2 + 5), (150, 64 * 3 + 63), (255, 64 * 1)])
+def test_m16f_optimistic_pass_overflow_restarts_the_workgroup(row, key):
+    """a key ~196 log2 units above the first tile's maximum: exp2 overflows in the optimistic hot loop (no maximum tracking there),
+    the row sum of that row becomes inf, the epilogue's check fires in ONE wave only and the whole workgroup (shared K / V^T rings)
+    runs again with the lazy-maximum loop -- twice the MFMAs, the right result, nothing stored from the first pass"""
+    st, tiles = _m16f_spiked(12.0, row=row, key=key, lazy=bool(row & 1))
+    assert st["mfma"] == 2 * 136 * tiles
+
+
+def test_m16f_restart_with_key_segments_and_ragged_tail():
+    """the K / V^T descriptors walk over the segments: a restart must rewind them (3 segments of 11 tiles + a ragged tail)"""
+    rng = np.random.default_rng(33)
+    Lq, Lk, nseg = 100, 64 * 10 + 17, 3
+    q = rng.standard_normal((1, Lq, 128)).astype(np.float32)
+    ks = [rng.standard_normal((1, Lk, 128)).astype(np.float32) for _ in range(nseg)]
+    vs = [rng.standard_normal((1, Lk, 128)).astype(np.float32) for _ in range(nseg)]
+    ks[1][0, 64 * 2 + 9] = q[0, 3] * 12.0                  # overflow in the hot loop of the SECOND segment
+    o, st = R.run(attn4.M16F, q, ks, vs, 1)
+    c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
+    ref = R.reference(_rt(q * c) / c, np.concatenate([_rt(x) for x in ks], 1), np.concatenate([_rt(x) for x in vs], 1), 1)
+    np.testing.assert_allclose(o, ref, rtol=2e-2, atol=6e-3)
+    assert st["mfma"] == 2 * 136 * 11 * nseg
+
+
+@pytest.mark.parametrize("Lk", [64 * 11, 513, 64 * 3])
+def test_m16f_raw_scale_callers_scale_q_in_the_prologue(Lk):
+    """sl2 != 0 (seam B3, sat/transformer_defaults.py:47-79: q arrives unscaled): the prologue multiplies the Q fragments by
+    scale * log2(e) and rounds to bf16 once more -- same kernel, same loop; reference = attention of the queries the loop sees"""
+    rng = np.random.default_rng(Lk)
+    q = rng.standard_normal((2, 300, 2 * 128)).astype(np.float32)
+    k = rng.standard_normal((2, Lk, 2 * 128)).astype(np.float32)
+    v = rng.standard_normal((2, Lk, 2 * 128)).astype(np.float32)
+    o, _ = R.run(attn4.M16F, q, [k], [v], 2, raw_scale=True)
+    c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
+    ref = R.reference(_rt(_rt(q) * c) / c, _rt(k), _rt(v), 2)
+    np.testing.assert_allclose(o, ref, rtol=2e-2, atol=6e-3)

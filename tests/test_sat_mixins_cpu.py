@@ -71,8 +71,9 @@ class _BlockStandIn:
     def __init__(self, cfg, sd):
         self.cfg, self.sd, self.calls, self.engine = cfg, sd, [], None
 
-    def block(self, layer_id, hidden, mod, text, clip, rope):
+    def block(self, layer_id, hidden, mod, text, clip, rope, cond_key=None):
         cfg = self.cfg
+        assert cond_key is not None and len(cond_key) == 2          # the host network's own (text, clip) objects
         B, Ltok, D = hidden.shape
         assert hidden.dtype == torch.bfloat16 and hidden.is_contiguous()
         assert mod.shape == (B, 6 * D) and mod.dtype == torch.float32 and mod.is_contiguous()
@@ -117,3 +118,65 @@ def test_engine_from_reference_shares_the_reference_parameters(golden_dir):
     assert set(dict(eng.named_parameters())) == set(net.state_dict())
     with pytest.raises(TypeError):
         sat_mixins.install(torch.nn.Linear(2, 2))
+
+
+def test_hooks_refuse_a_sequence_parallel_world(golden_dir, monkeypatch):
+    """both seams replace code that exchanges between sequence-parallel ranks (UlyessAttentionMixin.attention_fn,
+    dit...:351-379); with SAT's sequence-parallel world > 1 they must raise instead of attending to the local shard only."""
+    import sys
+    import types
+    from scail_amd import sat_mixins
+    from scail_amd import lib as L
+    stub = types.ModuleType("sat.mpu")
+    stub.get_sequence_parallel_world_size = lambda: 2
+    monkeypatch.setitem(sys.modules, "sat.mpu", stub)
+    assert sat_mixins._sequence_parallel_world_size() == 2
+    q = torch.zeros(1, 2, 8, 128, dtype=torch.bfloat16)
+    with pytest.raises(L.ScailHipError, match="sequence-parallel world size is 2"):
+        sat_mixins.HipAttentionMixin(backend=object())._hip_attention(q, q, q, None)
+    with pytest.raises(L.ScailHipError, match="sequence-parallel world size is 2"):
+        sat_mixins.HipLayerMixin(backend=object()).layer_forward(torch.zeros(1, 4, 8), None, layer_id=0)
+    stub.get_sequence_parallel_world_size = lambda: 1
+    assert sat_mixins._sequence_parallel_world_size() == 1
+
+    def boom():
+        raise AssertionError("sequence parallel group is not initialized")      # sat/mpu/initialize.py asserts when unset
+    stub.get_sequence_parallel_world_size = boom
+    assert sat_mixins._sequence_parallel_world_size() == 1
+
+
+def test_block_backend_conditioning_cache_is_per_forward():
+    """HipBackend.block caches the per-layer cross-attention K / V of ONE forward.  A new forward (layer 0) or new
+    conditioning objects must re-project, also when a freed tensor's address and _version come back (the old key)."""
+    from scail_amd import sat_mixins
+
+    class Eng:
+        def __init__(self):
+            self.n = 0
+
+        def kv_conditioning(self, text, clip):
+            self.n += 1
+            return {"tag": float(text.flatten()[0])}
+
+        def prepare(self):
+            return {}
+
+        def _rope(self, *a):
+            return None, None
+
+    class Step:
+        def block(self, layer, hidden, mod, cond, cos, sin):
+            return cond["tag"]
+
+    be = sat_mixins.HipBackend(Eng())
+    be._cstep = Step()
+    h = torch.zeros(1, 2, 4)
+    t1, c1 = torch.full((1, 2, 4), 1.0), torch.zeros(1, 2, 4)
+    assert [be.block(i, h, None, t1, c1, (1, 1, 1, 0, 0)) for i in range(3)] == [1.0, 1.0, 1.0] and be.engine.n == 1
+    assert be.block(0, h, None, t1, c1, (1, 1, 1, 0, 0)) == 1.0 and be.engine.n == 2          # next forward: layer 0 re-projects
+    t2 = torch.full((1, 2, 4), 2.0)                                                            # another prompt mid-stack
+    assert be.block(1, h, None, t2, c1, (1, 1, 1, 0, 0)) == 2.0 and be.engine.n == 3
+    # dtype-converted copies per layer, keyed on the host's own objects: no re-projection inside one forward
+    assert be.block(2, h, None, t2.clone(), c1.clone(), (1, 1, 1, 0, 0), cond_key=(t2, c1)) == 2.0 and be.engine.n == 3
+    t2.add_(1.0)                                                                               # in-place edit bumps _version
+    assert be.block(3, h, None, t2, c1, (1, 1, 1, 0, 0)) == 3.0 and be.engine.n == 4

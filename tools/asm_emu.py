@@ -599,6 +599,8 @@ class Emu:
                 self._wrv(w, d, R(0) & R(1))
             elif op == "v_or_b32":
                 self._wrv(w, d, R(0) | R(1))
+            elif op == "v_or3_b32":
+                self._wrv(w, d, R(0) | R(1) | R(2))
             elif op == "v_xor_b32":
                 self._wrv(w, d, R(0) ^ R(1))
             elif op == "v_lshl_add_u32":
@@ -629,7 +631,8 @@ class Emu:
                 body = op[len("v_cmp_"):]
                 cmp, ty = body.rsplit("_", 1)
                 x, y = (F(0), F(1)) if ty == "f32" else ((I(0), I(1)) if ty == "i32" else (R(0), R(1)))
-                r = {"gt": x > y, "lt": x < y, "ge": x >= y, "le": x <= y, "eq": x == y, "ne": x != y, "lg": x != y}[cmp]
+                r = {"gt": x > y, "lt": x < y, "ge": x >= y, "le": x <= y, "eq": x == y, "ne": x != y, "lg": x != y,
+                     "ngt": ~(x > y), "nlt": ~(x < y), "nge": ~(x >= y), "nle": ~(x <= y)}[cmp]        # n*: true for NaN operands
                 r = np.asarray(r) & w.exec
                 if d.kind == "vcc":
                     w.vcc = r

@@ -51,9 +51,11 @@ def reference(q, k, v, heads):
     return out
 
 
-def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = True, thr_log2: float = 8.0, program=None, mode=None):
+def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = True, thr_log2: float = 8.0, program=None, mode=None,
+        raw_scale: bool = False):
     """q (B, Lq, H*128) fp32; ksegs / vsegs: lists (one per segment) of (B, Lk, H*128) fp32.  Returns O (B, Lq, H*128) fp32
-    and the emulator statistics of the last workgroup."""
+    and the emulator statistics of the last workgroup.  raw_scale (qscale kernels): q goes in UNSCALED with sl2 = scale * log2(e)
+    as the kernel argument (the prologue multiplies the fragments), instead of pre-multiplied with sl2 = 0."""
     B, Lq, D = q.shape
     n_seg = len(ksegs)
     Lk = ksegs[0].shape[1]
@@ -63,7 +65,7 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     sl2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
     fold = getattr(cfg, "fold", False)
     # fold: the caller hands over q already multiplied by scale * log2(e) (one rounding to bf16, as scail_rmsnorm_rope_scaled does)
-    qb = to_bf16_bits(q * np.float32(sl2)) if fold else to_bf16_bits(q)
+    qb = to_bf16_bits(q * np.float32(sl2)) if (fold and not raw_scale) else to_bf16_bits(q)
     kb = np.stack([to_bf16_bits(x) for x in ksegs])                       # (S, B, Lk, D)
     vt = np.stack([transpose_v(to_bf16_bits(x), heads) for x in vsegs])    # (S, B, H, 128, Lkp)
     pq = mem.alloc("q", qb)
@@ -71,10 +73,11 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     pvt = mem.alloc("vt", vt)
     po = mem.alloc("o", np.zeros((B, Lq, D), dtype=np.uint16))
     prog = program if program is not None else attn4.Gen(cfg).program()
-    if fold:
-        sl2 = 1.0
+    thr = thr_log2 if fold else thr_log2 / sl2           # fold kernels see scores in log2 units
+    if fold and not raw_scale:
+        sl2 = 0.0 if getattr(cfg, "qscale", False) else 1.0       # qscale kernels: 0 = q is in log2 units already
     args = attn4.pack_args(pq, pk, pvt, po, Lq * D, D, B * Lk * D, Lk * D, D, B * heads * 128 * Lkp, heads * 128 * Lkp, Lq * D, D,
-                           heads, Lq, Lk, Lkp, n_seg, sl2, thr_log2 / sl2, n_batch=B, mode=mode)
+                           heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=B, mode=mode)
     stats = None
     for wid in range(attn4.grid_blocks(B, heads, Lq)):
         emu = E.Emu(prog, mem, n_waves=4, lds_bytes=cfg.lds_bytes, lazy=lazy)
@@ -92,6 +95,10 @@ def check_static(cfg: attn4.Cfg):
         nxt = g.iter_block((p + 1) % cfg.unroll, tail=False)
         errs += sched.check_hazards(body + nxt)
         errs += sched.check_hazards(body + g.iter_block((p + 1) % cfg.unroll, tail=True))
+        if getattr(cfg, "opt", False):      # the optimistic hot loop: into itself and into the (max-tracking) remainder chain
+            fast = g.iter_block(p, tail=False, nomax=True) + g.iter_end(p, "hotf", nomax=True)
+            errs += sched.check_hazards(fast + g.iter_block((p + 1) % cfg.unroll, tail=False, nomax=True))
+            errs += sched.check_hazards(fast + g.iter_block((p + 1) % cfg.unroll, tail=False, careful=True))
     errs += sched.check_hazards(g.prologue() + g.segment_start() + g.iter_block(0, tail=False))
     return errs
 
