@@ -5,7 +5,8 @@ One "step" = one full sampler step of the reference (sampling.py:960-963): a bat
 DiT forward over the L = 48 832 token sequence [ref | noise | pose] + CFG combine + Euler update on
 the fp32 state.  value = 37 632 noise tokens / t_step, whole job.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, or -- when WORLD_SIZE is not
+                                                        set -- this script re-executes itself under it with N local ranks)
 
 Inputs are synthetic and already resident in HBM when the timed region starts; weights
 are random-init bf16 of the 14B architecture (no checkpoint offline).  Nothing is skipped inside the
@@ -13,12 +14,17 @@ timed region: the step-invariant text/CLIP K,V cache of the engine is DISABLED h
 recomputes text_embedding / clip_proj / 40x K,V projections exactly like the reference does.
 
 N > 1 shards the token axis (sequence parallel, K/V all-gather over xGMI) -> "scaling": "strong".
+At N = 1 the timed step is the PRODUCT DEFAULT path: one call of the C executor (scail_dit_step, include/scail_dit.h) per network
+evaluation; the per-kernel times come from the executor's own HIP-event pairs on the launch stream (scail_dit_profile).
 The JSON line also carries
   roofline     MFMA roofline of the dominant kernel (self-attention flash kernel): algorithmic
                4*Lq*Lk*128*heads*B FLOP per launch / mean launch time measured with HIP events on the
                launch stream inside the timed region; peak 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md);
-  cpu_baseline the CPU oracle (fp32 port of the reference block) timed on this box's host cores after a warm-up at
-               several sequence lengths; t(L) = a L + b L^2 fitted and evaluated at the bench length (rank 0, N = 1);
+  roofline_gemm  the same for the six per-token GEMMs of a block taken together (36 % of the step's FLOPs);
+  cpu_baseline the CPU oracle (fp32 port of the reference block) timed on this box's host cores after a warm-up: the per-token
+               part at three sequence lengths, the self-attention (the L^2 term) separately on 2 of the 80 (batch, head)
+               pairs up to L = 24 416; fitted and
+               evaluated at the bench length (rank 0, N = 1; "kind": "port, extrapolated");
   config.vae   BASELINE config 4 (Wan2.1 VAE encode + decode at 81 x 512 x 896) run once after the timed region,
                with both roofline fractions (rank 0, N = 1 only).
 """
@@ -44,6 +50,10 @@ CONFIGS = {
                  time_freq_dim=256, time_embed_dim=5120), (21, 64, 112), 512, 257),
     "1.3b": (dict(hidden_size=1536, num_layers=30, num_attention_heads=12, inner_hidden_size=8960, text_dim=4096,
                   time_freq_dim=256, time_embed_dim=1536), (21, 64, 112), 512, 257),
+    # BASELINE config 5: 2 reference frames + 2 pose streams (an EXTENSION: the reference has exactly one of each, dit...:1559;
+    # parity is against the oracle extended the same way = unpinned by construction); L = 60 032 tokens
+    "14b-2char": (dict(hidden_size=5120, num_layers=40, num_attention_heads=40, inner_hidden_size=13824, text_dim=4096,
+                       time_freq_dim=256, time_embed_dim=5120), (21, 64, 112), 512, 257),
     "tiny": (dict(hidden_size=256, num_layers=2, num_attention_heads=2, inner_hidden_size=512, text_dim=64,
                   time_freq_dim=256, time_embed_dim=256), (4, 8, 8), 12, 5),
 }
@@ -79,45 +89,74 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
 
-def _nnls3(pts):
-    """Non-negative least squares of t = c + a L + b L^2 over the measured (L, t) points: every subset of active terms is
-    solved by ordinary least squares and the feasible (all coefficients >= 0) solution with the smallest residual wins."""
+def _nnls(cols, ts):
+    """Non-negative least squares of ts = sum_i coef_i * cols[i]: every subset of active terms is solved by ordinary least
+    squares and the feasible (all coefficients >= 0) solution with the smallest residual wins.  Returns (coef, rms residual)."""
     import itertools
     import numpy as np
-    Ls = np.array([q[0] for q in pts], dtype=np.float64)
-    ts = np.array([q[1] for q in pts], dtype=np.float64)
-    cols = [np.ones_like(Ls), Ls, Ls * Ls]
+    ts = np.asarray(ts, dtype=np.float64)
+    cols = [np.asarray(c, dtype=np.float64) for c in cols]
     best = None
-    for k in range(1, min(3, len(pts)) + 1):
-        for act in itertools.combinations(range(3), k):
+    for k in range(1, min(len(cols), len(ts)) + 1):
+        for act in itertools.combinations(range(len(cols)), k):
             A = np.stack([cols[i] for i in act], 1)
             sol, *_ = np.linalg.lstsq(A, ts, rcond=None)
             if (sol < 0).any():
                 continue
             res = float(((A @ sol - ts) ** 2).sum())
             if best is None or res < best[0] - 1e-12 or (abs(res - best[0]) <= 1e-12 and k > best[2]):
-                coef = [0.0, 0.0, 0.0]
+                coef = [0.0] * len(cols)
                 for i, v in zip(act, sol):
                     coef[i] = float(v)
                 best = (res, coef, k)
-    return best[1]
+    return best[1], (best[0] / len(ts)) ** 0.5
 
 
-def cpu_baseline(p, budget_s=28.0):
+def _physical_cores():
+    """Physical cores of the host (the figure north_star asks for), not hardware threads."""
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(p, L_bench):
     """Time the CPU oracle (fp32 restatement of the reference block, oracle/scail_oracle.py; reference
-    dit_video_crossattn_sc_xc.py:1009-1051) on a bounded sample: ONE transformer block at the real width, B = 2.
-      1. thread count: the block's largest projection (2016 x 5120 x 15360) is timed at 32 / 64 / 128 / all hardware
-         threads and the fastest is used (all 256 SMT threads of the GPU box's host are NOT the fastest for torch CPU);
-      2. one untimed warm-up call, then timed calls at several sequence lengths (latents (T, 32, 56), T = 1, 3, 5, 9 ->
-         L = 1008 ... 5488 tokens; as many as fit the time budget, at least two);
-      3. non-negative least squares fit  t(L) = c + a L + b L^2  (projections / MLP / norms scale with L,
-         self-attention with L^2 -- at the bench length attention is 62 % of the FLOPs, at the sample lengths 5-15 %, so
-         a single-length FLOP extrapolation would misprice it), evaluated at the bench length by the caller."""
+    dit_video_crossattn_sc_xc.py:1009-1051, sat/transformer_defaults.py:47-79) on a BOUNDED sample at the real width
+    (D = 5120, 40 heads, B = 2) and extrapolate to one block at the bench length:
+      1. thread count: the block's largest projection (2016 x 5120 x 15360) is timed at 32 / 64 / 128 / all hardware threads
+         and the fastest is used (all SMT threads of the GPU box's host are NOT the fastest for torch CPU);
+      2. per-token part (projections, MLP, norms, RoPE, the short-key cross attention): the whole block at L = 1008 / 2128 /
+         3248 with the time of its self-attention call taken out -> fit  c + a L  (exactly linear in L by construction);
+      3. self-attention (62 % of the step's FLOPs at the bench length, the L^2 term): O.sdpa alone on 2 of the 80 (batch,
+         head) pairs (same head-view call shape as in the block) at L = 3052 / 6104 / 12 208 / 24 416 (as many as fit ~25 s), scaled
+         to 80 pairs (the pairs are independent and each saturates the threads) -> fit  a2 L + b L^2; the bench length is
+         2x-4x the longest timed one (round 2 extrapolated the L^2 term 9x beyond its last sample);
+    Returns a dict with the fits, their rms residuals, the samples and t_block(L_bench)."""
     from oracle import scail_oracle as O
     import torch.nn.functional as F
     hw = os.cpu_count() or 1
     g = torch.Generator().manual_seed(0)
-    D = p["hidden_size"]
+    D, nh = p["hidden_size"], p["num_attention_heads"]
     xw, ww = torch.randn(2016, D, generator=g), torch.randn(3 * D, D, generator=g) * 0.02
     probe = {}
     for nt in sorted({min(hw, 32), min(hw, 64), min(hw, 128), hw}):
@@ -130,34 +169,61 @@ def cpu_baseline(p, budget_s=28.0):
     n_threads = min(probe, key=probe.get)
     torch.set_num_threads(n_threads)
     del xw, ww
-    cfg = O.DiTConfig(hidden_size=D, num_layers=1, num_attention_heads=p["num_attention_heads"],
+    cfg = O.DiTConfig(hidden_size=D, num_layers=1, num_attention_heads=nh,
                       inner_hidden_size=p["inner_hidden_size"], text_dim=64, time_embed_dim=D)
     sd = {k: torch.randn(s, generator=g) * 0.02 for k, s in O.state_dict_spec(cfg).items()
           if ".layers.0." in k or "adaln_layer" in k}
     Lt, Lc = 512, 257
     adaln, text, clip = torch.randn(2, 6 * D, generator=g), torch.randn(2, Lt, D, generator=g), torch.randn(2, Lc, D, generator=g)
+    self_t = [0.0]
+    plain = O.sdpa
 
-    def run(T):
+    def timed_sdpa(q, k, v):
+        if q.shape[2] != k.shape[2]:                      # text / CLIP cross attention: part of the per-token term
+            return plain(q, k, v)
+        t0 = time.perf_counter()
+        r = plain(q, k, v)
+        self_t[0] += time.perf_counter() - t0
+        return r
+
+    def run_block(T):
         cos, sin = O.rope_tables(cfg, T, 16, 28)
         h = torch.randn(2, cos.shape[0], D, generator=g)
+        self_t[0] = 0.0
+        O.sdpa = timed_sdpa
+        try:
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                O.block(cfg, sd, 0, h, adaln, text, clip, cos, sin)
+                dt = time.perf_counter() - t0
+        finally:
+            O.sdpa = plain
+        return cos.shape[0], dt, self_t[0]
+
+    run_block(1)                              # warm-up: thread pool, allocator, BLAS kernel selection
+    blocks = [run_block(T) for T in (1, 3, 5)]            # L = 1008, 2128, 3248
+    (c0, a1), res_tok = _nnls([[1.0] * len(blocks), [q[0] for q in blocks]], [q[1] - q[2] for q in blocks])
+    pairs_all, pairs = 2 * nh, 2
+    att = []                                  # (L, pairs, seconds for these pairs)
+    spent = 0.0
+    for La in ((3052, 6104, 12208, 24416) if D >= 1024 else (1024, 2048)):      # toy widths (tests): two short samples
+        # bounded sample: stop before a length whose predicted cost (4x the previous one) would push the attention samples past ~25 s
+        if len(att) >= 2 and spent + 4.0 * att[-1][2] > 25.0:
+            break
+        # the call shape the block uses: (1, pairs, L, 128) head views of token-major (1, L, pairs * 128) tensors
+        q, k, v = (O._heads(torch.randn(1, La, pairs * 128, generator=g), pairs) for _ in range(3))
         with torch.no_grad():
             t0 = time.perf_counter()
-            O.block(cfg, sd, 0, h, adaln, text, clip, cos, sin)
-            return cos.shape[0], time.perf_counter() - t0
-
-    _, spent = run(1)                        # warm-up: thread pool, allocator, BLAS kernel selection (counts against the budget)
-    pts = []
-    for T in (1, 3, 5, 9):
-        if len(pts) >= 2:
-            Ls, ts = pts[-1]
-            Ln = (1 + T) * 448 + T * 112
-            if spent + ts * (Ln / Ls) ** 1.5 > budget_s:
-                break
-        Ls, dt = run(T)
-        pts.append((Ls, dt))
-        spent += dt
-    c, a, b = _nnls3(pts)
-    return c, a, b, pts, n_threads, probe
+            plain(q, k, v)
+            att.append((La, pairs, time.perf_counter() - t0))
+        spent += att[-1][2]
+        del q, k, v
+    pts = [(La, dt * pairs_all / pr) for La, pr, dt in att]
+    (a2, b2), res_att = _nnls([[q[0] for q in pts], [q[0] ** 2 for q in pts]], [q[1] for q in pts])
+    t_tok = c0 + a1 * L_bench
+    t_att = a2 * L_bench + b2 * L_bench * L_bench
+    return dict(threads=n_threads, probe=probe, blocks=blocks, att=att, c=c0, a=a1, a2=a2, b=b2, res_tok=res_tok, res_att=res_att,
+                t_tok=t_tok, t_att=t_att, t_block=t_tok + t_att, max_timed_L=max(q[0] for q in pts))
 
 
 def _git_blob_sha1(path):
@@ -201,7 +267,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default=os.environ.get("SCAIL_BENCH_CONFIG", "14b"), choices=list(CONFIGS))
+    ap.add_argument("--config", default=os.environ.get("SCAIL_BENCH_CONFIG", "14b"), choices=list(CONFIGS),
+                    help="14b = the headline workload (BASELINE config 2); 14b-2char = BASELINE config 5 (2 ref + 2 pose streams, an extension, flagged)")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG ONLY: fewer layers (result flagged invalid)")
     ap.add_argument("--latent-hw", type=int, nargs=2, default=None, metavar=("H", "W"),
                     help="OTHER RESOLUTION (result flagged invalid for the headline metric): latent height / width, e.g. 60 104 = 480x832")
@@ -210,6 +277,15 @@ def main():
     ap.add_argument("--cfg-scale", type=float, default=4.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher -- the same command line the driver uses, one rank per GPU
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -243,14 +319,19 @@ def main():
                                latent_height=300, share_adaln=True, use_i2v_clip=True, device=dev, init_seed=1234, **p)
     net.cache_conditioning = False          # recompute text/CLIP K,V every step like the reference
     net.sp = sp
+    n_char = 2 if args.config == "14b-2char" else 1
+    # N = 1, one character: the product default -- every network evaluation is ONE scail_dit_step call and the kernel times come from
+    # the executor's own event pairs.  Sequence-parallel ranks (exchange in the host) and the multi-character extension run the
+    # per-op host path (same kernels, same order), timed by bracketing the tagged launches.
+    use_c = sp is None and n_char == 1 and net.use_c_step
     timer = KernelTimer()
-    net.kernel_timer = timer
+    net.kernel_timer = None if use_c else timer
 
     # ---- synthetic inputs, identical on every rank, already on the GPU ----
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(1, T, 16, H, W, generator=g).to(dev)
-    ref = torch.randn(1, 1, 16, H, W, generator=g).to(dev).to(torch.bfloat16)
-    pose = torch.randn(1, T, 16, H // 2, W // 2, generator=g).to(dev).to(torch.bfloat16)
+    ref = torch.randn(1, n_char, 16, H, W, generator=g).to(dev).to(torch.bfloat16)
+    pose = torch.randn(1, n_char * T, 16, H // 2, W // 2, generator=g).to(dev).to(torch.bfloat16)
     c_ctx = torch.randn(1, Lt, p["text_dim"], generator=g)
     c_ctx[:, 64:] = 0                        # zeroed padding rows (umt5.py:516-522)
     uc_ctx = torch.zeros(1, Lt, p["text_dim"])
@@ -279,6 +360,11 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if use_c:
+        if net._cstep is None:               # --warmup 0: create the executor handle outside the timed region
+            from scail_amd.cstep import CStep
+            net._cstep = CStep(net, net.prepare())
+        net._cstep.profile(True)
     timer.enabled = True
     barrier()
     t0 = time.perf_counter()
@@ -297,10 +383,19 @@ def main():
 
     hp, wp = H // 2, W // 2
     Lnoise = T * hp * wp
-    L = hp * wp + Lnoise + T * (H // 4) * (W // 4)
+    L = n_char * hp * wp + Lnoise + n_char * T * (H // 4) * (W // 4)
     t_step = elapsed / args.steps
     nh = p["num_attention_heads"]
-    attn_ms = timer.mean_ms("self_attn")
+    gemm_ms = gemm_n = None
+    if use_c:
+        cs = net._cstep
+        ms, n_att = cs.profile_read(cs.PROF_SELF_ATTN)
+        attn_ms = ms / n_att if n_att else None
+        gemm_ms, gemm_n = cs.profile_read(cs.PROF_GEMM)
+        cs.profile(False)
+    else:
+        attn_ms = timer.mean_ms("self_attn")
+        n_att = len(timer.events.get("self_attn", []))
     # one launch = local queries x all keys; in ulysses mode a launch covers heads/world heads of ONE source rank's queries
     sp_mode = sp.resolve_mode(nh) if sp is not None else "none"
     attn_heads = nh // world if sp_mode == "ulysses" else nh
@@ -345,8 +440,29 @@ def main():
         "roofline": {"bound": "mfma", "kernel": kname + " (self-attention)", "achieved": ach,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
                      "traffic": traffic, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,
-                     "launches_timed": len(timer.events.get("self_attn", []))},
+                     "launches_timed": n_att,
+                     "timed_by": "scail_dit_profile (event pairs inside the C executor)" if use_c else "HIP events around the tagged host launches"},
     }
+    out["config"]["path"] = "scail_dit_step (C executor, product default)" if use_c else "per-op host path (scail_amd.dit._run)"
+    if gemm_ms:
+        # the six per-token GEMMs of a block (qkv, attention out, cross q, cross out, MLP up, MLP down), all launches of the timed region
+        D_, FF_ = p["hidden_size"], p["inner_hidden_size"]
+        gflop = 2.0 * (2 * L) * D_ * (3 * D_ + 3 * D_ + 2 * FF_) * p["num_layers"] * args.steps
+        g_ach = gflop / (gemm_ms * 1e-3) / 1e12
+        g_traffic = None
+        try:
+            trg = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["gemm4_step"]
+            if trg.get("source_blob") == _git_blob_sha1(os.path.join(ROOT, "scail_amd", "csrc", "gemm4.s")) and trg["shape"] == {"M": 2 * L, "D": D_, "FF": FF_}:
+                g_traffic = trg["traffic_bytes_per_launch_mean"]
+        except Exception:
+            pass
+        out["roofline_gemm"] = {"bound": "mfma", "kernel": "scail_gemm4_e0 / e1 / e3 / e4 (generated 4-wave GEMM, 256x256x64 tiles; csrc/gemm4.s): the six per-token GEMMs of a block",
+                                "achieved": g_ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": g_ach / PEAK_BF16_TFLOPS,
+                                "traffic": g_traffic, "flop_per_launch": gflop / gemm_n, "ms_per_launch": gemm_ms / gemm_n, "launches_timed": gemm_n,
+                                "timed_by": "scail_dit_profile (event pairs inside the C executor)"}
+    if n_char > 1:
+        out["config"]["EXTENSION_not_in_reference"] = (f"{n_char} reference frames + {n_char} pose streams in one token sequence (BASELINE config 5); the reference "
+                                                       "has one of each (dit...:1559), so parity is against the oracle extended the same way: unpinned by construction")
     if args.layers is not None:
         out["config"]["INVALID_debug_layers"] = args.layers
     if args.latent_hw is not None:
@@ -354,17 +470,22 @@ def main():
     if rank == 0 and world == 1 and not args.no_vae:
         out["config"]["vae"] = vae_leg(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        c0, a, b, pts, nt, probe = cpu_baseline(p)
-        t_layer = c0 + a * L + b * L * L                 # one block, B = 2, at the bench length
-        t_cpu = p["num_layers"] * t_layer
+        cb = cpu_baseline(p, L)
+        t_cpu = p["num_layers"] * cb["t_block"]
         out["cpu_baseline"] = {
-            "value": Lnoise / t_cpu, "unit": "latent tokens/s", "cores": nt, "kind": "port",
-            "sample": f"oracle block (fp32, torch CPU, {nt} threads = fastest of "
-                      + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in sorted(probe.items())) + f" on the 2016x5120x15360 projection) at full width "
-                      f"D={p['hidden_size']}, B=2, after one warm-up call, timed at L = "
-                      + ", ".join(f"{Ls} ({dt:.2f} s)" for Ls, dt in pts) + f"; non-negative least-squares fit t(L) = c + a L + b L^2 "
-                      f"with c = {c0:.2f} s, a = {a:.3e} s/token, b = {b:.3e} s/token^2 -> {t_layer:.1f} s per block at L = {L} "
-                      f"(attention share {b * L * L / t_layer:.0%}), x {p['num_layers']} layers = {t_cpu:.0f} s per step "
+            "value": Lnoise / t_cpu, "unit": "latent tokens/s", "cores": _physical_cores(), "threads": cb["threads"],
+            "hardware_threads": os.cpu_count(), "kind": "port, extrapolated",
+            "fit": {"per_token_s": {"c": cb["c"], "a_per_token": cb["a"], "rms_residual_s": cb["res_tok"]},
+                    "self_attention_s": {"a_per_token": cb["a2"], "b_per_token2": cb["b"], "rms_residual_s": cb["res_att"]},
+                    "longest_timed_L": cb["max_timed_L"], "extrapolation_in_L": L / cb["max_timed_L"],
+                    "attention_share_at_bench_L": cb["t_att"] / cb["t_block"]},
+            "sample": f"oracle block (fp32, torch CPU, {cb['threads']} threads = fastest of "
+                      + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in sorted(cb["probe"].items())) + " on the 2016x5120x15360 projection) at full "
+                      f"width D={p['hidden_size']}, B=2, after one warm-up call: whole block at L = "
+                      + ", ".join(f"{Ls} ({dt:.2f} s, of which self-attention {ta:.2f} s)" for Ls, dt, ta in cb["blocks"])
+                      + "; self-attention alone (O.sdpa) on " + ", ".join(f"{pr} of 80 (batch, head) pairs at L = {La} ({dt:.2f} s)" for La, pr, dt in cb["att"])
+                      + f"; fits: per-token part {cb['c']:.2f} + {cb['a']:.3e} L s, self-attention {cb['a2']:.3e} L + {cb['b']:.3e} L^2 s "
+                      f"-> {cb['t_tok']:.1f} + {cb['t_att']:.1f} s per block at L = {L}, x {p['num_layers']} layers = {t_cpu:.0f} s per step "
                       f"(embeddings / final layer < 0.1 % not included)"}
     if rank == 0:
         print(json.dumps(out), flush=True)

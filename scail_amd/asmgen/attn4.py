@@ -97,6 +97,14 @@ class Cfg:
                            # matrix pipe): if any row of the workgroup has l >= 2^60 or NaN the WHOLE workgroup runs again with the
                            # lazy-maximum hot loop (mode 1), which is correct for any input
     head: float = 40.0     # (opt) headroom: exp2 overflows only when a score exceeds the first tile's row maximum by > 127 + head
+    pv_qb: bool = False    # (mi = 16) P.V MFMAs in query-block-major order (qb, db) instead of (db, qb): the P quad of query block qb is
+                           # first needed 8 qb MFMAs into its k-step instead of within the first four, so the exp / pack stream can
+                           # run evenly over the whole tile (sm_end ~ 58) without the forced clusters in front of a k-step
+    v_at: float = 2.0      # V^T(t) fragment reads: first at this gap unit, v_step apart (needed by the P.V MFMAs of their k-step)
+    v_step: float = 1.5
+    k_at: float = 18.0     # K(t+2) fragment reads: first at this gap unit (after the QK^T MFMAs that still read the old fragments), k_step apart
+    k_step: float = 2.0
+    late_extra: float = -1.0   # >= 0: sched.schedule(late_extra=...) -- one filler beyond ``cap`` in a gap when the stream is that many gaps late
     align: int = 0         # .p2align of the hot-loop entry labels (0 = none): code placement A/B (guide: hand-asm streams are
                            # sensitive to a uniform shift of the instruction stream)
 
@@ -326,9 +334,10 @@ class Gen:
         """O[db][qb] += V^T[db][ks] x P[qb][ks]; P[qb][ks] = the packed quad built in place from S[2 ks][qb], S[2 ks + 1][qb]."""
         out = []
         for ks in range(2):
-            for db in range(8):
-                for qb in range(4):
-                    out.append(isa.mfma16(O16(db, qb), Vtf16(db, ks), Pq16(cur, ks, qb), O16(db, qb), tag="pv"))
+            order = ([(db, qb) for qb in range(4) for db in range(8)] if self.cfg.pv_qb else
+                     [(db, qb) for db in range(8) for qb in range(4)])
+            for db, qb in order:
+                out.append(isa.mfma16(O16(db, qb), Vtf16(db, ks), Pq16(cur, ks, qb), O16(db, qb), tag="pv"))
             if self.cfg.lsum:
                 for qb in range(4):
                     out.append(isa.mfma16(LACC[qb], ONES, Pq16(cur, ks, qb), LACC[qb], tag="pv"))
@@ -505,7 +514,7 @@ class Gen:
             blk += self.dma_tile("k", (p + c.pk) % rd, c.dma_k_at * gs, c.dma_step * gs, careful=careful)
             blk += self.dma_tile("v", (p + c.pv) % rd, c.dma_v_at * gs, c.dma_step * gs)
         if "lds" not in abl:
-            blk += (self.v_frag_reads16 if m16 else self.v_frag_reads)(p % rd, (2.0 if not tail else 0.0) * gs, (1.5 if not tail else 1.0) * gs)
+            blk += (self.v_frag_reads16 if m16 else self.v_frag_reads)(p % rd, (c.v_at if not tail else 0.0) * gs, (c.v_step if not tail else 1.0) * gs)
         if not tail:
             blk += self.qk_mfmas16(nxt) if m16 else self.qk_mfmas(nxt)
             if careful:
@@ -515,10 +524,10 @@ class Gen:
         blk += self.pv_mfmas16(cur) if m16 else self.pv_mfmas(cur)
         if not tail:
             if "lds" not in abl:
-                blk += (self.k_frag_reads16 if m16 else self.k_frag_reads)((p + 2) % rd, 18.0 * gs, 2.0 * gs)
+                blk += (self.k_frag_reads16 if m16 else self.k_frag_reads)((p + 2) % rd, c.k_at * gs, c.k_step * gs)
             if "valu" not in abl and "max" not in abl and not nomax:
                 blk += self.rowmax16(nxt, (20.0, 36.0, 52.0, 68.0), 84.0) if m16 else self.rowmax(nxt, 21.0, 38.0, 52.0)
-        seq = sched.schedule(blk, cap=c.cap, lookahead=c.lookahead)
+        seq = sched.schedule(blk, cap=c.cap, lookahead=c.lookahead, late_extra=c.late_extra if c.late_extra >= 0 else None)
         seq = sched.insert_lgkm_waits(seq)
         return seq
 
@@ -1180,6 +1189,33 @@ def variant_cfgs():
     out.append(Cfg(name="scail_attn4_m16f_dmamid", dma_k_at=26.0, dma_v_at=42.0, dma_step=4.0, **F))
     for abl in ("dma", "lds", "valu", "max", "bar", "dma,lds,valu"):
         out.append(Cfg(name="scail_attn4_m16f_abl_" + abl.replace(",", "_"), abl=abl, **F))
+    # round 3: the shipped kernel's knobs (optimistic hot loop) -- A/B against the round-2 loop, code placement, softmax stream extent
+    P = dict(mi=16, fold=True, lsum=True, ragged=True, cap=1, sm_end=44.0, lookahead=2.0, qscale=True)
+    out.append(Cfg(name="scail_attn4_m16f_noopt", **P))                                  # round 2's hot loop (+ the prologue scaling)
+    out.append(Cfg(name="scail_attn4_m16f_opt_a6", opt=True, align=64, **P))
+    out.append(Cfg(name="scail_attn4_m16f_opt_a8", opt=True, align=256, **P))
+    for sm in (36.0, 48.0, 50.0):
+        out.append(Cfg(name=f"scail_attn4_m16f_opt_sm{int(sm)}", opt=True, **{**P, "sm_end": sm}))
+    for sm in (44.0, 52.0, 60.0):
+        out.append(Cfg(name=f"scail_attn4_m16f_opt_qb_sm{int(sm)}", opt=True, pv_qb=True, **{**P, "sm_end": sm}))
+    out.append(Cfg(name="scail_attn4_m16f_opt_c2", opt=True, **{**P, "cap": 2}))
+    out.append(Cfg(name="scail_attn4_m16f_opt_la1", opt=True, **{**P, "lookahead": 1.0}))
+    out.append(Cfg(name="scail_attn4_m16f_opt_la4", opt=True, **{**P, "lookahead": 4.0}))
+    out.append(Cfg(name="scail_attn4_m16f_opt_dmamid", opt=True, dma_k_at=26.0, dma_v_at=42.0, dma_step=4.0, **P))
+    out.append(Cfg(name="scail_attn4_m16f_opt_dmaspread", opt=True, dma_k_at=2.0, dma_v_at=34.0, dma_step=8.0, **P))
+    for abl in ("dma", "lds", "valu", "bar", "dma,lds,valu"):
+        out.append(Cfg(name="scail_attn4_m16f_opt_abl_" + abl.replace(",", "_"), opt=True, abl=abl, **P))
+    # evenly spread streams: P.V in query-block-major order, exp / pack over the whole tile, fragment reads and DMA pieces at a fixed pitch
+    U = dict(pv_qb=True, v_at=2.0, v_step=3.0, k_at=20.0, k_step=3.0, dma_k_at=1.0, dma_v_at=33.0, dma_step=8.0)
+    PU = {**P, **U}
+    out.append(Cfg(name="scail_attn4_m16f_u_c1", opt=True, **{**PU, "sm_end": 58.0}))
+    out.append(Cfg(name="scail_attn4_m16f_u_c1le2", opt=True, late_extra=2.0, **{**PU, "sm_end": 58.0}))
+    out.append(Cfg(name="scail_attn4_m16f_u_c1le4", opt=True, late_extra=4.0, **{**PU, "sm_end": 58.0}))
+    out.append(Cfg(name="scail_attn4_m16f_u_c1le2sm50", opt=True, late_extra=2.0, **{**PU, "sm_end": 50.0}))
+    out.append(Cfg(name="scail_attn4_m16f_u_c2", opt=True, **{**PU, "sm_end": 58.0, "cap": 2, "lookahead": 0.6}))
+    out.append(Cfg(name="scail_attn4_m16f_u_c2la2", opt=True, **{**PU, "sm_end": 58.0, "cap": 2}))
+    out.append(Cfg(name="scail_attn4_m16f_le2", opt=True, late_extra=2.0, **P))             # shipped targets + backlog relief
+    out.append(Cfg(name="scail_attn4_m16f_qb_le2", opt=True, late_extra=2.0, pv_qb=True, **P))
     out.append(Cfg(name="scail_attn4_m16_abl_fma", abl="fma", mi=16, cap=2, lookahead=2.0))
     out.append(Cfg(name="scail_attn4_m16_abl_fma_c3", abl="fma", mi=16, cap=3))
     out.append(Cfg(name="scail_attn4_m16_abl_fma_sm44", abl="fma", mi=16, cap=2, sm_end=44.0, lookahead=2.0))

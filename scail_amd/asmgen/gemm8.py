@@ -1,4 +1,4 @@
-"""gemm8 -- hand-scheduled 8-wave bf16 GEMM  y = epi(x W^T + b)  for gfx950 (generator of csrc/gemm8.s).
+"""gemm8 -- hand-scheduled 8-wave bf16 GEMM  y = epi(x W^T + b)  for gfx950 (measurement build only: scail_amd/build.py writes its assembly to build_abl/gemm8.s).
 
 Same problem, argument block, tile-order table and epilogues as gemm4.py (see there for the reference call sites); different
 occupancy: 8 waves = TWO per SIMD, each with 128 arch VGPRs + 128 AGPRs.  Measured on MI355X: with ONE wave per SIMD (gemm4) every
@@ -386,7 +386,8 @@ def main():
     import os
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    out = os.path.join(os.path.dirname(here), "csrc", "gemm8.s")
+    out = os.path.join(os.path.dirname(os.path.dirname(here)), "build_abl", "gemm8.s")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     text = assembly(DEFAULTS)
     if "--check" in sys.argv:
         sys.exit(0 if open(out).read() == text else 1)

@@ -98,9 +98,12 @@ def build_deps(block: Sequence[Instr]) -> List[Dict[int, int]]:
     return deps
 
 
-def schedule(block: Sequence[Instr], cap: int = 5, lookahead: float = 1.0, trailing_cap: int = 0) -> List[Instr]:
+def schedule(block: Sequence[Instr], cap: int = 5, lookahead: float = 1.0, trailing_cap: int = 0, late_extra: float = None) -> List[Instr]:
     """See module docstring.  ``target_gap`` of a filler = index of the MFMA after which it would like to sit (fractional
-    values order fillers inside a gap); a filler is not pulled earlier than ``target_gap - lookahead`` gaps."""
+    values order fillers inside a gap); a filler is not pulled earlier than ``target_gap - lookahead`` gaps.
+    ``late_extra``: a gap takes ONE filler beyond ``cap`` when the next candidate is already more than ``late_extra`` gaps behind
+    its target -- a backlog is worked off one extra instruction per gap instead of piling up until a dependent MFMA forces the
+    whole cluster into a single gap."""
     block = list(block)
     n = len(block)
     deps = build_deps(block)
@@ -147,7 +150,7 @@ def schedule(block: Sequence[Instr], cap: int = 5, lookahead: float = 1.0, trail
         force(m)
         placed = 0
         for i in fillers:
-            if placed >= cap:
+            if placed >= cap and not (late_extra is not None and placed == cap and block[i].target_gap <= g - late_extra):
                 break
             if i in pos or block[i].target_gap > g + lookahead:
                 continue

@@ -595,6 +595,7 @@ static std::map<std::tuple<int, int, int>, std::pair<uint32_t*, int>> g_gemm4_ta
 static std::mutex g_gemm4_mutex;
 static int g_gemm4_mode = 4;               // generated kernels where eligible: 4 = gemm4 (default), 0 = never (csrc/gemm.hip only), 8 = gemm8 (measurement build)
 static std::string g_gemm4_suffix;         // A/B variants of the measurement build ("gemm4_kernel:<suffix>")
+static int g_gemm4_table_mode = 0;         // tile -> XCD assignment of the order table (1, 2: measurement build A/B, knob "gemm4_table")
 
 static int gemm4_function(const std::string& name, hipFunction_t* fn) {
     std::lock_guard<std::mutex> lk(g_gemm4_mutex);
@@ -642,25 +643,46 @@ static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev_table, int* e
         scail_set_error("gemm4: hipGetDevice failed");
         return 2;
     }
-    auto key = std::make_tuple(dev, tm * 8 + (group_m & 7), tn);
+    auto key = std::make_tuple(dev, (tm * 8 + (group_m & 7)) * 4 + g_gemm4_table_mode, tn);
     auto it = g_gemm4_tables.find(key);
     if (it == g_gemm4_tables.end()) {
-        std::vector<uint32_t> order;
-        for (int g0 = 0; g0 < tm; g0 += group_m)
-            for (int n = 0; n < tn; ++n)
-                for (int m = g0; m < std::min(g0 + group_m, tm); ++m) order.push_back((uint32_t)m | ((uint32_t)n << 16));
-        const int T = (int)order.size(), per = (T + 7) / 8;
-        std::vector<uint32_t> table((size_t)per * 8);
-        for (int b = 0; b < per * 8; ++b) {
-            const int lin = (b & 7) * per + (b >> 3);
-            table[b] = lin < T ? order[lin] : 0xFFFFFFFFu;
+        // per-XCD tile sequences (workgroup b runs on XCD b % 8 and takes entry b >> 3 of that XCD's sequence)
+        std::vector<std::vector<uint32_t>> seq(8);
+        auto tile = [](int m, int n) { return (uint32_t)m | ((uint32_t)n << 16); };
+        const int n_groups = (tm + group_m - 1) / group_m;
+        if (g_gemm4_table_mode == 0) {
+            // every XCD walks a contiguous range of the grouped order
+            std::vector<uint32_t> order;
+            for (int g0 = 0; g0 < tm; g0 += group_m)
+                for (int n = 0; n < tn; ++n)
+                    for (int m = g0; m < std::min(g0 + group_m, tm); ++m) order.push_back(tile(m, n));
+            const int T = (int)order.size(), per = (T + 7) / 8;
+            for (int x = 0; x < 8; ++x)
+                for (int i = x * per; i < std::min((x + 1) * per, T); ++i) seq[x].push_back(order[i]);
+        } else if (g_gemm4_table_mode == 1) {
+            // (measurement build) m-groups dealt round-robin: the 8 XCDs work on 8 ADJACENT m-groups and sweep n together, so a
+            // W panel is wanted by all XCDs at about the same time (one HBM fetch, seven Infinity-Cache hits)
+            for (int g = 0; g < n_groups; ++g)
+                for (int n = 0; n < tn; ++n)
+                    for (int m = g * group_m; m < std::min((g + 1) * group_m, tm); ++m) seq[g % 8].push_back(tile(m, n));
+        } else {
+            // (measurement build) XCD pairs share an m-group and split its n sweep in halves: 16 instead of 32 live x panels
+            const int half = (tn + 1) / 2;
+            for (int g = 0; g < n_groups; ++g)
+                for (int hx = 0; hx < 2; ++hx)
+                    for (int n = hx * half; n < std::min((hx + 1) * half, tn); ++n)
+                        for (int m = g * group_m; m < std::min((g + 1) * group_m, tm); ++m) seq[2 * (g % 4) + hx].push_back(tile(m, n));
         }
+        size_t per = 0;
+        for (auto& q : seq) per = std::max(per, q.size());
+        std::vector<uint32_t> table(per * 8);
+        for (size_t b = 0; b < per * 8; ++b) table[b] = (b >> 3) < seq[b & 7].size() ? seq[b & 7][b >> 3] : 0xFFFFFFFFu;
         uint32_t* d = nullptr;
         if (hipMalloc(&d, table.size() * 4) != hipSuccess || hipMemcpy(d, table.data(), table.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
             scail_set_error("gemm4: cannot allocate the tile order table (the first call for a tile grid allocates; do it outside stream capture)");
             return 2;
         }
-        it = g_gemm4_tables.emplace(key, std::make_pair(d, per * 8)).first;
+        it = g_gemm4_tables.emplace(key, std::make_pair(d, (int)(per * 8))).first;
     }
     *dev_table = it->second.first;
     *entries = it->second.second;
@@ -708,6 +730,7 @@ int scail_gemm4_enable(int on) { g_gemm4_mode = on ? 4 : 0; return 0; }
 int scail_gemm4_knob(const char* knob, int value) {
     std::string k(knob);
     if (k == "gemm4") { g_gemm4_mode = (value == 4 || value == 8) ? value : (value ? 4 : 0); return 0; }
+    if (k == "gemm4_table") { g_gemm4_table_mode = (value >= 0 && value <= 2) ? value : 0; return 0; }
     if (k.rfind("gemm4_kernel", 0) == 0) { g_gemm4_suffix = k.size() > 13 ? "_" + k.substr(13) : ""; return 0; }
     return -1;
 }

@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _run(cmd, env_extra=None, timeout=600):
-    env = dict(os.environ)
+def _run(cmd, env_extra=None, timeout=600, base_env=None):
+    env = dict(os.environ if base_env is None else base_env)
     env.update(env_extra or {})
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -30,15 +30,21 @@ def test_bench_single_tiny():
         assert k in o, k
     assert o["n_gpus"] == 1 and o["config"]["finite"] and o["value"] > 0
     assert o["roofline"]["achieved"] > 0 and o["cpu_baseline"]["value"] > 0
+    assert o["config"]["path"].startswith("scail_dit_step") and o["roofline"]["timed_by"].startswith("scail_dit_profile")
+    assert o["roofline"]["launches_timed"] == 2 * 2                      # 2 layers x 2 timed steps, from the executor's own event pairs
+    assert o["cpu_baseline"]["kind"] == "port, extrapolated" and o["cpu_baseline"]["cores"] >= 1 and o["cpu_baseline"]["threads"] >= 1
 
 
 @pytest.mark.parametrize("mode", ["allgather", "ulysses"])
 def test_bench_two_ranks_one_gpu(mode):
     one = _run([sys.executable, "bench.py", "--config", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                "--master-addr", "127.0.0.1", "--master-port", "29641", "bench.py", "--gpus", "2", "--config", "tiny",
-                "--steps", "2", "--warmup", "1"],
-               {"SCAIL_DIST_BACKEND": "gloo", "SCAIL_SP_MODE": mode})
+    if mode == "allgather":          # the driver's launch line
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29641", "bench.py", "--gpus", "2"]
+    else:                            # a bare `python bench.py --gpus 2`: the script re-executes itself under torch.distributed.run
+        cmd = [sys.executable, "bench.py", "--gpus", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    two = _run(cmd + ["--config", "tiny", "--steps", "2", "--warmup", "1"], {"SCAIL_DIST_BACKEND": "gloo", "SCAIL_SP_MODE": mode}, base_env=env)
     assert two["n_gpus"] == 2 and two["config"]["finite"]
     assert two["config"]["parallelism"] == f"sp2-{mode}"
     assert "cpu_baseline" not in two

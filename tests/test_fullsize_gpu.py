@@ -107,6 +107,64 @@ def test_flash_attn_config2_length_sampled_rows():
     print(f"flash_attn L={L_TOK}: max abs err over sampled rows {worst:.3e}")
 
 
+def _prescaled_attention_case(T_, H_, W_):
+    """The self-attention launch EXACTLY as the step issues it (csrc/dit_step.hip dit_block; reference dit...:1058-1105 +
+    sat/transformer_defaults.py:47-79): k <- RMSNorm + RoPE in place on the k third of the (B, L, 3D) buffer, V^T staged, q <-
+    scail_rmsnorm_rope_scaled (log2 units), scail_flash_attn_bf16(..., SCAIL_ATTN_Q_PRESCALED) = scail_attn4_m16f, the kernel
+    bench.py times.  Reference: fp32 softmax of the scores of the queries the kernel sees, exp2(q' . k), on sampled rows."""
+    from scail_amd import lib, ops, rope
+    lib.load()
+    heads, D = 40, 5120
+    hp, wp = H_ // 2, W_ // 2
+    L = (1 + T_) * hp * wp + T_ * (H_ // 4) * (W_ // 4)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    qkv = torch.randn(2, L, 3 * D, device=DEV, generator=g).to(torch.bfloat16)
+    cos, sin = rope.build_tables(128, T_, hp, wp, 0, 0, 0, 120, max_T=21, max_H=150, max_W=270)
+    cos, sin = cos.to(DEV), sin.to(DEV)
+    assert cos.shape == (L, 64)
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    wq = (1.0 + 0.1 * torch.randn(D, device=DEV, generator=g)).float()
+    wk = (1.0 + 0.1 * torch.randn(D, device=DEV, generator=g)).float()
+    ops.rmsnorm_rope(k, wk, cos, sin, rows_per_batch=L)
+    vt = ops.transpose_v(v, heads)
+    ops.rmsnorm_rope(q, wq, cos, sin, rows_per_batch=L, out_scale=ops.ATTN_LOG2_SCALE)
+    # dominant keys (written AFTER the norm, in the units the kernel sees: score = alpha |q'_h|^2 ~ 2.1 alpha log2 units):
+    #   ~50 units above the row's other scores: inside the optimistic loop's headroom (one pass);
+    #   ~210 units: exp2 overflows in the hot loop -> that workgroup's restart with the lazy-maximum loop;
+    #   in the FIRST tile: the reference point itself becomes huge for the rows it dominates;  in the LAST (ragged) tile.
+    spikes = [(0, 5, 40000 % L, 23.5), (0, 300, 30000 % L, 102.0), (1, L - 1, L - 1, 23.5), (1, L - 140, 20, 102.0), (1, 777, L - 3, 102.0)]
+    for b, row, key, alpha in spikes:
+        k[b, key] = (q[b, row].float() * alpha).to(torch.bfloat16)
+    o = torch.empty(2, L, D, device=DEV, dtype=torch.bfloat16)
+    assert lib.load().scail_flash_attn_kernel_for(q.stride(1), k.stride(1), o.stride(1), L, L, 0, 1) == 4
+    ops.flash_attn(q, k, vt, out=o, q_prescaled=True)
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(0, 32), torch.arange(L - 192, L - 160), torch.arange(L - 32, L), torch.arange(255, 258),
+                      torch.tensor([300, 777, L - 140]), torch.randint(0, L, (154,), generator=torch.Generator().manual_seed(3))]).to(DEV)
+    worst = 0.0
+    for b in range(2):
+        for h in (0, 13, 20, 27, 39):
+            sl = slice(h * 128, (h + 1) * 128)
+            s = (q[b, rows, sl].float() @ k[b, :, sl].float().t()) * math.log(2.0)          # exp2(x) = exp(x ln 2)
+            ref = torch.softmax(s, dim=-1) @ v[b, :, sl].float()
+            got = o[b, rows, sl].float()
+            assert torch.isfinite(got).all()
+            worst = max(worst, float((got - ref).abs().max()))
+            torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2, msg=lambda m: f"batch {b} head {h}: {m}")
+            assert _cos(got, ref) >= 0.999
+    print(f"scail_attn4_m16f (prescaled q) L={L}: max abs err over sampled rows {worst:.3e}")
+
+
+def test_m16f_prescaled_attention_config2_length():
+    """(a') the kernel the bench times, at its own length: 512x896x81f, L = 48 832 = 763 whole key tiles"""
+    _prescaled_attention_case(T, H, W)
+
+
+def test_m16f_prescaled_attention_ragged_480x832():
+    """(a'') 480x832x81f: L = 42 510 = 664 key tiles + 14 keys (ragged last tile; ragged last query block of 14 rows)"""
+    _prescaled_attention_case(21, 60, 104)
+
+
 @pytest.fixture(scope="module")
 def one_layer_14b():
     """One transformer layer of the 14B architecture (D = 5120, 40 heads, FF = 13 824, text 4096) at the full config-2

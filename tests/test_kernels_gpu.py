@@ -500,8 +500,7 @@ def test_flash_attn_prescaled_queries(ops, B, H, Lq, Lk, which):
     vt = ops.transpose_v(gpu_bf16(v), H)
     o = torch.empty(B, Lq, D, device=DEV, dtype=torch.bfloat16)
     assert _which(qg, kg, o, prescaled=True) == which
-    if Lk % 64:
-        assert _which(qg, kg, o) == 8                            # a raw scale keeps the 8-wave kernel for ragged key counts
+    assert _which(qg, kg, o) == which                            # a raw scale no longer changes the kernel (round 3: Q scaled in the prologue)
     for thr in ((8, 0) if which == 4 else (8,)):
         L.set_option("attn4_thr", thr)
         try:
@@ -509,6 +508,52 @@ def test_flash_attn_prescaled_queries(ops, B, H, Lq, Lk, which):
         finally:
             L.set_option("attn4_thr", 8)
         close(o, ref, rtol=2e-2, atol=1e-2, msg=f"prescaled q, kernel {which}, thr {thr}")
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk", [(1, 2, 300, 513), (2, 1, 130, 1000), (1, 1, 700, 64 * 13 + 17), (2, 2, 260, 64 * 11)])
+def test_flash_attn_raw_scale_any_key_count_runs_the_4wave_kernel(ops, B, H, Lq, Lk):
+    """seam B3 (sat/transformer_defaults.py:47-79: q arrives unscaled, any key count): scail_attn4_m16f multiplies its Q fragments
+    by scale * log2(e) in the prologue; round 2 sent raw-scale callers to the 32x32 kernel and ragged key counts to the 8-wave one"""
+    D = H * 128
+    q, k, v = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3)
+    k[0, Lk - 3, :128] = bfr(q[0, 7, :128] * 3.0)
+    qg, kg = gpu_bf16(q), gpu_bf16(k)
+    vt = ops.transpose_v(gpu_bf16(v), H)
+    o = torch.empty(B, Lq, D, device=DEV, dtype=torch.bfloat16)
+    assert _which(qg, kg, o) == 4
+    ops.flash_attn(qg, kg, vt, out=o)
+    close(o, _attn_ref(q, k, v, H), rtol=2e-2, atol=1e-2, msg=f"raw scale, Lk={Lk}")
+    ops.flash_attn(qg, kg, vt, out=o, scale=0.05)                       # another scale than 1 / sqrt(128)
+    ref = O._merge(O.sdpa(O._heads(q, H) * (0.05 * math.sqrt(128.0)), O._heads(k, H), O._heads(v, H)))
+    close(o, ref, rtol=2e-2, atol=1e-2, msg="scale 0.05")
+    from scail_amd import lib as L
+    for bad in (0.0, -0.5, float("nan"), float("inf")):
+        with pytest.raises(L.ScailHipError, match="positive finite"):
+            ops.flash_attn(qg, kg, vt, out=o, scale=bad)
+
+
+@pytest.mark.parametrize("factor,prescaled", [(5.0, True), (12.0, True), (12.0, False), (30.0, True)])
+def test_flash_attn_optimistic_loop_overflow_restart(ops, factor, prescaled):
+    """scail_attn4_m16f's hot loop fixes the reference point of exp2 after the first tile (+ 40 log2 units of headroom) and tracks no
+    maximum; a key whose score exceeds that by more than ~100 (factor 12: ~196 log2 units above the first tile's maximum, factor
+    30: ~490) overflows, the row-sum check in the epilogue sees it and the workgroup runs again with the lazy-maximum loop.
+    factor 5 (~80 units) stays inside the headroom.  Spikes in several query blocks / heads / batch elements, in the hot loop
+    (tiles 1..) and in the remainder tiles, against the fp32 oracle."""
+    B, H, Lq, Lk = 2, 2, 700, 64 * 23 + 9
+    D = H * 128
+    c = ops.ATTN_LOG2_SCALE
+    q, k, v = rnd(B, Lq, D, seed=1), rnd(B, Lk, D, seed=2), rnd(B, Lk, D, seed=3)
+    for b, row, key, h in ((0, 7, 64 * 2 + 5, 0), (0, 300, 64 * 9, 1), (1, 699, Lk - 2, 0), (1, 513, 64 * 21 + 3, 1), (1, 100, 3, 1)):
+        k[b, key, h * 128:(h + 1) * 128] = bfr(q[b, row, h * 128:(h + 1) * 128] * factor)
+    if prescaled:
+        qp = bfr(q * c)
+        ref = _attn_ref(qp / c, k, v, H)
+        o = ops.flash_attn(gpu_bf16(qp), gpu_bf16(k), ops.transpose_v(gpu_bf16(v), H), q_prescaled=True)
+    else:
+        ref = _attn_ref(q, k, v, H)
+        o = ops.flash_attn(gpu_bf16(q), gpu_bf16(k), ops.transpose_v(gpu_bf16(v), H))
+    assert torch.isfinite(o.float()).all()
+    close(o, ref, rtol=2e-2, atol=1e-2, msg=f"spike factor {factor}")
 
 
 def test_flash_attn_prescaled_extreme_first_tile(ops):

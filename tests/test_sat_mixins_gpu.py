@@ -76,3 +76,39 @@ def test_layer_forward_hook_through_hip_backend(golden_dir):
     from scail_amd import lib as L
     with pytest.raises(L.ScailHipError, match="tokens do not match"):
         mix.layer_forward(oh[0][:, :-1].to(DEV).to(torch.bfloat16), None, layer_id=torch.tensor(0), **kw)
+
+
+def test_layer_forward_hook_second_conditioning_is_not_served_from_the_cache(golden_dir):
+    """the reference builds fresh encoder_outputs / image_clip_features every forward (dit...:1505-1515); after they are
+    freed the caching allocator commonly hands the same address (and _version 0) to the next forward's tensors.  A second prompt
+    must be projected again, not rendered with the first prompt's cached K / V."""
+    from scail_amd import sat_mixins
+    from scail_amd.dit import DiffusionTransformer
+    g = _load(golden_dir, "dit_tiny.npz")
+    cfg = O.DiTConfig(**O.TINY)
+    sd = O.make_state_dict(cfg, seed=int(g["seed"]))
+    eng = DiffusionTransformer(transformer_args=dict(model_parallel_size=1), num_frames=cfg.num_frames, latent_width=cfg.latent_width,
+                               latent_height=cfg.latent_height, hidden_size=cfg.hidden_size, text_dim=cfg.text_dim,
+                               num_layers=cfg.num_layers, num_attention_heads=cfg.num_attention_heads,
+                               time_freq_dim=cfg.time_freq_dim, time_embed_dim=cfg.time_embed_dim, share_adaln=True,
+                               inner_hidden_size=cfg.inner_hidden_size, use_i2v_clip=True, device=DEV)
+    eng.load_state_dict(sd, strict=True)
+    mix = sat_mixins.HipLayerMixin(sat_mixins.HipBackend(eng))
+    _, adaln = O.time_embeddings(cfg, sd, g["t"])
+    B, T, _, H, W = g["x"].shape
+    clip = O.clip_proj(cfg, sd, g["clip"]).repeat(2, 1, 1)
+    cos, sin = O.rope_tables(cfg, T, H // 2, W // 2)
+    _, oh = O.dit_forward(cfg, sd, g["x"], g["t"], g["ctx"], g["ref"], g["pose"], g["clip"], return_hidden=True)
+    hin = oh[0]
+    ptrs = []
+    for trial, ctx in enumerate((g["ctx"], torch.flip(g["ctx"], dims=[1]) * 1.5)):
+        text = O.text_embedding(cfg, sd, ctx)
+        want = O.block(cfg, sd, 0, hin, adaln, text, clip, cos, sin)
+        text_g, clip_g = text.to(DEV).to(torch.bfloat16), clip.to(DEV).to(torch.bfloat16)      # fresh tensors, as in a new forward
+        ptrs.append(text_g.data_ptr())
+        kw = dict(emb=adaln.to(DEV).to(torch.bfloat16), encoder_outputs=text_g, image_clip_features=clip_g,
+                  rope_T=T, rope_H=H // 2, rope_W=W // 2, rope_H_shift=0, rope_W_shift=0)
+        out = mix.layer_forward(hin.to(DEV).to(torch.bfloat16), None, layer_id=torch.tensor(0), **kw)
+        torch.testing.assert_close(out.float().cpu(), want, rtol=2e-2, atol=2e-2, msg=lambda m: f"conditioning {trial}: {m}")
+        del text_g, clip_g, kw, out
+    print("conditioning tensor addresses of the two forwards:", ptrs)

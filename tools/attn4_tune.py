@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--skip-check", action="store_true")
     ap.add_argument("--prescaled", action="store_true", help="hand q over in log2 units (scale == 0 path: the fold variants need it)")
     ap.add_argument("--full", action="store_true", help="also time the 40-head launch of the best variant")
+    ap.add_argument("--full-also", default="", help="more variants for the 40-head launch (comma separated; '' = the shipped kernel)")
     a = ap.parse_args()
     lib.load()
     g = torch.Generator(device=DEV).manual_seed(0)
@@ -132,13 +133,20 @@ def main():
         vt = ops.transpose_v(v, 40)
         out = torch.empty(2, a.L, D, device=DEV, dtype=torch.bfloat16)
         fl = 4.0 * a.L * a.L * 128 * 40 * 2
-        for xcd in (1, 0, 1, 0):
+        if a.prescaled:
+            q = (q.float() * ops.ATTN_LOG2_SCALE).to(torch.bfloat16)
+        for var in [bestvar] + [x for x in a.full_also.split(",") if x]:
+            setk(var)
+            med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out, **akw), 3)
+            print(json.dumps({"kernel": f"attn4 variant {var}, 40 heads", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9}), flush=True)
+        setk(bestvar)
+        for xcd in (1, 0):
             lib.tune_set("attn4_xcd", xcd)
-            med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), 3)
+            med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out, **akw), 3)
             print(json.dumps({"kernel": f"attn4 variant {bestvar}, 40 heads, xcd-aware ids {xcd}", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9}), flush=True)
         lib.tune_set("attn4_xcd", 1)
         lib.tune_set("attn4", 0)
-        med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out), 3)
+        med, best = timeit(lambda: ops.flash_attn(q, k, vt, out=out, **akw), 3)
         print(json.dumps({"kernel": "8-wave swp, 40 heads", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9}), flush=True)
 
 
