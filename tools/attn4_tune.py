@@ -60,7 +60,7 @@ def main():
     g = torch.Generator(device=DEV).manual_seed(0)
     rn = lambda *s: torch.randn(*s, device=DEV, generator=g).to(torch.bfloat16)
     variants = a.variants.split(",")
-    setk = lambda v: lib.tune_set("attn4_kernel" + (":" + v if v else ""), 0)
+    setk = lambda v: lib.tune_set("attn4_kernel" + (":" + v if v and v != "default" else ""), 0)      # "" / "default" = the shipped kernel
 
     if not a.skip_check:
         # ---- correctness: ragged Lq, several tile counts (all remainder paths), spiked keys (rescale), 2 segments ----
@@ -125,7 +125,7 @@ def main():
         results.append((med, var))
         print(json.dumps({"kernel": f"attn4 variant {var}", "ms": med, "TFLOPs": fl / med / 1e9, "best_TFLOPs": fl / best / 1e9, "max_err": err}), flush=True)
     if a.full:
-        bestvar = min(r for r in results if not r[1].startswith("abl"))[1]
+        bestvar = min(r for r in results if "abl" not in r[1])[1]
         setk(bestvar)
         D = 40 * 128
         qkv = rn(2, a.L, 3 * D)
