@@ -1136,7 +1136,7 @@ DEFAULT = Cfg(rd=4, cap=5, name="scail_attn4")
 # the shipped kernel: M16F (16x16x32 MFMAs, scores in log2 units -- q pre-multiplied by scale * log2 e, or multiplied in the prologue for
 # raw-scale callers --, running maximum folded into the accumulator init, optimistic hot loop).  DEFAULT (32x32x16 MFMAs, scale per
 # score; round 2's raw-scale kernel) lives on in the measurement build and in the emulator tests
-M16F = Cfg(name="scail_attn4_m16f", mi=16, fold=True, lsum=True, ragged=True, cap=1, sm_end=44.0, lookahead=2.0, qscale=True, opt=True)
+M16F = Cfg(name="scail_attn4_m16f", mi=16, fold=True, lsum=True, ragged=True, cap=1, sm_end=44.0, lookahead=2.0, qscale=True, opt=True, pv_qb=True)
 SHIPPED = [M16F]
 
 
@@ -1192,6 +1192,7 @@ def variant_cfgs():
     # round 3: the shipped kernel's knobs (optimistic hot loop) -- A/B against the round-2 loop, code placement, softmax stream extent
     P = dict(mi=16, fold=True, lsum=True, ragged=True, cap=1, sm_end=44.0, lookahead=2.0, qscale=True)
     out.append(Cfg(name="scail_attn4_m16f_noopt", **P))                                  # round 2's hot loop (+ the prologue scaling)
+    out.append(Cfg(name="scail_attn4_m16f_opt_db", opt=True, **P))                       # optimistic loop, P.V in (db, qb) order
     out.append(Cfg(name="scail_attn4_m16f_opt_a6", opt=True, align=64, **P))
     out.append(Cfg(name="scail_attn4_m16f_opt_a8", opt=True, align=256, **P))
     for sm in (36.0, 48.0, 50.0):

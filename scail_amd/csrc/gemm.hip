@@ -595,7 +595,7 @@ static std::map<std::tuple<int, int, int>, std::pair<uint32_t*, int>> g_gemm4_ta
 static std::mutex g_gemm4_mutex;
 static int g_gemm4_mode = 4;               // generated kernels where eligible: 4 = gemm4 (default), 0 = never (csrc/gemm.hip only), 8 = gemm8 (measurement build)
 static std::string g_gemm4_suffix;         // A/B variants of the measurement build ("gemm4_kernel:<suffix>")
-static int g_gemm4_table_mode = 0;         // tile -> XCD assignment of the order table (1, 2: measurement build A/B, knob "gemm4_table")
+static int g_gemm4_table_mode = 1;         // tile -> XCD assignment of the order table (0, 2: measurement build A/B, knob "gemm4_table")
 
 static int gemm4_function(const std::string& name, hipFunction_t* fn) {
     std::lock_guard<std::mutex> lk(g_gemm4_mutex);
@@ -634,8 +634,8 @@ static int gemm4_function(const std::string& name, hipFunction_t* fn) {
     return 0;
 }
 
-// Tile order table (asmgen/gemm4.py tile_table): workgroup id b runs on XCD b % 8; every XCD walks a contiguous range of the
-// grouped order (group_m m-tiles x one n-tile at a time), so the 32 tiles in flight on an XCD share ~4 + 8 operand panels in L2.
+// Tile order table: workgroup id b runs on XCD b % 8 and takes entry b >> 3 of that XCD's sequence; a sequence is made of whole tile
+// groups (group_m m-tiles x one n-tile at a time), so the 32 tiles in flight on an XCD share ~4 + 8 operand panels in its L2.
 static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev_table, int* entries) {
     std::lock_guard<std::mutex> lk(g_gemm4_mutex);
     int dev = 0;
@@ -651,7 +651,7 @@ static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev_table, int* e
         auto tile = [](int m, int n) { return (uint32_t)m | ((uint32_t)n << 16); };
         const int n_groups = (tm + group_m - 1) / group_m;
         if (g_gemm4_table_mode == 0) {
-            // every XCD walks a contiguous range of the grouped order
+            // (round 1 / 2, measurement build) every XCD walks a contiguous range of the grouped order: 8 distant m-regions
             std::vector<uint32_t> order;
             for (int g0 = 0; g0 < tm; g0 += group_m)
                 for (int n = 0; n < tn; ++n)
@@ -660,8 +660,9 @@ static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev_table, int* e
             for (int x = 0; x < 8; ++x)
                 for (int i = x * per; i < std::min((x + 1) * per, T); ++i) seq[x].push_back(order[i]);
         } else if (g_gemm4_table_mode == 1) {
-            // (measurement build) m-groups dealt round-robin: the 8 XCDs work on 8 ADJACENT m-groups and sweep n together, so a
-            // W panel is wanted by all XCDs at about the same time (one HBM fetch, seven Infinity-Cache hits)
+            // default (round 3): m-groups dealt round-robin: the 8 XCDs work on 8 ADJACENT m-groups and sweep n together, so a W
+            // panel is wanted by all XCDs at about the same time (one HBM fetch, seven Infinity-Cache hits): +1.0-1.8 % on the qkv /
+            // MLP shapes over the contiguous ranges (profiles/r03_gemm_table_modes.log), neutral on the N = 5120 ones
             for (int g = 0; g < n_groups; ++g)
                 for (int n = 0; n < tn; ++n)
                     for (int m = g * group_m; m < std::min((g + 1) * group_m, tm); ++m) seq[g % 8].push_back(tile(m, n));
@@ -730,7 +731,7 @@ int scail_gemm4_enable(int on) { g_gemm4_mode = on ? 4 : 0; return 0; }
 int scail_gemm4_knob(const char* knob, int value) {
     std::string k(knob);
     if (k == "gemm4") { g_gemm4_mode = (value == 4 || value == 8) ? value : (value ? 4 : 0); return 0; }
-    if (k == "gemm4_table") { g_gemm4_table_mode = (value >= 0 && value <= 2) ? value : 0; return 0; }
+    if (k == "gemm4_table") { g_gemm4_table_mode = (value >= 0 && value <= 2) ? value : 1; return 0; }
     if (k.rfind("gemm4_kernel", 0) == 0) { g_gemm4_suffix = k.size() > 13 ? "_" + k.substr(13) : ""; return 0; }
     return -1;
 }

@@ -549,8 +549,8 @@ def test_flash_attn_optimistic_loop_overflow_restart(ops, factor, prescaled):
         qp = bfr(q * c)
         ref = _attn_ref(qp / c, k, v, H)
         o = ops.flash_attn(gpu_bf16(qp), gpu_bf16(k), ops.transpose_v(gpu_bf16(v), H), q_prescaled=True)
-    else:
-        ref = _attn_ref(q, k, v, H)
+    else:       # raw scale: the prologue rounds q * scale * log2(e) to bf16 -- reference = the queries the loop sees, as in the prescaled case
+        ref = _attn_ref(bfr(q * c) / c, k, v, H)
         o = ops.flash_attn(gpu_bf16(q), gpu_bf16(k), ops.transpose_v(gpu_bf16(v), H))
     assert torch.isfinite(o.float()).all()
     close(o, ref, rtol=2e-2, atol=1e-2, msg=f"spike factor {factor}")

@@ -43,6 +43,6 @@ for (N, K, epi, tag) in shapes:
         L.tune_set("gemm_group_m", grp)
         ms = timeit(lambda: ops.gemm(x, w, b, out=y, epilogue=epi, **kw))
         print(json.dumps({"shape": [M, N, K], "what": tag, "table_mode": mode, "group_m": grp, "ms": ms, "TFLOPs": fl / ms / 1e9}), flush=True)
-    L.tune_set("gemm4_table", 0)
+    L.tune_set("gemm4_table", 1)
     L.tune_set("gemm_group_m", 4)
     del x, w, y
