@@ -1217,6 +1217,23 @@ def variant_cfgs():
     out.append(Cfg(name="scail_attn4_m16f_u_c2la2", opt=True, **{**PU, "sm_end": 58.0, "cap": 2}))
     out.append(Cfg(name="scail_attn4_m16f_le2", opt=True, late_extra=2.0, **P))             # shipped targets + backlog relief
     out.append(Cfg(name="scail_attn4_m16f_qb_le2", opt=True, late_extra=2.0, pv_qb=True, **P))
+    # second sweep around the shipped schedule (query-block-major P.V, exp / pack stream over gaps 0..88)
+    Q = {**P, "opt": True, "pv_qb": True}
+    for sm in (40.0, 48.0):
+        out.append(Cfg(name=f"scail_attn4_m16f_q_sm{int(sm)}", **{**Q, "sm_end": sm}))
+    out.append(Cfg(name="scail_attn4_m16f_q_le4", late_extra=4.0, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_le8", late_extra=8.0, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_v20", v_step=2.0, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_v30", v_step=3.0, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_k16", k_at=16.0, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_k24s25", k_at=24.0, k_step=2.5, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_k20s30", k_at=20.0, k_step=3.0, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_dmamid", dma_k_at=26.0, dma_v_at=42.0, dma_step=4.0, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_dmaspread", dma_k_at=1.0, dma_v_at=33.0, dma_step=8.0, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_dmalate", dma_k_at=49.0, dma_v_at=56.0, dma_step=1.7, **Q))
+    out.append(Cfg(name="scail_attn4_m16f_q_la1", **{**Q, "lookahead": 1.0}))
+    out.append(Cfg(name="scail_attn4_m16f_q_la4", **{**Q, "lookahead": 4.0}))
+    out.append(Cfg(name="scail_attn4_m16f_q_u_le4", late_extra=4.0, v_step=3.0, k_at=20.0, k_step=3.0, dma_k_at=1.0, dma_v_at=33.0, dma_step=8.0, **Q))
     out.append(Cfg(name="scail_attn4_m16_abl_fma", abl="fma", mi=16, cap=2, lookahead=2.0))
     out.append(Cfg(name="scail_attn4_m16_abl_fma_c3", abl="fma", mi=16, cap=3))
     out.append(Cfg(name="scail_attn4_m16_abl_fma_sm44", abl="fma", mi=16, cap=2, sm_end=44.0, lookahead=2.0))

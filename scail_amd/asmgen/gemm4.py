@@ -568,15 +568,23 @@ class Gen:
                       isa.vop("v_mul_lo_u32", goff, bq, ST[12]), isa.vop("v_lshl_add_u32", goff, g, I32(4), goff)]
             e += [isa.v_cmp("v_cmp_lt_u32", row, S_M),
                   Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+            # residual / gate operands of the WHOLE row block first (fragment registers v64.. are dead here), ONE wait, then the
+            # arithmetic and the stores: round 2 waited vmcnt(0) after every quad's loads -- 64 dependent L2 round trips per lane,
+            # ~13 % of a K = 5120 tile's time (profiles/r03_gemm_table_modes.log: 1253 vs 1364 TFLOP/s for K = 5120 / 13 824)
+            RP = lambda k: V(64 + 2 * k, 2)
+            GQ = lambda k: V(96 + 4 * k, 4)
+            if c.epi in (3, 4):
+                for k, (noff, accq, bq_) in enumerate(quads):
+                    e.append(isa.global_load(2, RP(k), roff, noff * 2, saddr=S_RES, extra_reads=[EXEC]))
+                    if c.epi == 3:
+                        e.append(isa.global_load(4, GQ(k), goff, noff * 4, saddr=S_GATE, extra_reads=[EXEC]))
+                e.append(isa.waitcnt(vmcnt=0))
             for k, (noff, accq, bq_) in enumerate(quads):
                 base = 170 + 16 * (k % 2)         # two rotating register groups
                 f = [V(base + i) for i in range(4)]
-                w, rp, r_, u2, gq = V(base + 4, 2), V(base + 6, 2), V(base + 8), [V(base + 9), V(base + 10)], V(base + 12, 4)
+                w, r_, u2 = V(base + 4, 2), V(base + 8), [V(base + 9), V(base + 10)]
+                rp, gq = RP(k), GQ(k)
                 acc = accq(mb)
-                if c.epi in (3, 4):
-                    e.append(isa.global_load(2, rp, roff, noff * 2, saddr=S_RES, extra_reads=[EXEC]))
-                if c.epi == 3:
-                    e.append(isa.global_load(4, gq, goff, noff * 4, saddr=S_GATE, extra_reads=[EXEC]))
                 for i in range(4):
                     e += [isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)),
                           isa.vop("v_add_f32", f[i], f[i], bq_.sub(i))]
@@ -587,7 +595,6 @@ class Gen:
                               isa.vop("v_mul_f32", u, u, f[i]), isa.vop("v_exp_f32", u, u), isa.vop("v_add_f32", u, F32(1.0), u),
                               isa.vop("v_rcp_f32", u, u), isa.vop("v_fma_f32", f[i], Neg(f[i]), u, f[i])]
                 if c.epi in (3, 4):
-                    e.append(isa.waitcnt(vmcnt=0))
                     if c.epi == 3:
                         for i in range(4):
                             e.append(isa.vop("v_mul_f32", f[i], f[i], gq.sub(i)))
