@@ -553,37 +553,67 @@ class Gen:
             K0, K1 = 0.7978845608028654, 0.044715
             sc = 2.0 * 1.4426950408889634
             e += [isa.vop("v_mov_b32", KC0, F32(K0 * sc)), isa.vop("v_mov_b32", KC1, F32(K0 * K1 * sc))]
-        for mb in range(n_mb):
-            row, yoff, roff, goff, bq = V(164), V(165), V(166), V(167), V(168)
-            e += [isa.vop("v_add_u32", row, mw, ql)]
+        # Row blocks as a two-stage software pipeline (epilogues 3 / 4 read a residual row block, 3 also the gate of the row's batch
+        # element): the operands of block mb + 1 are requested BEFORE block mb is waited for, with a COUNTED wait -- loads return in
+        # order, so "at most <loads of block mb + 1> outstanding" means block mb's have landed; the stores never have to be waited
+        # for.  Round 2 waited vmcnt(0) after every quad's loads: 64 dependent L2 round trips per lane, ~9 % of a K = 5120 tile's time
+        # (out-projection 1253 vs 1364 TFLOP/s for the K = 13 824 MLP-down, profiles/r03_gemm_table_modes.log).
+        # Registers (the fragment / staging registers v0..v159 are dead here): bias quads v0.., residual pairs v64.. and gate quads
+        # v96.. in two sets by block parity (mi = 32, measurement build: one set, uncounted wait).
+        pipelined = c.mi == 16 and c.epi in (3, 4)
+        nq = len(quads)
+        RP = lambda par, k: V(64 + (16 * par if pipelined else 0) + 2 * k, 2)
+        GQ = lambda par, k: V(96 + (32 * par if pipelined else 0) + 4 * k, 4)
+        ADDR = lambda par: [V((164 if par == 0 or not pipelined else 204) + i) for i in range(5)]        # row, yoff, roff, goff, bq
+
+        def addresses(mb):
+            row, yoff, roff, goff, bq = ADDR(mb & 1)
+            o_ = [isa.vop("v_add_u32", row, mw, ql)]
             if mb:
-                e += [isa.vop("v_add_u32", row, I32(rows_mb * mb), row)]
-            e += [isa.vop("v_mul_lo_u32", yoff, row, ldcb), isa.vop("v_lshl_add_u32", yoff, g, I32(3), yoff)]
+                o_ += [isa.vop("v_add_u32", row, I32(rows_mb * mb), row)]
+            o_ += [isa.vop("v_mul_lo_u32", yoff, row, ldcb), isa.vop("v_lshl_add_u32", yoff, g, I32(3), yoff)]
             if c.epi in (3, 4):
-                e += [isa.vop("v_mul_lo_u32", roff, row, ST[7]), isa.vop("v_lshl_add_u32", roff, g, I32(3), roff)]
+                o_ += [isa.vop("v_mul_lo_u32", roff, row, ST[7]), isa.vop("v_lshl_add_u32", roff, g, I32(3), roff)]
             if c.epi == 3:
                 # batch index of the row: floor((m + 0.5) / rows_per_batch); rows_per_batch == 0 -> 0
-                e += [isa.vop("v_cvt_f32_u32", bq, row), isa.vop("v_add_f32", bq, F32(0.5), bq), isa.vop("v_mul_f32", bq, bq, RCP),
-                      isa.vop("v_cvt_u32_f32", bq, bq), isa.vop("v_and_b32", bq, ST[9], bq),
-                      isa.vop("v_mul_lo_u32", goff, bq, ST[12]), isa.vop("v_lshl_add_u32", goff, g, I32(4), goff)]
-            e += [isa.v_cmp("v_cmp_lt_u32", row, S_M),
-                  Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
-            # residual / gate operands of the WHOLE row block first (fragment registers v64.. are dead here), ONE wait, then the
-            # arithmetic and the stores: round 2 waited vmcnt(0) after every quad's loads -- 64 dependent L2 round trips per lane,
-            # ~13 % of a K = 5120 tile's time (profiles/r03_gemm_table_modes.log: 1253 vs 1364 TFLOP/s for K = 5120 / 13 824)
-            RP = lambda k: V(64 + 2 * k, 2)
-            GQ = lambda k: V(96 + 4 * k, 4)
-            if c.epi in (3, 4):
-                for k, (noff, accq, bq_) in enumerate(quads):
-                    e.append(isa.global_load(2, RP(k), roff, noff * 2, saddr=S_RES, extra_reads=[EXEC]))
-                    if c.epi == 3:
-                        e.append(isa.global_load(4, GQ(k), goff, noff * 4, saddr=S_GATE, extra_reads=[EXEC]))
-                e.append(isa.waitcnt(vmcnt=0))
+                o_ += [isa.vop("v_cvt_f32_u32", bq, row), isa.vop("v_add_f32", bq, F32(0.5), bq), isa.vop("v_mul_f32", bq, bq, RCP),
+                       isa.vop("v_cvt_u32_f32", bq, bq), isa.vop("v_and_b32", bq, ST[9], bq),
+                       isa.vop("v_mul_lo_u32", goff, bq, ST[12]), isa.vop("v_lshl_add_u32", goff, g, I32(4), goff)]
+            return o_
+
+        def mask(mb):       # EXEC = rows of this block that exist (the full mask stays in S_SAVE)
+            return [isa.v_cmp("v_cmp_lt_u32", ADDR(mb & 1)[0], S_M),
+                    Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+
+        unmask = lambda: [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+
+        def loads(mb):
+            _, _, roff, goff, _ = ADDR(mb & 1)
+            o_ = []
+            for k, (noff, accq, bq_) in enumerate(quads):
+                o_.append(isa.global_load(2, RP(mb & 1, k), roff, noff * 2, saddr=S_RES, extra_reads=[EXEC]))
+                if c.epi == 3:
+                    o_.append(isa.global_load(4, GQ(mb & 1, k), goff, noff * 4, saddr=S_GATE, extra_reads=[EXEC]))
+            return o_
+
+        n_loads = nq * (2 if c.epi == 3 else 1)
+        if pipelined:
+            e += addresses(0) + mask(0) + loads(0) + unmask()
+        for mb in range(n_mb):
+            if pipelined:
+                if mb + 1 < n_mb:
+                    e += addresses(mb + 1) + mask(mb + 1) + loads(mb + 1) + unmask()
+                e += mask(mb) + [isa.waitcnt(vmcnt=n_loads if mb + 1 < n_mb else 0)]
+            else:
+                e += addresses(mb) + mask(mb)
+                if c.epi in (3, 4):
+                    e += loads(mb) + [isa.waitcnt(vmcnt=0)]
+            yoff = ADDR(mb & 1)[1]
             for k, (noff, accq, bq_) in enumerate(quads):
                 base = 170 + 16 * (k % 2)         # two rotating register groups
                 f = [V(base + i) for i in range(4)]
                 w, r_, u2 = V(base + 4, 2), V(base + 8), [V(base + 9), V(base + 10)]
-                rp, gq = RP(k), GQ(k)
+                rp, gq = RP(mb & 1, k), GQ(mb & 1, k)
                 acc = accq(mb)
                 for i in range(4):
                     e += [isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)),

@@ -75,15 +75,29 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_kernel(
 // ------------------------------------------------------------------------------------------------
 // RMSNorm over D (+ optional interleaved RoPE with per-token pair tables)
 // ------------------------------------------------------------------------------------------------
+// Output layout: row-major (row stride ldy, slab_w == 0), or COLUMN SLABS (slab_w > 0): the D columns are cut into D / slab_w
+// slabs, slab g holds a dense (rows, slab_w) matrix at y + g * slab_stride -- the send layout of the Ulysses head <-> sequence
+// all-to-all (scail_amd/parallel.py: one slab per destination rank), written by the norm itself instead of a pack pass.
+// w == nullptr: no normalisation / RoPE / scale, a plain copy into the chosen layout (the V third of the exchange).
 __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
     const u16* __restrict__ x, int64_t ldx, u16* __restrict__ y, int64_t ldy,
     const float* __restrict__ w, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
-    int64_t rows_per_batch, int D, int head_dim, float eps, float out_scale) {
+    int64_t rows_per_batch, int D, int head_dim, float eps, float out_scale, int slab_w, int64_t slab_stride) {
     __shared__ float red[4];
     const int64_t r = blockIdx.x;
     const u16* xr = x + r * ldx;
     u16* yr = y + r * ldy;
     const int nvec = D >> 3;
+    auto dst = [&](int c) -> u16* {                      // 16-byte chunk c of this row in the output layout
+        if (slab_w == 0) return yr + (int64_t)c * 8;
+        const int col = c * 8, gsl = col / slab_w;
+        return y + (int64_t)gsl * slab_stride + r * slab_w + (col - gsl * slab_w);
+    };
+    if (w == nullptr) {
+        for (int c = threadIdx.x; c < nvec; c += ROW_THREADS)
+            *reinterpret_cast<uint4*>(dst(c)) = *reinterpret_cast<const uint4*>(xr + (int64_t)c * 8);
+        return;
+    }
     float v[ROW_MAXV][8];
     float q = 0.f;
 #pragma unroll
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] *= out_scale;       // 1.0f (exact) unless the caller folds a scale into the row
-            *reinterpret_cast<uint4*>(yr + (int64_t)c * 8) = pack8(o);
+            *reinterpret_cast<uint4*>(dst(c)) = pack8(o);
         }
     }
 }
@@ -361,10 +375,9 @@ extern "C" int scail_rmsnorm_rope(const scail_bf16* x, int64_t ldx, scail_bf16* 
     return scail_rmsnorm_rope_scaled(x, ldx, y, ldy, w, cos_tab, sin_tab, rows, rows_per_batch, D, head_dim, eps, 1.0f, stream);
 }
 
-extern "C" int scail_rmsnorm_rope_scaled(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t ldy,
-                                         const float* w, const float* cos_tab, const float* sin_tab,
-                                         int64_t rows, int64_t rows_per_batch, int64_t D, int64_t head_dim,
-                                         float eps, float out_scale, void* stream) {
+static int rmsnorm_rope_launch(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t ldy, const float* w, const float* cos_tab,
+                               const float* sin_tab, int64_t rows, int64_t rows_per_batch, int64_t D, int64_t head_dim, float eps,
+                               float out_scale, int64_t slab_w, int64_t slab_stride, void* stream) {
     SCAIL_REQUIRE(D % 8 == 0 && D <= ROW_THREADS * 8 * ROW_MAXV, "D must be a multiple of 8 and <= 6144");
     SCAIL_REQUIRE(head_dim % 8 == 0 && D % head_dim == 0, "head_dim must be a multiple of 8 dividing D");
     SCAIL_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "strides must keep 16-byte alignment");
@@ -372,10 +385,29 @@ extern "C" int scail_rmsnorm_rope_scaled(const scail_bf16* x, int64_t ldx, scail
     SCAIL_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && aligned16(cos_tab) && aligned16(sin_tab),
                   "pointers must be 16-byte aligned");
     SCAIL_REQUIRE(rows_per_batch > 0, "rows_per_batch must be positive");
+    SCAIL_REQUIRE(slab_w == 0 || (slab_w % 8 == 0 && D % slab_w == 0 && slab_stride % 8 == 0 && slab_stride >= rows * slab_w),
+                  "slab width must be a multiple of 8 dividing D, slab stride a multiple of 8 and >= rows * slab_w");
     if (rows == 0) return 0;
     hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
-                       x, ldx, y, ldy, w, cos_tab, sin_tab, rows_per_batch, (int)D, (int)head_dim, eps, out_scale);
+                       x, ldx, y, ldy, w, cos_tab, sin_tab, rows_per_batch, (int)D, (int)head_dim, eps, out_scale, (int)slab_w, slab_stride);
     return scail_check_launch("rmsnorm_rope");
+}
+
+extern "C" int scail_rmsnorm_rope_scaled(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t ldy,
+                                         const float* w, const float* cos_tab, const float* sin_tab,
+                                         int64_t rows, int64_t rows_per_batch, int64_t D, int64_t head_dim,
+                                         float eps, float out_scale, void* stream) {
+    SCAIL_REQUIRE(w != nullptr, "null weight");
+    return rmsnorm_rope_launch(x, ldx, y, ldy, w, cos_tab, sin_tab, rows, rows_per_batch, D, head_dim, eps, out_scale, 0, 0, stream);
+}
+
+extern "C" int scail_rmsnorm_rope_slabs(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t slab_w, int64_t slab_stride,
+                                        const float* w, const float* cos_tab, const float* sin_tab,
+                                        int64_t rows, int64_t rows_per_batch, int64_t D, int64_t head_dim,
+                                        float eps, float out_scale, void* stream) {
+    SCAIL_REQUIRE(slab_w > 0, "slab width must be positive");
+    SCAIL_REQUIRE(w != nullptr || (cos_tab == nullptr && sin_tab == nullptr), "a plain slab copy (w == NULL) takes no RoPE tables");
+    return rmsnorm_rope_launch(x, ldx, y, 0, w, cos_tab, sin_tab, rows, rows_per_batch, D, head_dim, eps, out_scale, slab_w, slab_stride, stream);
 }
 
 extern "C" int scail_transpose_v(const scail_bf16* v, int64_t ldv, int64_t v_batch_stride,

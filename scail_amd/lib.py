@@ -22,6 +22,7 @@ SIGNATURES = {
     "scail_layernorm_affine": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _f, _p],
     "scail_rmsnorm_rope": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _p],
     "scail_rmsnorm_rope_scaled": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
+    "scail_rmsnorm_rope_slabs": [_p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
     "scail_transpose_v": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "scail_flash_attn_bf16": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],

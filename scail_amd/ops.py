@@ -131,6 +131,27 @@ def rmsnorm_rope(x, w, cos=None, sin=None, out=None, rows_per_batch=None, head_d
     return out
 
 
+def rmsnorm_rope_slabs(x, w, out, cos=None, sin=None, rows_per_batch=None, head_dim=128, eps=1e-6, out_scale=1.0):
+    """RMSNorm (+RoPE, x out_scale) of x (rows, D) (row-strided view ok) written as COLUMN SLABS: out (n_slabs, rows, D / n_slabs)
+    contiguous -- the (destination rank, token, head-group columns) send layout of the Ulysses all-to-all.  ``w`` None: plain copy of
+    x into that layout (include/scail_hip.h scail_rmsnorm_rope_slabs)."""
+    _chk(x, bf16, "rmsnorm_rope_slabs.x"); _chk(out, bf16, "rmsnorm_rope_slabs.out")
+    rows, D, ldx = _rowmajor2d(x, "rmsnorm_rope_slabs.x")
+    if out.dim() != 3 or not out.is_contiguous() or out.shape[1] != rows or out.shape[0] * out.shape[2] != D:
+        raise L.ScailHipError(f"rmsnorm_rope_slabs.out must be a contiguous (n_slabs, {rows}, {D} / n_slabs) tensor, got {tuple(out.shape)}")
+    if w is not None:
+        _chk(w, f32, "w")
+    if cos is not None:
+        _chk(cos, f32, "cos"); _chk(sin, f32, "sin")
+        assert cos.is_contiguous() and sin.is_contiguous() and cos.shape[1] == head_dim // 2
+        rows_per_batch = cos.shape[0] if rows_per_batch is None else rows_per_batch
+    else:
+        rows_per_batch = rows if rows_per_batch is None else rows_per_batch
+    L.call("scail_rmsnorm_rope_slabs", x.data_ptr(), ldx, out.data_ptr(), out.shape[2], out.stride(0), _ptr(w), _ptr(cos), _ptr(sin),
+           rows, rows_per_batch, D, head_dim, eps, float(out_scale), _stream())
+    return out
+
+
 def transpose_v(v, heads, head_dim=128, out=None):
     """v (B, Lk, heads*head_dim) bf16 (strided view ok) -> vt (B, heads, head_dim, ceil64(Lk))."""
     _chk(v, bf16, "transpose_v.v")

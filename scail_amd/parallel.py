@@ -287,9 +287,12 @@ class SequenceParallel:
             with ctx(b):
                 # projection + norm + RoPE per element: the exchange of element b runs under the projection of element b+1
                 ops.gemm(xn[b], lw["qkv_w"], lw["qkv_b"], out=qkv[b])
-                ops.rmsnorm_rope(qkv[b:b + 1, :, D:2 * D], lw["kn"], cos, sin, rows_per_batch=Ltok, eps=eps)
-                ops.rmsnorm_rope(qkv[b:b + 1, :, :D], lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps, out_scale=ops.ATTN_LOG2_SCALE)
-                send[b].copy_(qkv[b].view(Ltok, 3, N, Dn).permute(1, 2, 0, 3))           # (q|k|v, dst rank, Ltok, Dn)
+                # the norm + RoPE kernels write the SEND layout (dst rank, Ltok, Dn) themselves -- one column slab per destination
+                # rank -- instead of normalising in place and packing afterwards (the reference's `.permute().contiguous()` before
+                # all_to_all_single, sat/mpu/ulysses_attn_layer.py:65-80); v is a plain copy into the same layout
+                self.pack_rows(qkv[b, :, D:2 * D], send[b, 1], lw["kn"], cos, sin, Ltok, eps, 1.0)
+                self.pack_rows(qkv[b, :, :D], send[b, 0], lw["qn"], cos, sin, Ltok, eps, ops.ATTN_LOG2_SCALE)     # q in log2 units
+                self.pack_rows(qkv[b, :, 2 * D:], send[b, 2], None, None, None, Ltok, eps, 1.0)
                 fwd.append([self.backend.all_to_all(recv[b, j], send[b, j], async_op=True) for j in range(3)])
         bwd = []
         for b in range(B):
@@ -308,6 +311,15 @@ class SequenceParallel:
             for st in self._streams[:min(B, 2)]:
                 main.wait_stream(st)
         return att
+
+    @staticmethod
+    def pack_rows(x, out, w, cos, sin, Ltok, eps, out_scale):
+        """x (Ltok, D) view -> out (N, Ltok, D / N): RMSNorm + RoPE (w given) or plain copy (w None) straight into the send layout
+        of the head <-> sequence all-to-all.  On the GPU one kernel (scail_rmsnorm_rope_slabs); the CPU branch serves the gloo /
+        oracle-compute tests of the exchange logic and states what the kernel computes."""
+        if x.is_cuda:
+            return ops.rmsnorm_rope_slabs(x, w, out, cos, sin, rows_per_batch=Ltok, eps=eps, out_scale=out_scale)
+        raise L.ScailHipError("sequence-parallel self-attention needs GPU tensors (scail_amd has no CPU path)")
 
     def self_attention_allgather(self, net, lw, xn, qkv, vt_loc, cos, sin, att, Ltok, eps):
         """xn (B, Lloc, D) -> att (B, Lloc, D): per CFG batch element K / V projection, K norm + RoPE and the all-gather of

@@ -206,6 +206,33 @@ def test_rmsnorm_rope(ops, heads):
     assert torch.equal(o2, xg[..., D:2 * D])
 
 
+@pytest.mark.parametrize("heads,n_slabs", [(4, 2), (8, 8), (4, 1)])
+def test_rmsnorm_rope_slabs(ops, heads, n_slabs):
+    """scail_rmsnorm_rope_slabs: the q / k norm + RoPE (and the plain copy of v) written as one dense column slab per destination rank
+    = the send layout of the Ulysses all-to-all (sat/mpu/ulysses_attn_layer.py:65-80: permute + contiguous), bit-identical to the
+    row-major kernel followed by that permute."""
+    cfg = O.DiTConfig(hidden_size=128 * heads, num_attention_heads=heads, latent_height=32, latent_width=32, num_frames=13)
+    cos, sin = O.rope_tables(cfg, 3, 6, 4)
+    cg, sg = cos[:, 0::2].contiguous().to(DEV), sin[:, 0::2].contiguous().to(DEV)
+    Ltok, D = cos.shape[0], 128 * heads
+    Dn = D // n_slabs
+    x, w = rnd(Ltok, 3 * D, seed=1), (1 + 0.1 * rnd(D, seed=2)).to(DEV)
+    xg = gpu_bf16(x)
+    for col, wt, tabs, scale in ((0, w, (cg, sg), ops.ATTN_LOG2_SCALE), (1, w, (cg, sg), 1.0), (1, w, (None, None), 1.0), (2, None, (None, None), 1.0)):
+        src = xg[:, col * D:(col + 1) * D]
+        slabs = torch.full((n_slabs, Ltok, Dn), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.rmsnorm_rope_slabs(src, wt, slabs, tabs[0], tabs[1], out_scale=scale)
+        if wt is None:
+            rows = src.clone()
+        else:
+            rows = torch.empty(Ltok, D, device=DEV, dtype=torch.bfloat16)
+            ops.rmsnorm_rope(src, wt, tabs[0], tabs[1], out=rows, out_scale=scale)
+        assert torch.equal(slabs, rows.view(Ltok, n_slabs, Dn).permute(1, 0, 2)), (col, scale)
+    from scail_amd import lib as L
+    with pytest.raises(L.ScailHipError, match="contiguous"):
+        ops.rmsnorm_rope_slabs(xg[:, :D], w, torch.empty(n_slabs, Ltok + 1, Dn, device=DEV, dtype=torch.bfloat16))
+
+
 def test_rope_tables_match_oracle():
     from scail_amd import rope
     cfg = O.DiTConfig(**O.TINY)
