@@ -662,10 +662,21 @@ static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev_table, int* e
         } else if (g_gemm4_table_mode == 1) {
             // default (round 3): m-groups dealt round-robin: the 8 XCDs work on 8 ADJACENT m-groups and sweep n together, so a W
             // panel is wanted by all XCDs at about the same time (one HBM fetch, seven Infinity-Cache hits): +1.0-1.8 % on the qkv /
-            // MLP shapes over the contiguous ranges (profiles/r03_gemm_table_modes.log), neutral on the N = 5120 ones
-            for (int g = 0; g < n_groups; ++g)
+            // MLP shapes over the contiguous ranges (profiles/r03_gemm_table_modes.log), neutral on the N = 5120 ones.
+            // Only WHOLE rows of 8 groups are dealt; the tiles of the remaining < 8 groups are split evenly over the XCDs in grouped
+            // order (dealing 6 or 12 groups -- the 6 104- / 12 208-row GEMMs of one sequence-parallel rank at 8 ranks -- would leave
+            // XCDs idle or doubly loaded: measured 262 instead of ~220 ms of GEMM time per step, profiles/r03_sp8_kernel_stats.md)
+            const int dealt = n_groups / 8 * 8;
+            for (int g = 0; g < dealt; ++g)
                 for (int n = 0; n < tn; ++n)
                     for (int m = g * group_m; m < std::min((g + 1) * group_m, tm); ++m) seq[g % 8].push_back(tile(m, n));
+            std::vector<uint32_t> rest;
+            for (int g = dealt; g < n_groups; ++g)
+                for (int n = 0; n < tn; ++n)
+                    for (int m = g * group_m; m < std::min((g + 1) * group_m, tm); ++m) rest.push_back(tile(m, n));
+            const int T = (int)rest.size(), per = (T + 7) / 8;
+            for (int x = 0; x < 8; ++x)
+                for (int i = x * per; i < std::min((x + 1) * per, T); ++i) seq[x].push_back(rest[i]);
         } else {
             // (measurement build) XCD pairs share an m-group and split its n sweep in halves: 16 instead of 32 live x panels
             const int half = (tn + 1) / 2;

@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""profiles/traffic.json from a PMC summary (tools/run_r03_*.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, one counter set per
+pass, tools/rocpd_counters.py per-kernel means).  Bytes = 2 * FETCH_SIZE KiB * 1024 (the guide's gfx950 correction: 128-byte
+requests tallied at 64 bytes) + WRITE_SIZE KiB * 1024.  Each entry is stamped with the git blob id of the kernel source in the
+working tree: run it on the SAME tree the PMC passes ran on (bench.py drops an entry whose blob differs from the tree's).
+usage: python tools/update_traffic.py <pmc_summary.txt> <note>"""
+import hashlib
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def blob(path):
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def main():
+    src, note = sys.argv[1], sys.argv[2]
+    d = {}
+    for line in open(src):
+        m = re.match(r"(\S+)\s+(\S+)\s+mean/launch\s+(\S+)\s+launches\s+(\d+)", line)
+        if m:
+            d[(m.group(1), m.group(2))] = float(m.group(3))
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    tr = json.load(open(path))
+    f, w = d[("scail_attn4_m16f", "FETCH_SIZE")], d[("scail_attn4_m16f", "WRITE_SIZE")]
+    tr["flash_attn_self"] = {
+        "shape": {"B": 2, "heads": 40, "Lq": 48832, "Lk": 48832}, "fetch_kib": f, "write_kib": w,
+        "traffic_bytes": (2 * f + w) * 1024,
+        "kernel": "scail_attn4_m16f (16x16x32 MFMAs, queries in log2 units, optimistic hot loop, XCD-aware workgroup ids)",
+        "source": "attn4.s", "source_blob": blob(os.path.join(ROOT, "scail_amd", "csrc", "attn4.s")),
+        "measured": note + "; algorithmic bytes per launch = Q + K + V^T + O of 80 (batch, head) slices = 4.0 GB"}
+    # the six per-token GEMMs of a block: launches per layer e0 x 2 (qkv, cross q), e3 x 2 (attention out, MLP down), e1 (MLP up), e4 (cross out)
+    n = {"e0": 2, "e1": 1, "e3": 2, "e4": 1}
+    tf = sum(d[("scail_gemm4_" + k, "FETCH_SIZE")] * c for k, c in n.items())
+    tw = sum(d[("scail_gemm4_" + k, "WRITE_SIZE")] * c for k, c in n.items())
+    tr["gemm4_step"] = {
+        "shape": {"M": 97664, "D": 5120, "FF": 13824}, "fetch_kib_per_layer": tf, "write_kib_per_layer": tw,
+        "traffic_bytes_per_layer": (2 * tf + tw) * 1024, "traffic_bytes_per_launch_mean": (2 * tf + tw) * 1024 / 6,
+        "algorithmic_bytes_per_layer": 21.0e9,
+        "kernel": "scail_gemm4_e0 / e1 / e3 / e4, the six per-token GEMMs of one block (tools/gemm_layer_pmc_probe.py)",
+        "source": "gemm4.s", "source_blob": blob(os.path.join(ROOT, "scail_amd", "csrc", "gemm4.s")), "measured": note}
+    json.dump(tr, open(path, "w"), indent=1)
+    print(json.dumps({k: tr[k] for k in ("flash_attn_self", "gemm4_step")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
