@@ -271,6 +271,24 @@ def test_gemm_config2_size_sampled_rows(ops):
         del x, w, y
 
 
+@pytest.mark.parametrize("M,N", [(6104, 1536), (12208, 512), (24 * 256, 256), (36 * 256 + 17, 768), (70 * 256, 256), (2048, 2560)])
+def test_gemm4_tile_table_covers_every_tile(ops, M, N):
+    """the tile -> XCD order table of the generated GEMM (csrc/gemm.hip gemm4_table): whole rows of 8 m-groups dealt round-robin, the
+    remaining groups split evenly -- EVERY output tile computed exactly once for group counts below 8 (6: one sequence-parallel rank of 8),
+    between 8 and 16 (12, 9 + ragged), a multiple of 8 + remainder (17.5), and a single group; all rows against an fp32 GEMM on the GPU"""
+    K = 128
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    x = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    from scail_amd import lib as L
+    assert L.load().scail_gemm_kernel_for(K, N, 0, M, N, K, L.EPI_BIAS) == 4
+    ops.gemm(x, w, None, out=y)
+    ref = x.float() @ w.float().t()
+    assert torch.isfinite(y.float()).all(), "a tile was never written"
+    torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=1e-2)
+
+
 # ------------------------------------------------------------------------------------------------
 # every schedule of the attention kernel that can be selected (default = software-pipelined 4/4) must give the
 # same results: lock-step (2), lock-step + LDS-DMA staging (258), 4-wave x 2 workgroups (66), software-pipelined
