@@ -34,11 +34,11 @@ from . import isa, sched
 from .isa import A, S, V, I32, F32, Neg, VCC, EXEC, M0, Instr
 
 KERNARG_SIZE = 112
-KERNARG_FMT = "<7Q4q4i8x"      # x w bias y resid gate table | lda ldc ldr gs | M N K rows_per_batch
+KERNARG_FMT = "<7Q4q4i2i"      # x w bias y resid gate table | lda ldc ldr gs | M N K rows_per_batch | grid workgroups, table entries
 
 
-def pack_args(x, w, bias, y, resid, gate, table, lda, ldc, ldr, gs, M, N, K, rpb) -> bytes:
-    b = struct.pack(KERNARG_FMT, x, w, bias, y, resid, gate, table, lda, ldc, ldr, gs, M, N, K, rpb)
+def pack_args(x, w, bias, y, resid, gate, table, lda, ldc, ldr, gs, M, N, K, rpb, grid=0, entries=0) -> bytes:
+    b = struct.pack(KERNARG_FMT, x, w, bias, y, resid, gate, table, lda, ldc, ldr, gs, M, N, K, rpb, grid, entries)
     assert len(b) == KERNARG_SIZE
     return b
 
@@ -89,6 +89,8 @@ class Cfg:
     ne: int = 4            # stage "spread": pieces written right after the barrier (the other 16 - ne spread over k-steps 0-2)
     late_from: float = 1.0
     late_step: float = 3.7
+    persist: bool = False  # (dma2, mi = 16) PERSISTENT workgroups: workgroup b walks table entries b, b + grid, b + 2 grid ... and issues the
+                           # first two DMA tiles of its NEXT tile before the epilogue of the current one (see program_persistent)
     name: str = "scail_gemm4_e0"
     abl: str = ""
 
@@ -132,6 +134,10 @@ S_XLDS, S_WLDS = S(53), S(54)                # LDS byte offset of this wave's DM
 ST = [S(56 + i) for i in range(16)]          # s56..s71 temporaries
 S_SAVE = S(72, 2)
 S_WOFF, S_WMAX = S(74), S(75)                # wpacked: byte offset of the current k-tile block inside the packed W panel, its last value
+# persistent kernels: working copies of the operand pointers (the originals stay in s8..s19), the entry walked, next tile
+S_XC, S_WC, S_YC, S_BC, S_RC, S_GC = S(76, 2), S(78, 2), S(80, 2), S(82, 2), S(84, 2), S(86, 2)
+S_E, S_NVALID, S_G, S_ENT, S_M0N, S_N0N = S(88), S(89), S(90), S(91), S(92), S(93)
+S_TABC = S(94, 2)
 
 
 class Gen:
@@ -426,13 +432,14 @@ class Gen:
             for par in range(2):
                 o += [isa.vop("v_add_u32", t[8], I32(4 * par), t[6]), isa.vop("v_xor_b32", t[8], t[4], t[8]),
                       isa.vop("v_lshl_add_u32", WRADDR[0][par], t[8], I32(4), t[7]), isa.vop("v_add_u32", WRADDR[1][par], I32(65536), WRADDR[0][par])]
-        for i in range(256):
-            o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
+        zero_acc = [isa.vop("v_accvgpr_write_b32", A(i), I32(0)) for i in range(256)]
         # pipeline fill: tiles 0 and 1 in LDS (tile 2 in flight in staging set 0 for the register path), first fragments of tile 0
         if dma:
-            o += self.dma_tile(0, 0, 0) + self.dma_tile(1, 0, 0)
+            # the 32 LDS-DMA pieces go out first and the 256 accumulator clears run under their latency
+            o += self.dma_tile(0, 0, 0) + self.dma_tile(1, 0, 0) + zero_acc
             o += [isa.waitcnt(vmcnt=0), isa.barrier()]
         elif c.stage == "spread":
+            o += zero_acc
             ld = lambda q, k: isa.buffer_load(4, STG(q, *self.PIECES[k]), (XDMA if self.PIECES[k][0] == 0 else WDMA)[self.PIECES[k][1]],
                                               S_XRSRC if self.PIECES[k][0] == 0 else S_WRSRC, S_KOFF, 0)
             wr = lambda q, slot, k: isa.ds_write(16, WRADDR[slot][self.PIECES[k][1] & 1], STG(q, *self.PIECES[k]),
@@ -444,6 +451,7 @@ class Gen:
             o += [ld(1, k) for k in range(c.ne)]                                                                              # tile 3 early -> set 1
             o += [isa.waitcnt(lgkmcnt=0), isa.barrier()]
         else:
+            o += zero_acc
             o += self.load_tile(0, 0, 0) + self.load_tile(1, 0, 0) + [isa.waitcnt(vmcnt=0)]
             o += self.write_tile(0, 0, 0, 0) + self.write_tile(1, 1, 0, 0) + self.load_tile(0, 0, 0)
             o += [isa.waitcnt(lgkmcnt=0), isa.barrier()]
@@ -648,7 +656,234 @@ class Gen:
     def _pad_between_labels(seq: List[Instr]) -> List[Instr]:
         return sched.pad_hazards(seq)
 
+    # =============================================================================================
+    # PERSISTENT form (cfg.persist; dma2 + 16x16x32 only).  A 512-register workgroup has no co-resident partner, so everything
+    # around the k-loop of a tile is exposed: workgroup launch, the descriptor / address set-up, the latency of the first two k-tiles
+    # and the epilogue -- 9 % of a K = 5120 tile (profiles/r03_gemm_epilogue_probe.log: t(K) of the bias-only kernel).  Here a
+    # workgroup walks table entries b, b + grid, b + 2 grid, ... (grid is a multiple of 8, so it stays on its XCD's sequence, and the
+    # 32 workgroups of an XCD still work on 32 consecutive entries of it), and at the end of a tile it
+    #   1. requests what the epilogue needs of the CURRENT tile (bias quads, residual / gate operands of the first two row blocks),
+    #   2. looks up its NEXT tile, re-points the descriptors and issues that tile's first two k-tiles (32 LDS-DMA pieces per wave)
+    #      -- always, also when there is no next tile (the pieces then re-read the last tile; the operation counts behind the
+    #      counted waits stay static),
+    #   3. runs the epilogue of the current tile under the latency of those pieces (it touches neither LDS nor v64..v95),
+    #   4. clears the accumulators and enters the loop again.
+    # Register plan of the epilogue: bias quads v0..v31, residual pairs v96..v127 and gate quads v128..v191 in two sets by row-block
+    # parity, constants / addresses / working groups v192..v226; v64..v95 (fragment and DMA source addresses) stay live.
+    # =============================================================================================
+    def tile_setup(self, tag: str) -> List[Instr]:
+        """S_E -> S_M0N / S_N0N, descriptors and x source offsets of that tile (S_NVALID = 1), or S_NVALID = 0 and nothing touched."""
+        o: List[Instr] = []
+        ent, t = ST[13], T_        # scalar temporaries s69..s71, s64, s65: the epilogue keeps its own in ST[4..6], ST[10..12]
+        o += [isa.sop("s_mov_b32", S_NVALID, I32(0)), isa.sop("s_cmp_lt_u32", None, S_E, S_ENT), isa.branch("s_cbranch_scc0", f"L_none{tag}"),
+              isa.sop("s_lshl_b32", ST[14], S_E, I32(2)), isa.sop("s_add_u32", S_TABC.sub(0), S_TAB.sub(0), ST[14]),
+              isa.sop("s_addc_u32", S_TABC.sub(1), S_TAB.sub(1), I32(0)), isa.s_load(1, ent, S_TABC, 0), isa.waitcnt(lgkmcnt=0),
+              isa.sop("s_cmp_eq_u32", None, ent, I32(0xFFFFFFFF)), isa.branch("s_cbranch_scc1", f"L_none{tag}"),
+              isa.sop("s_mov_b32", S_NVALID, I32(1)),
+              isa.sop("s_and_b32", ST[14], ent, I32(0xFFFF)), isa.sop("s_lshr_b32", ST[15], ent, I32(16)),
+              isa.sop("s_lshl_b32", S_M0N, ST[14], I32(8)), isa.sop("s_lshl_b32", S_N0N, ST[15], I32(8)),
+              Instr("s_mov_b64", [S_XC], [S_X], cls=isa.SALU), Instr("s_mov_b64", [S_WC], [S_W], cls=isa.SALU)]
+        o += self.addr64_madd(S_XC, S_M0N, S_LDA.sub(0), 1) + self.addr64_madd(S_WC, S_N0N, S_K, 1)
+        for rs, ptr in ((S_XRSRC, S_XC), (S_WRSRC, S_WC)):
+            o += [isa.sop("s_mov_b32", rs.sub(0), ptr.sub(0)), isa.sop("s_and_b32", rs.sub(1), ptr.sub(1), I32(0xFFFF))]
+        # x source offsets: piece i of this wave = tile rows 64 w + 8 i + (lane >> 3) clamped to the tile's last valid row, chunk
+        # (lane & 7) ^ ((row >> 1) & 7) of the 128-byte k-row (as in prologue(); W's do not depend on the tile)
+        mlast, ldab = ST[8], ST[9]
+        o += [isa.sop("s_sub_u32", mlast, S_M, S_M0N), isa.sop("s_sub_u32", mlast, mlast, I32(1)),
+              isa.sop("s_lshl_b32", ldab, S_LDA.sub(0), I32(1)),
+              isa.vop("v_lshrrev_b32", t[3], I32(3), LANE), isa.vop("v_and_b32", t[4], I32(7), LANE), isa.vop("v_lshlrev_b32", t[5], I32(6), S_WAVE)]
+        for i in range(8):
+            o += [isa.vop("v_add_u32", t[6], I32(8 * i), t[3]), isa.vop("v_add_u32", t[6], t[6], t[5]),
+                  isa.vop("v_lshrrev_b32", t[7], I32(1), t[6]), isa.vop("v_and_b32", t[7], I32(7), t[7]), isa.vop("v_xor_b32", t[7], t[4], t[7]),
+                  isa.vop("v_min_u32", t[8], t[6], mlast), isa.vop("v_mul_lo_u32", t[8], t[8], ldab),
+                  isa.vop("v_lshl_add_u32", t[8], t[7], I32(4), t[8]), isa.vop("v_subrev_u32", XDMA[i], I32(1024 * (i & 3)), t[8])]
+        o += [isa.label(f"L_none{tag}"), isa.nop(7),
+              isa.sop("s_mov_b32", S_KOFF, I32(0))]
+        return o
+
+    def program_persistent(self) -> List[Instr]:
+        c = self.cfg
+        assert c.stage == "dma2" and c.mi == 16 and not c.wpacked and not c.stagger
+        # ---- once per workgroup: everything of prologue() that does not depend on the tile --------------------------------------
+        o: List[Instr] = [isa.label(c.name)]
+        o += [isa.s_load(8, S(8, 8), S_KARG, 0), isa.s_load(4, S(16, 4), S_KARG, 32), isa.s_load(2, S_TAB, S_KARG, 48),
+              isa.s_load(8, S(24, 8), S_KARG, 56), isa.s_load(4, S(32, 4), S_KARG, 88), isa.s_load(2, S(S_G.idx, 2), S_KARG, 104),
+              isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", T_[0], I32(6), V(0)),
+              isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, T_[0]),
+              isa.sop("s_mov_b32", S_E, S_WG),
+              isa.sop("s_lshr_b32", S_WM, S_WAVE, I32(1)), isa.sop("s_and_b32", S_WN, S_WAVE, I32(1))]
+        for rs in (S_XRSRC, S_WRSRC):
+            o += [isa.sop("s_mov_b32", rs.sub(2), I32(0xFFFFFFFF)), isa.sop("s_mov_b32", rs.sub(3), I32(0x00020000))]
+        kb2 = ST[7]
+        o += [isa.sop("s_lshl_b32", kb2, S_K, I32(1)),
+              isa.sop("s_lshr_b32", S_KT, S_K, I32(6)), isa.sop("s_sub_u32", ST[8], S_KT, I32(1)), isa.sop("s_lshl_b32", S_KMAX, ST[8], I32(7)),
+              isa.sop("s_lshl_b32", S_XLDS, S_WAVE, I32(13)), isa.sop("s_add_u32", S_WLDS, S_XLDS, I32(32768))]
+        ql, g, t = T_[1], T_[2], T_
+        o += [isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
+        o += [isa.vop("v_lshrrev_b32", t[3], I32(1), ql), isa.vop("v_and_b32", t[3], I32(7), t[3]), isa.vop("v_lshlrev_b32", t[4], I32(7), ql),
+              isa.vop("v_lshlrev_b32", t[5], I32(14), S_WM), isa.vop("v_add_u32", t[5], t[5], t[4]),
+              isa.vop("v_lshlrev_b32", t[6], I32(14), S_WN), isa.vop("v_add_u32", t[6], t[6], t[4]),
+              isa.vop("v_add_u32", t[6], I32(32768), t[6])]
+        for ks in range(2):
+            o += [isa.vop("v_or_b32", t[7], I32(4 * ks), g), isa.vop("v_xor_b32", t[7], t[7], t[3]),
+                  isa.vop("v_lshl_add_u32", XADDR[0][ks], t[7], I32(4), t[5]), isa.vop("v_lshl_add_u32", WADDR[0][ks], t[7], I32(4), t[6]),
+                  isa.vop("v_add_u32", XADDR[1][ks], I32(65536), XADDR[0][ks]), isa.vop("v_add_u32", WADDR[1][ks], I32(65536), WADDR[0][ks])]
+        # W source offsets (tile independent: the descriptor base carries n0)
+        o += [isa.vop("v_lshrrev_b32", t[3], I32(3), LANE), isa.vop("v_and_b32", t[4], I32(7), LANE), isa.vop("v_lshlrev_b32", t[5], I32(6), S_WAVE)]
+        for i in range(8):
+            o += [isa.vop("v_add_u32", t[6], I32(8 * i), t[3]), isa.vop("v_add_u32", t[6], t[6], t[5]),
+                  isa.vop("v_lshrrev_b32", t[7], I32(1), t[6]), isa.vop("v_and_b32", t[7], I32(7), t[7]), isa.vop("v_xor_b32", t[7], t[4], t[7]),
+                  isa.vop("v_mul_lo_u32", t[9], t[6], kb2), isa.vop("v_lshl_add_u32", t[9], t[7], I32(4), t[9]),
+                  isa.vop("v_subrev_u32", WDMA[i], I32(1024 * (i & 3)), t[9])]
+        # ---- the first tile: nothing to overlap with ------------------------------------------------------------------------------
+        o += self.tile_setup("_first")
+        o += [isa.sop("s_cmp_eq_u32", None, S_NVALID, I32(0)), isa.branch("s_cbranch_scc1", "L_exit"),
+              isa.sop("s_mov_b32", S_M0T, S_M0N), isa.sop("s_mov_b32", S_N0T, S_N0N)]
+        zero_acc = [isa.vop("v_accvgpr_write_b32", A(i), I32(0)) for i in range(256)]
+        o += self.dma_tile(0, 0, 0) + self.dma_tile(1, 0, 0) + zero_acc
+        o += [isa.waitcnt(vmcnt=0), isa.barrier(), isa.label("L_enter"), isa.nop(7), isa.sop("s_mov_b32", S_T, I32(0))]
+        o = sched.pad_hazards(sched.insert_lgkm_waits(o))
+        o += self.first_reads()
+        # ---- the k-loop (unchanged) -------------------------------------------------------------------------------------------------
+        o += self.loop()                                  # ends: L_done, vmcnt(0), lgkmcnt(0)
+        # ---- tile end ---------------------------------------------------------------------------------------------------------------
+        e: List[Instr] = [isa.barrier()]                  # every wave has read its last fragments: both LDS slots are free
+        n_mb, rows_mb = 8, 16
+        quads = [(16 * nb, (lambda mb, nb=nb: ACC16(nb, mb)), V(nb * 4, 4)) for nb in range(8)]
+        nq = len(quads)
+        nw, mw, ldcb = ST[4], ST[5], ST[6]
+        e += [isa.sop("s_lshl_b32", nw, S_WN, I32(7)), isa.sop("s_add_u32", nw, nw, S_N0T)]
+        e += [Instr("s_mov_b64", [S_YC], [S_Y], cls=isa.SALU)] + self.addr64_madd(S_YC, nw, I32(1), 1)
+        for i in range(32):
+            e.append(isa.vop("v_mov_b32", V(i), I32(0)))
+        # 1. what the epilogue needs of this tile: bias quads ...
+        e += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias"),
+              Instr("s_mov_b64", [S_BC], [S_BIAS], cls=isa.SALU)]
+        e += self.addr64_madd(S_BC, nw, I32(1), 2)
+        e += [isa.vop("v_lshlrev_b32", t[3], I32(4), g)]
+        for noff, _, bq_ in quads:
+            e.append(isa.global_load(4, bq_, t[3], noff * 4, saddr=S_BC))
+        e += [isa.label("L_nobias"), isa.nop(7)]
+        e += [isa.sop("s_lshl_b32", mw, S_WM, I32(7)), isa.sop("s_add_u32", mw, mw, S_M0T)]
+        RCP, KC0, KC1 = V(192), V(193), V(194)
+        ldrb = ST[10]
+        if c.epi in (3, 4):
+            e += [Instr("s_mov_b64", [S_RC], [S_RES], cls=isa.SALU)] + self.addr64_madd(S_RC, nw, I32(1), 1)
+            e += [isa.sop("s_lshl_b32", ldrb, S_LDR.sub(0), I32(1))]
+        if c.epi == 3:
+            e += [Instr("s_mov_b64", [S_GC], [S_GATE], cls=isa.SALU)] + self.addr64_madd(S_GC, nw, I32(1), 2)
+            e += [isa.vop("v_cvt_f32_u32", RCP, S_RPB), isa.vop("v_rcp_f32", RCP, RCP),
+                  isa.sop("s_cmp_eq_u32", None, S_RPB, I32(0)), isa.sop("s_cselect_b32", ST[11], I32(0), I32(0xFFFFFFFF)),
+                  isa.sop("s_lshl_b32", ST[12], S_GS.sub(0), I32(2))]
+        if c.epi == 1:
+            K0, K1 = 0.7978845608028654, 0.044715
+            sc = 2.0 * 1.4426950408889634
+            e += [isa.vop("v_mov_b32", KC0, F32(K0 * sc)), isa.vop("v_mov_b32", KC1, F32(K0 * K1 * sc))]
+        e += [isa.sop("s_lshl_b32", ldcb, S_LDC.sub(0), I32(1))]
+        RP = lambda par, k: V(96 + 16 * par + 2 * k, 2)
+        GQ = lambda par, k: V(128 + 32 * par + 4 * k, 4)
+        ADDR = lambda par: [V(195 + 5 * par + i) for i in range(5)]        # row, yoff, roff, goff, bq
+
+        def addresses(mb):
+            row, yoff, roff, goff, bq = ADDR(mb & 1)
+            o_ = [isa.vop("v_add_u32", row, mw, ql)]
+            if mb:
+                o_ += [isa.vop("v_add_u32", row, I32(rows_mb * mb), row)]
+            o_ += [isa.vop("v_mul_lo_u32", yoff, row, ldcb), isa.vop("v_lshl_add_u32", yoff, g, I32(3), yoff)]
+            if c.epi in (3, 4):
+                o_ += [isa.vop("v_mul_lo_u32", roff, row, ldrb), isa.vop("v_lshl_add_u32", roff, g, I32(3), roff)]
+            if c.epi == 3:
+                o_ += [isa.vop("v_cvt_f32_u32", bq, row), isa.vop("v_add_f32", bq, F32(0.5), bq), isa.vop("v_mul_f32", bq, bq, RCP),
+                       isa.vop("v_cvt_u32_f32", bq, bq), isa.vop("v_and_b32", bq, ST[11], bq),
+                       isa.vop("v_mul_lo_u32", goff, bq, ST[12]), isa.vop("v_lshl_add_u32", goff, g, I32(4), goff)]
+            return o_
+
+        def mask(mb):
+            return [isa.v_cmp("v_cmp_lt_u32", ADDR(mb & 1)[0], S_M),
+                    Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+
+        unmask = lambda: [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+
+        def loads(mb):
+            _, _, roff, goff, _ = ADDR(mb & 1)
+            o_ = []
+            if c.epi in (3, 4):
+                for k, (noff, accq, bq_) in enumerate(quads):
+                    o_.append(isa.global_load(2, RP(mb & 1, k), roff, noff * 2, saddr=S_RC, extra_reads=[EXEC]))
+                    if c.epi == 3:
+                        o_.append(isa.global_load(4, GQ(mb & 1, k), goff, noff * 4, saddr=S_GC, extra_reads=[EXEC]))
+            return o_
+
+        n_loads = nq * (2 if c.epi == 3 else 1 if c.epi == 4 else 0)
+        # ... and the residual / gate operands of the first two row blocks (both register sets are free here)
+        for mb in (0, 1):
+            e += addresses(mb) + mask(mb) + loads(mb) + unmask()
+        # 2. the next tile: descriptors, source offsets, its first two k-tiles (issued unconditionally, see above)
+        e += [isa.sop("s_add_u32", S_E, S_E, S_G)]
+        e += self.tile_setup("_next")
+        n_dma = 32
+        e += self.dma_tile(0, 0, 0) + self.dma_tile(1, 0, 0)
+        # 3. the epilogue of the current tile.  Vector-memory operations retire in issue order: a counted wait names how many
+        #    operations issued AFTER the wanted ones may still be in flight.
+        for mb in range(n_mb):
+            if mb >= 1 and mb + 1 < n_mb:
+                e += addresses(mb + 1) + mask(mb + 1) + loads(mb + 1) + unmask()
+            if mb == 0:
+                after = n_loads + n_dma                       # block 1's operands, the DMA pieces
+            elif mb == 1:
+                after = n_dma + nq + n_loads                  # the DMA pieces, block 0's stores, block 2's operands
+            else:
+                after = nq + (n_loads if mb + 1 < n_mb else 0)
+            e += mask(mb) + [isa.waitcnt(vmcnt=min(after, 63))]
+            yoff = ADDR(mb & 1)[1]
+            for k, (noff, accq, bq_) in enumerate(quads):
+                base = 205 + 11 * (k % 2)
+                f = [V(base + i) for i in range(4)]
+                w, r_, u2 = V(base + 4 + ((base + 4) & 1), 2), V(base + 7), [V(base + 8), V(base + 9)]
+                rp, gq = RP(mb & 1, k), GQ(mb & 1, k)
+                acc = accq(mb)
+                for i in range(4):
+                    e += [isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)), isa.vop("v_add_f32", f[i], f[i], bq_.sub(i))]
+                if c.epi == 1:
+                    for i in range(4):
+                        u = u2[i & 1]
+                        e += [isa.vop("v_mul_f32", u, f[i], f[i]), isa.vop("v_fma_f32", u, u, KC1, KC0),
+                              isa.vop("v_mul_f32", u, u, f[i]), isa.vop("v_exp_f32", u, u), isa.vop("v_add_f32", u, F32(1.0), u),
+                              isa.vop("v_rcp_f32", u, u), isa.vop("v_fma_f32", f[i], Neg(f[i]), u, f[i])]
+                if c.epi in (3, 4):
+                    if c.epi == 3:
+                        for i in range(4):
+                            e.append(isa.vop("v_mul_f32", f[i], f[i], gq.sub(i)))
+                    for i in range(4):
+                        src = rp.sub(i >> 1)
+                        e += [isa.vop("v_lshlrev_b32", r_, I32(16), src) if (i & 1) == 0 else isa.vop("v_and_b32", r_, I32(0xFFFF0000), src),
+                              isa.vop("v_add_f32", f[i], f[i], r_)]
+                st = isa.global_store(2, yoff, w, noff * 2, saddr=S_YC, extra_reads=[EXEC])
+                if c.nt_store:
+                    st.text += " nt"
+                e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]), st]
+            e += unmask()
+        # 4. next tile (its DMA pieces are older than everything the epilogue issued: with at most 63 operations left in flight
+        #    they have landed) or the end
+        e += [isa.sop("s_cmp_eq_u32", None, S_NVALID, I32(0)), isa.branch("s_cbranch_scc1", "L_exit"),
+              isa.sop("s_mov_b32", S_M0T, S_M0N), isa.sop("s_mov_b32", S_N0T, S_N0N)]
+        e += [isa.vop("v_accvgpr_write_b32", A(i), I32(0)) for i in range(256)]
+        e += [isa.waitcnt(vmcnt=0 if (n_loads * 6 + nq * 8) < 63 else 63), isa.barrier(), isa.branch("s_branch", "L_enter")]
+        e += [isa.label("L_exit"), isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
+        prog = o + sched.pad_hazards(sched.insert_lgkm_waits(e))
+        return prog
+
     def program(self) -> List[Instr]:
+        if self.cfg.persist:
+            prog = self.program_persistent()
+            pre = f"L_{self.cfg.name}"
+            for i in prog:
+                if i.label and i.label.startswith("L_"):
+                    new = pre + i.label[1:]
+                    if getattr(i, "text", None):
+                        i.text = i.text.replace(i.label, new)
+                    i.label = new
+            return prog
         prog = self.prologue() + self.loop() + self.epilogue()
         pre = f"L_{self.cfg.name}"
         for i in prog:
@@ -766,6 +1001,7 @@ def pack_w(w_bits, N: int, K: int):
 
 def variant_cfgs():
     out = [Cfg(epi=e, name=f"scail_gemm4_e{e}_reg") for e in (0, 1, 3, 4)]       # round-2 first version: register staging, 32x32x16
+    out += [Cfg(epi=e, name=f"scail_gemm4_e{e}_pst", persist=True, **SHIPPED) for e in (0, 1, 3, 4)]      # round 3: persistent workgroups
     for cap in (2, 4):
         out.append(Cfg(epi=0, cap=cap, name=f"scail_gemm4_e0_c{cap}"))
     out.append(Cfg(epi=0, stage="dma", name="scail_gemm4_e0_lds_dma"))

@@ -585,7 +585,7 @@ struct Gemm4Args {
     const void* x; const void* w; const void* bias; void* y; const void* resid; const void* gate; const void* table;
     int64_t lda, ldc, ldr, gs;
     int32_t M, N, K, rows_per_batch;
-    int32_t pad[2];
+    int32_t grid, entries;      // persistent kernels: workgroups launched (a multiple of 8) and entries of the order table
 };
 static_assert(sizeof(Gemm4Args) == 112, "Gemm4Args must match asmgen/gemm4.py KERNARG_SIZE");
 // per-device caches (a code object / a hipMalloc'd table belongs to the device that was current when it was created)
@@ -701,6 +701,20 @@ static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev_table, int* e
     return 0;
 }
 
+static int gemm4_cu_count() {
+    static std::map<int, int> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_gemm4_mutex);
+    auto it = cache.find(dev);
+    if (it == cache.end()) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        it = cache.emplace(dev, n).first;
+    }
+    return it->second;
+}
+
 // Frees the tile-order tables of EVERY device (scail_release_caches, include/scail_hip.h): call with no launch in flight.
 int scail_gemm4_release_tables() {
     std::lock_guard<std::mutex> lk(g_gemm4_mutex);
@@ -773,7 +787,7 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
         const int epi4 = epilogue == SCAIL_EPI_RESID ? (gate != nullptr ? 3 : 4) : epilogue;
         const bool is8 = g_gemm4_mode == 8;
         std::string name = std::string(is8 ? "scail_gemm8_e" : "scail_gemm4_e") + std::to_string(epi4);
-        if (epi4 == 0) name += g_gemm4_suffix;            // A/B variants exist for the bias epilogue only (ablation build)
+        if (epi4 == 0 || g_gemm4_suffix == "_pst") name += g_gemm4_suffix;      // A/B variants: bias epilogue only, except the persistent set (ablation build)
         hipFunction_t fn;
         if (int rc = gemm4_function(name, &fn)) return rc;
         uint32_t* table;
@@ -783,10 +797,19 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
         a.x = x; a.w = w; a.bias = bias; a.y = y; a.resid = resid; a.gate = gate; a.table = table;
         a.lda = lda; a.ldc = ldc; a.ldr = ldr; a.gs = gate_stride;
         a.M = (int32_t)M; a.N = (int32_t)N; a.K = (int32_t)K; a.rows_per_batch = (int32_t)rows_per_batch;
-        a.pad[0] = a.pad[1] = 0;
+        // persistent kernels (name ends in "_pst"): one workgroup per CU, rounded down to a multiple of 8 so that workgroup b keeps
+        // walking the sequence of XCD b % 8 (entries b, b + grid, b + 2 grid, ...)
+        unsigned grid = (unsigned)entries;
+        const bool persistent = name.size() > 4 && name.compare(name.size() - 4, 4, "_pst") == 0;
+        if (persistent) {
+            int cus = gemm4_cu_count();
+            if (cus < 8) cus = 8;
+            grid = std::min<unsigned>((unsigned)entries, (unsigned)(cus / 8 * 8));
+        }
+        a.grid = (int32_t)grid; a.entries = (int32_t)entries;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)entries, 1, 1, is8 ? 512 : 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
+        hipError_t e = hipModuleLaunchKernel(fn, grid, 1, 1, is8 ? 512 : 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
         if (e != hipSuccess) {
             scail_set_error(std::string("gemm4: launch failed: ") + hipGetErrorString(e));
             return 2;

@@ -35,7 +35,9 @@ def _variant(name):
                                         ("scail_gemm4p_e3", (264, 256, 448)),             # ... 7 k-tiles
                                         ("scail_gemm4_e0_reg", (300, 256, 192)),          # measurement build: register staging, 32x32x16
                                         ("scail_gemm4_e0_dma2", (300, 256, 320)),         # ... LDS-DMA two tiles deep, 32x32x16
-                                        ("scail_gemm4_e0_spread", (256, 256, 256))])
+                                        ("scail_gemm4_e0_spread", (256, 256, 256)),
+                                        ("scail_gemm4_e3_pst", (1300, 512, 192)),         # measurement build: persistent workgroups, 12 tiles on 8 workgroups
+                                        ("scail_gemm4_e0_pst", (520, 256, 128))])         # ... 3 tiles, idle workgroups
 def test_gemm4_emulated(name, shape):
     cfg = _variant(name)
     assert R.check_static(cfg) == [], "hazard distances of the generated loop / prologue"

@@ -20,7 +20,7 @@ def gelu_tanh(x):
     return 0.5 * x * (1.0 + np.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
 
 
-def run(cfg: gemm4.Cfg, x, w, bias=None, resid=None, gate=None, rows_per_batch=0, lda=None, lazy=True):
+def run(cfg: gemm4.Cfg, x, w, bias=None, resid=None, gate=None, rows_per_batch=0, lda=None, lazy=True, grid=8):
     """x (M, K), w (N, K), bias (N) | None, resid (M, N) | None, gate (nb, N) | None  (fp32 in; bf16 operands)."""
     M, K = x.shape
     N = w.shape[0]
@@ -38,9 +38,11 @@ def run(cfg: gemm4.Cfg, x, w, bias=None, resid=None, gate=None, rows_per_batch=0
     table = np.array(gemm4.tile_table(M, N), dtype=np.uint32)
     pt = mem.alloc("table", table)
     prog = gemm4.Gen(cfg).program()
-    args = gemm4.pack_args(px, pw, pb, py, pr, pg, pt, lda, N, N, N if gate is not None else 0, M, N, K, rows_per_batch)
+    # persistent kernels: fewer workgroups than tiles (a multiple of 8, like the launcher's), each walks entries wg, wg + grid, ...
+    grid = min(len(table), grid) if getattr(cfg, "persist", False) else len(table)
+    args = gemm4.pack_args(px, pw, pb, py, pr, pg, pt, lda, N, N, N if gate is not None else 0, M, N, K, rows_per_batch, grid, len(table))
     stats = None
-    for wg in range(len(table)):
+    for wg in range(grid):
         emu = E.Emu(prog, mem, n_waves=4, lds_bytes=131072, lazy=lazy)
         emu.launch(args, block_id=(wg, 0, 0))
         stats = emu.waves[0].stats
@@ -64,6 +66,8 @@ def reference(cfg, x, w, bias=None, resid=None, gate=None, rows_per_batch=0):
 
 def check_static(cfg):
     g = gemm4.Gen(cfg)
+    if getattr(cfg, "persist", False):
+        return sched.check_hazards(g.loop() + g.loop()) + sched.check_hazards([i for i in g.program()])
     lp = g.loop()
     return sched.check_hazards(lp + lp) + sched.check_hazards(g.prologue() + lp)
 
