@@ -2,7 +2,16 @@
 
 Reference call site: F.scaled_dot_product_attention in sat/transformer_defaults.py:67-72 reached from
 dit_video_crossattn_sc_xc.py:1058-1105 (no mask, scale 1/sqrt(128)); same C entry point as the 8-wave kernel of
-csrc/attn.hip (scail_flash_attn_bf16), which selects this kernel for long key sequences (Lk % 64 == 0, no accumulate).
+csrc/attn.hip (scail_flash_attn_bf16), which selects the kernel generated here for Lk >= 512 without accumulate.
+
+Two kernel families come out of this generator:
+  * ``M16F`` = scail_attn4_m16f, THE SHIPPED KERNEL (Cfg(mi=16, fold, lsum, ragged, qscale, opt, pv_qb)): 16x16x32 MFMAs, scores in
+    log2 units (q arrives multiplied by scale * log2 e, or the prologue multiplies the Q fragments for raw-scale callers), the
+    reference maximum folded into the accumulator init of the first QK^T MFMA, row sums on the matrix pipe, any key count, an
+    optimistic hot loop that tracks no maximum and is verified on the row sums (see Cfg.opt), P.V in query-block-major order;
+  * ``DEFAULT`` = scail_attn4, the 32x32x16 kernel of round 2 (scale per score, lazy running maximum in every iteration): measurement
+    build and emulator tests only.
+The description below is the common structure (register map of the 32x32x16 form; the 16x16x32 maps are the ``*16`` helpers).
 
 Shape of the kernel (MI355X guide: "4-wave, one-wave-per-SIMD" attention structure):
   * workgroup = 256 query rows = 4 waves x 64 rows; ONE wave per SIMD with the whole 512-register file:
@@ -21,11 +30,13 @@ Shape of the kernel (MI355X guide: "4-wave, one-wave-per-SIMD" attention structu
                                               phase B: P(t) V(t)  ||  row max of S(t+1)             ||  K(t+2) fragment reads
     The non-MFMA instructions are placed into the gaps between MFMAs by sched.schedule (<= CAP per gap).
   * online softmax with a LAZY running max: the O / l rescale (an out-of-line subroutine) runs only when some row's tile
-    maximum exceeds the running maximum by more than ``thr`` (raw-score units; kernel argument): exact arithmetic otherwise
-    (P <= 2^(thr * scale * log2 e)), and on random or real data it fires once per block.
+    maximum exceeds the running maximum by more than ``thr`` (kernel argument; raw-score units for DEFAULT, log2 units for the fold
+    kernels): exact arithmetic otherwise, and on random or real data it fires once per block.  M16F's hot loop drops even that check
+    (Cfg.opt) and keeps it in the remainder iterations and in the second pass of a workgroup whose optimistic pass overflowed.
 
-Limits of this version (the C entry falls back to the 8-wave kernel otherwise): Lk % 64 == 0, head_dim 128, no accumulate;
-Lq * q_rs, Lk * k_rs and 128 * Lkp below 2^31 elements (32-bit byte offsets inside one (batch, head) slice).
+Limits (the C entry falls back to the 8-wave kernel otherwise): head_dim 128, no accumulate, Lk >= 512 (any count for M16F, whole
+64-key tiles for DEFAULT); Lq * q_rs, Lk * k_rs and 128 * Lkp below 2^31 elements (32-bit byte offsets inside one (batch, head) slice);
+(Lq / 256)^2 * heads * batch below 2^31 (reciprocal-multiplication decode of the workgroup id).
 """
 from __future__ import annotations
 

@@ -921,15 +921,6 @@ int scail_conv_tune(int v);
 static int g_attn_variant = 8 | (2 << 12);
 extern "C" int scail_tune_set(const char* knob, int value) {
     if (std::string(knob) == "attn_variant") {
-#if 0
-        // timing ablations (wrong results on purpose; tools/microbench.py): lock-step bits 4 / 5, software-pipelined sub-code 5
-        const int low = value & 0xFFFFF;
-        if (low == 18 || low == 34 || low == 50 || ((value & 8) && ((value >> 12) & 15) == 5)) {
-            scail_set_error("scail_tune_set: attn_variant " + std::to_string(value) +
-                            " is a timing ablation (wrong results); rebuild with SCAIL_ABLATIONS=1 to enable it");
-            return 1;
-        }
-#endif
         if (value & (512 | 1024 | 2048)) {
             scail_set_error("scail_tune_set: attn_variant " + std::to_string(value) + " selects a removed kernel (half-tile pipelines)");
             return 1;

@@ -289,6 +289,23 @@ def test_gemm4_tile_table_covers_every_tile(ops, M, N):
     torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=1e-2)
 
 
+def test_release_caches_then_relaunch(ops):
+    """scail_release_caches frees the per-device tile-order tables; the next launch of a grid re-creates what it needs"""
+    from scail_amd import lib as L
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(2304, 128, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(512, 128, device=DEV, generator=g) / math.sqrt(128)).to(torch.bfloat16)
+    y0 = ops.gemm(x, w, None)
+    torch.cuda.synchronize()
+    L.call("scail_release_caches")
+    y1 = ops.gemm(x, w, None)
+    L.call("scail_release_caches")
+    L.call("scail_release_caches")                       # idempotent
+    y2 = ops.gemm(x, w, None)
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+    torch.testing.assert_close(y0.float(), x.float() @ w.float().t(), rtol=1e-2, atol=1e-2)
+
+
 # ------------------------------------------------------------------------------------------------
 # every schedule of the attention kernel that can be selected (default = software-pipelined 4/4) must give the
 # same results: lock-step (2), lock-step + LDS-DMA staging (258), 4-wave x 2 workgroups (66), software-pipelined
