@@ -209,7 +209,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 // the patch costs 4 input frames per 2 outputs instead of 3 per 1, and there are half as many barriers per MFMA.
 // KT: temporal taps (3, or 1 for the 1x3x3 convolution behind the nearest 2x upsample: UPS, patch voxel (h, w) reads input
 // (h >> 1, w >> 1); no temporal halo, 3 tap rows per slice).
-template <int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1, int KT = 3, bool UPS = false> struct HaloCfg {
+template <int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1, int KT = 3, bool UPS = false, int PF = 0> struct HaloCfg {
     static constexpr int PS = SWZ ? CS : CS + 8, WS = SWZ ? 3 * CS : 3 * CS + 8;   // strides in elements
     static constexpr int PVOX = (NF + KT - 1) * HT_FVOX;
     static constexpr int PCH = PVOX * (CS / 8), WCH = BN * 3 * (CS / 8);
@@ -217,7 +217,10 @@ template <int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1, int KT = 3
     static constexpr int LDS = (PVOX * PS + NWB * BN * WS) * 2;
 };
 
-template <int EPI, int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1, int KT = 3, bool UPS = false>   // BN = 96 (three 32-channel blocks) or 32 (narrow outputs: the RGB head)
+// PF: fragment prefetch.  0 = reads where the source puts them (hipcc issues them just in time: `ds_read; s_waitcnt; mfma`, the LDS
+// latency of every group is exposed to the wave and only the SIMD's other wave covers it); 1 = the fragments of tap dw + 1 (2 k-steps x
+// (NF + NBLK) reads) are requested, behind a scheduling barrier, before the MFMAs of tap dw run.
+template <int EPI, int CS, int NWB, bool SWZ = false, int BN = 96, int NF = 1, int KT = 3, bool UPS = false, int PF = 0>   // BN = 96 (three 32-channel blocks) or 32 (narrow outputs: the RGB head)
 __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_kernel(ConvParams p) {
     using Cfg = HaloCfg<CS, NWB, SWZ, BN, NF, KT>;
     constexpr int NBLK = BN / 32, HT_PVOX = Cfg::PVOX;
@@ -309,6 +312,7 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
             const int toff = (dt * (HT_TH + 2) + dh) * (HT_TW + 2);
             const u16* pr_ = pa + toff * PS;
             const u16* wr_ = wb + cur * BN * WS;
+            if constexpr (PF == 0) {
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
 #pragma unroll
@@ -325,6 +329,34 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
 #pragma unroll
                         for (int f = 0; f < NF; ++f) acc[f][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[f], acc[f][nb], 0, 0, 0);
                     }
+                }
+            }
+            } else {
+                static_assert(!SWZ || PF == 0, "the prefetch variant uses the padded layout");
+                constexpr int KS = CS / 16;
+                bf16x8 xfb[2][KS][NF], wfb[2][KS][NBLK];
+                auto fetch = [&](int b, int dw) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) xfb[b][ks][f] = *reinterpret_cast<const bf16x8*>(pr_ + (f * HT_FVOX + dw) * PS + ks * 16);
+#pragma unroll
+                        for (int nb = 0; nb < NBLK; ++nb) wfb[b][ks][nb] = *reinterpret_cast<const bf16x8*>(wr_ + nb * 32 * WS + dw * CS + wsw[ks]);
+                    }
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    if (dw + 1 < 3) fetch((dw + 1) & 1, dw + 1);
+                    __builtin_amdgcn_sched_barrier(0);       // the requests of tap dw + 1 stay in front of the MFMAs of tap dw
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                        for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+                            for (int f = 0; f < NF; ++f)
+                                acc[f][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfb[dw & 1][ks][nb], xfb[dw & 1][ks][f], acc[f][nb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (NWB == 1) __syncthreads();           // single buffer: every wave has read this row's tile
@@ -625,7 +657,7 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_, ##__VA_ARGS__>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
     }
         const int hbn = p.N <= 32 ? 32 : 96;
-        const int nf = ((g_conv_halo == 4 || fuse) && hbn == 96 && p.To >= 2) ? 2 : 1;   // output frames per workgroup (an odd last frame pair wastes half a tile: 1 / 81)
+        const int nf = ((g_conv_halo == 4 || g_conv_halo == 5 || fuse) && hbn == 96 && p.To >= 2) ? 2 : 1;   // output frames per workgroup (an odd last frame pair wastes half a tile: 1 / 81)
         if (fuse) {                                                        // fused RMS_norm + SiLU epilogue: one N tile
             SCAIL_REQUIRE(p.N <= 96 && resid == nullptr && (reinterpret_cast<uintptr_t>(gamma) & 15) == 0,
                           "conv + norm fusion needs N <= 96, no residual, 16-byte aligned gamma");
@@ -638,6 +670,10 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
         if (hbn == 32) {
             if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 32) else HALO_LAUNCH(0, 32, 1, false, 32)
+#ifdef SCAIL_ABLATIONS
+        } else if (nf == 2 && g_conv_halo == 5) {                          // fragment prefetch one tap ahead (A/B)
+            if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96, 2, 3, false, 1) else HALO_LAUNCH(0, 32, 1, false, 96, 2, 3, false, 1)
+#endif
         } else if (nf == 2) {
             if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96, 2) else HALO_LAUNCH(0, 32, 1, false, 96, 2)
 #ifdef SCAIL_ABLATIONS
