@@ -44,6 +44,21 @@ def main():
         "algorithmic_bytes_per_layer": 21.0e9,
         "kernel": "scail_gemm4_e0 / e1 / e3 / e4, the six per-token GEMMs of one block (tools/gemm_layer_pmc_probe.py)",
         "source": "gemm4.s", "source_blob": blob(os.path.join(ROOT, "scail_amd", "csrc", "gemm4.s")), "measured": note}
+    # the dominant VAE convolution launches (tools/conv_pmc_probe.py, one shape per PMC run: lines "conv C=<C> <counter> <value>")
+    conv = {}
+    for line in open(src):
+        m = re.match(r"conv C=(\d+)\s+(\S+)\s+(\S+)", line)
+        if m:
+            conv.setdefault(int(m.group(1)), {})[m.group(2)] = float(m.group(3))
+    for C, v in conv.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            H, W = {96: (512, 896), 192: (256, 448), 384: (128, 224)}[C]
+            alg = 2.0 * 21 * H * W * C * 2 + 27 * C * C * 2
+            tr[f"conv_halo_c{C}"] = {
+                "shape": {"T": 21, "H": H, "W": W, "C": C}, "fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"],
+                "traffic_bytes": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, "algorithmic_bytes": alg,
+                "kernel": "conv_halo_kernel<0, 32, 1, false, 96, 2, 3, false> (3x3x3 causal convolution, two output frames per workgroup)",
+                "source": "conv.hip", "source_blob": blob(os.path.join(ROOT, "scail_amd", "csrc", "conv.hip")), "measured": note}
     json.dump(tr, open(path, "w"), indent=1)
     print(json.dumps({k: tr[k] for k in ("flash_attn_self", "gemm4_step")}, indent=1))
 
