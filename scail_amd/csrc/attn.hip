@@ -918,6 +918,7 @@ int scail_gemm_tune(int v);
 int scail_gemm4_knob(const char* knob, int value);
 int scail_gemm_group_m(int v);
 int scail_conv_tune(int v);
+int scail_conv4_kernel(const char* suffix);
 static int g_attn_variant = 8 | (2 << 12);
 extern "C" int scail_tune_set(const char* knob, int value) {
     if (std::string(knob) == "attn_variant") {
@@ -943,7 +944,8 @@ extern "C" int scail_tune_set(const char* knob, int value) {
     }
     if (std::string(knob).rfind("gemm4", 0) == 0) return scail_gemm4_knob(knob, value);     // "gemm4" on / off, "gemm4_kernel:<suffix>"
     if (std::string(knob) == "gemm_tile") return scail_gemm_tune(value);
-    if (std::string(knob) == "conv_halo") return scail_conv_tune(value);
+    if (std::string(knob) == "conv_halo") return scail_conv_tune(value);                    // 0-5 halo layouts; 10 / 11: generated conv4 kernel off / on
+    if (std::string(knob).rfind("conv4_kernel", 0) == 0) return scail_conv4_kernel(std::string(knob).size() > 13 ? knob + 12 : "");   // "conv4_kernel:_<suffix>"
     if (std::string(knob) == "gemm_group_m") return scail_gemm_group_m(value);
     scail_set_error(std::string("scail_tune_set: unknown knob ") + knob);
     return 1;

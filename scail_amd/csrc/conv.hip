@@ -11,6 +11,9 @@
 // reference's 1/4/4-frame chunking and its per-conv feature caches are unnecessary (the equivalence is
 // pinned by oracle/wan_vae_oracle.py against the chunked reference).
 #include "common.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
 
 #define CBM 128
 #define CBK 64
@@ -604,11 +607,68 @@ __global__ void from_channels_last_kernel(const u16* __restrict__ x, int64_t ldx
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// ------------------------------------------------------------------------------------------------
+// conv4: the hand-scheduled 3x3x3 kernels (2 frames x 16 x 16 voxels x 96 channels per workgroup, one wave per SIMD, chunk-planar
+// patch in LDS written by LDS-DMA with the padding supplied by the buffer descriptors' range check).  gfx950 assembly GENERATED by
+// scail_amd/asmgen/conv4.py (csrc/conv4.s), embedded as a code object.  Kernel argument block = asmgen/conv4.py KERNARG_FMT.
+// ------------------------------------------------------------------------------------------------
+static const unsigned char k_conv4_hsaco[] = {
+#include "conv4_hsaco.inc"
+};
+struct Conv4Args {
+    const void* x; const void* w; const void* bias; void* y; const void* resid;
+    int32_t Ti, To, H, W;
+    int32_t Cin, N, Kpad, pt;
+    int32_t tiles_h, tiles_w, tiles_n; uint32_t magic_n;
+    uint32_t magic_w, magic_h; int32_t n_slices, ot_mul;
+    int32_t ot_off, pad_;
+    int64_t ldc, ldr;
+};
+static_assert(sizeof(Conv4Args) == 128, "Conv4Args must match asmgen/conv4.py KERNARG_SIZE");
+static std::map<int, hipModule_t> g_conv4_modules;                          // device -> loaded code object
+static std::map<std::pair<int, std::string>, hipFunction_t> g_conv4_fn;     // (device, kernel name)
+static std::mutex g_conv4_mutex;
+static std::string g_conv4_suffix;                                          // measurement build: "conv4_kernel:<suffix>"
+
+static int conv4_function(const std::string& name, hipFunction_t* fn) {
+    std::lock_guard<std::mutex> lk(g_conv4_mutex);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        scail_set_error("conv4: hipGetDevice failed");
+        return 2;
+    }
+    auto mit = g_conv4_modules.find(dev);
+    if (mit == g_conv4_modules.end()) {
+        hipModule_t mod = nullptr;
+        hipError_t e = hipModuleLoadData(&mod, k_conv4_hsaco);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("conv4: hipModuleLoadData failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        mit = g_conv4_modules.emplace(dev, mod).first;
+    }
+    auto it = g_conv4_fn.find(std::make_pair(dev, name));
+    if (it == g_conv4_fn.end()) {
+        hipFunction_t f;
+        hipError_t e = hipModuleGetFunction(&f, mit->second, name.c_str());
+        if (e != hipSuccess) {
+            scail_set_error("conv4: kernel " + name + " is not in the embedded code object: " + hipGetErrorString(e));
+            return 2;
+        }
+        it = g_conv4_fn.emplace(std::make_pair(dev, name), f).first;
+    }
+    *fn = it->second;
+    return 0;
+}
+
 #ifdef SCAIL_ABLATIONS
 static int g_conv_halo = 4;                                    // measurement build: A/B of the halo-kernel layouts (comment below)
-int scail_conv_tune(int v) { g_conv_halo = v; return 0; }
+static int g_conv4 = 0;
+int scail_conv_tune(int v) { if (v >= 10) g_conv4 = v - 10; else g_conv_halo = v; return 0; }     // 10 / 11: generated kernel off / on
+int scail_conv4_kernel(const char* suffix) { g_conv4_suffix = suffix ? suffix : ""; if (!g_conv4_suffix.empty() && g_conv4_suffix[0] == ':') g_conv4_suffix = "_" + g_conv4_suffix.substr(1); return 0; }
 #else
 static constexpr int g_conv_halo = 4;
+static constexpr int g_conv4 = 0;
 #endif
 
 static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
@@ -639,6 +699,29 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
     // 2 = 32-channel slices, swizzled unpadded layout with two W buffers (one barrier per tap row), 2 workgroups per CU --
     // measured equal (283 / 490 ms vs 281 / 487 ms encode / decode): the barrier is not what bounds the kernel
     const bool fuse = gamma != nullptr;       // conv + RMS_norm + SiLU: always the halo kernel, whatever the knob says
+    if (g_conv4 && !fuse && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups && p.ph == 1 && p.pw == 1 &&
+        p.Ho == p.Hi && p.Wo == p.Wi && p.Cin % 32 == 0 && p.N % 96 == 0 && p.To >= 2 && p.pt >= 0 && p.pt <= 2 &&
+        ldc < (1 << 20) && ldr < (1 << 20) && (int64_t)p.Hi * p.Wi * p.Cin * 2 < (1ll << 31) && (int64_t)p.Ho * p.Wo * std::max(ldc, ldr) * 2 < (1ll << 32)) {
+        Conv4Args a;
+        a.x = x; a.w = w; a.bias = bias; a.y = y; a.resid = resid;
+        a.Ti = p.Ti; a.To = p.To; a.H = p.Ho; a.W = p.Wo; a.Cin = p.Cin; a.N = p.N; a.Kpad = p.Kpad; a.pt = p.pt;
+        a.tiles_h = (p.Ho + 15) / 16; a.tiles_w = (p.Wo + 15) / 16; a.tiles_n = p.N / 96;
+        auto magic31 = [](int d) { return (uint32_t)(((1ull << 31) + (uint64_t)d - 1) / (uint64_t)d); };
+        a.magic_n = magic31(a.tiles_n); a.magic_w = magic31(a.tiles_w); a.magic_h = magic31(a.tiles_h);
+        a.n_slices = p.Cin / 32; a.ot_mul = p.ot_mul; a.ot_off = p.ot_off; a.pad_ = 0; a.ldc = ldc; a.ldr = resid ? ldr : ldc;
+        const int64_t tiles = (int64_t)((p.To + 1) / 2) * a.tiles_h * a.tiles_w * a.tiles_n;
+        SCAIL_REQUIRE(tiles < (1ll << 24), "too many tiles");        // the kernel's magic-number divisions are exact below 2^31 / divisor
+        hipFunction_t fn;
+        if (int rc = conv4_function(std::string(resid ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
+        size_t sz = sizeof(a);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)tiles, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("conv4: launch failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        return 0;
+    }
     if ((g_conv_halo || fuse) && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups &&
         p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
         p.Cin % ((g_conv_halo == 1 && p.N > 32 && !fuse) ? 48 : 32) == 0 && (fuse || p.N <= 32 || p.N >= 48)) {

@@ -1,0 +1,89 @@
+"""Run the generated conv4 kernels (scail_amd/asmgen/conv4.py) in the CPU emulator on small convolutions.  TEST INFRASTRUCTURE."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from scail_amd.asmgen import conv4, sched  # noqa: E402
+from tools import asm_emu as E  # noqa: E402
+from tools.attn4_emu_run import from_bf16_bits, to_bf16_bits  # noqa: E402
+
+
+def pack_weight(w, kpad=None):
+    """(N, Cin, 3, 3, 3) -> (N, Kpad) with k = ((dt 3 + dh) 3 + dw) Cin + c   (scail_amd.ops.prep_conv_weight)."""
+    N, Cin = w.shape[:2]
+    k = 27 * Cin
+    kpad = kpad or (k + 63) // 64 * 64
+    out = np.zeros((N, kpad), dtype=np.float32)
+    out[:, :k] = w.transpose(0, 2, 3, 4, 1).reshape(N, k)
+    return out
+
+
+def run(cfg: conv4.Cfg, x, w, bias=None, resid=None, pt=2, To=None, ot_mul=1, ot_off=0, y_frames=None, ldc=None, lazy=True, wgs=None):
+    """x (Ti, H, W, Cin), w (N, Cin, 3, 3, 3), bias (N) | None, resid (frames, H, W, N) | None; fp32 in, bf16 operands."""
+    Ti, H, W, Cin = x.shape
+    N = w.shape[0]
+    To = To if To is not None else Ti + pt - 2
+    y_frames = y_frames or (To * ot_mul + ot_off)
+    ldc = ldc or N
+    wp = pack_weight(w)
+    mem = E.Memory(size=1 << 27)
+    px = mem.alloc("x", to_bf16_bits(x))
+    pw = mem.alloc("w", to_bf16_bits(wp))
+    pb = mem.alloc("bias", bias.astype(np.float32)) if bias is not None else 0
+    py = mem.alloc("y", np.full((y_frames, H, W, ldc), 0x7FC0, dtype=np.uint16))
+    pr = mem.alloc("resid", to_bf16_bits(resid)) if resid is not None else 0
+    prog = conv4.Gen(cfg).program()
+    args = conv4.pack_args(px, pw, pb, py, pr, Ti, To, H, W, Cin, N, wp.shape[1], pt, ot_mul, ot_off, ldc, resid.shape[-1] if resid is not None else 0)
+    stats = None
+    for wg in (range(conv4.grid_blocks(To, H, W, N)) if wgs is None else wgs):
+        emu = E.Emu(prog, mem, n_waves=4, lds_bytes=conv4.LDS_BYTES, lazy=lazy)
+        emu.launch(args, block_id=(wg, 0, 0))
+        stats = emu.waves[0].stats
+    return from_bf16_bits(mem.read_back("y")).reshape(y_frames, H, W, ldc), stats
+
+
+def reference(x, w, bias=None, resid=None, pt=2, To=None):
+    rt = lambda a: from_bf16_bits(to_bf16_bits(a)).astype(np.float64)
+    Ti, H, W, Cin = x.shape
+    N = w.shape[0]
+    To = To if To is not None else Ti + pt - 2
+    xp = np.zeros((Ti + pt + 2, H + 2, W + 2, Cin))
+    xp[pt:pt + Ti, 1:-1, 1:-1] = rt(x)
+    wr = rt(w)
+    y = np.zeros((To, H, W, N))
+    for dt in range(3):
+        for dh in range(3):
+            for dw in range(3):
+                y += np.einsum("thwc,nc->thwn", xp[dt:dt + To, dh:dh + H, dw:dw + W], wr[:, :, dt, dh, dw])
+    if bias is not None:
+        y = y + bias.astype(np.float64)
+    if resid is not None:
+        y = y + rt(resid)
+    return y
+
+
+def check_static(cfg):
+    g = conv4.Gen(cfg)
+    body = g.slice_body()
+    return sched.check_hazards(body + body) + sched.check_hazards(g.prologue() + body) + sched.check_hazards(g.epilogue())
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    for cfg in conv4.DEFAULTS:
+        Ti, H, W, Cin, N = 3, 20, 18, 64, 96
+        x = rng.standard_normal((Ti, H, W, Cin)).astype(np.float32)
+        w = (rng.standard_normal((N, Cin, 3, 3, 3)) / np.sqrt(27 * Cin)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        resid = rng.standard_normal((Ti, H, W, N)).astype(np.float32) if cfg.epi == 3 else None
+        print(cfg.name, "static", check_static(cfg)[:3])
+        y, st = run(cfg, x, w, bias, resid)
+        ref = reference(x, w, bias, resid)
+        print("   max abs err", np.abs(y - ref).max(), "ref absmax", np.abs(ref).max(), st)

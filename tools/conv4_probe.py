@@ -1,0 +1,78 @@
+#!/usr/bin/env python
+"""GPU check + A/B of the generated 3x3x3 convolution kernels (scail_amd/asmgen/conv4.py) against the hipcc halo kernel.
+Measurement build:  SCAIL_ABLATIONS=1 python tools/conv4_probe.py [--variants ,abl_dma,...] [--frames 21]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scail_amd import lib, ops as O  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variants", default="")
+ap.add_argument("--frames", type=int, default=21)
+ap.add_argument("--skip-check", action="store_true")
+a = ap.parse_args()
+lib.load()
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(0)
+variants = a.variants.split(",")
+
+
+def setk(v):
+    lib.tune_set("conv4_kernel" + (":" + v if v else ""), 0)
+
+
+if not a.skip_check:
+    # ragged tiles, odd frame count, residual, two N tiles; against torch fp32 on the bf16-rounded operands
+    for (T, H, W, Cin, N, res) in ((3, 20, 18, 64, 96, False), (5, 33, 40, 32, 192, True), (2, 16, 16, 96, 96, True)):
+        x = torch.randn(T, H, W, Cin, device=dev, generator=g).to(torch.bfloat16)
+        w = torch.randn(N, Cin, 3, 3, 3, device=dev, generator=g) * 0.05
+        b = torch.randn(N, device=dev, generator=g)
+        wp = O.prep_conv_weight(w, b)
+        r = torch.randn(T, H, W, N, device=dev, generator=g).to(torch.bfloat16) if res else None
+        xr = F.pad(x.float().permute(3, 0, 1, 2)[None], (1, 1, 1, 1, 2, 0))
+        ref = F.conv3d(xr, w.to(torch.bfloat16).float(), b)[0].permute(1, 2, 3, 0)
+        if res:
+            ref = ref + r.float()
+        for mode in (10, 11):
+            lib.tune_set("conv_halo", mode)
+            for var in (variants if mode == 11 else [""]):
+                if "abl" in var or (res and var):
+                    continue
+                setk(var)
+                out = torch.full((T, H, W, N), float("nan"), device=dev, dtype=torch.bfloat16)
+                O.conv3d_cl(x, wp, (T, H, W), out=out, **(dict(resid=r) if res else {}))
+                torch.cuda.synchronize()
+                err = (out.float() - ref).abs()
+                print(json.dumps(dict(check=[T, H, W, Cin, N, res], conv4=mode == 11, variant=var, max_err=float(err.max()), nan=int(torch.isnan(out.float()).sum()),
+                                      ok=bool(err.max() < 0.06))), flush=True)
+    setk("")
+
+for C, H, W in ((96, 512, 896), (192, 256, 448), (384, 128, 224)):
+    T = a.frames
+    x = torch.randn(T, H, W, C, device=dev, generator=g).to(torch.bfloat16)
+    wp = O.prep_conv_weight(torch.randn(C, C, 3, 3, 3, device=dev, generator=g) * 0.02, torch.randn(C, device=dev, generator=g))
+    out = torch.empty(T, H, W, C, device=dev, dtype=torch.bfloat16)
+    fl = 2.0 * T * H * W * C * C * 27
+    ref = None
+    for mode, var in [(10, "")] + [(11, v) for v in variants]:
+        lib.tune_set("conv_halo", mode)
+        setk(var)
+        f = lambda: O.conv3d_cl(x, wp, (T, H, W), out=out)
+        out.zero_()
+        f(); f(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+        if ref is None:
+            ref = out.clone()
+        print(json.dumps(dict(C=C, H=H, W=W, T=T, kernel="halo (hipcc)" if mode == 10 else "conv4" + var, ms=sorted(ts)[2], tflops=fl / sorted(ts)[2] / 1e9,
+                              maxdiff_vs_halo=float((out.float() - ref.float()).abs().max()))), flush=True)
+lib.tune_set("conv_halo", 10)
+setk("")
