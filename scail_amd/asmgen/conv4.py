@@ -31,17 +31,20 @@ from . import isa, sched
 from .isa import A, S, V, I32, F32, VCC, EXEC, M0, Instr
 
 KERNARG_SIZE = 128
-# x w bias y resid | Ti To H W | Cin N Kpad pt | tiles_h tiles_w tiles_n magic_n | magic_w magic_h n_slices ot_mul | ot_off pad | ldc ldr
-KERNARG_FMT = "<5Q4i4i3iI2I2ii4x2q"
+# x w bias y resid | Ti To H W | Cin N Kpad pt | tiles_h tiles_w tiles_n magic_n | magic_w magic_h n_slices ot_mul | ot_off per_xcd | ldc ldr
+KERNARG_FMT = "<5Q4i4i3iI2I2iii2q"
 
 TH, TW, NF = 16, 16, 2
 PR, PC = TH + 2, TW + 2                 # patch rows / columns
 FVOX = 384                              # voxels reserved per patch frame (324 used; 6 DMA pieces of 64)
-PLANE = 4 * FVOX * 16                   # bytes per chunk plane: 24576
-PATCH = 4 * PLANE                       # 98304
+PLN = FVOX * 16                         # bytes of one chunk plane of one frame: 6144 (a multiple of 256: fragment reads are conflict-free)
+FSLOT = 4 * PLN                         # one patch frame of a 32-channel slice: 24576
+NSLOT = 5                               # ring of frame slots: the 4 frames of a slice + 1 (frames of the next slice arrive as the taps release the old ones)
 WBUF = 8192                             # bytes per W tap buffer (96 rows x 64 B used; 8 DMA pieces of 1 KB)
-NWB = 3
-LDS_BYTES = PATCH + NWB * WBUF          # 122880
+NWB = 4                                 # W tiles in flight: tap g + 4 is requested during tap g
+WREG = NWB * WBUF                       # the W ring sits first (32768 = a power of two: the ring index wraps with one AND)
+PBASE0 = WREG
+LDS_BYTES = WREG + NSLOT * FSLOT        # 155648
 OOB = 0x7FFFFF00                        # lane offset that fails every descriptor's range check (-> zeros)
 
 
@@ -53,13 +56,19 @@ def pack_args(x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt=2, ot_mul=1, 
     """ldc / ldr: output / residual row strides in elements (0 = N)."""
     th, tw, tn = (H + TH - 1) // TH, (W + TW - 1) // TW, (N + 95) // 96
     b = struct.pack(KERNARG_FMT, x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt, th, tw, tn, magic31(tn), magic31(tw), magic31(th),
-                    Cin // 32, ot_mul, ot_off, ldc or N, ldr or N)
+                    Cin // 32, ot_mul, ot_off, (grid_tiles(To, H, W, N) + 7) // 8, ldc or N, ldr or N)
     assert len(b) == KERNARG_SIZE, len(b)
     return b
 
 
-def grid_blocks(T, H, W, N) -> int:
+def grid_tiles(T, H, W, N) -> int:
     return ((T + NF - 1) // NF) * ((H + TH - 1) // TH) * ((W + TW - 1) // TW) * ((N + 95) // 96)
+
+
+def grid_blocks(T, H, W, N) -> int:
+    """workgroups launched: workgroup b runs on XCD b % 8 and takes tile (b % 8) * per_xcd + b / 8 -- every XCD a contiguous range
+    (the n tiles of a patch and neighbouring patches share an L2); ids beyond the last tile exit at once."""
+    return (grid_tiles(T, H, W, N) + 7) // 8 * 8
 
 
 @dataclass
@@ -72,21 +81,23 @@ class Cfg:
     rd_step: float = 3.0
     dma_at: float = 4.0     # gap of the first W-tile DMA piece of tap + 3, the second dma_step later
     dma_step: float = 20.0
+    p_at: float = 12.0      # gap of the tap's patch DMA piece
     abl: str = ""
 
 
 # ---- registers ------------------------------------------------------------------------------------------------------------------
 def ACC(nb, mb): return A((nb * 8 + mb) * 4, 4)
-def XF(s, mb): return A(192 + s * 32 + mb * 4, 4)          # x fragments (B operand), set s
-def WF(s, nb): return V(s * 24 + nb * 4, 4)                 # W fragments (A operand), set s
+def WF(s, nb): return V(s * 24 + nb * 4, 4)                 # W fragments (A operand), set s = tap % 3 (27 taps: the sets line up across slices)
+def XF(s, mb): return A(192 + s * 32 + mb * 4, 4) if s < 2 else V(72 + mb * 4, 4)      # x fragments (B operand), set s
 
 
-PB = V(48)                                                  # per-lane patch fragment base
-WB = V(49)                                                  # per-lane W fragment base (inside a buffer)
-PDMA = [V(50 + k) for k in range(6)]                        # per-lane source offsets of the 6 voxel groups of a patch frame
-WDMA = [V(56 + i) for i in range(2)]                        # per-lane source offsets of this wave's 2 W-tile pieces
-LANE = V(58)
-T_ = [V(60 + i) for i in range(60)]                         # v60..v119 temporaries (prologue / epilogue)
+PBASE = [V(104 + dt) for dt in range(3)]                    # per-lane fragment base inside the slot of patch frame f + dt of the current slice
+WB = V(107)                                                 # per-lane W fragment base inside the W ring (advances one buffer per tap)
+PDMA = [V(108 + k) for k in range(6)]                       # per-lane source offsets of the 6 voxel groups of a patch frame (chunk = wave)
+WDMA = [V(114 + i) for i in range(2)]                       # per-lane source offsets of this wave's 2 W-tile pieces
+LANE = V(116)
+T_ = [V(120 + i) for i in range(40)]                        # v120..v159 temporaries
+EPI_BQ, EPI_RP, EPI_F = 160, 184, 200                       # epilogue: bias quads v160..183, residual pairs v184..195, staging v200..215
 
 S_KARG = S(0, 2)
 S_WG = S(2)
@@ -95,18 +106,19 @@ S_TI, S_T, S_H, S_Wd = S(20), S(21), S(22), S(23)            # input frames, out
 S_CIN, S_N, S_KPAD, S_PT = S(24), S(25), S(26), S(27)
 S_TLH, S_TLW, S_TLN, S_MGN = S(28), S(29), S(30), S(31)
 S_MGW, S_MGH, S_NSL, S_OTM = S(32), S(33), S(34), S(35)
-S_OTO = S(36)
+S_OTO, S_PER = S(36), S(37)
 S_LDC, S_LDR = S(40, 2), S(42, 2)
-S_XRW = S(44, 4)                                            # buffer descriptor of THIS wave's patch frame (frame = wave)
-S_WR = S(48, 4)                                             # W descriptor of this workgroup's 96 rows
-S_WAVE, S_F, S_RH = S(52), S(53), S(54)
-S_T0, S_H0, S_W0, S_N0 = S(55), S(56), S(57), S(58)
-S_SL, S_XOFF, S_WNEXT, S_CIN2 = S(59), S(60), S(61), S(62)   # slice counter, channel byte offset of the slice, W source offset of the next DMA tap, 2 Cin
-S_PLDS, S_WLDS = S(63), S(64)                               # LDS byte offset of this wave's patch frame / W piece
-S_FB = S(66, 2)                                             # input frame bytes (64 bit)
-S_YF, S_RF = S(68, 2), S(70, 2)                             # output / residual frame base of this wave
-ST = [S(72 + i) for i in range(16)]                         # s72..s87 temporaries
-S_SAVE = S(88, 2)
+S_XR = [S(44 + 4 * j, 4) for j in range(4)]                 # buffer descriptors of the 4 input frames of the patch (num_records = 0: a padding frame)
+S_YF, S_RF, S_SAVE = S(44, 2), S(46, 2), S(48, 2)           # epilogue (the descriptors are dead by then): output / residual frame base, exec
+S_WR = S(60, 4)                                             # W descriptor of this workgroup's 96 rows
+S_WAVE, S_F, S_RH = S(64), S(65), S(66)
+S_T0, S_H0, S_W0, S_N0 = S(67), S(68), S(69), S(70)
+S_SL, S_XOFF, S_XOFFN = S(71), S(72), S(73)                 # slice counter, channel byte offset of this / the next slice
+S_WNEXT, S_CIN2, S_C26 = S(74), S(75), S(76)                # W source offset of the next DMA tap, 2 Cin, 26 * 2 Cin - 64
+S_WM0 = S(77)                                               # LDS offset of this wave's first piece in the W buffer of the current tap
+S_SLOT = [S(78 + j) for j in range(4)]                      # LDS offset (plane of this wave) of the slot the next load of patch frame j goes to
+ST = [S(82 + i) for i in range(16)]                         # s82..s97 temporaries
+N_SGPR = 98
 
 
 class Gen:
@@ -114,109 +126,151 @@ class Gen:
         self.cfg = cfg
 
     # ---- building blocks -------------------------------------------------------------------------------------------------------
-    @staticmethod
-    def tap_off(tap: int, mb: int) -> int:
-        dt, dh, dw = tap // 9, (tap // 3) % 3, tap % 3
-        return (dt * FVOX + (mb + dh) * PC + dw) * 16
-
     def mfmas(self, s: int) -> List[Instr]:
         # n-block major: the A fragment (W) stays for 8 consecutive MFMAs
         return [isa.mfma16(ACC(nb, mb), WF(s, nb), XF(s, mb), ACC(nb, mb), tag="mm") for nb in range(6) for mb in range(8)]
 
     def frag_reads(self, s: int, tap: int, t0: float, step: float) -> List[Instr]:
-        """fragments of ``tap`` into set s: 6 W quads from W buffer tap % 3, 8 x quads from the patch, in the order the MFMAs want them."""
+        """fragments of ``tap`` into set s: 6 W quads from the W buffer WB points at, 8 x quads from the slot of patch frame f + dt."""
+        dt, dh, dw = tap // 9, (tap // 3) % 3, tap % 3
         out = []
-        wbuf = tap % NWB
         order = [("w", 0)] + [("x", mb) for mb in range(8)] + [("w", nb) for nb in range(1, 6)]
         for k, (kind, i) in enumerate(order):
             if kind == "w":
-                out.append(isa.ds_read_b128(WF(s, i), WB, wbuf * WBUF + i * 1024, target_gap=t0 + step * k))
+                out.append(isa.ds_read_b128(WF(s, i), WB, i * 1024, target_gap=t0 + step * k))
             else:
-                out.append(isa.ds_read_b128(XF(s, i), PB, self.tap_off(tap, i), target_gap=t0 + step * k))
+                out.append(isa.ds_read_b128(XF(s, i), PBASE[dt], ((i + dh) * PC + dw) * 16, target_gap=t0 + step * k))
         return out
 
-    def w_dma(self, wbuf: int, t0: float, step: float) -> List[Instr]:
-        """this wave's 2 pieces (of 8: pieces w and w + 4; rows >= 96 fail the range check = zeros) of the W tile at S_WNEXT."""
+    def w_dma(self, t0: float, step: float, need: int) -> List[Instr]:
+        """this wave's 2 pieces (of 8: pieces w and w + 4; rows >= 96 fail the range check = zeros) of the W tile at S_WNEXT -> the buffer
+        S_WM0 points at; then both move on (ring of NWB buffers; the tap after the 27th is tap 0 of the next slice)."""
         out = []
         for i in range(2):
-            out.append(isa.sop("s_add_u32", M0, S_WLDS, I32(wbuf * WBUF + 4096 * i), target_gap=t0 + step * i - 0.5))
-            out.append(isa.buffer_load_lds(WDMA[i], S_WR, S_WNEXT, 0, target_gap=t0 + step * i, tag="dma"))
+            out.append(isa.sop("s_add_u32", M0, S_WM0, I32(4096 * i), target_gap=t0 + step * i - 0.5))
+            d = isa.buffer_load_lds(WDMA[i], S_WR, S_WNEXT, 0, target_gap=t0 + step * i, tag="dma")
+            d.need = need
+            out.append(d)
+        out += [isa.sop("s_add_u32", S_WM0, S_WM0, I32(WBUF), target_gap=t0 + step + 1.0),
+                isa.sop("s_and_b32", S_WM0, S_WM0, I32(WREG - 1), target_gap=t0 + step + 1.2)]
         return out
 
-    def patch_dma(self) -> List[Instr]:
-        """this wave's patch frame (frame = wave) of the current slice: 4 chunk planes x 6 voxel groups = 24 pieces."""
-        out = []
-        for c in range(4):
-            for k in range(6):
-                out.append(isa.sop("s_add_u32", M0, S_PLDS, I32(c * PLANE + k * 1024 - 16 * c)))     # the instruction offset moves the LDS side too
-                out.append(isa.buffer_load_lds(PDMA[k], S_XRW, S_XOFF, 16 * c, tag="pdma"))
-        return out
+    def w_next(self, issued_tap: int, tg: float) -> List[Instr]:
+        """advance S_WNEXT past tap ``issued_tap`` (0..26) of a slice."""
+        if issued_tap == 26:      # its successor is tap 0 of the following slice: back 26 taps, forward one slice (64 bytes)
+            return [isa.sop("s_sub_u32", S_WNEXT, S_WNEXT, S_C26, target_gap=tg)]
+        return [isa.sop("s_add_u32", S_WNEXT, S_WNEXT, S_CIN2, target_gap=tg)]
 
-    def tap_block(self, tap: int) -> List[Instr]:
-        """One tap of the unrolled slice body, scheduled: top (fragments of this tap in registers, W tile of the next tap landed,
-        barrier) + 48 MFMAs with the next tap's fragment reads and the W DMA of tap + 3 in their gaps."""
+    def patch_piece(self, j: int, k: int, soff, tg: float, need: int) -> List[Instr]:
+        """voxel group k of this wave's chunk plane of patch frame j -> the slot S_SLOT[j] points at."""
+        d = isa.buffer_load_lds(PDMA[k], S_XR[j], soff, 0, target_gap=tg, tag="pdma")
+        d.need = need
+        return [isa.sop("s_add_u32", M0, S_SLOT[j], I32(k * 1024), target_gap=tg - 0.5), d]
+
+    def slot_next(self, j: int, tg: float) -> List[Instr]:
+        """the next load of frame j goes one slot down the ring (4 frames per slice, 5 slots: -1 mod 5)."""
+        t = ST[0]
+        return [isa.sop("s_sub_u32", t, S_SLOT[j], I32(FSLOT), target_gap=tg), isa.sop("s_cmp_lt_u32", None, t, I32(PBASE0), target_gap=tg + 0.1),
+                isa.sop("s_cselect_b32", ST[1], I32(NSLOT * FSLOT), I32(0), target_gap=tg + 0.2), isa.sop("s_add_u32", S_SLOT[j], t, ST[1], target_gap=tg + 0.3)]
+
+    def pbase_next(self, dt: int, tg: float) -> List[Instr]:
+        t0, t1 = T_[0], T_[1]
+        return [isa.vop("v_subrev_u32", t0, I32(FSLOT), PBASE[dt], target_gap=tg), isa.v_cmp("v_cmp_gt_u32", I32(PBASE0), t0, target_gap=tg + 0.1),
+                isa.vop("v_add_u32", t1, I32(NSLOT * FSLOT), t0, target_gap=tg + 0.2), isa.v_cndmask(PBASE[dt], t0, t1, target_gap=tg + 0.3)]
+
+    # which patch pieces a tap issues: (frame, voxel group, next slice?, needed at the top of relative tap)
+    PIECES = {**{i: (3, i, False, 17) for i in range(6)}, **{6 + i: (0, i, True, 26) for i in range(6)},
+              **{12 + i: (1, i, True, 26) for i in range(6)}, **{18 + i: (2, i, True, 27 + 8) for i in range(6)}}
+
+    def tap_fillers(self, tap: int) -> List[Instr]:
         c = self.cfg
         abl = c.abl.split(",")
-        s = tap & 1
-        top = [isa.waitcnt(lgkmcnt=0), isa.waitcnt(vmcnt=2)] + ([] if "bar" in abl else [isa.barrier()])
+        s = tap % 3
         blk: List[Instr] = []
-        if tap + 1 < 27 and "lds" not in abl:
-            blk += self.frag_reads(s ^ 1, tap + 1, c.rd_at, c.rd_step)
+        if "lds" not in abl:
+            blk += [isa.vop("v_add_u32", WB, I32(WBUF), WB, target_gap=0.0), isa.vop("v_and_b32", WB, I32(WREG - 1), WB, target_gap=0.1)]
+            blk += self.frag_reads((s + 1) % 3, (tap + 1) % 27, c.rd_at, c.rd_step)
         if "dma" not in abl:
-            blk += self.w_dma(tap % NWB, c.dma_at, c.dma_step)
-            # advance the W stream: the tap just requested was tap + 3 of this slice (or (tap + 3) - 27 of the next one)
-            nxt = tap + 3
-            if nxt % 27 == 26:      # its successor is tap 0 of the following slice: back 26 taps, forward one slice (64 bytes)
-                blk += [isa.sop("s_mul_i32", ST[0], S_CIN2, I32(26), target_gap=c.dma_at + c.dma_step + 1.0),
-                        isa.sop("s_sub_u32", S_WNEXT, S_WNEXT, ST[0], target_gap=c.dma_at + c.dma_step + 1.2),
-                        isa.sop("s_add_u32", S_WNEXT, S_WNEXT, I32(64), target_gap=c.dma_at + c.dma_step + 1.4)]
-            else:
-                blk += [isa.sop("s_add_u32", S_WNEXT, S_WNEXT, S_CIN2, target_gap=c.dma_at + c.dma_step + 1.0)]
-        blk += self.mfmas(s)
-        seq = sched.schedule(blk, cap=c.cap, lookahead=c.lookahead)
-        return top + seq
+            blk += self.w_dma(c.dma_at, c.dma_step, need=tap + NWB - 1)
+            blk += self.w_next((tap + NWB) % 27, c.dma_at + c.dma_step + 1.5)
+            if tap in self.PIECES and "patch" not in abl:
+                j, k, nxt, need = self.PIECES[tap]
+                blk += self.patch_piece(j, k, S_XOFFN if nxt else S_XOFF, c.p_at, need)
+                if k == 5:
+                    blk += self.slot_next(j, c.p_at + 1.0)
+        if tap in (10, 19, 26):
+            blk += self.pbase_next({10: 0, 19: 1, 26: 2}[tap], 40.0)
+        return blk
+
+    def tap_block(self, tap: int) -> List[Instr]:
+        """One tap of the unrolled slice body, scheduled: 48 MFMAs with the next tap's fragment reads, the W DMA of tap + 4 and a patch
+        piece of the frames that are due in their gaps.  (The top -- waits + barrier -- is added by slice_body, which knows the DMA order.)"""
+        c = self.cfg
+        return sched.schedule(self.tap_fillers(tap) + self.mfmas(tap % 3), cap=c.cap, lookahead=c.lookahead)
+
+    def slice_body(self) -> List[Instr]:
+        """One 32-channel slice = 27 taps.  At the top of tap i: this tap's fragments are in registers (lgkmcnt 0), every DMA whose data
+        the reads issued during tap i need has landed (counted vmcnt: DMAs retire in order) -- in every wave (barrier)."""
+        c = self.cfg
+        abl = c.abl.split(",")
+        blocks = [self.tap_block(t) for t in range(27)]
+        dmas = [[i for i in blk if i.cls == isa.LDS_DMA] for blk in blocks]
+        o: List[Instr] = [isa.label("L_slice"), isa.nop(7)]
+        for tap in range(27):
+            # DMAs in issue order up to here: the previous slice's (their deadlines are 27 taps earlier) + this slice's before tap
+            hist = [d.need - 27 for blk in dmas for d in blk] + [d.need for blk in dmas[:tap] for d in blk]
+            due = [k for k, need in enumerate(hist) if need <= tap]
+            top = [isa.waitcnt(lgkmcnt=0)]
+            if due:
+                top.append(isa.waitcnt(vmcnt=len(hist) - 1 - due[-1]))
+            if "bar" not in abl:
+                top.append(isa.barrier())
+            o += top + blocks[tap]
+        o += [isa.sop("s_add_u32", S_SL, S_SL, I32(1)), isa.sop("s_mov_b32", S_XOFF, S_XOFFN),
+              isa.sop("s_add_u32", ST[0], S_SL, I32(1)), isa.sop("s_add_u32", ST[1], S_XOFF, I32(64)),
+              isa.sop("s_cmp_lt_u32", None, ST[0], S_NSL), isa.sop("s_cselect_b32", S_XOFFN, ST[1], I32(0)),      # no slice after the last: re-read slice 0 (unused)
+              isa.sop("s_cmp_lt_u32", None, S_SL, S_NSL), isa.branch("s_cbranch_scc1", "L_slice")]
+        return o
 
     # ---- prologue ----------------------------------------------------------------------------------------------------------------
-    def addr64_madd(self, ptr: isa.Reg, a, b, shift: int) -> List[Instr]:
-        """ptr(64) += (a * b) << shift   (a, b: 32-bit SGPRs / immediates, unsigned)."""
-        lo, hi = ST[0], ST[1]
-        st = S(ST[2].idx, 2)
-        return [isa.sop("s_mul_i32", lo, a, b), isa.sop("s_mul_hi_u32", hi, a, b),
-                isa.sop("s_mov_b32", st.sub(0), lo), isa.sop("s_mov_b32", st.sub(1), hi), isa.sop("s_lshl_b64", st, st, I32(shift)),
-                isa.sop("s_add_u32", ptr.sub(0), ptr.sub(0), st.sub(0)), isa.sop("s_addc_u32", ptr.sub(1), ptr.sub(1), st.sub(1))]
-
     def prologue(self) -> List[Instr]:
         c = self.cfg
         o: List[Instr] = [isa.label(c.name)]
         o += [isa.s_load(8, S(8, 8), S_KARG, 0), isa.s_load(2, S_RES, S_KARG, 32), isa.s_load(4, S(20, 4), S_KARG, 40),
               isa.s_load(4, S(24, 4), S_KARG, 56), isa.s_load(4, S(28, 4), S_KARG, 72), isa.s_load(4, S(32, 4), S_KARG, 88),
-              isa.s_load(1, S_OTO, S_KARG, 104), isa.s_load(4, S(40, 4), S_KARG, 112),
+              isa.s_load(2, S(36, 2), S_KARG, 104), isa.s_load(4, S(40, 4), S_KARG, 112),
               isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", T_[0], I32(6), V(0)),
               isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, T_[0]),
               isa.sop("s_lshr_b32", S_F, S_WAVE, I32(1)), isa.sop("s_and_b32", S_RH, S_WAVE, I32(1))]
-        # ---- workgroup id -> (frame pair, tile row, tile column, n tile); n fastest ----
-        tt = ST[4]
+        # ---- workgroup id b -> tile (b % 8) * per_xcd + b / 8 -> (frame pair, tile row, tile column, n tile); n fastest ----
+        tt, wid = ST[4], ST[3]
         q1, q2, q3 = ST[5], ST[6], ST[7]
-        o += [isa.sop("s_lshl_b32", tt, S_WG, I32(1)), isa.sop("s_mul_hi_u32", q1, tt, S_MGN),                 # q1 = wid / tiles_n
-              isa.sop("s_mul_i32", tt, q1, S_TLN), isa.sop("s_sub_u32", tt, S_WG, tt), isa.sop("s_mul_i32", S_N0, tt, I32(96)),
+        o += [isa.sop("s_and_b32", tt, S_WG, I32(7)), isa.sop("s_mul_i32", tt, tt, S_PER), isa.sop("s_lshr_b32", wid, S_WG, I32(3)),
+              isa.sop("s_add_u32", wid, wid, tt),
+              isa.sop("s_lshl_b32", tt, wid, I32(1)), isa.sop("s_mul_hi_u32", q1, tt, S_MGN),                   # q1 = tile / tiles_n
+              isa.sop("s_mul_i32", tt, q1, S_TLN), isa.sop("s_sub_u32", tt, wid, tt), isa.sop("s_mul_i32", S_N0, tt, I32(96)),
               isa.sop("s_lshl_b32", tt, q1, I32(1)), isa.sop("s_mul_hi_u32", q2, tt, S_MGW),                   # q2 = q1 / tiles_w
               isa.sop("s_mul_i32", tt, q2, S_TLW), isa.sop("s_sub_u32", tt, q1, tt), isa.sop("s_lshl_b32", S_W0, tt, I32(4)),
               isa.sop("s_lshl_b32", tt, q2, I32(1)), isa.sop("s_mul_hi_u32", q3, tt, S_MGH),                   # q3 = q2 / tiles_h
               isa.sop("s_mul_i32", tt, q3, S_TLH), isa.sop("s_sub_u32", tt, q2, tt), isa.sop("s_lshl_b32", S_H0, tt, I32(4)),
-              isa.sop("s_lshl_b32", S_T0, q3, I32(1))]
+              isa.sop("s_lshl_b32", S_T0, q3, I32(1)),
+              isa.sop("s_cmp_ge_u32", None, S_T0, S_T), isa.branch("s_cbranch_scc1", "L_exit")]                # an id beyond the last tile
         # ---- input frame bytes (64 bit) = H * W * Cin * 2 ----
+        fb = S(ST[14].idx, 2)
         o += [isa.sop("s_mul_i32", ST[8], S_H, S_Wd), isa.sop("s_lshl_b32", S_CIN2, S_CIN, I32(1)),
-              isa.sop("s_mul_i32", S_FB.sub(0), ST[8], S_CIN2), isa.sop("s_mul_hi_u32", S_FB.sub(1), ST[8], S_CIN2)]
-        # ---- this wave's patch frame: input frame t = t0 - pt + wave; descriptor base = x + t * FB, num_records = FB (0 when t is outside [0, Ti)) ----
+              isa.sop("s_mul_i32", fb.sub(0), ST[8], S_CIN2), isa.sop("s_mul_hi_u32", fb.sub(1), ST[8], S_CIN2),
+              isa.sop("s_mul_i32", S_C26, S_CIN2, I32(26)), isa.sop("s_sub_u32", S_C26, S_C26, I32(64))]
+        # ---- patch frame j: input frame t = t0 - pt + j; descriptor base = x + t * FB, num_records = FB (0 when t is outside [0, Ti)) ----
         tfr = ST[9]
-        o += [isa.sop("s_add_u32", tfr, S_T0, S_WAVE), isa.sop("s_sub_u32", tfr, tfr, S_PT),                  # may wrap below 0 -> huge unsigned
-              isa.sop("s_cmp_lt_u32", None, tfr, S_TI), isa.sop("s_cselect_b32", ST[10], S_FB.sub(0), I32(0)),   # num_records
-              isa.sop("s_cselect_b32", tfr, tfr, I32(0))]
-        o += [isa.sop("s_mul_i32", ST[0], S_FB.sub(0), tfr), isa.sop("s_mul_hi_u32", ST[1], S_FB.sub(0), tfr),
-              isa.sop("s_mul_i32", ST[2], S_FB.sub(1), tfr), isa.sop("s_add_u32", ST[1], ST[1], ST[2]),
-              isa.sop("s_add_u32", S_XRW.sub(0), S_X.sub(0), ST[0]), isa.sop("s_addc_u32", ST[1], S_X.sub(1), ST[1]),
-              isa.sop("s_and_b32", S_XRW.sub(1), ST[1], I32(0xFFFF)), isa.sop("s_mov_b32", S_XRW.sub(2), ST[10]),
-              isa.sop("s_mov_b32", S_XRW.sub(3), I32(0x00020000))]
+        for j in range(4):
+            o += [isa.sop("s_add_u32", tfr, S_T0, I32(j)), isa.sop("s_sub_u32", tfr, tfr, S_PT),                 # may wrap below 0 -> huge unsigned
+                  isa.sop("s_cmp_lt_u32", None, tfr, S_TI), isa.sop("s_cselect_b32", ST[10], fb.sub(0), I32(0)),   # num_records
+                  isa.sop("s_cselect_b32", tfr, tfr, I32(0)),
+                  isa.sop("s_mul_i32", ST[0], fb.sub(0), tfr), isa.sop("s_mul_hi_u32", ST[1], fb.sub(0), tfr),
+                  isa.sop("s_mul_i32", ST[2], fb.sub(1), tfr), isa.sop("s_add_u32", ST[1], ST[1], ST[2]),
+                  isa.sop("s_add_u32", S_XR[j].sub(0), S_X.sub(0), ST[0]), isa.sop("s_addc_u32", ST[1], S_X.sub(1), ST[1]),
+                  isa.sop("s_and_b32", S_XR[j].sub(1), ST[1], I32(0xFFFF)), isa.sop("s_mov_b32", S_XR[j].sub(2), ST[10]),
+                  isa.sop("s_mov_b32", S_XR[j].sub(3), I32(0x00020000))]
         # ---- W descriptor: base = w + n0 * Kpad * 2, num_records = min(96, N - n0) * Kpad * 2 ----
         kp2 = ST[11]
         o += [isa.sop("s_lshl_b32", kp2, S_KPAD, I32(1)),
@@ -225,13 +279,15 @@ class Gen:
               isa.sop("s_and_b32", S_WR.sub(1), ST[1], I32(0xFFFF)),
               isa.sop("s_sub_u32", ST[2], S_N, S_N0), isa.sop("s_min_u32", ST[2], ST[2], I32(96)), isa.sop("s_mul_i32", S_WR.sub(2), ST[2], kp2),
               isa.sop("s_mov_b32", S_WR.sub(3), I32(0x00020000))]
-        # ---- LDS offsets of this wave's DMA regions ----
-        o += [isa.sop("s_mul_i32", S_PLDS, S_WAVE, I32(FVOX * 16)),
-              isa.sop("s_lshl_b32", S_WLDS, S_WAVE, I32(10)), isa.sop("s_add_u32", S_WLDS, S_WLDS, I32(PATCH))]
+        # ---- LDS targets of this wave's DMA pieces: chunk plane `wave` of a frame slot; piece `wave` of a W buffer ----
+        o += [isa.sop("s_mul_i32", ST[0], S_WAVE, I32(PLN)), isa.sop("s_add_u32", ST[0], ST[0], I32(PBASE0)),
+              isa.sop("s_lshl_b32", S_WM0, S_WAVE, I32(10))]
+        for j, slot in ((0, 0), (1, 1), (2, 2), (3, 3)):          # slice 0: frame j -> slot j
+            o.append(isa.sop("s_add_u32", S_SLOT[j], ST[0], I32(slot * FSLOT)))
         t = T_
-        # ---- patch voxel groups: lane l of group k = patch voxel pv = 64 k + l = (r, col); source offset inside the frame, or OOB ----
-        hm1, wm1 = ST[12], ST[13]
-        o += [isa.sop("s_sub_u32", hm1, S_H0, I32(1)), isa.sop("s_sub_u32", wm1, S_W0, I32(1))]
+        # ---- patch voxel groups: lane l of group k = patch voxel pv = 64 k + l = (r, col); source offset inside the frame (chunk = wave), or OOB ----
+        hm1, wm1, w16 = ST[12], ST[13], ST[1]
+        o += [isa.sop("s_sub_u32", hm1, S_H0, I32(1)), isa.sop("s_sub_u32", wm1, S_W0, I32(1)), isa.sop("s_lshl_b32", w16, S_WAVE, I32(4))]
         for k in range(6):
             pv, r, col, hi, wi, ok = t[1], t[2], t[3], t[4], t[5], t[6]
             o += [isa.vop("v_add_u32", pv, I32(64 * k), LANE),
@@ -242,7 +298,7 @@ class Gen:
                   isa.v_cndmask(ok, I32(0), I32(1)),
                   isa.v_cmp("v_cmp_gt_u32", S_Wd, wi), isa.v_cndmask(t[8], I32(0), I32(1)), isa.vop("v_and_b32", ok, ok, t[8]),
                   isa.v_cmp("v_cmp_gt_u32", I32(PR * PC), pv), isa.v_cndmask(t[8], I32(0), I32(1)), isa.vop("v_and_b32", ok, ok, t[8]),
-                  isa.vop("v_add_u32", t[7], t[7], wi), isa.vop("v_mul_lo_u32", t[7], t[7], S_CIN2),
+                  isa.vop("v_add_u32", t[7], t[7], wi), isa.vop("v_mul_lo_u32", t[7], t[7], S_CIN2), isa.vop("v_add_u32", t[7], w16, t[7]),
                   isa.v_cmp("v_cmp_ne_u32", I32(0), ok), isa.vop("v_mov_b32", t[9], I32(OOB)),
                   isa.v_cndmask(PDMA[k], t[9], t[7])]
         # ---- W pieces of this wave: piece w + 4 i = rows 16 (w + 4 i) + l / 4, LDS position q = l % 4 holds source chunk q ^ ((row >> 1) & 3) ----
@@ -255,36 +311,31 @@ class Gen:
         # ---- fragment bases ----
         ql, g = t[10], t[11]
         o += [isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
-        # patch: chunk plane g, voxel (frame f, row 8 rh, column ql)
-        o += [isa.sop("s_mul_i32", ST[0], S_F, I32(FVOX)), isa.sop("s_mul_i32", ST[1], S_RH, I32(8 * PC)), isa.sop("s_add_u32", ST[0], ST[0], ST[1]),
-              isa.vop("v_add_u32", t[1], ST[0], ql), isa.vop("v_lshlrev_b32", t[1], I32(4), t[1]),
-              isa.vop("v_mul_u32_u24", t[2], I32(PLANE), g), isa.vop("v_add_u32", PB, t[1], t[2])]
-        # W: row ql (64 B), chunk g ^ ((ql >> 1) & 3)
+        # patch: slot of frame f + dt, chunk plane g, voxel (row 8 rh, column ql)
+        o += [isa.sop("s_mul_i32", ST[0], S_RH, I32(8 * PC)), isa.vop("v_add_u32", t[1], ST[0], ql), isa.vop("v_lshlrev_b32", t[1], I32(4), t[1]),
+              isa.vop("v_mul_u32_u24", t[2], I32(PLN), g), isa.vop("v_add_u32", t[1], t[1], t[2]),
+              isa.sop("s_mul_i32", ST[1], S_F, I32(FSLOT)), isa.sop("s_add_u32", ST[1], ST[1], I32(PBASE0))]
+        for dt in range(3):
+            o += [isa.sop("s_add_u32", ST[2], ST[1], I32(dt * FSLOT)), isa.vop("v_add_u32", PBASE[dt], ST[2], t[1])]
+        # W: row ql (64 B), chunk g ^ ((ql >> 1) & 3); buffer 0
         o += [isa.vop("v_lshrrev_b32", t[1], I32(1), ql), isa.vop("v_and_b32", t[1], I32(3), t[1]), isa.vop("v_xor_b32", t[1], g, t[1]),
-              isa.vop("v_lshlrev_b32", t[2], I32(6), ql), isa.vop("v_lshl_add_u32", WB, t[1], I32(4), t[2]),
-              isa.vop("v_add_u32", WB, I32(PATCH), WB)]
+              isa.vop("v_lshlrev_b32", t[2], I32(6), ql), isa.vop("v_lshl_add_u32", WB, t[1], I32(4), t[2])]
+        # ---- streams: patch frames 0, 1, 2 of slice 0, W taps 0 .. 3 ----
+        o += [isa.sop("s_mov_b32", S_SL, I32(0)), isa.sop("s_mov_b32", S_XOFF, I32(0)), isa.sop("s_mov_b32", S_WNEXT, I32(0)),
+              isa.sop("s_cmp_lt_u32", None, I32(1), S_NSL), isa.sop("s_cselect_b32", S_XOFFN, I32(64), I32(0))]
+        for j in range(3):
+            for k in range(6):
+                o += self.patch_piece(j, k, S_XOFF, 0, 0)
+        # where the body's loads go: frame 3 of slice 0 -> slot 3; frames 0, 1, 2 of slice 1 -> slots 4, 0, 1
+        for j in range(3):
+            o += self.slot_next(j, 0)
+        for b in range(NWB):
+            o += self.w_dma(0, 0, 0) + self.w_next(b, 0)
         for i in range(192):
             o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
-        # ---- streams: W taps 0, 1, 2 of slice 0 ----
-        o += [isa.sop("s_mov_b32", S_SL, I32(0)), isa.sop("s_mov_b32", S_XOFF, I32(0)), isa.sop("s_mov_b32", S_WNEXT, I32(0))]
-        for b in range(3):
-            o += self.w_dma(b, 0, 0) + [isa.sop("s_add_u32", S_WNEXT, S_WNEXT, S_CIN2)]
+        o += [isa.waitcnt(vmcnt=0), isa.barrier()]
+        o += self.frag_reads(0, 0, 0, 0)
         return sched.pad_hazards(sched.insert_lgkm_waits(o))
-
-    def slice_body(self) -> List[Instr]:
-        """One 32-channel slice: patch in, 27 taps."""
-        o: List[Instr] = [isa.label("L_slice"), isa.nop(7)]
-        pre: List[Instr] = [isa.barrier()]                         # every wave is done with the previous slice's patch
-        pre += self.patch_dma()
-        pre += [isa.waitcnt(vmcnt=0), isa.barrier()]
-        pre += self.frag_reads(0, 0, 0, 0)
-        o += sched.pad_hazards(pre)
-        for tap in range(27):
-            o += self.tap_block(tap)
-        o += [isa.waitcnt(lgkmcnt=0),
-              isa.sop("s_add_u32", S_SL, S_SL, I32(1)), isa.sop("s_add_u32", S_XOFF, S_XOFF, I32(64)),
-              isa.sop("s_cmp_lt_u32", None, S_SL, S_NSL), isa.branch("s_cbranch_scc1", "L_slice")]
-        return o
 
     # ---- epilogue ----------------------------------------------------------------------------------------------------------------
     def epilogue(self) -> List[Instr]:
@@ -292,7 +343,7 @@ class Gen:
         y / resid rows: voxel index ((frame * ot_mul + ot_off) * H + row) * W + column, strides ldc / ldr elements."""
         c = self.cfg
         t = T_
-        e: List[Instr] = [isa.waitcnt(vmcnt=0), isa.nop(15), isa.nop(15)]
+        e: List[Instr] = [isa.waitcnt(vmcnt=0, lgkmcnt=0), isa.nop(15), isa.nop(15)]
         ql, g = t[10], t[11]
         tf, tfo, hw = ST[4], ST[5], ST[6]
         ldc2, ldr2 = ST[13], ST[14]
@@ -309,9 +360,9 @@ class Gen:
                   isa.sop("s_lshl_b32", ST[7], S_N0, I32(1)),
                   isa.sop("s_add_u32", base.sub(0), base.sub(0), ST[7]), isa.sop("s_addc_u32", base.sub(1), base.sub(1), I32(0))]
         # bias quads (zeros when bias == NULL)
-        BQ = [V(120 + 4 * nb, 4) for nb in range(6)]
+        BQ = [V(EPI_BQ + 4 * nb, 4) for nb in range(6)]
         for i in range(24):
-            e.append(isa.vop("v_mov_b32", V(120 + i), I32(0)))
+            e.append(isa.vop("v_mov_b32", V(EPI_BQ + i), I32(0)))
         e += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias"),
               isa.sop("s_lshl_b32", ST[7], S_N0, I32(2)), isa.sop("s_add_u32", S_BIAS.sub(0), S_BIAS.sub(0), ST[7]),
               isa.sop("s_addc_u32", S_BIAS.sub(1), S_BIAS.sub(1), I32(0)), isa.vop("v_lshlrev_b32", t[1], I32(4), g)]
@@ -324,7 +375,7 @@ class Gen:
               isa.sop("s_cmp_lt_u32", None, tf, S_T), isa.sop("s_cselect_b32", ST[8], S_Wd, I32(0))]      # frame outside [0, To): no column is valid
         row0 = ST[9]
         e += [isa.sop("s_lshl_b32", row0, S_RH, I32(3)), isa.sop("s_add_u32", row0, row0, S_H0)]
-        RP = [V(144 + 2 * nb, 2) for nb in range(6)]
+        RP = [V(EPI_RP + 2 * nb, 2) for nb in range(6)]
         for mb in range(8):
             yoff, roff, vox, hrow = t[4], t[5], t[6], ST[10]
             e += [isa.sop("s_add_u32", hrow, row0, I32(mb)),
@@ -340,7 +391,7 @@ class Gen:
                     e.append(isa.global_load(2, RP[nb], roff, 32 * nb, saddr=S_RF, extra_reads=[EXEC]))
                 e.append(isa.waitcnt(vmcnt=0))
             for nb in range(6):
-                base = 160 + 8 * (nb % 2)
+                base = EPI_F + 8 * (nb % 2)
                 f = [V(base + i) for i in range(4)]
                 w, r_ = V(base + 4, 2), V(base + 6)
                 acc = ACC(nb, mb)
@@ -354,7 +405,7 @@ class Gen:
                 e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
                       isa.global_store(2, yoff, w, 32 * nb, saddr=S_YF, extra_reads=[EXEC])]
             e += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
-        e += [isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
+        e += [isa.waitcnt(vmcnt=0), isa.label("L_exit"), Instr("s_endpgm", cls=isa.BRANCH)]
         return sched.pad_hazards(e)
 
     def program(self) -> List[Instr]:
@@ -399,7 +450,7 @@ def kernel_text(c: Cfg) -> str:
 \t\t.amdhsa_system_sgpr_workgroup_id_z 1
 \t\t.amdhsa_system_vgpr_workitem_id 0
 \t\t.amdhsa_next_free_vgpr 512
-\t\t.amdhsa_next_free_sgpr 96
+\t\t.amdhsa_next_free_sgpr {N_SGPR}
 \t\t.amdhsa_accum_offset 256
 \t\t.amdhsa_reserve_vcc 1
 \t\t.amdhsa_float_round_mode_32 0
@@ -454,11 +505,12 @@ DEFAULTS = [Cfg(epi=0, name="scail_conv4_e0"), Cfg(epi=3, name="scail_conv4_e3")
 
 def variant_cfgs():
     out = []
-    for abl in ("dma", "lds", "bar", "dma,lds"):
+    for abl in ("dma", "lds", "bar", "dma,lds", "patch"):
         out.append(Cfg(epi=0, abl=abl, name="scail_conv4_e0_abl_" + abl.replace(",", "_")))
     out.append(Cfg(epi=0, cap=2, name="scail_conv4_e0_c2"))
     out.append(Cfg(epi=0, rd_step=2.0, name="scail_conv4_e0_rd2"))
     out.append(Cfg(epi=0, rd_at=6.0, rd_step=2.5, name="scail_conv4_e0_rd6"))
+    out.append(Cfg(epi=0, p_at=30.0, dma_at=10.0, name="scail_conv4_e0_p30"))
     return out
 
 

@@ -621,7 +621,7 @@ struct Conv4Args {
     int32_t Cin, N, Kpad, pt;
     int32_t tiles_h, tiles_w, tiles_n; uint32_t magic_n;
     uint32_t magic_w, magic_h; int32_t n_slices, ot_mul;
-    int32_t ot_off, pad_;
+    int32_t ot_off, per_xcd;
     int64_t ldc, ldr;
 };
 static_assert(sizeof(Conv4Args) == 128, "Conv4Args must match asmgen/conv4.py KERNARG_SIZE");
@@ -708,14 +708,17 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         a.tiles_h = (p.Ho + 15) / 16; a.tiles_w = (p.Wo + 15) / 16; a.tiles_n = p.N / 96;
         auto magic31 = [](int d) { return (uint32_t)(((1ull << 31) + (uint64_t)d - 1) / (uint64_t)d); };
         a.magic_n = magic31(a.tiles_n); a.magic_w = magic31(a.tiles_w); a.magic_h = magic31(a.tiles_h);
-        a.n_slices = p.Cin / 32; a.ot_mul = p.ot_mul; a.ot_off = p.ot_off; a.pad_ = 0; a.ldc = ldc; a.ldr = resid ? ldr : ldc;
+        a.n_slices = p.Cin / 32; a.ot_mul = p.ot_mul; a.ot_off = p.ot_off; a.ldc = ldc; a.ldr = resid ? ldr : ldc;
         const int64_t tiles = (int64_t)((p.To + 1) / 2) * a.tiles_h * a.tiles_w * a.tiles_n;
         SCAIL_REQUIRE(tiles < (1ll << 24), "too many tiles");        // the kernel's magic-number divisions are exact below 2^31 / divisor
+        // workgroup b runs on XCD b % 8 and takes tile (b % 8) * per_xcd + b / 8: a contiguous range per XCD (the n tiles of a patch and
+        // its neighbours share an L2); ids past the last tile exit at once
+        a.per_xcd = (int32_t)((tiles + 7) / 8);
         hipFunction_t fn;
         if (int rc = conv4_function(std::string(resid ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)tiles, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)a.per_xcd * 8u, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
         if (e != hipSuccess) {
             scail_set_error(std::string("conv4: launch failed: ") + hipGetErrorString(e));
             return 2;
