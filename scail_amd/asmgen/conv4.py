@@ -88,16 +88,24 @@ class Cfg:
 # ---- registers ------------------------------------------------------------------------------------------------------------------
 def ACC(nb, mb): return A((nb * 8 + mb) * 4, 4)
 def WF(s, nb): return V(s * 24 + nb * 4, 4)                 # W fragments (A operand), set s = tap % 3 (27 taps: the sets line up across slices)
-def XF(s, mb): return A(192 + s * 32 + mb * 4, 4) if s < 2 else V(72 + mb * 4, 4)      # x fragments (B operand), set s
 
 
-PBASE = [V(104 + dt) for dt in range(3)]                    # per-lane fragment base inside the slot of patch frame f + dt of the current slice
-WB = V(107)                                                 # per-lane W fragment base inside the W ring (advances one buffer per tap)
-PDMA = [V(108 + k) for k in range(6)]                       # per-lane source offsets of the 6 voxel groups of a patch frame (chunk = wave)
-WDMA = [V(114 + i) for i in range(2)]                       # per-lane source offsets of this wave's 2 W-tile pieces
-LANE = V(116)
-T_ = [V(120 + i) for i in range(40)]                        # v120..v159 temporaries
-EPI_BQ, EPI_RP, EPI_F = 160, 184, 200                       # epilogue: bias quads v160..183, residual pairs v184..195, staging v200..215
+def XF(s, r):
+    """x fragments (B operand): patch row r (0..9) of tap group (dt, dw), set s = group % 3: the 10 rows serve the 3 taps dh = 0, 1, 2."""
+    if s == 0:
+        return A(192 + 4 * r, 4)
+    if s == 1:
+        return A(232 + 4 * r, 4) if r < 6 else V(72 + 4 * (r - 6), 4)
+    return V(88 + 4 * r, 4)
+
+
+PBASE = [V(128 + dt) for dt in range(3)]                    # per-lane fragment base inside the slot of patch frame f + dt of the current slice
+WB = V(131)                                                 # per-lane W fragment base inside the W ring (advances one buffer per tap)
+PDMA = [V(132 + k) for k in range(6)]                       # per-lane source offsets of the 6 voxel groups of a patch frame (chunk = wave)
+WDMA = [V(138 + i) for i in range(2)]                       # per-lane source offsets of this wave's 2 W-tile pieces
+LANE = V(141)
+T_ = [V(144 + i) for i in range(40)]                        # v144..v183 temporaries
+EPI_BQ, EPI_RP, EPI_F = 184, 208, 220                       # epilogue: bias quads v184..207, residual pairs v208..219, staging v220..235
 
 S_KARG = S(0, 2)
 S_WG = S(2)
@@ -115,10 +123,11 @@ S_WAVE, S_F, S_RH = S(64), S(65), S(66)
 S_T0, S_H0, S_W0, S_N0 = S(67), S(68), S(69), S(70)
 S_SL, S_XOFF, S_XOFFN = S(71), S(72), S(73)                 # slice counter, channel byte offset of this / the next slice
 S_WNEXT, S_CIN2, S_C26 = S(74), S(75), S(76)                # W source offset of the next DMA tap, 2 Cin, 26 * 2 Cin - 64
+S_C3, S_C5 = S(98), S(99)                                   # 3 * 2 Cin, 5 * 2 Cin
 S_WM0 = S(77)                                               # LDS offset of this wave's first piece in the W buffer of the current tap
 S_SLOT = [S(78 + j) for j in range(4)]                      # LDS offset (plane of this wave) of the slot the next load of patch frame j goes to
 ST = [S(82 + i) for i in range(16)]                         # s82..s97 temporaries
-N_SGPR = 98
+N_SGPR = 100
 
 
 class Gen:
@@ -126,25 +135,31 @@ class Gen:
         self.cfg = cfg
 
     # ---- building blocks -------------------------------------------------------------------------------------------------------
-    def mfmas(self, s: int) -> List[Instr]:
-        # n-block major: the A fragment (W) stays for 8 consecutive MFMAs
-        return [isa.mfma16(ACC(nb, mb), WF(s, nb), XF(s, mb), ACC(nb, mb), tag="mm") for nb in range(6) for mb in range(8)]
+    # Tap order: position i = (dt 3 + dw) 3 + dh -- dh innermost: the 10 patch rows of a group (dt, dw) are read once and serve 3 taps.
+    @staticmethod
+    def tap_id(i: int) -> int:
+        """weight tap (dt 3 + dh) 3 + dw of position i."""
+        dt, dw, dh = i // 9, (i // 3) % 3, i % 3
+        return (dt * 3 + dh) * 3 + dw
 
-    def frag_reads(self, s: int, tap: int, t0: float, step: float) -> List[Instr]:
-        """fragments of ``tap`` into set s: 6 W quads from the W buffer WB points at, 8 x quads from the slot of patch frame f + dt."""
-        dt, dh, dw = tap // 9, (tap // 3) % 3, tap % 3
-        out = []
-        order = [("w", 0)] + [("x", mb) for mb in range(8)] + [("w", nb) for nb in range(1, 6)]
-        for k, (kind, i) in enumerate(order):
-            if kind == "w":
-                out.append(isa.ds_read_b128(WF(s, i), WB, i * 1024, target_gap=t0 + step * k))
-            else:
-                out.append(isa.ds_read_b128(XF(s, i), PBASE[dt], ((i + dh) * PC + dw) * 16, target_gap=t0 + step * k))
-        return out
+    def mfmas(self, i: int) -> List[Instr]:
+        # n-block major: the A fragment (W) stays for 8 consecutive MFMAs
+        ws, xs, dh = i % 3, (i // 3) % 3, i % 3
+        return [isa.mfma16(ACC(nb, mb), WF(ws, nb), XF(xs, mb + dh), ACC(nb, mb), tag="mm") for nb in range(6) for mb in range(8)]
+
+    def w_reads(self, i: int, t0: float, step: float) -> List[Instr]:
+        """the 6 W quads of position i from the W buffer WB points at."""
+        return [isa.ds_read_b128(WF(i % 3, nb), WB, nb * 1024, target_gap=t0 + step * nb) for nb in range(6)]
+
+    def x_reads(self, grp: int, rows, t0: float, step: float) -> List[Instr]:
+        """patch rows ``rows`` of tap group grp = dt 3 + dw (of the slice the PBASE registers point into) -> set grp % 3."""
+        dt, dw = grp // 3, grp % 3
+        return [isa.ds_read_b128(XF(grp % 3, r), PBASE[dt], (r * PC + dw) * 16, target_gap=t0 + step * k) for k, r in enumerate(rows)]
 
     def w_dma(self, t0: float, step: float, need: int) -> List[Instr]:
         """this wave's 2 pieces (of 8: pieces w and w + 4; rows >= 96 fail the range check = zeros) of the W tile at S_WNEXT -> the buffer
-        S_WM0 points at; then both move on (ring of NWB buffers; the tap after the 27th is tap 0 of the next slice)."""
+        S_WM0 points at; then the ring moves on.  (Splitting the DMA work by kind instead -- waves 0, 1 the W tiles, waves 2, 3 the patch frames,
+        so that a W tile never queues behind a patch piece from HBM in the in-order return queue -- measured 1-2 % SLOWER.)"""
         out = []
         for i in range(2):
             out.append(isa.sop("s_add_u32", M0, S_WM0, I32(4096 * i), target_gap=t0 + step * i - 0.5))
@@ -155,11 +170,13 @@ class Gen:
                 isa.sop("s_and_b32", S_WM0, S_WM0, I32(WREG - 1), target_gap=t0 + step + 1.2)]
         return out
 
-    def w_next(self, issued_tap: int, tg: float) -> List[Instr]:
-        """advance S_WNEXT past tap ``issued_tap`` (0..26) of a slice."""
-        if issued_tap == 26:      # its successor is tap 0 of the following slice: back 26 taps, forward one slice (64 bytes)
+    def w_next(self, pos: int, tg: float) -> List[Instr]:
+        """advance S_WNEXT from the weight tap of position ``pos`` (0..26) to that of the next position."""
+        if pos == 26:             # position 0 of the following slice: back 26 taps, forward one slice (64 bytes)
             return [isa.sop("s_sub_u32", S_WNEXT, S_WNEXT, S_C26, target_gap=tg)]
-        return [isa.sop("s_add_u32", S_WNEXT, S_WNEXT, S_CIN2, target_gap=tg)]
+        d = self.tap_id(pos + 1) - self.tap_id(pos)
+        return [isa.sop("s_add_u32", S_WNEXT, S_WNEXT, {3: S_C3, 1: S_CIN2}[d], target_gap=tg) if d > 0 else
+                isa.sop("s_sub_u32", S_WNEXT, S_WNEXT, {-5: S_C5}[d], target_gap=tg)]
 
     def patch_piece(self, j: int, k: int, soff, tg: float, need: int) -> List[Instr]:
         """voxel group k of this wave's chunk plane of patch frame j -> the slot S_SLOT[j] points at."""
@@ -178,35 +195,39 @@ class Gen:
         return [isa.vop("v_subrev_u32", t0, I32(FSLOT), PBASE[dt], target_gap=tg), isa.v_cmp("v_cmp_gt_u32", I32(PBASE0), t0, target_gap=tg + 0.1),
                 isa.vop("v_add_u32", t1, I32(NSLOT * FSLOT), t0, target_gap=tg + 0.2), isa.v_cndmask(PBASE[dt], t0, t1, target_gap=tg + 0.3)]
 
-    # which patch pieces a tap issues: (frame, voxel group, next slice?, needed at the top of relative tap)
-    PIECES = {**{i: (3, i, False, 17) for i in range(6)}, **{6 + i: (0, i, True, 26) for i in range(6)},
-              **{12 + i: (1, i, True, 26) for i in range(6)}, **{18 + i: (2, i, True, 27 + 8) for i in range(6)}}
+    # which patch piece a position issues: (frame, voxel group, next slice?, needed at the top of relative position).  Frame 2 is first read
+    # (wave frame 1, dt = 1: group 3) during positions 6..8, frame 3 (group 6) during 15..17, frames 0 / 1 of the next slice during 24..26;
+    # their slots were released by frames 1 (after the top of 15), 2 (24), 3 (24) of the slice before and 0 (6) of this one.
+    PIECES = {**{i: (3, i, False, 15) for i in range(6)}, **{6 + i: (0, i, True, 24) for i in range(6)},
+              **{12 + i: (1, i, True, 24) for i in range(6)}, **{18 + i: (2, i, True, 27 + 6) for i in range(6)}}
+    XSPLIT = ((0, 1, 2, 3), (4, 5, 6), (7, 8, 9))          # rows of the next group read during dh = 0, 1, 2 of this one
 
-    def tap_fillers(self, tap: int) -> List[Instr]:
+    def tap_fillers(self, i: int) -> List[Instr]:
         c = self.cfg
         abl = c.abl.split(",")
-        s = tap % 3
         blk: List[Instr] = []
         if "lds" not in abl:
             blk += [isa.vop("v_add_u32", WB, I32(WBUF), WB, target_gap=0.0), isa.vop("v_and_b32", WB, I32(WREG - 1), WB, target_gap=0.1)]
-            blk += self.frag_reads((s + 1) % 3, (tap + 1) % 27, c.rd_at, c.rd_step)
+            rows = self.XSPLIT[i % 3]
+            blk += self.w_reads((i + 1) % 27, c.rd_at, c.rd_step)
+            blk += self.x_reads((i // 3 + 1) % 9, rows, c.rd_at + 6 * c.rd_step, c.rd_step)
         if "dma" not in abl:
-            blk += self.w_dma(c.dma_at, c.dma_step, need=tap + NWB - 1)
-            blk += self.w_next((tap + NWB) % 27, c.dma_at + c.dma_step + 1.5)
-            if tap in self.PIECES and "patch" not in abl:
-                j, k, nxt, need = self.PIECES[tap]
+            blk += self.w_dma(c.dma_at, c.dma_step, need=i + NWB - 1)
+            blk += self.w_next((i + NWB) % 27, c.dma_at + c.dma_step + 1.5)
+            if i in self.PIECES and "patch" not in abl:
+                j, k, nxt, need = self.PIECES[i]
                 blk += self.patch_piece(j, k, S_XOFFN if nxt else S_XOFF, c.p_at, need)
                 if k == 5:
                     blk += self.slot_next(j, c.p_at + 1.0)
-        if tap in (10, 19, 26):
-            blk += self.pbase_next({10: 0, 19: 1, 26: 2}[tap], 40.0)
+        if i in (10, 19, 26):
+            blk += self.pbase_next({10: 0, 19: 1, 26: 2}[i], 40.0)
         return blk
 
     def tap_block(self, tap: int) -> List[Instr]:
         """One tap of the unrolled slice body, scheduled: 48 MFMAs with the next tap's fragment reads, the W DMA of tap + 4 and a patch
         piece of the frames that are due in their gaps.  (The top -- waits + barrier -- is added by slice_body, which knows the DMA order.)"""
         c = self.cfg
-        return sched.schedule(self.tap_fillers(tap) + self.mfmas(tap % 3), cap=c.cap, lookahead=c.lookahead)
+        return sched.schedule(self.tap_fillers(tap) + self.mfmas(tap), cap=c.cap, lookahead=c.lookahead)
 
     def slice_body(self) -> List[Instr]:
         """One 32-channel slice = 27 taps.  At the top of tap i: this tap's fragments are in registers (lgkmcnt 0), every DMA whose data
@@ -259,7 +280,8 @@ class Gen:
         fb = S(ST[14].idx, 2)
         o += [isa.sop("s_mul_i32", ST[8], S_H, S_Wd), isa.sop("s_lshl_b32", S_CIN2, S_CIN, I32(1)),
               isa.sop("s_mul_i32", fb.sub(0), ST[8], S_CIN2), isa.sop("s_mul_hi_u32", fb.sub(1), ST[8], S_CIN2),
-              isa.sop("s_mul_i32", S_C26, S_CIN2, I32(26)), isa.sop("s_sub_u32", S_C26, S_C26, I32(64))]
+              isa.sop("s_mul_i32", S_C26, S_CIN2, I32(26)), isa.sop("s_sub_u32", S_C26, S_C26, I32(64)),
+              isa.sop("s_mul_i32", S_C3, S_CIN2, I32(3)), isa.sop("s_mul_i32", S_C5, S_CIN2, I32(5))]
         # ---- patch frame j: input frame t = t0 - pt + j; descriptor base = x + t * FB, num_records = FB (0 when t is outside [0, Ti)) ----
         tfr = ST[9]
         for j in range(4):
@@ -320,6 +342,15 @@ class Gen:
         # W: row ql (64 B), chunk g ^ ((ql >> 1) & 3); buffer 0
         o += [isa.vop("v_lshrrev_b32", t[1], I32(1), ql), isa.vop("v_and_b32", t[1], I32(3), t[1]), isa.vop("v_xor_b32", t[1], g, t[1]),
               isa.vop("v_lshlrev_b32", t[2], I32(6), ql), isa.vop("v_lshl_add_u32", WB, t[1], I32(4), t[2])]
+        # ---- bias quads of this lane's channels n0 + 16 nb + 4 (l / 16) + e (zeros when bias == NULL): they wait in v184..207 for the epilogue ----
+        for i in range(24):
+            o.append(isa.vop("v_mov_b32", V(EPI_BQ + i), I32(0)))
+        o += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias"),
+              isa.sop("s_lshl_b32", ST[7], S_N0, I32(2)), isa.sop("s_add_u32", S_BIAS.sub(0), S_BIAS.sub(0), ST[7]),
+              isa.sop("s_addc_u32", S_BIAS.sub(1), S_BIAS.sub(1), I32(0)), isa.vop("v_lshlrev_b32", t[1], I32(4), g)]
+        for nb in range(6):
+            o.append(isa.global_load(4, V(EPI_BQ + 4 * nb, 4), t[1], 64 * nb, saddr=S_BIAS))
+        o += [isa.label("L_nobias"), isa.nop(7)]
         # ---- streams: patch frames 0, 1, 2 of slice 0, W taps 0 .. 3 ----
         o += [isa.sop("s_mov_b32", S_SL, I32(0)), isa.sop("s_mov_b32", S_XOFF, I32(0)), isa.sop("s_mov_b32", S_WNEXT, I32(0)),
               isa.sop("s_cmp_lt_u32", None, I32(1), S_NSL), isa.sop("s_cselect_b32", S_XOFFN, I32(64), I32(0))]
@@ -334,7 +365,7 @@ class Gen:
         for i in range(192):
             o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
         o += [isa.waitcnt(vmcnt=0), isa.barrier()]
-        o += self.frag_reads(0, 0, 0, 0)
+        o += self.w_reads(0, 0, 0) + self.x_reads(0, range(10), 0, 0)
         return sched.pad_hazards(sched.insert_lgkm_waits(o))
 
     # ---- epilogue ----------------------------------------------------------------------------------------------------------------
@@ -359,37 +390,41 @@ class Gen:
                   isa.sop("s_add_u32", base.sub(0), src.sub(0), ST[2]), isa.sop("s_addc_u32", base.sub(1), src.sub(1), ST[3]),
                   isa.sop("s_lshl_b32", ST[7], S_N0, I32(1)),
                   isa.sop("s_add_u32", base.sub(0), base.sub(0), ST[7]), isa.sop("s_addc_u32", base.sub(1), base.sub(1), I32(0))]
-        # bias quads (zeros when bias == NULL)
-        BQ = [V(EPI_BQ + 4 * nb, 4) for nb in range(6)]
-        for i in range(24):
-            e.append(isa.vop("v_mov_b32", V(EPI_BQ + i), I32(0)))
-        e += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias"),
-              isa.sop("s_lshl_b32", ST[7], S_N0, I32(2)), isa.sop("s_add_u32", S_BIAS.sub(0), S_BIAS.sub(0), ST[7]),
-              isa.sop("s_addc_u32", S_BIAS.sub(1), S_BIAS.sub(1), I32(0)), isa.vop("v_lshlrev_b32", t[1], I32(4), g)]
-        for nb in range(6):
-            e.append(isa.global_load(4, BQ[nb], t[1], 64 * nb, saddr=S_BIAS))
-        e += [isa.waitcnt(vmcnt=0), isa.label("L_nobias"), isa.nop(7)]
+        BQ = [V(EPI_BQ + 4 * nb, 4) for nb in range(6)]          # bias quads, loaded by the prologue
         # column and frame validity are the same for all 8 row blocks
         wcol = t[2]
         e += [isa.vop("v_add_u32", wcol, S_W0, ql),
               isa.sop("s_cmp_lt_u32", None, tf, S_T), isa.sop("s_cselect_b32", ST[8], S_Wd, I32(0))]      # frame outside [0, To): no column is valid
         row0 = ST[9]
         e += [isa.sop("s_lshl_b32", row0, S_RH, I32(3)), isa.sop("s_add_u32", row0, row0, S_H0)]
-        RP = [V(EPI_RP + 2 * nb, 2) for nb in range(6)]
-        for mb in range(8):
+        def row_setup(mb, want_y, want_r):
+            """offsets of row block mb in t[4] (y) / t[5] (resid); exec = lanes with a voxel inside the tensor (saved exec in S_SAVE)."""
             yoff, roff, vox, hrow = t[4], t[5], t[6], ST[10]
-            e += [isa.sop("s_add_u32", hrow, row0, I32(mb)),
-                  isa.sop("s_cmp_lt_u32", None, hrow, S_H), isa.sop("s_cselect_b32", ST[11], ST[8], I32(0)),      # columns allowed in this row
-                  isa.sop("s_mul_i32", ST[12], hrow, S_Wd),
-                  isa.vop("v_add_u32", vox, ST[12], wcol),
-                  isa.vop("v_mul_lo_u32", yoff, vox, ldc2), isa.vop("v_lshl_add_u32", yoff, g, I32(3), yoff),
-                  isa.v_cmp("v_cmp_gt_u32", ST[11], wcol),
+            r = [isa.sop("s_add_u32", hrow, row0, I32(mb)),
+                 isa.sop("s_cmp_lt_u32", None, hrow, S_H), isa.sop("s_cselect_b32", ST[11], ST[8], I32(0)),      # columns allowed in this row
+                 isa.sop("s_mul_i32", ST[12], hrow, S_Wd),
+                 isa.vop("v_add_u32", vox, ST[12], wcol)]
+            if want_y:
+                r += [isa.vop("v_mul_lo_u32", yoff, vox, ldc2), isa.vop("v_lshl_add_u32", yoff, g, I32(3), yoff)]
+            if want_r:
+                r += [isa.vop("v_mul_lo_u32", roff, vox, ldr2), isa.vop("v_lshl_add_u32", roff, g, I32(3), roff)]
+            r += [isa.v_cmp("v_cmp_gt_u32", ST[11], wcol),
                   Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
-            if c.epi == 3:
-                e += [isa.vop("v_mul_lo_u32", roff, vox, ldr2), isa.vop("v_lshl_add_u32", roff, g, I32(3), roff)]
+            return r
+
+        restore = lambda: [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+        RP = lambda mb, nb: V(mb * 12 + 2 * nb, 2)          # residual pairs: the fragment registers v0..v95 are free now
+        if c.epi == 3:
+            # every residual load first (48 per lane), one wait
+            for mb in range(8):
+                e += row_setup(mb, False, True)
                 for nb in range(6):
-                    e.append(isa.global_load(2, RP[nb], roff, 32 * nb, saddr=S_RF, extra_reads=[EXEC]))
-                e.append(isa.waitcnt(vmcnt=0))
+                    e.append(isa.global_load(2, RP(mb, nb), t[5], 32 * nb, saddr=S_RF, extra_reads=[EXEC]))
+                e += restore()
+            e.append(isa.waitcnt(vmcnt=0))
+        for mb in range(8):
+            e += row_setup(mb, True, False)
+            yoff = t[4]
             for nb in range(6):
                 base = EPI_F + 8 * (nb % 2)
                 f = [V(base + i) for i in range(4)]
@@ -399,13 +434,13 @@ class Gen:
                     e += [isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)), isa.vop("v_add_f32", f[i], f[i], BQ[nb].sub(i))]
                 if c.epi == 3:
                     for i in range(4):
-                        src = RP[nb].sub(i >> 1)
+                        src = RP(mb, nb).sub(i >> 1)
                         e += [isa.vop("v_lshlrev_b32", r_, I32(16), src) if (i & 1) == 0 else isa.vop("v_and_b32", r_, I32(0xFFFF0000), src),
                               isa.vop("v_add_f32", f[i], f[i], r_)]
                 e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
                       isa.global_store(2, yoff, w, 32 * nb, saddr=S_YF, extra_reads=[EXEC])]
-            e += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
-        e += [isa.waitcnt(vmcnt=0), isa.label("L_exit"), Instr("s_endpgm", cls=isa.BRANCH)]
+            e += restore()
+        e += [isa.label("L_exit"), Instr("s_endpgm", cls=isa.BRANCH)]      # (stores may still be in flight: the hardware drains them)
         return sched.pad_hazards(e)
 
     def program(self) -> List[Instr]:

@@ -74,5 +74,17 @@ for C, H, W in ((96, 512, 896), (192, 256, 448), (384, 128, 224)):
             ref = out.clone()
         print(json.dumps(dict(C=C, H=H, W=W, T=T, kernel="halo (hipcc)" if mode == 10 else "conv4" + var, ms=sorted(ts)[2], tflops=fl / sorted(ts)[2] / 1e9,
                               maxdiff_vs_halo=float((out.float() - ref.float()).abs().max()))), flush=True)
+    # with the residual epilogue (the second convolution of a ResidualBlock)
+    r = torch.randn(T, H, W, C, device=dev, generator=g).to(torch.bfloat16)
+    for mode in (10, 11):
+        lib.tune_set("conv_halo", mode)
+        setk("")
+        f = lambda: O.conv3d_cl(x, wp, (T, H, W), out=out, resid=r)
+        f(); f(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+        print(json.dumps(dict(C=C, H=H, W=W, T=T, resid=True, kernel="halo (hipcc)" if mode == 10 else "conv4", ms=sorted(ts)[2], tflops=fl / sorted(ts)[2] / 1e9)), flush=True)
 lib.tune_set("conv_halo", 10)
 setk("")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """The dominant convolution launches of the Wan2.1 VAE on the product library (3x3x3 causal 'same', channels-last, 21 frames):
 C = 96 @ 512x896, C = 192 @ 256x448, C = 384 @ 128x224, `iters` launches each: the process rocprofv3 --pmc wraps for the fabric traffic
-of conv_halo_kernel (FETCH_SIZE / WRITE_SIZE in separate passes).  usage: python tools/conv_pmc_probe.py <C: 96 | 192 | 384> [iters]   (one shape per run: the three share a kernel name)"""
+of conv_halo_kernel (FETCH_SIZE / WRITE_SIZE in separate passes).  usage: python tools/conv_pmc_probe.py <C: 96 | 192 | 384> [iters] [conv4]   (one shape per run: the three share a kernel name;
+"conv4": the generated kernel through the measurement build's knob, SCAIL_ABLATIONS=1)"""
 import os
 import sys
 
@@ -13,6 +14,8 @@ from scail_amd import lib, ops as O  # noqa: E402
 which = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 lib.load()
+if len(sys.argv) > 3 and sys.argv[3] == "conv4":
+    lib.tune_set("conv_halo", 11)
 g = torch.Generator(device="cuda").manual_seed(0)
 T = 21
 for C, H, W in ((96, 512, 896), (192, 256, 448), (384, 128, 224)):
