@@ -30,9 +30,9 @@ from typing import List
 from . import isa, sched
 from .isa import A, S, V, I32, F32, VCC, EXEC, M0, Instr
 
-KERNARG_SIZE = 128
-# x w bias y resid | Ti To H W | Cin N Kpad pt | tiles_h tiles_w tiles_n magic_n | magic_w magic_h n_slices ot_mul | ot_off per_xcd | ldc ldr
-KERNARG_FMT = "<5Q4i4i3iI2I2iii2q"
+KERNARG_SIZE = 136
+# x w bias y resid | Ti To H W | Cin N Kpad pt | tiles_h tiles_w tiles_n magic_n | magic_w magic_h n_slices ot_mul | ot_off per_xcd | ldc ldr | wgs_per_xcd tiles
+KERNARG_FMT = "<5Q4i4i3iI2I2iii2q2i"
 
 TH, TW, NF = 16, 16, 2
 PR, PC = TH + 2, TW + 2                 # patch rows / columns
@@ -52,11 +52,12 @@ def magic31(d: int) -> int:
     return -(-(1 << 31) // d)
 
 
-def pack_args(x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt=2, ot_mul=1, ot_off=0, ldc=0, ldr=0) -> bytes:
-    """ldc / ldr: output / residual row strides in elements (0 = N)."""
+def pack_args(x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt=2, ot_mul=1, ot_off=0, ldc=0, ldr=0, cus=256) -> bytes:
+    """ldc / ldr: output / residual row strides in elements (0 = N); cus: compute units (one persistent workgroup each)."""
     th, tw, tn = (H + TH - 1) // TH, (W + TW - 1) // TW, (N + 95) // 96
     b = struct.pack(KERNARG_FMT, x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt, th, tw, tn, magic31(tn), magic31(tw), magic31(th),
-                    Cin // 32, ot_mul, ot_off, (grid_tiles(To, H, W, N) + 7) // 8, ldc or N, ldr or N)
+                    Cin // 32, ot_mul, ot_off, (grid_tiles(To, H, W, N) + 7) // 8, ldc or N, ldr or N,
+                    grid_blocks(To, H, W, N, cus) // 8, grid_tiles(To, H, W, N))
     assert len(b) == KERNARG_SIZE, len(b)
     return b
 
@@ -65,10 +66,11 @@ def grid_tiles(T, H, W, N) -> int:
     return ((T + NF - 1) // NF) * ((H + TH - 1) // TH) * ((W + TW - 1) // TW) * ((N + 95) // 96)
 
 
-def grid_blocks(T, H, W, N) -> int:
-    """workgroups launched: workgroup b runs on XCD b % 8 and takes tile (b % 8) * per_xcd + b / 8 -- every XCD a contiguous range
-    (the n tiles of a patch and neighbouring patches share an L2); ids beyond the last tile exit at once."""
-    return (grid_tiles(T, H, W, N) + 7) // 8 * 8
+def grid_blocks(T, H, W, N, cus=256) -> int:
+    """workgroups launched: persistent, at most one per compute unit, a multiple of 8.  Workgroup b runs on XCD b % 8 and walks the tiles
+    (b % 8) * per_xcd + b / 8 + i * (grid / 8) of that XCD's contiguous range (the n tiles of a patch and neighbouring patches share an L2)."""
+    per = (grid_tiles(T, H, W, N) + 7) // 8
+    return 8 * min(per, max(cus // 8, 1))
 
 
 @dataclass
@@ -82,6 +84,8 @@ class Cfg:
     dma_at: float = 4.0     # gap of the first W-tile DMA piece of tap + 3, the second dma_step later
     dma_step: float = 20.0
     p_at: float = 12.0      # gap of the tap's patch DMA piece
+    stagger: int = 14       # workgroup i of an XCD starts i * 64 * stagger cycles late: the tiles' load / store bursts of the 256 workgroups do not coincide
+    prof: bool = False      # measurement variant: s_memtime stamps around the phases of a tile; wave 0 of every workgroup writes the sums to `resid`
     abl: str = ""
 
 
@@ -109,25 +113,33 @@ EPI_BQ, EPI_RP, EPI_F = 184, 208, 220                       # epilogue: bias qua
 
 S_KARG = S(0, 2)
 S_WG = S(2)
+S_TILE, S_G, S_TEND = S(3), S(4), S(5)                      # this workgroup's current tile, its stride (workgroups per XCD), end of the XCD's range
+S_ET0, S_EH0, S_EW0, S_EN0 = S(6), S(7), S(18), S(19)       # coordinates of the tile whose accumulators wait for the epilogue
 S_X, S_Wp, S_BIAS, S_Y, S_RES = S(8, 2), S(10, 2), S(12, 2), S(14, 2), S(16, 2)
 S_TI, S_T, S_H, S_Wd = S(20), S(21), S(22), S(23)            # input frames, output frames, rows, columns
 S_CIN, S_N, S_KPAD, S_PT = S(24), S(25), S(26), S(27)
 S_TLH, S_TLW, S_TLN, S_MGN = S(28), S(29), S(30), S(31)
 S_MGW, S_MGH, S_NSL, S_OTM = S(32), S(33), S(34), S(35)
 S_OTO, S_PER = S(36), S(37)
+S_KP2 = S(37)                                               # 2 Kpad (takes the place of per_xcd once the tile range is known)
+S_SAVE = S(38, 2)                                           # epilogue: saved exec
 S_LDC, S_LDR = S(40, 2), S(42, 2)
 S_XR = [S(44 + 4 * j, 4) for j in range(4)]                 # buffer descriptors of the 4 input frames of the patch (num_records = 0: a padding frame)
-S_YF, S_RF, S_SAVE = S(44, 2), S(46, 2), S(48, 2)           # epilogue (the descriptors are dead by then): output / residual frame base, exec
 S_WR = S(60, 4)                                             # W descriptor of this workgroup's 96 rows
 S_WAVE, S_F, S_RH = S(64), S(65), S(66)
 S_T0, S_H0, S_W0, S_N0 = S(67), S(68), S(69), S(70)
 S_SL, S_XOFF, S_XOFFN = S(71), S(72), S(73)                 # slice counter, channel byte offset of this / the next slice
 S_WNEXT, S_CIN2, S_C26 = S(74), S(75), S(76)                # W source offset of the next DMA tap, 2 Cin, 26 * 2 Cin - 64
-S_C3, S_C5 = S(98), S(99)                                   # 3 * 2 Cin, 5 * 2 Cin
 S_WM0 = S(77)                                               # LDS offset of this wave's first piece in the W buffer of the current tap
 S_SLOT = [S(78 + j) for j in range(4)]                      # LDS offset (plane of this wave) of the slot the next load of patch frame j goes to
 ST = [S(82 + i) for i in range(16)]                         # s82..s97 temporaries
-N_SGPR = 100
+S_C3, S_C5 = S(98), S(99)                                   # 3 * 2 Cin, 5 * 2 Cin
+S_FB = S(100, 2)                                            # bytes of an input frame (64 bit)
+S_YF, S_RF = S(0, 2), S(96, 2)                              # epilogue: output / residual frame base (the kernarg pointer and two temporaries are free then)
+S_LDR2 = S(2)                                               # epilogue: residual row stride in bytes (the workgroup id is consumed at entry)
+N_SGPR = 102
+S_PROFWG = S(43)                                            # (prof variant; the unused high word of ldr) workgroup id
+PBL, WBL = V(142), V(143)                                   # per-lane parts of the fragment bases (tile independent)
 
 
 class Gen:
@@ -135,6 +147,36 @@ class Gen:
         self.cfg = cfg
 
     # ---- building blocks -------------------------------------------------------------------------------------------------------
+    N_PHASE = 8
+    PROF_PREV, PROF_T = V(236), V(237)
+
+    def stamp(self, phase: int) -> List[Instr]:
+        """(prof variant) cycles since the previous stamp are added to phase ``phase`` (v240 + phase); phase < 0: just restart the clock."""
+        if not self.cfg.prof:
+            return []
+        tm = S(ST[0].idx, 2)
+        i = Instr("s_memtime", [tm], [], cls=isa.SALU)
+        i.text = f"s_memtime {tm}"
+        o = [i, isa.waitcnt(lgkmcnt=0)]
+        if phase >= 0:
+            o += [isa.vop("v_sub_u32", self.PROF_T, tm.sub(0), self.PROF_PREV), isa.vop("v_add_u32", V(240 + phase), V(240 + phase), self.PROF_T)]
+        o += [isa.vop("v_mov_b32", self.PROF_PREV, tm.sub(0))]
+        return o
+
+    def prof_init(self) -> List[Instr]:
+        return [isa.vop("v_mov_b32", V(240 + i), I32(0)) for i in range(self.N_PHASE)] if self.cfg.prof else []
+
+    def prof_dump(self) -> List[Instr]:
+        """wave 0, lane 0: phase sums -> resid[workgroup][8] (uint32)."""
+        if not self.cfg.prof:
+            return []
+        o = [isa.sop("s_cmp_eq_u32", None, S_WAVE, I32(0)), isa.branch("s_cbranch_scc0", "L_exit"),
+             isa.sop("s_lshl_b32", ST[0], S_PROFWG, I32(5)), isa.vop("v_lshlrev_b32", T_[1], I32(2), LANE), isa.vop("v_add_u32", T_[1], ST[0], T_[1]),
+             Instr("s_mov_b64", [EXEC], [I32(1)], cls=isa.SALU)]
+        for i in range(self.N_PHASE):
+            o.append(isa.global_store(1, T_[1], V(240 + i), 4 * i, saddr=S_RES, extra_reads=[EXEC]))
+        return o
+
     # Tap order: position i = (dt 3 + dw) 3 + dh -- dh innermost: the 10 patch rows of a group (dt, dw) are read once and serve 3 taps.
     @staticmethod
     def tap_id(i: int) -> int:
@@ -253,60 +295,102 @@ class Gen:
               isa.sop("s_cmp_lt_u32", None, S_SL, S_NSL), isa.branch("s_cbranch_scc1", "L_slice")]
         return o
 
-    # ---- prologue ----------------------------------------------------------------------------------------------------------------
-    def prologue(self) -> List[Instr]:
+    # ---- entry, per-tile setup, epilogue --------------------------------------------------------------------------------------------
+    # The workgroups are PERSISTENT (one per compute unit): the setup and the first DMAs of the next tile are issued BEFORE the epilogue of
+    # the tile just finished, whose stores then hide the DMA latency; a one-tile-per-workgroup launch measured 9.5 us of fixed cost per tile
+    # (launch, kernel arguments, exposed first loads, store drain) against 38 us of taps on the 96-channel shape.
+    def entry(self) -> List[Instr]:
         c = self.cfg
+        t = T_
         o: List[Instr] = [isa.label(c.name)]
         o += [isa.s_load(8, S(8, 8), S_KARG, 0), isa.s_load(2, S_RES, S_KARG, 32), isa.s_load(4, S(20, 4), S_KARG, 40),
               isa.s_load(4, S(24, 4), S_KARG, 56), isa.s_load(4, S(28, 4), S_KARG, 72), isa.s_load(4, S(32, 4), S_KARG, 88),
-              isa.s_load(2, S(36, 2), S_KARG, 104), isa.s_load(4, S(40, 4), S_KARG, 112),
-              isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", T_[0], I32(6), V(0)),
-              isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, T_[0]),
+              isa.s_load(2, S(36, 2), S_KARG, 104), isa.s_load(4, S(40, 4), S_KARG, 112), isa.s_load(2, S(4, 2), S_KARG, 128),
+              isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", t[0], I32(6), V(0)),
+              isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, t[0]),
               isa.sop("s_lshr_b32", S_F, S_WAVE, I32(1)), isa.sop("s_and_b32", S_RH, S_WAVE, I32(1))]
-        # ---- workgroup id b -> tile (b % 8) * per_xcd + b / 8 -> (frame pair, tile row, tile column, n tile); n fastest ----
-        tt, wid = ST[4], ST[3]
+        # ---- this workgroup's tiles: XCD x = b % 8 owns [x per_xcd, min((x + 1) per_xcd, tiles)); start at x per_xcd + b / 8, stride S_G ----
+        o += [isa.sop("s_and_b32", ST[0], S_WG, I32(7)), isa.sop("s_mul_i32", ST[1], ST[0], S_PER), isa.sop("s_lshr_b32", S_TILE, S_WG, I32(3)),
+              isa.sop("s_add_u32", S_TILE, S_TILE, ST[1]), isa.sop("s_add_u32", ST[1], ST[1], S_PER), isa.sop("s_min_u32", S_TEND, S_TEND, ST[1]),
+              isa.sop("s_cmp_ge_u32", None, S_TILE, S_TEND), isa.branch("s_cbranch_scc1", "L_exit")]
+        # ---- constants ----
+        o += [isa.sop("s_lshl_b32", S_KP2, S_KPAD, I32(1)),
+              isa.sop("s_mul_i32", ST[8], S_H, S_Wd), isa.sop("s_lshl_b32", S_CIN2, S_CIN, I32(1)),
+              isa.sop("s_mul_i32", S_FB.sub(0), ST[8], S_CIN2), isa.sop("s_mul_hi_u32", S_FB.sub(1), ST[8], S_CIN2),
+              isa.sop("s_mul_i32", S_C26, S_CIN2, I32(26)), isa.sop("s_sub_u32", S_C26, S_C26, I32(64)),
+              isa.sop("s_mul_i32", S_C3, S_CIN2, I32(3)), isa.sop("s_mul_i32", S_C5, S_CIN2, I32(5))]
+        # ---- W pieces of this wave: piece w + 4 i = rows 16 (w + 4 i) + l / 4, LDS position q = l % 4 holds source chunk q ^ ((row >> 1) & 3) ----
+        o += [isa.vop("v_lshrrev_b32", t[1], I32(2), LANE), isa.vop("v_and_b32", t[2], I32(3), LANE)]
+        for i in range(2):
+            o += [isa.sop("s_add_u32", ST[0], S_WAVE, I32(4 * i)), isa.sop("s_lshl_b32", ST[0], ST[0], I32(4)),
+                  isa.vop("v_add_u32", t[3], ST[0], t[1]),                                                        # row
+                  isa.vop("v_lshrrev_b32", t[4], I32(1), t[3]), isa.vop("v_and_b32", t[4], I32(3), t[4]), isa.vop("v_xor_b32", t[4], t[2], t[4]),
+                  isa.vop("v_mul_lo_u32", t[5], t[3], S_KP2), isa.vop("v_lshl_add_u32", WDMA[i], t[4], I32(4), t[5])]
+        # ---- per-lane parts of the fragment bases ----
+        ql, g = t[10], t[11]
+        o += [isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
+        # patch: chunk plane g, voxel (row 8 rh, column ql) of the slot of frame f (+ dt slots, + the ring position: tile_setup)
+        o += [isa.sop("s_mul_i32", ST[0], S_RH, I32(8 * PC)), isa.vop("v_add_u32", t[1], ST[0], ql), isa.vop("v_lshlrev_b32", t[1], I32(4), t[1]),
+              isa.vop("v_mul_u32_u24", t[2], I32(PLN), g), isa.vop("v_add_u32", t[1], t[1], t[2]),
+              isa.sop("s_mul_i32", ST[1], S_F, I32(FSLOT)), isa.sop("s_add_u32", ST[1], ST[1], I32(PBASE0)), isa.vop("v_add_u32", PBL, ST[1], t[1])]
+        # W: row ql (64 B), chunk g ^ ((ql >> 1) & 3)
+        o += [isa.vop("v_lshrrev_b32", t[1], I32(1), ql), isa.vop("v_and_b32", t[1], I32(3), t[1]), isa.vop("v_xor_b32", t[1], g, t[1]),
+              isa.vop("v_lshlrev_b32", t[2], I32(6), ql), isa.vop("v_lshl_add_u32", WBL, t[1], I32(4), t[2])]
+        o += [isa.sop("s_mov_b32", self.HAVE_PREV, I32(0))]       # no tile waits for its epilogue yet
+        if c.stagger:
+            # All workgroups start together and a tile takes every one of them the same time: unstaggered, the first loads of 256 tiles
+            # (27 MB) and the stores of 256 tiles (25 MB) hit HBM at once and each costs ~7-10 k cycles of blocked VMEM issue per tile
+            # (profiles/r03_conv4_phases.log) while the memory idles during the taps.
+            sl = Instr("s_sleep", cls=isa.SALU)
+            sl.text = f"s_sleep {c.stagger}"
+            o += [isa.sop("s_lshr_b32", ST[0], S_WG, I32(3)), isa.label("L_stagger"), isa.sop("s_cmp_eq_u32", None, ST[0], I32(0)),
+                  isa.branch("s_cbranch_scc1", "L_staggered"), sl, isa.sop("s_sub_u32", ST[0], ST[0], I32(1)), isa.branch("s_branch", "L_stagger"),
+                  isa.label("L_staggered")]
+        if c.prof:
+            o += [isa.sop("s_mov_b32", S_PROFWG, S_WG)] + self.prof_init() + self.stamp(-1)
+        return sched.pad_hazards(sched.insert_lgkm_waits(o))
+
+    HAVE_PREV = S(41)                                           # (the unused high word of ldc)  0: first tile; 1: a finished tile's accumulators wait; 3: ... and no tile follows
+
+    def tile_setup(self) -> List[Instr]:
+        """S_TILE -> coordinates, descriptors, per-lane patch offsets, ring positions; the first DMAs (frames 0, 1, 2 of slice 0, W taps 0..3),
+        the bias quads."""
+        t = T_
+        o: List[Instr] = [isa.label("L_tile"), isa.nop(7)]
+        o += [isa.sop("s_bitcmp1_b32", None, self.HAVE_PREV, I32(1)), isa.branch("s_cbranch_scc1", "L_epilogue")]     # nothing follows: only the epilogue
+        tt = ST[4]
         q1, q2, q3 = ST[5], ST[6], ST[7]
-        o += [isa.sop("s_and_b32", tt, S_WG, I32(7)), isa.sop("s_mul_i32", tt, tt, S_PER), isa.sop("s_lshr_b32", wid, S_WG, I32(3)),
-              isa.sop("s_add_u32", wid, wid, tt),
-              isa.sop("s_lshl_b32", tt, wid, I32(1)), isa.sop("s_mul_hi_u32", q1, tt, S_MGN),                   # q1 = tile / tiles_n
-              isa.sop("s_mul_i32", tt, q1, S_TLN), isa.sop("s_sub_u32", tt, wid, tt), isa.sop("s_mul_i32", S_N0, tt, I32(96)),
+        o += [isa.sop("s_lshl_b32", tt, S_TILE, I32(1)), isa.sop("s_mul_hi_u32", q1, tt, S_MGN),                # q1 = tile / tiles_n
+              isa.sop("s_mul_i32", tt, q1, S_TLN), isa.sop("s_sub_u32", tt, S_TILE, tt), isa.sop("s_mul_i32", S_N0, tt, I32(96)),
               isa.sop("s_lshl_b32", tt, q1, I32(1)), isa.sop("s_mul_hi_u32", q2, tt, S_MGW),                   # q2 = q1 / tiles_w
               isa.sop("s_mul_i32", tt, q2, S_TLW), isa.sop("s_sub_u32", tt, q1, tt), isa.sop("s_lshl_b32", S_W0, tt, I32(4)),
               isa.sop("s_lshl_b32", tt, q2, I32(1)), isa.sop("s_mul_hi_u32", q3, tt, S_MGH),                   # q3 = q2 / tiles_h
               isa.sop("s_mul_i32", tt, q3, S_TLH), isa.sop("s_sub_u32", tt, q2, tt), isa.sop("s_lshl_b32", S_H0, tt, I32(4)),
-              isa.sop("s_lshl_b32", S_T0, q3, I32(1)),
-              isa.sop("s_cmp_ge_u32", None, S_T0, S_T), isa.branch("s_cbranch_scc1", "L_exit")]                # an id beyond the last tile
-        # ---- input frame bytes (64 bit) = H * W * Cin * 2 ----
-        fb = S(ST[14].idx, 2)
-        o += [isa.sop("s_mul_i32", ST[8], S_H, S_Wd), isa.sop("s_lshl_b32", S_CIN2, S_CIN, I32(1)),
-              isa.sop("s_mul_i32", fb.sub(0), ST[8], S_CIN2), isa.sop("s_mul_hi_u32", fb.sub(1), ST[8], S_CIN2),
-              isa.sop("s_mul_i32", S_C26, S_CIN2, I32(26)), isa.sop("s_sub_u32", S_C26, S_C26, I32(64)),
-              isa.sop("s_mul_i32", S_C3, S_CIN2, I32(3)), isa.sop("s_mul_i32", S_C5, S_CIN2, I32(5))]
+              isa.sop("s_lshl_b32", S_T0, q3, I32(1))]
         # ---- patch frame j: input frame t = t0 - pt + j; descriptor base = x + t * FB, num_records = FB (0 when t is outside [0, Ti)) ----
         tfr = ST[9]
         for j in range(4):
             o += [isa.sop("s_add_u32", tfr, S_T0, I32(j)), isa.sop("s_sub_u32", tfr, tfr, S_PT),                 # may wrap below 0 -> huge unsigned
-                  isa.sop("s_cmp_lt_u32", None, tfr, S_TI), isa.sop("s_cselect_b32", ST[10], fb.sub(0), I32(0)),   # num_records
+                  isa.sop("s_cmp_lt_u32", None, tfr, S_TI), isa.sop("s_cselect_b32", ST[10], S_FB.sub(0), I32(0)),   # num_records
                   isa.sop("s_cselect_b32", tfr, tfr, I32(0)),
-                  isa.sop("s_mul_i32", ST[0], fb.sub(0), tfr), isa.sop("s_mul_hi_u32", ST[1], fb.sub(0), tfr),
-                  isa.sop("s_mul_i32", ST[2], fb.sub(1), tfr), isa.sop("s_add_u32", ST[1], ST[1], ST[2]),
+                  isa.sop("s_mul_i32", ST[0], S_FB.sub(0), tfr), isa.sop("s_mul_hi_u32", ST[1], S_FB.sub(0), tfr),
+                  isa.sop("s_mul_i32", ST[2], S_FB.sub(1), tfr), isa.sop("s_add_u32", ST[1], ST[1], ST[2]),
                   isa.sop("s_add_u32", S_XR[j].sub(0), S_X.sub(0), ST[0]), isa.sop("s_addc_u32", ST[1], S_X.sub(1), ST[1]),
                   isa.sop("s_and_b32", S_XR[j].sub(1), ST[1], I32(0xFFFF)), isa.sop("s_mov_b32", S_XR[j].sub(2), ST[10]),
                   isa.sop("s_mov_b32", S_XR[j].sub(3), I32(0x00020000))]
         # ---- W descriptor: base = w + n0 * Kpad * 2, num_records = min(96, N - n0) * Kpad * 2 ----
-        kp2 = ST[11]
-        o += [isa.sop("s_lshl_b32", kp2, S_KPAD, I32(1)),
-              isa.sop("s_mul_i32", ST[0], S_N0, kp2), isa.sop("s_mul_hi_u32", ST[1], S_N0, kp2),
+        o += [isa.sop("s_mul_i32", ST[0], S_N0, S_KP2), isa.sop("s_mul_hi_u32", ST[1], S_N0, S_KP2),
               isa.sop("s_add_u32", S_WR.sub(0), S_Wp.sub(0), ST[0]), isa.sop("s_addc_u32", ST[1], S_Wp.sub(1), ST[1]),
               isa.sop("s_and_b32", S_WR.sub(1), ST[1], I32(0xFFFF)),
-              isa.sop("s_sub_u32", ST[2], S_N, S_N0), isa.sop("s_min_u32", ST[2], ST[2], I32(96)), isa.sop("s_mul_i32", S_WR.sub(2), ST[2], kp2),
+              isa.sop("s_sub_u32", ST[2], S_N, S_N0), isa.sop("s_min_u32", ST[2], ST[2], I32(96)), isa.sop("s_mul_i32", S_WR.sub(2), ST[2], S_KP2),
               isa.sop("s_mov_b32", S_WR.sub(3), I32(0x00020000))]
-        # ---- LDS targets of this wave's DMA pieces: chunk plane `wave` of a frame slot; piece `wave` of a W buffer ----
+        # ---- ring positions: slice 0's frame j -> slot j; W buffer 0 ----
         o += [isa.sop("s_mul_i32", ST[0], S_WAVE, I32(PLN)), isa.sop("s_add_u32", ST[0], ST[0], I32(PBASE0)),
               isa.sop("s_lshl_b32", S_WM0, S_WAVE, I32(10))]
-        for j, slot in ((0, 0), (1, 1), (2, 2), (3, 3)):          # slice 0: frame j -> slot j
-            o.append(isa.sop("s_add_u32", S_SLOT[j], ST[0], I32(slot * FSLOT)))
-        t = T_
+        for j in range(4):
+            o.append(isa.sop("s_add_u32", S_SLOT[j], ST[0], I32(j * FSLOT)))
+        o += [isa.vop("v_mov_b32", PBASE[0], PBL), isa.vop("v_add_u32", PBASE[1], I32(FSLOT), PBL), isa.vop("v_add_u32", PBASE[2], I32(2 * FSLOT), PBL),
+              isa.vop("v_mov_b32", WB, WBL)]
         # ---- patch voxel groups: lane l of group k = patch voxel pv = 64 k + l = (r, col); source offset inside the frame (chunk = wave), or OOB ----
         hm1, wm1, w16 = ST[12], ST[13], ST[1]
         o += [isa.sop("s_sub_u32", hm1, S_H0, I32(1)), isa.sop("s_sub_u32", wm1, S_W0, I32(1)), isa.sop("s_lshl_b32", w16, S_WAVE, I32(4))]
@@ -323,34 +407,7 @@ class Gen:
                   isa.vop("v_add_u32", t[7], t[7], wi), isa.vop("v_mul_lo_u32", t[7], t[7], S_CIN2), isa.vop("v_add_u32", t[7], w16, t[7]),
                   isa.v_cmp("v_cmp_ne_u32", I32(0), ok), isa.vop("v_mov_b32", t[9], I32(OOB)),
                   isa.v_cndmask(PDMA[k], t[9], t[7])]
-        # ---- W pieces of this wave: piece w + 4 i = rows 16 (w + 4 i) + l / 4, LDS position q = l % 4 holds source chunk q ^ ((row >> 1) & 3) ----
-        o += [isa.vop("v_lshrrev_b32", t[1], I32(2), LANE), isa.vop("v_and_b32", t[2], I32(3), LANE)]
-        for i in range(2):
-            o += [isa.sop("s_add_u32", ST[0], S_WAVE, I32(4 * i)), isa.sop("s_lshl_b32", ST[0], ST[0], I32(4)),
-                  isa.vop("v_add_u32", t[3], ST[0], t[1]),                                                        # row
-                  isa.vop("v_lshrrev_b32", t[4], I32(1), t[3]), isa.vop("v_and_b32", t[4], I32(3), t[4]), isa.vop("v_xor_b32", t[4], t[2], t[4]),
-                  isa.vop("v_mul_lo_u32", t[5], t[3], kp2), isa.vop("v_lshl_add_u32", WDMA[i], t[4], I32(4), t[5])]
-        # ---- fragment bases ----
-        ql, g = t[10], t[11]
-        o += [isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
-        # patch: slot of frame f + dt, chunk plane g, voxel (row 8 rh, column ql)
-        o += [isa.sop("s_mul_i32", ST[0], S_RH, I32(8 * PC)), isa.vop("v_add_u32", t[1], ST[0], ql), isa.vop("v_lshlrev_b32", t[1], I32(4), t[1]),
-              isa.vop("v_mul_u32_u24", t[2], I32(PLN), g), isa.vop("v_add_u32", t[1], t[1], t[2]),
-              isa.sop("s_mul_i32", ST[1], S_F, I32(FSLOT)), isa.sop("s_add_u32", ST[1], ST[1], I32(PBASE0))]
-        for dt in range(3):
-            o += [isa.sop("s_add_u32", ST[2], ST[1], I32(dt * FSLOT)), isa.vop("v_add_u32", PBASE[dt], ST[2], t[1])]
-        # W: row ql (64 B), chunk g ^ ((ql >> 1) & 3); buffer 0
-        o += [isa.vop("v_lshrrev_b32", t[1], I32(1), ql), isa.vop("v_and_b32", t[1], I32(3), t[1]), isa.vop("v_xor_b32", t[1], g, t[1]),
-              isa.vop("v_lshlrev_b32", t[2], I32(6), ql), isa.vop("v_lshl_add_u32", WB, t[1], I32(4), t[2])]
-        # ---- bias quads of this lane's channels n0 + 16 nb + 4 (l / 16) + e (zeros when bias == NULL): they wait in v184..207 for the epilogue ----
-        for i in range(24):
-            o.append(isa.vop("v_mov_b32", V(EPI_BQ + i), I32(0)))
-        o += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias"),
-              isa.sop("s_lshl_b32", ST[7], S_N0, I32(2)), isa.sop("s_add_u32", S_BIAS.sub(0), S_BIAS.sub(0), ST[7]),
-              isa.sop("s_addc_u32", S_BIAS.sub(1), S_BIAS.sub(1), I32(0)), isa.vop("v_lshlrev_b32", t[1], I32(4), g)]
-        for nb in range(6):
-            o.append(isa.global_load(4, V(EPI_BQ + 4 * nb, 4), t[1], 64 * nb, saddr=S_BIAS))
-        o += [isa.label("L_nobias"), isa.nop(7)]
+        o += self.stamp(0)                                        # phase 0: tile decode, descriptors, lane offsets
         # ---- streams: patch frames 0, 1, 2 of slice 0, W taps 0 .. 3 ----
         o += [isa.sop("s_mov_b32", S_SL, I32(0)), isa.sop("s_mov_b32", S_XOFF, I32(0)), isa.sop("s_mov_b32", S_WNEXT, I32(0)),
               isa.sop("s_cmp_lt_u32", None, I32(1), S_NSL), isa.sop("s_cselect_b32", S_XOFFN, I32(64), I32(0))]
@@ -362,23 +419,50 @@ class Gen:
             o += self.slot_next(j, 0)
         for b in range(NWB):
             o += self.w_dma(0, 0, 0) + self.w_next(b, 0)
-        for i in range(192):
-            o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
-        o += [isa.waitcnt(vmcnt=0), isa.barrier()]
-        o += self.w_reads(0, 0, 0) + self.x_reads(0, range(10), 0, 0)
-        return sched.pad_hazards(sched.insert_lgkm_waits(o))
+        # ---- bias quads of this lane's channels n0 + 16 nb + 4 (l / 16) + e (zeros when bias == NULL): the accumulators start from them ----
+        g = t[11]
+        for i in range(24):
+            o.append(isa.vop("v_mov_b32", V(EPI_BQ + i), I32(0)))
+        o += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias"),
+              isa.sop("s_lshl_b32", ST[7], S_N0, I32(2)), isa.sop("s_add_u32", ST[2], S_BIAS.sub(0), ST[7]),
+              isa.sop("s_addc_u32", ST[3], S_BIAS.sub(1), I32(0)), isa.vop("v_lshlrev_b32", t[1], I32(4), g)]
+        for nb in range(6):
+            o.append(isa.global_load(4, V(EPI_BQ + 4 * nb, 4), t[1], 64 * nb, saddr=S(ST[2].idx, 2)))
+        o += [isa.label("L_nobias"), isa.nop(7)] + self.stamp(1) + [                                             # phase 1: DMA + bias issue
+              isa.sop("s_cmp_eq_u32", None, self.HAVE_PREV, I32(0)), isa.branch("s_cbranch_scc1", "L_first")]
+        return sched.pad_hazards(o)
 
-    # ---- epilogue ----------------------------------------------------------------------------------------------------------------
+    def tile_start(self) -> List[Instr]:
+        """accumulators = bias, first DMAs landed (every wave), first fragments."""
+        o: List[Instr] = [isa.label("L_first"), isa.waitcnt(vmcnt=0), isa.label("L_start"), isa.nop(7)]
+        for nb in range(6):
+            for mb in range(8):
+                for i in range(4):
+                    o.append(isa.vop("v_accvgpr_write_b32", ACC(nb, mb).sub(i), V(EPI_BQ + 4 * nb + i)))
+        o += [isa.barrier()]
+        o += self.w_reads(0, 0, 0) + self.x_reads(0, range(10), 0, 0)
+        o = sched.pad_hazards(o)
+        return o + self.stamp(5)                                  # phase 5: accumulators = bias, barrier (first tile: + the wait for the first loads)
+
+    def tile_end(self) -> List[Instr]:
+        """after the last slice: every wave is done with the LDS contents; remember the tile for the epilogue; next tile (or none)."""
+        o = self.stamp(6) + [isa.waitcnt(lgkmcnt=0), isa.barrier()] + self.stamp(7) + [       # phase 6: the slices; 7: the closing barrier
+             isa.sop("s_mov_b32", S_ET0, S_T0), isa.sop("s_mov_b32", S_EH0, S_H0), isa.sop("s_mov_b32", S_EW0, S_W0), isa.sop("s_mov_b32", S_EN0, S_N0),
+             isa.sop("s_add_u32", S_TILE, S_TILE, S_G), isa.sop("s_cmp_lt_u32", None, S_TILE, S_TEND),
+             isa.sop("s_cselect_b32", self.HAVE_PREV, I32(1), I32(3)), isa.branch("s_branch", "L_tile")]
+        return sched.pad_hazards(o)
+
     def epilogue(self) -> List[Instr]:
-        """lane: voxel (frame t0 + f, row h0 + 8 rh + mb, column w0 + l % 16), channels n0 + 16 nb + 4 (l / 16) + e;
-        y / resid rows: voxel index ((frame * ot_mul + ot_off) * H + row) * W + column, strides ldc / ldr elements."""
+        """lane: voxel (frame t0 + f, row h0 + 8 rh + mb, column w0 + l % 16), channels n0 + 16 nb + 4 (l / 16) + e of tile (S_ET0, ...);
+        y / resid rows: voxel index ((frame * ot_mul + ot_off) * H + row) * W + column, strides ldc / ldr elements.  The bias is in the
+        accumulators already."""
         c = self.cfg
         t = T_
-        e: List[Instr] = [isa.waitcnt(vmcnt=0, lgkmcnt=0), isa.nop(15), isa.nop(15)]
+        e: List[Instr] = [isa.label("L_epilogue"), isa.nop(15), isa.nop(15)]
         ql, g = t[10], t[11]
         tf, tfo, hw = ST[4], ST[5], ST[6]
-        ldc2, ldr2 = ST[13], ST[14]
-        e += [isa.sop("s_add_u32", tf, S_T0, S_F),                                                               # output frame
+        ldc2, ldr2 = ST[13], S_LDR2
+        e += [isa.sop("s_add_u32", tf, S_ET0, S_F),                                                              # output frame
               isa.sop("s_mul_i32", tfo, tf, S_OTM), isa.sop("s_add_u32", tfo, tfo, S_OTO),                       # its frame slot in y / resid
               isa.sop("s_mul_i32", hw, S_H, S_Wd),
               isa.sop("s_lshl_b32", ldc2, S_LDC.sub(0), I32(1)), isa.sop("s_lshl_b32", ldr2, S_LDR.sub(0), I32(1))]
@@ -388,15 +472,15 @@ class Gen:
                   isa.sop("s_mul_i32", ST[2], ST[0], tfo), isa.sop("s_mul_hi_u32", ST[3], ST[0], tfo), isa.sop("s_mul_i32", ST[7], ST[1], tfo),
                   isa.sop("s_add_u32", ST[3], ST[3], ST[7]),
                   isa.sop("s_add_u32", base.sub(0), src.sub(0), ST[2]), isa.sop("s_addc_u32", base.sub(1), src.sub(1), ST[3]),
-                  isa.sop("s_lshl_b32", ST[7], S_N0, I32(1)),
+                  isa.sop("s_lshl_b32", ST[7], S_EN0, I32(1)),
                   isa.sop("s_add_u32", base.sub(0), base.sub(0), ST[7]), isa.sop("s_addc_u32", base.sub(1), base.sub(1), I32(0))]
-        BQ = [V(EPI_BQ + 4 * nb, 4) for nb in range(6)]          # bias quads, loaded by the prologue
         # column and frame validity are the same for all 8 row blocks
         wcol = t[2]
-        e += [isa.vop("v_add_u32", wcol, S_W0, ql),
+        e += [isa.vop("v_add_u32", wcol, S_EW0, ql),
               isa.sop("s_cmp_lt_u32", None, tf, S_T), isa.sop("s_cselect_b32", ST[8], S_Wd, I32(0))]      # frame outside [0, To): no column is valid
         row0 = ST[9]
-        e += [isa.sop("s_lshl_b32", row0, S_RH, I32(3)), isa.sop("s_add_u32", row0, row0, S_H0)]
+        e += [isa.sop("s_lshl_b32", row0, S_RH, I32(3)), isa.sop("s_add_u32", row0, row0, S_EH0)]
+
         def row_setup(mb, want_y, want_r):
             """offsets of row block mb in t[4] (y) / t[5] (resid); exec = lanes with a voxel inside the tensor (saved exec in S_SAVE)."""
             yoff, roff, vox, hrow = t[4], t[5], t[6], ST[10]
@@ -413,38 +497,49 @@ class Gen:
             return r
 
         restore = lambda: [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
-        RP = lambda mb, nb: V(mb * 12 + 2 * nb, 2)          # residual pairs: the fragment registers v0..v95 are free now
+        OUT = lambda mb, nb: V(mb * 12 + 2 * nb, 2)         # packed outputs (and, before, the residual pairs): the fragment registers v0..v95 are free now
         if c.epi == 3:
-            # every residual load first (48 per lane), one wait
+            # every residual load first (48 per lane)
             for mb in range(8):
                 e += row_setup(mb, False, True)
                 for nb in range(6):
-                    e.append(isa.global_load(2, RP(mb, nb), t[5], 32 * nb, saddr=S_RF, extra_reads=[EXEC]))
+                    e.append(isa.global_load(2, OUT(mb, nb), t[5], 32 * nb, saddr=S_RF, extra_reads=[EXEC]))
                 e += restore()
             e.append(isa.waitcnt(vmcnt=0))
+        # phase 1: accumulators (+ residual) -> packed bf16 in registers; the next tile's first DMAs and bias loads fly meanwhile
         for mb in range(8):
-            e += row_setup(mb, True, False)
-            yoff = t[4]
             for nb in range(6):
                 base = EPI_F + 8 * (nb % 2)
                 f = [V(base + i) for i in range(4)]
-                w, r_ = V(base + 4, 2), V(base + 6)
+                r_ = V(base + 6)
                 acc = ACC(nb, mb)
                 for i in range(4):
-                    e += [isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)), isa.vop("v_add_f32", f[i], f[i], BQ[nb].sub(i))]
+                    e.append(isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)))
                 if c.epi == 3:
                     for i in range(4):
-                        src = RP(mb, nb).sub(i >> 1)
+                        src = OUT(mb, nb).sub(i >> 1)
                         e += [isa.vop("v_lshlrev_b32", r_, I32(16), src) if (i & 1) == 0 else isa.vop("v_and_b32", r_, I32(0xFFFF0000), src),
                               isa.vop("v_add_f32", f[i], f[i], r_)]
-                e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
-                      isa.global_store(2, yoff, w, 32 * nb, saddr=S_YF, extra_reads=[EXEC])]
+                e += [isa.vop("v_cvt_pk_bf16_f32", OUT(mb, nb).sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", OUT(mb, nb).sub(1), f[2], f[3])]
+        # everything older has landed (the stores of the tile before were issued a whole tile ago): the accumulators can take the next tile's
+        # bias as soon as the stores are issued -- these drain behind the next tile's taps
+        e += self.stamp(2)                                        # phase 2: accumulators -> packed outputs
+        e.append(isa.waitcnt(vmcnt=0))
+        e += self.stamp(3)                                        # phase 3: wait for the next tile's first loads
+        for mb in range(8):
+            e += row_setup(mb, True, False)
+            for nb in range(6):
+                e.append(isa.global_store(2, t[4], OUT(mb, nb), 32 * nb, saddr=S_YF, extra_reads=[EXEC]))
             e += restore()
-        e += [isa.label("L_exit"), Instr("s_endpgm", cls=isa.BRANCH)]      # (stores may still be in flight: the hardware drains them)
+        e += self.stamp(4)                                        # phase 4: stores
+        e += [isa.sop("s_bitcmp1_b32", None, self.HAVE_PREV, I32(1)), isa.branch("s_cbranch_scc1", "L_done" if c.prof else "L_exit"), isa.branch("s_branch", "L_start")]
         return sched.pad_hazards(e)
 
     def program(self) -> List[Instr]:
-        prog = self.prologue() + self.slice_body() + self.epilogue()
+        # entry -> L_tile: setup + first DMAs (or straight to the epilogue when no tile follows) -> [first tile: L_first] / [else: L_epilogue -> L_start]
+        # -> slices -> tile_end -> L_tile ...
+        prog = (self.entry() + self.tile_setup() + self.epilogue() + self.tile_start() + self.slice_body() + self.tile_end()
+                + [isa.label("L_done")] + self.prof_dump() + [isa.label("L_exit"), Instr("s_endpgm", cls=isa.BRANCH)])
         pre = f"L_{self.cfg.name}"
         for i in prog:
             if i.label and i.label.startswith("L_"):
@@ -543,6 +638,10 @@ def variant_cfgs():
     for abl in ("dma", "lds", "bar", "dma,lds", "patch"):
         out.append(Cfg(epi=0, abl=abl, name="scail_conv4_e0_abl_" + abl.replace(",", "_")))
     out.append(Cfg(epi=0, cap=2, name="scail_conv4_e0_c2"))
+    out.append(Cfg(epi=0, prof=True, name="scail_conv4_e0_prof"))
+    out.append(Cfg(epi=0, prof=True, stagger=0, name="scail_conv4_e0_prof_s0"))
+    for st in (0, 7, 28, 56):
+        out.append(Cfg(epi=0, stagger=st, name=f"scail_conv4_e0_s{st}"))
     out.append(Cfg(epi=0, rd_step=2.0, name="scail_conv4_e0_rd2"))
     out.append(Cfg(epi=0, rd_at=6.0, rd_step=2.5, name="scail_conv4_e0_rd6"))
     out.append(Cfg(epi=0, p_at=30.0, dma_at=10.0, name="scail_conv4_e0_p30"))

@@ -623,8 +623,9 @@ struct Conv4Args {
     uint32_t magic_w, magic_h; int32_t n_slices, ot_mul;
     int32_t ot_off, per_xcd;
     int64_t ldc, ldr;
+    int32_t wgs_per_xcd, tiles;      // persistent workgroups per XCD (the tile stride of a workgroup), tiles in all
 };
-static_assert(sizeof(Conv4Args) == 128, "Conv4Args must match asmgen/conv4.py KERNARG_SIZE");
+static_assert(sizeof(Conv4Args) == 136, "Conv4Args must match asmgen/conv4.py KERNARG_SIZE");
 static std::map<int, hipModule_t> g_conv4_modules;                          // device -> loaded code object
 static std::map<std::pair<int, std::string>, hipFunction_t> g_conv4_fn;     // (device, kernel name)
 static std::mutex g_conv4_mutex;
@@ -711,14 +712,20 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         a.n_slices = p.Cin / 32; a.ot_mul = p.ot_mul; a.ot_off = p.ot_off; a.ldc = ldc; a.ldr = resid ? ldr : ldc;
         const int64_t tiles = (int64_t)((p.To + 1) / 2) * a.tiles_h * a.tiles_w * a.tiles_n;
         SCAIL_REQUIRE(tiles < (1ll << 24), "too many tiles");        // the kernel's magic-number divisions are exact below 2^31 / divisor
-        // workgroup b runs on XCD b % 8 and takes tile (b % 8) * per_xcd + b / 8: a contiguous range per XCD (the n tiles of a patch and
-        // its neighbours share an L2); ids past the last tile exit at once
+        // persistent workgroups, one per compute unit: workgroup b runs on XCD b % 8 and walks the tiles (b % 8) * per_xcd + b / 8 + i * wgs_per_xcd
+        // of that XCD's contiguous range (the n tiles of a patch and its neighbours share an L2)
         a.per_xcd = (int32_t)((tiles + 7) / 8);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+        a.wgs_per_xcd = std::min<int32_t>(a.per_xcd, cus / 8);
+        a.tiles = (int32_t)tiles;
         hipFunction_t fn;
-        if (int rc = conv4_function(std::string(resid ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
+        // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)
+        const bool prof = g_conv4_suffix.find("prof") != std::string::npos;
+        if (int rc = conv4_function(std::string(resid && !prof ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)a.per_xcd * 8u, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)a.wgs_per_xcd * 8u, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
         if (e != hipSuccess) {
             scail_set_error(std::string("conv4: launch failed: ") + hipGetErrorString(e));
             return 2;

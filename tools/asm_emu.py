@@ -326,7 +326,7 @@ class Emu:
             if getattr(ins, "lgkmcnt", None) is not None:
                 self._drain(w, "lgkm", ins.lgkmcnt)
             return
-        if op in ("s_nop", "s_setprio"):
+        if op in ("s_nop", "s_setprio", "s_sleep"):
             return
         if op == "s_barrier":
             w.at_barrier = True
@@ -512,6 +512,8 @@ class Emu:
             r = min(sgn(a), sgn(b)); self._wrs(w, d, r); w.scc = int(sgn(a) <= sgn(b))
         elif op == "s_cselect_b32":
             self._wrs(w, d, a if w.scc else b)
+        elif op == "s_bitcmp1_b32":
+            w.scc = int((a >> (b & 31)) & 1)
         elif op in ("s_cmp_eq_u64", "s_cmp_lg_u64"):
             x, y = self._rds64(w, s[0]), self._rds64(w, s[1])
             w.scc = int((x == y) == op.startswith("s_cmp_eq"))

@@ -25,7 +25,7 @@ def pack_weight(w, kpad=None):
     return out
 
 
-def run(cfg: conv4.Cfg, x, w, bias=None, resid=None, pt=2, To=None, ot_mul=1, ot_off=0, y_frames=None, ldc=None, lazy=True, wgs=None):
+def run(cfg: conv4.Cfg, x, w, bias=None, resid=None, pt=2, To=None, ot_mul=1, ot_off=0, y_frames=None, ldc=None, lazy=True, wgs=None, cus=256):
     """x (Ti, H, W, Cin), w (N, Cin, 3, 3, 3), bias (N) | None, resid (frames, H, W, N) | None; fp32 in, bf16 operands."""
     Ti, H, W, Cin = x.shape
     N = w.shape[0]
@@ -40,9 +40,9 @@ def run(cfg: conv4.Cfg, x, w, bias=None, resid=None, pt=2, To=None, ot_mul=1, ot
     py = mem.alloc("y", np.full((y_frames, H, W, ldc), 0x7FC0, dtype=np.uint16))
     pr = mem.alloc("resid", to_bf16_bits(resid)) if resid is not None else 0
     prog = conv4.Gen(cfg).program()
-    args = conv4.pack_args(px, pw, pb, py, pr, Ti, To, H, W, Cin, N, wp.shape[1], pt, ot_mul, ot_off, ldc, resid.shape[-1] if resid is not None else 0)
+    args = conv4.pack_args(px, pw, pb, py, pr, Ti, To, H, W, Cin, N, wp.shape[1], pt, ot_mul, ot_off, ldc, resid.shape[-1] if resid is not None else 0, cus)
     stats = None
-    for wg in (range(conv4.grid_blocks(To, H, W, N)) if wgs is None else wgs):
+    for wg in (range(conv4.grid_blocks(To, H, W, N, cus)) if wgs is None else wgs):
         emu = E.Emu(prog, mem, n_waves=4, lds_bytes=conv4.LDS_BYTES, lazy=lazy)
         emu.launch(args, block_id=(wg, 0, 0))
         stats = emu.waves[0].stats
@@ -72,7 +72,8 @@ def reference(x, w, bias=None, resid=None, pt=2, To=None):
 def check_static(cfg):
     g = conv4.Gen(cfg)
     body = g.slice_body()
-    return sched.check_hazards(body + body) + sched.check_hazards(g.prologue() + body) + sched.check_hazards(g.epilogue())
+    return (sched.check_hazards(body + body) + sched.check_hazards(g.tile_start() + body) + sched.check_hazards(g.entry() + g.tile_setup() + g.epilogue() + g.tile_start())
+            + sched.check_hazards(body + g.tile_end() + g.tile_setup()))
 
 
 if __name__ == "__main__":

@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--variants", default="")
 ap.add_argument("--frames", type=int, default=21)
 ap.add_argument("--skip-check", action="store_true")
+ap.add_argument("--prof", action="store_true", help="phase timers of the _prof variant (s_memtime), per tile")
+ap.add_argument("--fit", action="store_true", help="per-tile / per-tap cost of conv4: N = 96, Cin = 32 .. 192 on the 512 x 896 shape")
 a = ap.parse_args()
 lib.load()
 dev = "cuda"
@@ -52,6 +54,63 @@ if not a.skip_check:
                 print(json.dumps(dict(check=[T, H, W, Cin, N, res], conv4=mode == 11, variant=var, max_err=float(err.max()), nan=int(torch.isnan(out.float()).sum()),
                                       ok=bool(err.max() < 0.06))), flush=True)
     setk("")
+
+if a.prof:
+    lib.tune_set("conv_halo", 11)
+    names = ["setup", "dma_issue", "acc_to_regs", "wait_first_loads", "stores", "acc_init_barrier", "slices", "closing_barrier"]
+    for C, H, W in ((96, 512, 896), (192, 256, 448), (384, 128, 224)):
+        T = a.frames
+        x = torch.randn(T, H, W, C, device=dev, generator=g).to(torch.bfloat16)
+        wp = O.prep_conv_weight(torch.randn(C, C, 3, 3, 3, device=dev, generator=g) * 0.02, torch.randn(C, device=dev, generator=g))
+        out = torch.empty(T, H, W, C, device=dev, dtype=torch.bfloat16)
+        dbg = torch.zeros_like(out)
+        tiles = (T + 1) // 2 * (H // 16) * (W // 16) * (C // 96)
+        for pv in ("prof", "prof_s0"):
+            setk(pv)
+            O.conv3d_cl(x, wp, (T, H, W), out=out, resid=dbg)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dbg.zero_()
+            e0.record(); O.conv3d_cl(x, wp, (T, H, W), out=out, resid=dbg); e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            d = dbg.view(-1).view(torch.int32)[:256 * 8].view(256, 8).double()
+            per_wg_tiles = tiles / 256.0
+            mean = d.mean(0) / per_wg_tiles
+            total = float(d.sum(1).mean())
+            print(json.dumps(dict(prof=pv, C=C, ms=ms, tiles_per_wg=per_wg_tiles, total_cycles_per_wg=total, mhz=total / ms / 1e3,
+                                  cycles_per_tile={n: round(float(v)) for n, v in zip(names, mean)},
+                                  taps_per_tile=27 * C // 32, cycles_per_tap=float(mean[6]) / (27 * C // 32))), flush=True)
+        setk("")
+        del x, out, dbg
+    lib.tune_set("conv_halo", 10)
+    sys.exit(0)
+
+if a.fit:
+    lib.tune_set("conv_halo", 11)
+    T, H, W, N = a.frames, 512, 896, 96
+    tiles = (T + 1) // 2 * (H // 16) * (W // 16)
+    pts = []
+    for Cin in (32, 64, 96, 128, 192):
+        x = torch.randn(T, H, W, Cin, device=dev, generator=g).to(torch.bfloat16)
+        wp = O.prep_conv_weight(torch.randn(N, Cin, 3, 3, 3, device=dev, generator=g) * 0.02, torch.randn(N, device=dev, generator=g))
+        out = torch.empty(T, H, W, N, device=dev, dtype=torch.bfloat16)
+        f = lambda: O.conv3d_cl(x, wp, (T, H, W), out=out)
+        f(); f(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+        ms = sorted(ts)[2]
+        per_tile_us = ms * 1e3 / (tiles / 256.0)
+        pts.append((Cin // 32, per_tile_us))
+        print(json.dumps(dict(fit=True, Cin=Cin, ms=ms, tiles=tiles, us_per_tile_per_cu=per_tile_us, tflops=2.0 * T * H * W * N * Cin * 27 / ms / 1e9)), flush=True)
+        del x, out
+    n = len(pts); sx = sum(p[0] for p in pts); sy = sum(p[1] for p in pts); sxx = sum(p[0] ** 2 for p in pts); sxy = sum(p[0] * p[1] for p in pts)
+    slope = (n * sxy - sx * sy) / (n * sxx - sx * sx); icpt = (sy - slope * sx) / n
+    print(json.dumps(dict(fit=True, us_per_slice=slope, us_per_tap=slope / 27, us_fixed_per_tile=icpt,
+                          note="48 MFMAs of 16 cycles per tap = 768 cycles = 0.32 us at 2.4 GHz / 0.40 us at 1.9 GHz")), flush=True)
+    lib.tune_set("conv_halo", 10)
+    sys.exit(0)
 
 for C, H, W in ((96, 512, 896), (192, 256, 448), (384, 128, 224)):
     T = a.frames

@@ -1,7 +1,10 @@
 #!/bin/bash
-# round 3, call k: first GPU run of the generated conv4 kernel (check + A/B vs the hipcc halo kernel)
+# round 3, call k: the generated conv4 kernel (check + A/B vs the hipcc halo kernel + phase timers)
 mkdir -p gpurun_out
 export SCAIL_ABLATIONS=1
-timeout 600 python tools/conv4_probe.py --variants ",abl_dma,abl_lds,abl_bar,abl_dma_lds,abl_patch,c2,rd2,rd6,p30" > gpurun_out/r03_conv4_probe.log 2>&1
+timeout 600 python tools/conv4_probe.py --variants ",s0,s7,s28,s56" > gpurun_out/r03_conv4_probe.log 2>&1
 echo "exit $?" >> gpurun_out/r03_conv4_probe.log
-tail -50 gpurun_out/r03_conv4_probe.log
+timeout 300 python tools/conv4_probe.py --prof --skip-check >> gpurun_out/r03_conv4_probe.log 2>&1
+echo "exit $?" >> gpurun_out/r03_conv4_probe.log
+grep -v '"check"' gpurun_out/r03_conv4_probe.log | cut -c1-600
+grep -c '"ok": true' gpurun_out/r03_conv4_probe.log; grep -c '"ok": false' gpurun_out/r03_conv4_probe.log; true
