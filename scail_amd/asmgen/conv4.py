@@ -84,7 +84,7 @@ class Cfg:
     dma_at: float = 4.0     # gap of the first W-tile DMA piece of tap + 3, the second dma_step later
     dma_step: float = 20.0
     p_at: float = 12.0      # gap of the tap's patch DMA piece
-    stagger: int = 14       # workgroup i of an XCD starts i * 64 * stagger cycles late: the tiles' load / store bursts of the 256 workgroups do not coincide
+    stagger: int = 0        # (A/B) workgroup i of an XCD starts i * 64 * stagger cycles late; measured neutral to -1 %: the per-tile cost is VMEM issue, not an HBM burst
     prof: bool = False      # measurement variant: s_memtime stamps around the phases of a tile; wave 0 of every workgroup writes the sums to `resid`
     abl: str = ""
 
@@ -140,6 +140,14 @@ S_LDR2 = S(2)                                               # epilogue: residual
 N_SGPR = 102
 S_PROFWG = S(43)                                            # (prof variant; the unused high word of ldr) workgroup id
 PBL, WBL = V(142), V(143)                                   # per-lane parts of the fragment bases (tile independent)
+# epilogue staging (a row block of 16 voxels x 96 channels goes through LDS so that global stores / residual loads are whole contiguous lines):
+STG_VOX = 208                                               # bytes per staged voxel (192 + 16: conflict-free 8-byte writes, 16-byte aligned chunks)
+STG_WAVE = 16 * STG_VOX                                     # 3328 bytes per wave, in frame slot 3 (idle between a tile's last tap and the next tile's first)
+E_W = V(208)                                                # LDS address of this lane's accumulator-layout piece: voxel l % 16, channels 4 (l / 16) + 16 nb
+E_R = [V(209 + i) for i in range(3)]                        # LDS address of this lane's memory-layout chunk j = 64 i + l: voxel j / 12, 16-byte chunk j % 12
+E_V = [V(212 + i) for i in range(3)]                        # its voxel j / 12
+E_Y = [V(215 + i) for i in range(3)]                        # its byte offset in an output row: (j / 12) * ldc * 2 + (j % 12) * 16
+E_Z = [V(218 + i) for i in range(3)]                        # ... in a residual row
 
 
 class Gen:
@@ -336,6 +344,19 @@ class Gen:
         # W: row ql (64 B), chunk g ^ ((ql >> 1) & 3)
         o += [isa.vop("v_lshrrev_b32", t[1], I32(1), ql), isa.vop("v_and_b32", t[1], I32(3), t[1]), isa.vop("v_xor_b32", t[1], g, t[1]),
               isa.vop("v_lshlrev_b32", t[2], I32(6), ql), isa.vop("v_lshl_add_u32", WBL, t[1], I32(4), t[2])]
+        # ---- epilogue staging addresses ----
+        sb = ST[2]
+        o += [isa.sop("s_mul_i32", sb, S_WAVE, I32(STG_WAVE)), isa.sop("s_add_u32", sb, sb, I32(PBASE0 + 3 * FSLOT)),
+              isa.sop("s_lshl_b32", ST[3], S_LDC.sub(0), I32(1)), isa.sop("s_lshl_b32", ST[4], S_LDR.sub(0), I32(1)),
+              isa.vop("v_mul_u32_u24", t[1], I32(STG_VOX), ql), isa.vop("v_lshl_add_u32", t[1], g, I32(3), t[1]), isa.vop("v_add_u32", E_W, sb, t[1])]
+        for i in range(3):
+            j, vx, c12 = t[1], t[2], t[3]
+            o += [isa.vop("v_add_u32", j, I32(64 * i), LANE), isa.vop("v_mul_u32_u24", vx, I32(171), j), isa.vop("v_lshrrev_b32", vx, I32(11), vx),   # j / 12 (j < 192)
+                  isa.vop("v_mul_u32_u24", c12, I32(12), vx), isa.vop("v_sub_u32", c12, j, c12), isa.vop("v_lshlrev_b32", c12, I32(4), c12),
+                  isa.vop("v_mov_b32", E_V[i], vx),
+                  isa.vop("v_mul_u32_u24", t[4], I32(STG_VOX), vx), isa.vop("v_add_u32", t[4], t[4], c12), isa.vop("v_add_u32", E_R[i], sb, t[4]),
+                  isa.vop("v_mul_lo_u32", t[4], vx, ST[3]), isa.vop("v_add_u32", E_Y[i], t[4], c12),
+                  isa.vop("v_mul_lo_u32", t[4], vx, ST[4]), isa.vop("v_add_u32", E_Z[i], t[4], c12)]
         o += [isa.sop("s_mov_b32", self.HAVE_PREV, I32(0))]       # no tile waits for its epilogue yet
         if c.stagger:
             # All workgroups start together and a tile takes every one of them the same time: unstaggered, the first loads of 256 tiles
@@ -474,66 +495,86 @@ class Gen:
                   isa.sop("s_add_u32", base.sub(0), src.sub(0), ST[2]), isa.sop("s_addc_u32", base.sub(1), src.sub(1), ST[3]),
                   isa.sop("s_lshl_b32", ST[7], S_EN0, I32(1)),
                   isa.sop("s_add_u32", base.sub(0), base.sub(0), ST[7]), isa.sop("s_addc_u32", base.sub(1), base.sub(1), I32(0))]
-        # column and frame validity are the same for all 8 row blocks
-        wcol = t[2]
-        e += [isa.vop("v_add_u32", wcol, S_EW0, ql),
-              isa.sop("s_cmp_lt_u32", None, tf, S_T), isa.sop("s_cselect_b32", ST[8], S_Wd, I32(0))]      # frame outside [0, To): no column is valid
+        # frame validity is the same for all 8 row blocks; lane validity = its voxel's column (memory layout: voxel E_V[i] of the 16)
+        VCOL = [t[12 + i] for i in range(3)]
+        e += [isa.vop("v_add_u32", VCOL[i], S_EW0, E_V[i]) for i in range(3)]
+        e += [isa.sop("s_cmp_lt_u32", None, tf, S_T), isa.sop("s_cselect_b32", ST[8], S_Wd, I32(0))]      # frame outside [0, To): no column is valid
         row0 = ST[9]
         e += [isa.sop("s_lshl_b32", row0, S_RH, I32(3)), isa.sop("s_add_u32", row0, row0, S_EH0)]
+        voff = t[4]
 
-        def row_setup(mb, want_y, want_r):
-            """offsets of row block mb in t[4] (y) / t[5] (resid); exec = lanes with a voxel inside the tensor (saved exec in S_SAVE)."""
-            yoff, roff, vox, hrow = t[4], t[5], t[6], ST[10]
-            r = [isa.sop("s_add_u32", hrow, row0, I32(mb)),
-                 isa.sop("s_cmp_lt_u32", None, hrow, S_H), isa.sop("s_cselect_b32", ST[11], ST[8], I32(0)),      # columns allowed in this row
-                 isa.sop("s_mul_i32", ST[12], hrow, S_Wd),
-                 isa.vop("v_add_u32", vox, ST[12], wcol)]
-            if want_y:
-                r += [isa.vop("v_mul_lo_u32", yoff, vox, ldc2), isa.vop("v_lshl_add_u32", yoff, g, I32(3), yoff)]
-            if want_r:
-                r += [isa.vop("v_mul_lo_u32", roff, vox, ldr2), isa.vop("v_lshl_add_u32", roff, g, I32(3), roff)]
-            r += [isa.v_cmp("v_cmp_gt_u32", ST[11], wcol),
-                  Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
-            return r
+        def row_sgprs(mb, cols, rowoff, ld2):
+            """cols = columns allowed in row block mb (0: the row / frame is outside the tensor), rowoff = byte offset of its first voxel."""
+            hrow = ST[10]
+            return [isa.sop("s_add_u32", hrow, row0, I32(mb)),
+                    isa.sop("s_cmp_lt_u32", None, hrow, S_H), isa.sop("s_cselect_b32", cols, ST[8], I32(0)),
+                    isa.sop("s_mul_i32", ST[12], hrow, S_Wd), isa.sop("s_add_u32", ST[12], ST[12], S_EW0), isa.sop("s_mul_i32", rowoff, ST[12], ld2)]
 
-        restore = lambda: [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
-        OUT = lambda mb, nb: V(mb * 12 + 2 * nb, 2)         # packed outputs (and, before, the residual pairs): the fragment registers v0..v95 are free now
-        if c.epi == 3:
-            # every residual load first (48 per lane)
-            for mb in range(8):
-                e += row_setup(mb, False, True)
-                for nb in range(6):
-                    e.append(isa.global_load(2, OUT(mb, nb), t[5], 32 * nb, saddr=S_RF, extra_reads=[EXEC]))
-                e += restore()
-            e.append(isa.waitcnt(vmcnt=0))
-        # phase 1: accumulators (+ residual) -> packed bf16 in registers; the next tile's first DMAs and bias loads fly meanwhile
-        for mb in range(8):
+        def masked(cols, i, ins_list):
+            return ([isa.v_cmp("v_cmp_gt_u32", cols, VCOL[i]),
+                     Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)] + ins_list +
+                    [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)])
+
+        OUT = lambda mb, nb: V(mb * 12 + 2 * nb, 2)         # packed outputs in accumulator layout (the fragment registers v0..v95 are free now)
+        LQ = lambda mb, i: V(mb * 12 + 4 * i, 4)            # (e3) residual row block mb in memory layout: the same 12 registers
+        RB = lambda k, nb: V(96 + 12 * k + 2 * nb, 2)       # (e3) residual pairs back in accumulator layout, two row blocks in flight
+        RQ = lambda k, i: V(96 + 12 * k + 4 * i, 4)         # output row block in memory layout, two in flight
+        F = lambda k: [V(120 + 4 * k + i) for i in range(4)]
+
+        def to_packed(mb, k):
+            """accumulators of row block mb (+ residual pairs RB[k]) -> packed bf16 OUT(mb, .)."""
+            r = []
             for nb in range(6):
-                base = EPI_F + 8 * (nb % 2)
-                f = [V(base + i) for i in range(4)]
-                r_ = V(base + 6)
+                f = F(nb % 2)
                 acc = ACC(nb, mb)
                 for i in range(4):
-                    e.append(isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)))
+                    r.append(isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)))
                 if c.epi == 3:
+                    r_ = t[16 + (nb % 2)]
                     for i in range(4):
-                        src = OUT(mb, nb).sub(i >> 1)
-                        e += [isa.vop("v_lshlrev_b32", r_, I32(16), src) if (i & 1) == 0 else isa.vop("v_and_b32", r_, I32(0xFFFF0000), src),
+                        src = RB(k, nb).sub(i >> 1)
+                        r += [isa.vop("v_lshlrev_b32", r_, I32(16), src) if (i & 1) == 0 else isa.vop("v_and_b32", r_, I32(0xFFFF0000), src),
                               isa.vop("v_add_f32", f[i], f[i], r_)]
-                e += [isa.vop("v_cvt_pk_bf16_f32", OUT(mb, nb).sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", OUT(mb, nb).sub(1), f[2], f[3])]
-        # everything older has landed (the stores of the tile before were issued a whole tile ago): the accumulators can take the next tile's
-        # bias as soon as the stores are issued -- these drain behind the next tile's taps
+                r += [isa.vop("v_cvt_pk_bf16_f32", OUT(mb, nb).sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", OUT(mb, nb).sub(1), f[2], f[3])]
+            return r
+
+        if c.epi == 3:
+            # residual rows: whole lines from memory (3 x 16 bytes per lane and row block, everything requested first), through LDS into the
+            # accumulator layout
+            for mb in range(8):
+                e += row_sgprs(mb, ST[11], ST[7], ldr2)
+                for i in range(3):
+                    e += masked(ST[11], i, [isa.vop("v_add_u32", voff, ST[7], E_Z[i]),
+                                            isa.global_load(4, LQ(mb, i), voff, 0, saddr=S_RF, extra_reads=[EXEC])])
+            e.append(isa.waitcnt(vmcnt=0))
+            for mb in range(9):
+                if mb < 8:
+                    e += [isa.ds_write(16, E_R[i], LQ(mb, i)) for i in range(3)]
+                    e += [isa.ds_read(8, RB(mb % 2, nb), E_W, 32 * nb) for nb in range(6)]
+                if mb >= 1:
+                    e += to_packed(mb - 1, (mb - 1) % 2)
+        else:
+            for mb in range(8):
+                e += to_packed(mb, 0)
         e += self.stamp(2)                                        # phase 2: accumulators -> packed outputs
+        # the next tile's first loads have landed by now (the stores of the tile before were issued a whole tile ago): the accumulators can
+        # take the next tile's bias as soon as the stores are issued -- these drain behind the next tile's taps
         e.append(isa.waitcnt(vmcnt=0))
         e += self.stamp(3)                                        # phase 3: wait for the next tile's first loads
-        for mb in range(8):
-            e += row_setup(mb, True, False)
-            for nb in range(6):
-                e.append(isa.global_store(2, t[4], OUT(mb, nb), 32 * nb, saddr=S_YF, extra_reads=[EXEC]))
-            e += restore()
+        # row blocks through LDS into the memory layout: 3 stores of 64 x 16 contiguous bytes instead of 6 of 64 x 8 scattered ones
+        for mb in range(9):
+            if mb < 8:
+                e += [isa.ds_write(8, E_W, OUT(mb, nb), 32 * nb) for nb in range(6)]
+                e += [isa.ds_read_b128(RQ(mb % 2, i), E_R[i]) for i in range(3)]
+            if mb >= 1:
+                pm = mb - 1
+                e += row_sgprs(pm, ST[11], ST[7], ldc2)
+                for i in range(3):
+                    e += masked(ST[11], i, [isa.vop("v_add_u32", voff, ST[7], E_Y[i]),
+                                            isa.global_store(4, voff, RQ(pm % 2, i), 0, saddr=S_YF, extra_reads=[EXEC])])
         e += self.stamp(4)                                        # phase 4: stores
         e += [isa.sop("s_bitcmp1_b32", None, self.HAVE_PREV, I32(1)), isa.branch("s_cbranch_scc1", "L_done" if c.prof else "L_exit"), isa.branch("s_branch", "L_start")]
-        return sched.pad_hazards(e)
+        return sched.pad_hazards(sched.insert_lgkm_waits(e))
 
     def program(self) -> List[Instr]:
         # entry -> L_tile: setup + first DMAs (or straight to the epilogue when no tile follows) -> [first tile: L_first] / [else: L_epilogue -> L_start]
@@ -639,9 +680,7 @@ def variant_cfgs():
         out.append(Cfg(epi=0, abl=abl, name="scail_conv4_e0_abl_" + abl.replace(",", "_")))
     out.append(Cfg(epi=0, cap=2, name="scail_conv4_e0_c2"))
     out.append(Cfg(epi=0, prof=True, name="scail_conv4_e0_prof"))
-    out.append(Cfg(epi=0, prof=True, stagger=0, name="scail_conv4_e0_prof_s0"))
-    for st in (0, 7, 28, 56):
-        out.append(Cfg(epi=0, stagger=st, name=f"scail_conv4_e0_s{st}"))
+    out.append(Cfg(epi=0, stagger=14, name="scail_conv4_e0_s14"))
     out.append(Cfg(epi=0, rd_step=2.0, name="scail_conv4_e0_rd2"))
     out.append(Cfg(epi=0, rd_at=6.0, rd_step=2.5, name="scail_conv4_e0_rd6"))
     out.append(Cfg(epi=0, p_at=30.0, dma_at=10.0, name="scail_conv4_e0_p30"))

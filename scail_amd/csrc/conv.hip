@@ -662,21 +662,26 @@ static int conv4_function(const std::string& name, hipFunction_t* fn) {
     return 0;
 }
 
+static int g_conv4 = 1;                                        // option "conv4": the generated kernels where scail_conv3d_kernel_for says 4
+int scail_conv4_enable(int v) { g_conv4 = v != 0; return 0; }
 #ifdef SCAIL_ABLATIONS
 static int g_conv_halo = 4;                                    // measurement build: A/B of the halo-kernel layouts (comment below)
-static int g_conv4 = 0;
 int scail_conv_tune(int v) { if (v >= 10) g_conv4 = v - 10; else g_conv_halo = v; return 0; }     // 10 / 11: generated kernel off / on
 int scail_conv4_kernel(const char* suffix) { g_conv4_suffix = suffix ? suffix : ""; if (!g_conv4_suffix.empty() && g_conv4_suffix[0] == ':') g_conv4_suffix = "_" + g_conv4_suffix.substr(1); return 0; }
 #else
 static constexpr int g_conv_halo = 4;
-static constexpr int g_conv4 = 0;
 #endif
 
-static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
-                       const scail_bf16* resid, int64_t ldr, const float* gamma, const int32_t* geom, void* stream) {
-    // geom: Ti Hi Wi Cin | To Ho Wo | kt kh kw | st sh sw | pt ph pw | ups | ot_mul ot_off | N Kpad
-    ConvParams p;
-    p.x = x; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc; p.resid = resid; p.ldr = ldr; p.gamma = gamma;
+// the shapes the generated kernels cover: 3x3x3, stride 1, 'same' spatial extent, 0..2 padding frames in front, whole 32-channel slices and
+// 96-channel output tiles, at least one frame pair, 32-bit byte offsets inside a frame
+static bool conv4_eligible(const ConvParams& p, int64_t ldc, int64_t ldr) {
+    return p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups && p.ph == 1 && p.pw == 1 &&
+           p.Ho == p.Hi && p.Wo == p.Wi && p.Cin % 32 == 0 && p.N % 96 == 0 && p.To >= 2 && p.pt >= 0 && p.pt <= 2 &&
+           ldc % 8 == 0 && ldr % 8 == 0 && ldc < (1 << 20) && ldr < (1 << 20) && (int64_t)p.Hi * p.Wi * p.Cin * 2 < (1ll << 31) &&
+           (int64_t)p.Ho * p.Wo * std::max(ldc, ldr) * 2 < (1ll << 32);
+}
+
+static void conv_params(ConvParams& p, const int32_t* geom) {
     p.Ti = geom[0]; p.Hi = geom[1]; p.Wi = geom[2]; p.Cin = geom[3];
     p.To = geom[4]; p.Ho = geom[5]; p.Wo = geom[6];
     p.kt = geom[7]; p.kh = geom[8]; p.kw = geom[9];
@@ -686,6 +691,21 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
     p.N = geom[19]; p.Kpad = geom[20];
     p.Ktrue = p.kt * p.kh * p.kw * p.Cin;
     p.M = (int64_t)p.To * p.Ho * p.Wo;
+}
+
+extern "C" int scail_conv3d_kernel_for(const int32_t* geom, int64_t ldc, int64_t ldr, int fused_norm) {
+    if (geom == nullptr) return 0;
+    ConvParams p;
+    conv_params(p, geom);
+    return (g_conv4 && !fused_norm && conv4_eligible(p, ldc, ldr > 0 ? ldr : ldc)) ? 4 : 0;
+}
+
+static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
+                       const scail_bf16* resid, int64_t ldr, const float* gamma, const int32_t* geom, void* stream) {
+    // geom: Ti Hi Wi Cin | To Ho Wo | kt kh kw | st sh sw | pt ph pw | ups | ot_mul ot_off | N Kpad
+    ConvParams p;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc; p.resid = resid; p.ldr = ldr; p.gamma = gamma;
+    conv_params(p, geom);
     SCAIL_REQUIRE(p.Cin % 8 == 0, "Cin must be a multiple of 8 (pad the channels)");
     SCAIL_REQUIRE(p.N % 8 == 0 && p.Kpad % CBK == 0 && p.Kpad >= p.Ktrue, "N % 8 == 0, Kpad % 64 == 0, Kpad >= taps*Cin");
     SCAIL_REQUIRE(ldc % 4 == 0 && (resid == nullptr || ldr % 4 == 0), "output / residual row strides must be multiples of 4");
@@ -700,9 +720,8 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
     // 2 = 32-channel slices, swizzled unpadded layout with two W buffers (one barrier per tap row), 2 workgroups per CU --
     // measured equal (283 / 490 ms vs 281 / 487 ms encode / decode): the barrier is not what bounds the kernel
     const bool fuse = gamma != nullptr;       // conv + RMS_norm + SiLU: always the halo kernel, whatever the knob says
-    if (g_conv4 && !fuse && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups && p.ph == 1 && p.pw == 1 &&
-        p.Ho == p.Hi && p.Wo == p.Wi && p.Cin % 32 == 0 && p.N % 96 == 0 && p.To >= 2 && p.pt >= 0 && p.pt <= 2 &&
-        ldc < (1 << 20) && ldr < (1 << 20) && (int64_t)p.Hi * p.Wi * p.Cin * 2 < (1ll << 31) && (int64_t)p.Ho * p.Wo * std::max(ldc, ldr) * 2 < (1ll << 32)) {
+    if (g_conv4 && !fuse && conv4_eligible(p, ldc, resid ? ldr : ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(resid) & 15) == 0) {      // (16-byte row chunks; the arena's tensors always are)
         Conv4Args a;
         a.x = x; a.w = w; a.bias = bias; a.y = y; a.resid = resid;
         a.Ti = p.Ti; a.To = p.To; a.H = p.Ho; a.W = p.Wo; a.Cin = p.Cin; a.N = p.N; a.Kpad = p.Kpad; a.pt = p.pt;

@@ -28,6 +28,7 @@ SIGNATURES = {
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
     "scail_flash_attn_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i, _i],
     "scail_gemm_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i],
+    "scail_conv3d_kernel_for": [_p, _i64, _i64, _i],
     "scail_cross_attn2_bf16": [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                                _i64, _i64, _i64, _f, _p],
     "scail_timestep_embedding": [_p, _p, _i64, _i64, _p],

@@ -1,0 +1,56 @@
+"""CPU emulation (tools/asm_emu.py) of the generated 3x3x3 causal convolution kernels (scail_amd/asmgen/conv4.py, csrc/conv4.s): the
+generator produces hazard-free code whose results equal the fp64 convolution of the bf16-rounded operands (reference CausalConv3d,
+sgm/models/wan_vae.py:17-36), under the emulator's lazy (latest-allowed) completion of LDS / memory operations -- the mode that exposes
+a missing or too-weak s_waitcnt.  Covers the frame-slot ring (more slices than slots), ragged tiles, an odd frame count, two n tiles,
+several tiles per persistent workgroup, the residual epilogue, padded output rows and the chunked-decode frame mapping."""
+import numpy as np
+import pytest
+
+from scail_amd.asmgen import conv4
+from tools import conv4_emu_run as R
+
+
+def _case(Ti, H, W, Cin, N, resid, seed=0, frames=None):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((Ti, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((N, Cin, 3, 3, 3)) / np.sqrt(27 * Cin)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((frames or Ti, H, W, N)).astype(np.float32) if resid else None
+    return x, w, b, r
+
+
+def _cfg(name):
+    return [c for c in conv4.DEFAULTS + conv4.variant_cfgs() if c.name == name][0]
+
+
+def test_conv4_static_hazards():
+    for cfg in conv4.DEFAULTS:
+        assert R.check_static(cfg) == [], cfg.name
+
+
+@pytest.mark.parametrize("name,shape,cus", [("scail_conv4_e0", (2, 16, 16, 32, 96), 256),         # one tile, one slice
+                                            ("scail_conv4_e3", (2, 16, 16, 224, 96), 256),        # 7 slices: the 5-slot frame ring wraps
+                                            ("scail_conv4_e3", (3, 18, 20, 64, 192), 8),          # ragged tiles, odd frame count, 2 n tiles, 2 tiles per workgroup
+                                            ("scail_conv4_e0", (5, 16, 40, 32, 96), 8)])          # 9 tiles on 8 workgroups: one walks two, a frame pair past the end
+def test_conv4_emulated(name, shape, cus):
+    cfg = _cfg(name)
+    x, w, b, r = _case(*shape, resid=cfg.epi == 3)
+    y, _ = R.run(cfg, x, w, b, r, cus=cus)
+    ref = R.reference(x, w, b, r)
+    err = np.abs(y - ref)
+    assert not np.isnan(y).any(), "every output voxel is written"
+    assert err.max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max()), float(err.max())     # one bf16 rounding of the output
+
+
+def test_conv4_emulated_row_stride_frame_mapping_no_bias():
+    """ldc > N (the output is a channel slice of a wider tensor), output frame t -> slot 2 t + 1 (the interleaving of the decoder's temporal
+    upsampling), pt = 0 with two extra input frames in front (a chunk with its cache frames), bias == NULL."""
+    cfg = _cfg("scail_conv4_e0")
+    Ti, H, W, Cin, N = 4, 16, 16, 32, 96
+    x, w, _, _ = _case(Ti, H, W, Cin, N, False, seed=3)
+    To = Ti - 2
+    y, _ = R.run(cfg, x, w, None, None, pt=0, To=To, ot_mul=2, ot_off=1, y_frames=2 * To + 1, ldc=128)
+    ref = R.reference(x, w, None, None, pt=0, To=To)
+    assert np.isnan(y[0::2]).all() and np.isnan(y[:, :, :, N:]).all(), "nothing outside the addressed frames / channels is written"
+    err = np.abs(y[1::2, :, :, :N] - ref)
+    assert err.max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max()), float(err.max())

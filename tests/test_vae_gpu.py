@@ -32,19 +32,27 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm()))
 
 
-@pytest.fixture(params=[4, 3, 2, 1, 0])
+@pytest.fixture(params=[44, 4, 3, 2, 1, 0])
 def conv_halo(request):
-    """every path of the 3x3x3 convolution: halo-tile kernel with 32-channel slices padded / one W buffer (default),
-    32-channel slices swizzled / two W buffers, 48-channel slices, and the gather kernel"""
+    """every path of the 3x3x3 convolution: the generated conv4 kernels where eligible (44: the product configuration), else / with the option
+    "conv4" off (4) the halo-tile kernel with 32-channel slices padded / one W buffer, two frames per workgroup; measurement build: 32-channel
+    slices swizzled / two W buffers, 48-channel slices, and the gather kernel"""
     from scail_amd import lib as L
-    if request.param == 4:                              # the product layout
-        yield 4
+    if request.param == 44:
+        yield 44
         return
-    if not L.ABLATIONS:
-        pytest.skip("kernel variant of the measurement build (run with SCAIL_ABLATIONS=1)")
-    L.tune_set("conv_halo", request.param)
-    yield request.param
-    L.tune_set("conv_halo", 4)
+    L.set_option("conv4", 0)
+    try:
+        if request.param == 4:
+            yield 4
+            return
+        if not L.ABLATIONS:
+            pytest.skip("kernel variant of the measurement build (run with SCAIL_ABLATIONS=1)")
+        L.tune_set("conv_halo", request.param)
+        yield request.param
+        L.tune_set("conv_halo", 4)
+    finally:
+        L.set_option("conv4", 1)
 
 
 @pytest.mark.parametrize("cin,cout,k,thw", [(16, 32, (3, 3, 3), (5, 10, 12)), (96, 96, (3, 3, 3), (5, 10, 12)),
@@ -68,6 +76,55 @@ def test_causal_conv3d(cin, cout, k, thw, conv_halo):
     r = bfr(torch.randn(cout, T, H, W, generator=g))
     y2 = ops.conv3d_cl(_cl(x), wp, (T, H, W), resid=_cl(r))
     torch.testing.assert_close(_pl(y2)[:cout], ref + r, rtol=2e-2, atol=2e-2)
+
+
+def _geom(Ti, H, W, Cin, To, N, Kpad, pt=2, ot_mul=1, ot_off=0):
+    import ctypes as C
+    return (C.c_int32 * 21)(Ti, H, W, Cin, To, H, W, 3, 3, 3, 1, 1, 1, pt, 1, 1, 0, ot_mul, ot_off, N, Kpad)
+
+
+@pytest.mark.parametrize("cin,cout,thw", [(96, 96, (5, 33, 40)),        # 3 slices, ragged tiles, odd frame count
+                                          (224, 192, (4, 16, 50)),      # 7 slices (the frame-slot ring wraps), 2 n tiles
+                                          (32, 96, (2, 16, 16)),        # one slice, one tile
+                                          (384, 384, (6, 20, 36))])     # 12 slices, 4 n tiles
+def test_conv4_generated_kernels(cin, cout, thw):
+    """the generated kernels (csrc/conv4.s; scail_conv3d_kernel_for == 4) against torch's fp32 convolution of the bf16-rounded operands:
+    plain, residual, and -- on the first shape -- a chunk with its two cache frames in front (pt = 0), interleaved output frames
+    (ot_mul / ot_off) and an output that is a channel slice of a wider tensor (ldc > N)."""
+    import ctypes as C
+    from scail_amd import lib as L, ops
+    g = torch.Generator().manual_seed(7)
+    T, H, W = thw
+    x = bfr(torch.randn(cin, T, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, 3, 3, 3, generator=g) / (cin * 27) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    r = bfr(torch.randn(cout, T, H, W, generator=g))
+    ref = V.causal_conv3d(x[None], w, b)[0]
+    wp = ops.prep_conv_weight(w.to(DEV), b.to(DEV))
+    assert L.load().scail_conv3d_kernel_for(C.cast(_geom(T, H, W, cin, T, cout, wp["Kpad"]), C.c_void_p), cout, cout, 0) == 4
+    assert L.load().scail_conv3d_kernel_for(C.cast(_geom(T, H, W, cin, T, cout, wp["Kpad"]), C.c_void_p), cout, 0, 1) == 0      # fused norm: csrc/conv.hip
+    assert L.load().scail_conv3d_kernel_for(C.cast(_geom(1, H, W, cin, 1, cout, wp["Kpad"]), C.c_void_p), cout, 0, 0) == 0      # a single frame
+    y = torch.full((T, H, W, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.conv3d_cl(_cl(x), wp, (T, H, W), out=y)
+    torch.testing.assert_close(_pl(y), ref, rtol=2e-2, atol=2e-2)
+    y2 = ops.conv3d_cl(_cl(x), wp, (T, H, W), resid=_cl(r))
+    torch.testing.assert_close(_pl(y2), ref + r, rtol=2e-2, atol=2e-2)
+    L.set_option("conv4", 0)
+    try:
+        y_old = ops.conv3d_cl(_cl(x), wp, (T, H, W))
+    finally:
+        L.set_option("conv4", 1)
+    assert float((y.float() - y_old.float()).abs().max()) <= 2.0 ** -6 * float(ref.abs().max()), "conv4 vs the halo kernel: summation order only"
+    if cin != 96:
+        return
+    # a chunk of 3 output frames whose input carries the 2 cache frames: no padding in front; outputs land in slots 1, 3, 5 of a 7-frame,
+    # 128-channel tensor
+    To = T - 2
+    out = torch.full((2 * To + 1, H, W, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.conv3d_cl(_cl(x), wp, (To, H, W), pad=(0, 1, 1), out=out, ot_mul=2, ot_off=1)
+    want = ref[:, 2:]                                              # frames 2.. of the causal result = 'valid' in time
+    torch.testing.assert_close(out[1::2, :, :, :cout].float().cpu().permute(3, 0, 1, 2), want, rtol=2e-2, atol=2e-2)
+    assert torch.isnan(out[0::2].float()).all() and torch.isnan(out[:, :, :, cout:].float()).all(), "nothing else is written"
 
 
 @pytest.mark.parametrize("C,T,H,W", [(32, 5, 8, 12), (192, 2, 9, 21), (384, 3, 6, 10)])

@@ -382,6 +382,8 @@ class Emu:
             self._queue(w, "lgkm", commit)
             return
         if op.startswith("ds_write"):
+            # LDS instructions of one wave execute in order: the wave's older ds_reads sample their data before this write lands
+            self._drain(w, "lgkm", 0)
             data = self._regs(w, s[1])
             nb = s[1].n * 4
             addr = (self._rd(w, s[0]).astype(np.int64) + ins.offset)

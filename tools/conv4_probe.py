@@ -65,7 +65,7 @@ if a.prof:
         out = torch.empty(T, H, W, C, device=dev, dtype=torch.bfloat16)
         dbg = torch.zeros_like(out)
         tiles = (T + 1) // 2 * (H // 16) * (W // 16) * (C // 96)
-        for pv in ("prof", "prof_s0"):
+        for pv in ("prof",):
             setk(pv)
             O.conv3d_cl(x, wp, (T, H, W), out=out, resid=dbg)
             torch.cuda.synchronize()
