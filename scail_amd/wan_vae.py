@@ -188,7 +188,8 @@ class WanVAE_(nn.Module):
         T, H, Wd, _ = x.shape
         h = ops.conv3d_cl(x, W[n + ".shortcut"], (T, H, Wd)) if (n + ".shortcut") in W else x
         y = ops.rms_silu(x, W[n + ".residual.0.gamma"])
-        if ops.conv_norm_fusable(W[n + ".residual.2"], y.shape[3]):       # conv -> RMS_norm -> SiLU in one kernel
+        if ops.conv_norm_fusable(W[n + ".residual.2"], y.shape[3]) and not ops.conv_generated(W[n + ".residual.2"], y.shape):
+            # conv -> RMS_norm -> SiLU in one kernel (shapes the generated convolution kernels do not cover)
             y = ops.conv3d_cl_norm(y, W[n + ".residual.2"], W[n + ".residual.3.gamma"])
         else:
             y = ops.conv3d_cl(y, W[n + ".residual.2"], (T, H, Wd))
