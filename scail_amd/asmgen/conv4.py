@@ -37,8 +37,9 @@ KERNARG_FMT = "<5Q4i4i3iI2I2iii2q2i"
 TH, TW, NF = 16, 16, 2
 PR, PC = TH + 2, TW + 2                 # patch rows / columns
 FVOX = 384                              # voxels reserved per patch frame (324 used; 6 DMA pieces of 64)
-PLN = FVOX * 16                         # bytes of one chunk plane of one frame: 6144 (a multiple of 256: fragment reads are conflict-free)
-FSLOT = 4 * PLN                         # one patch frame of a 32-channel slice: 24576
+PCL = 20                                # voxels per patch row in LDS (18 used: a multiple of 4 keeps the chunk swizzle a function of the column)
+ROWB = PCL * 64                         # bytes per patch row in LDS: a voxel's 32-channel slice is 64 contiguous bytes (4 chunks of 16)
+FSLOT = FVOX * 64                       # one patch frame of a 32-channel slice: 24576 (18 x 20 voxels = 23040 used; 24 DMA pieces of 16 voxels)
 NSLOT = 5                               # ring of frame slots: the 4 frames of a slice + 1 (frames of the next slice arrive as the taps release the old ones)
 WBUF = 8192                             # bytes per W tap buffer (96 rows x 64 B used; 8 DMA pieces of 1 KB)
 NWB = 4                                 # W tiles in flight: tap g + 4 is requested during tap g
@@ -105,7 +106,7 @@ def XF(s, r):
 
 PBASE = [V(128 + dt) for dt in range(3)]                    # per-lane fragment base inside the slot of patch frame f + dt of the current slice
 WB = V(131)                                                 # per-lane W fragment base inside the W ring (advances one buffer per tap)
-PDMA = [V(132 + k) for k in range(6)]                       # per-lane source offsets of the 6 voxel groups of a patch frame (chunk = wave)
+PDMA = [V(132 + k) for k in range(6)]                       # per-lane source offsets of this wave's 6 pieces (16 voxels x 4 chunks each) of a patch frame
 WDMA = [V(138 + i) for i in range(2)]                       # per-lane source offsets of this wave's 2 W-tile pieces
 LANE = V(141)
 T_ = [V(144 + i) for i in range(40)]                        # v144..v183 temporaries
@@ -139,7 +140,9 @@ S_YF, S_RF = S(0, 2), S(96, 2)                              # epilogue: output /
 S_LDR2 = S(2)                                               # epilogue: residual row stride in bytes (the workgroup id is consumed at entry)
 N_SGPR = 102
 S_PROFWG = S(43)                                            # (prof variant; the unused high word of ldr) workgroup id
-PBL, WBL = V(142), V(143)                                   # per-lane parts of the fragment bases (tile independent)
+PBL, WBL = V(142), V(143)                                   # tile-independent parts of the fragment bases
+LP = [V(221 + dw) for dw in range(3)]                       # the lane's place in a patch row shifted by dw columns: (u 64 + ((chunk ^ ((u >> 1) & 3)) 16), u = l % 16 + dw
+XB = V(224)                                                 # fragment base of the tap group being read
 # epilogue staging (a row block of 16 voxels x 96 channels goes through LDS so that global stores / residual loads are whole contiguous lines):
 STG_VOX = 208                                               # bytes per staged voxel (192 + 16: conflict-free 8-byte writes, 16-byte aligned chunks)
 STG_WAVE = 16 * STG_VOX                                     # 3328 bytes per wave, in frame slot 3 (idle between a tile's last tap and the next tile's first)
@@ -204,7 +207,11 @@ class Gen:
     def x_reads(self, grp: int, rows, t0: float, step: float) -> List[Instr]:
         """patch rows ``rows`` of tap group grp = dt 3 + dw (of the slice the PBASE registers point into) -> set grp % 3."""
         dt, dw = grp // 3, grp % 3
-        return [isa.ds_read_b128(XF(grp % 3, r), PBASE[dt], (r * PC + dw) * 16, target_gap=t0 + step * k) for k, r in enumerate(rows)]
+        return [isa.ds_read_b128(XF(grp % 3, r), XB, r * ROWB, target_gap=t0 + step * k) for k, r in enumerate(rows)]
+
+    def xb_set(self, grp: int, tg: float) -> List[Instr]:
+        """fragment base of tap group grp = dt 3 + dw: slot of frame f + dt (+ this wave's first row) + the lane's place in a row shifted by dw."""
+        return [isa.vop("v_add_u32", XB, PBASE[grp // 3], LP[grp % 3], target_gap=tg)]
 
     def w_dma(self, t0: float, step: float, need: int) -> List[Instr]:
         """this wave's 2 pieces (of 8: pieces w and w + 4; rows >= 96 fail the range check = zeros) of the W tile at S_WNEXT -> the buffer
@@ -229,10 +236,10 @@ class Gen:
                 isa.sop("s_sub_u32", S_WNEXT, S_WNEXT, {-5: S_C5}[d], target_gap=tg)]
 
     def patch_piece(self, j: int, k: int, soff, tg: float, need: int) -> List[Instr]:
-        """voxel group k of this wave's chunk plane of patch frame j -> the slot S_SLOT[j] points at."""
+        """piece wave + 4 k (16 voxels x 64 bytes) of patch frame j -> the slot S_SLOT[j] points at."""
         d = isa.buffer_load_lds(PDMA[k], S_XR[j], soff, 0, target_gap=tg, tag="pdma")
         d.need = need
-        return [isa.sop("s_add_u32", M0, S_SLOT[j], I32(k * 1024), target_gap=tg - 0.5), d]
+        return [isa.sop("s_add_u32", M0, S_SLOT[j], I32(k * 4096), target_gap=tg - 0.5), d]
 
     def slot_next(self, j: int, tg: float) -> List[Instr]:
         """the next load of frame j goes one slot down the ring (4 frames per slice, 5 slots: -1 mod 5)."""
@@ -259,6 +266,8 @@ class Gen:
         if "lds" not in abl:
             blk += [isa.vop("v_add_u32", WB, I32(WBUF), WB, target_gap=0.0), isa.vop("v_and_b32", WB, I32(WREG - 1), WB, target_gap=0.1)]
             rows = self.XSPLIT[i % 3]
+            if i % 3 == 0:
+                blk += self.xb_set((i // 3 + 1) % 9, 0.2)
             blk += self.w_reads((i + 1) % 27, c.rd_at, c.rd_step)
             blk += self.x_reads((i // 3 + 1) % 9, rows, c.rd_at + 6 * c.rd_step, c.rd_step)
         if "dma" not in abl:
@@ -337,10 +346,13 @@ class Gen:
         # ---- per-lane parts of the fragment bases ----
         ql, g = t[10], t[11]
         o += [isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
-        # patch: chunk plane g, voxel (row 8 rh, column ql) of the slot of frame f (+ dt slots, + the ring position: tile_setup)
-        o += [isa.sop("s_mul_i32", ST[0], S_RH, I32(8 * PC)), isa.vop("v_add_u32", t[1], ST[0], ql), isa.vop("v_lshlrev_b32", t[1], I32(4), t[1]),
-              isa.vop("v_mul_u32_u24", t[2], I32(PLN), g), isa.vop("v_add_u32", t[1], t[1], t[2]),
-              isa.sop("s_mul_i32", ST[1], S_F, I32(FSLOT)), isa.sop("s_add_u32", ST[1], ST[1], I32(PBASE0)), isa.vop("v_add_u32", PBL, ST[1], t[1])]
+        # patch: row 8 rh of the slot of frame f (+ dt slots, + the ring position: tile_setup); the lane's place in a row per column shift
+        o += [isa.sop("s_mul_i32", ST[0], S_RH, I32(8 * ROWB)), isa.sop("s_mul_i32", ST[1], S_F, I32(FSLOT)), isa.sop("s_add_u32", ST[1], ST[1], ST[0]),
+              isa.sop("s_add_u32", ST[1], ST[1], I32(PBASE0)), isa.vop("v_mov_b32", PBL, ST[1])]
+        for dw in range(3):
+            u, fz = t[1], t[2]
+            o += [isa.vop("v_add_u32", u, I32(dw), ql), isa.vop("v_lshrrev_b32", fz, I32(1), u), isa.vop("v_and_b32", fz, I32(3), fz),
+                  isa.vop("v_xor_b32", fz, g, fz), isa.vop("v_lshlrev_b32", fz, I32(4), fz), isa.vop("v_lshl_add_u32", LP[dw], u, I32(6), fz)]
         # W: row ql (64 B), chunk g ^ ((ql >> 1) & 3)
         o += [isa.vop("v_lshrrev_b32", t[1], I32(1), ql), isa.vop("v_and_b32", t[1], I32(3), t[1]), isa.vop("v_xor_b32", t[1], g, t[1]),
               isa.vop("v_lshlrev_b32", t[2], I32(6), ql), isa.vop("v_lshl_add_u32", WBL, t[1], I32(4), t[2])]
@@ -406,26 +418,31 @@ class Gen:
               isa.sop("s_sub_u32", ST[2], S_N, S_N0), isa.sop("s_min_u32", ST[2], ST[2], I32(96)), isa.sop("s_mul_i32", S_WR.sub(2), ST[2], S_KP2),
               isa.sop("s_mov_b32", S_WR.sub(3), I32(0x00020000))]
         # ---- ring positions: slice 0's frame j -> slot j; W buffer 0 ----
-        o += [isa.sop("s_mul_i32", ST[0], S_WAVE, I32(PLN)), isa.sop("s_add_u32", ST[0], ST[0], I32(PBASE0)),
-              isa.sop("s_lshl_b32", S_WM0, S_WAVE, I32(10))]
+        o += [isa.sop("s_lshl_b32", S_WM0, S_WAVE, I32(10)), isa.sop("s_add_u32", ST[0], S_WM0, I32(PBASE0))]
         for j in range(4):
             o.append(isa.sop("s_add_u32", S_SLOT[j], ST[0], I32(j * FSLOT)))
         o += [isa.vop("v_mov_b32", PBASE[0], PBL), isa.vop("v_add_u32", PBASE[1], I32(FSLOT), PBL), isa.vop("v_add_u32", PBASE[2], I32(2 * FSLOT), PBL),
               isa.vop("v_mov_b32", WB, WBL)]
-        # ---- patch voxel groups: lane l of group k = patch voxel pv = 64 k + l = (r, col); source offset inside the frame (chunk = wave), or OOB ----
-        hm1, wm1, w16 = ST[12], ST[13], ST[1]
-        o += [isa.sop("s_sub_u32", hm1, S_H0, I32(1)), isa.sop("s_sub_u32", wm1, S_W0, I32(1)), isa.sop("s_lshl_b32", w16, S_WAVE, I32(4))]
+        # ---- patch pieces of this wave: piece wave + 4 i = patch voxels p = 16 (wave + 4 i) + l / 4 = (r, col) of the 18 x 20 LDS grid; LDS
+        # position q = l % 4 of a voxel holds source chunk q ^ ((col >> 1) & 3) (conflict-free fragment reads, like the W tile); source offset
+        # inside the frame, or OOB (padding columns 18, 19, voxels past 360, rows / columns outside the tensor) ----
+        hm1, wm1 = ST[12], ST[13]
+        o += [isa.sop("s_sub_u32", hm1, S_H0, I32(1)), isa.sop("s_sub_u32", wm1, S_W0, I32(1)), isa.sop("s_lshl_b32", ST[1], S_WAVE, I32(4)),
+              isa.vop("v_lshrrev_b32", t[12], I32(2), LANE), isa.vop("v_and_b32", t[13], I32(3), LANE)]
         for k in range(6):
             pv, r, col, hi, wi, ok = t[1], t[2], t[3], t[4], t[5], t[6]
-            o += [isa.vop("v_add_u32", pv, I32(64 * k), LANE),
-                  isa.vop("v_mul_u32_u24", r, I32(3641), pv), isa.vop("v_lshrrev_b32", r, I32(16), r),             # r = pv / 18 (pv < 384)
-                  isa.vop("v_mul_u32_u24", col, I32(18), r), isa.vop("v_sub_u32", col, pv, col),
+            o += [isa.sop("s_add_u32", ST[2], ST[1], I32(64 * k)), isa.vop("v_add_u32", pv, ST[2], t[12]),
+                  isa.vop("v_mul_u32_u24", r, I32(3277), pv), isa.vop("v_lshrrev_b32", r, I32(16), r),             # r = pv / 20 (pv < 384)
+                  isa.vop("v_mul_u32_u24", col, I32(PCL), r), isa.vop("v_sub_u32", col, pv, col),
                   isa.vop("v_add_u32", hi, hm1, r), isa.vop("v_add_u32", wi, wm1, col),                             # wraps below 0 -> huge unsigned
                   isa.v_cmp("v_cmp_gt_u32", S_H, hi), isa.vop("v_mul_lo_u32", t[7], hi, S_Wd),
                   isa.v_cndmask(ok, I32(0), I32(1)),
                   isa.v_cmp("v_cmp_gt_u32", S_Wd, wi), isa.v_cndmask(t[8], I32(0), I32(1)), isa.vop("v_and_b32", ok, ok, t[8]),
-                  isa.v_cmp("v_cmp_gt_u32", I32(PR * PC), pv), isa.v_cndmask(t[8], I32(0), I32(1)), isa.vop("v_and_b32", ok, ok, t[8]),
-                  isa.vop("v_add_u32", t[7], t[7], wi), isa.vop("v_mul_lo_u32", t[7], t[7], S_CIN2), isa.vop("v_add_u32", t[7], w16, t[7]),
+                  isa.v_cmp("v_cmp_gt_u32", I32(PC), col), isa.v_cndmask(t[8], I32(0), I32(1)), isa.vop("v_and_b32", ok, ok, t[8]),
+                  isa.v_cmp("v_cmp_gt_u32", I32(PR * PCL), pv), isa.v_cndmask(t[8], I32(0), I32(1)), isa.vop("v_and_b32", ok, ok, t[8]),
+                  isa.vop("v_add_u32", t[7], t[7], wi), isa.vop("v_mul_lo_u32", t[7], t[7], S_CIN2),
+                  isa.vop("v_lshrrev_b32", t[8], I32(1), col), isa.vop("v_and_b32", t[8], I32(3), t[8]), isa.vop("v_xor_b32", t[8], t[13], t[8]),
+                  isa.vop("v_lshl_add_u32", t[7], t[8], I32(4), t[7]),
                   isa.v_cmp("v_cmp_ne_u32", I32(0), ok), isa.vop("v_mov_b32", t[9], I32(OOB)),
                   isa.v_cndmask(PDMA[k], t[9], t[7])]
         o += self.stamp(0)                                        # phase 0: tile decode, descriptors, lane offsets
@@ -461,7 +478,7 @@ class Gen:
                 for i in range(4):
                     o.append(isa.vop("v_accvgpr_write_b32", ACC(nb, mb).sub(i), V(EPI_BQ + 4 * nb + i)))
         o += [isa.barrier()]
-        o += self.w_reads(0, 0, 0) + self.x_reads(0, range(10), 0, 0)
+        o += self.xb_set(0, 0) + self.w_reads(0, 0, 0) + self.x_reads(0, range(10), 0, 0)
         o = sched.pad_hazards(o)
         return o + self.stamp(5)                                  # phase 5: accumulators = bias, barrier (first tile: + the wait for the first loads)
 

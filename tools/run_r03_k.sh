@@ -2,7 +2,7 @@
 # round 3, call k: the generated conv4 kernel (check + A/B vs the hipcc halo kernel + phase timers)
 mkdir -p gpurun_out
 export SCAIL_ABLATIONS=1
-timeout 600 python tools/conv4_probe.py --variants ",s0" > gpurun_out/r03_conv4_probe.log 2>&1
+timeout 600 python tools/conv4_probe.py --variants "" > gpurun_out/r03_conv4_probe.log 2>&1
 echo "exit $?" >> gpurun_out/r03_conv4_probe.log
 timeout 300 python tools/conv4_probe.py --prof --skip-check >> gpurun_out/r03_conv4_probe.log 2>&1
 echo "exit $?" >> gpurun_out/r03_conv4_probe.log
