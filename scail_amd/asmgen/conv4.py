@@ -1,25 +1,41 @@
 """conv4 -- hand-scheduled 3x3x3 causal convolution for the Wan2.1 VAE on gfx950 (generator of csrc/conv4.s).
 
-Reference: CausalConv3d (sgm/models/wan_vae.py:17-36: F.pad(2 frames in front, 1 voxel around) + nn.Conv3d(k = 3, stride 1)) as
-used by every ResidualBlock (wan_vae.py:162-205) -- 26 of the 33 decoder convolutions, > 90 % of the VAE's FLOPs.  Same C entry
-point as the kernels of csrc/conv.hip (scail_conv3d_cl), which selects this kernel for kt = kh = kw = 3, stride 1, Cin % 32 == 0,
-N % 96 == 0.
+Reference: CausalConv3d (sgm/models/wan_vae.py:17-36: F.pad(2 frames in front, 1 voxel around) + nn.Conv3d(k = 3, stride 1)) as used by
+every ResidualBlock (wan_vae.py:162-205) -- > 90 % of the VAE's FLOPs.  Same C entry point as the kernels of csrc/conv.hip
+(scail_conv3d_cl), which runs these kernels where scail_conv3d_kernel_for says 4: kt = kh = kw = 3, stride 1, 'same' spatial extent, 0..2
+padding frames in front, Cin % 32 == 0, N % 96 == 0, at least two output frames.  Epilogues: e0  y = conv + bias;  e3  y = resid + conv + bias.
 
 Shape (the gemm4 / attn4 structure: 4 waves, one per SIMD, accumulators in the AGPR file, LDS-DMA staging, MFMA-spine scheduling):
-  * channels-last activations x (T, H, W, Cin), y (T, H, W, N) bf16; weights (N, Kpad) bf16 with k = ((dt 3 + dh) 3 + dw) Cin + c
-    (scail_amd.ops.prep_conv_weight); output frame t sees input frames t - 2 .. t (causal), rows / columns -1 .. +1.
-  * workgroup = 2 output frames x 16 x 16 voxels x 96 output channels.  Wave w: frame w >> 1, rows 8 (w & 1) .. + 7 -> 8 voxel
-    blocks of 16 (one patch row each) x 6 channel blocks of 16 = 48 v_mfma_f32_16x16x32_bf16 per (tap, 32-channel slice);
-    192 accumulators per lane in a[0:191]; x fragments (MFMA B operand) in a[192:255] (two sets), W fragments (A) in v[0:47].
-  * the input PATCH of a 32-channel slice -- 4 frames x 18 x 18 voxels -- lives in LDS in a CHUNK-PLANAR layout: plane c (0..3) holds
-    the 16-byte chunk c (8 channels) of every patch voxel, voxel (p, r, col) at  c * 24576 + p * 6144 + (r * 18 + col) * 16.
-    Written by LDS-DMA (64 consecutive voxels of a plane per instruction, wave w loads patch frame w; out-of-range voxels and the
-    causal frames t < 0 read zeros through the buffer descriptor's range check), read as B fragments: lane (voxel l % 16, chunk
-    l / 16) -> 16 consecutive voxels of 4 planes = all 64 banks exactly once, and a tap is a plain immediate offset
-    ((dt * 384 + dh * 18 + dw) * 16): no swizzle, no padding, no per-tap address arithmetic.
-  * the W tile of one tap (96 rows x 64 B) arrives by LDS-DMA three taps ahead into three 8 KB buffers (rows unpadded, 16-byte chunk
+  * channels-last activations x (Ti, H, W, Cin), y (frames, H, W, ldc) bf16; weights (N, Kpad) bf16, k = ((dt 3 + dh) 3 + dw) Cin + c
+    (scail_amd.ops.prep_conv_weight); output frame t sees input frames t - pt .. t - pt + 2, rows / columns -1 .. +1.
+  * TILE = 2 output frames x 16 x 16 voxels x 96 output channels.  Wave w: frame w >> 1, rows 8 (w & 1) .. + 7 -> 8 voxel blocks of 16 (one
+    patch row each) x 6 channel blocks of 16 = 48 v_mfma_f32_16x16x32_bf16 per (tap, 32-channel slice); 192 accumulators per lane in a[0:191].
+  * PERSISTENT workgroups, one per compute unit: workgroup b runs on XCD b % 8 and walks a stride of that XCD's contiguous tile range (n tiles
+    of a patch and neighbouring patches share an L2: 1.4-1.8 x the algorithmic traffic where the one-tile-per-workgroup hipcc kernel moves
+    2.6-5 x).  The next tile's setup, first DMAs and bias loads are issued BEFORE the finished tile's epilogue, which hides their latency.
+  * the input PATCH of a 32-channel slice -- 4 frames x 18 x 18 voxels -- lives in LDS voxel-major: a voxel's slice is 64 contiguous bytes,
+    rows of 20 voxels, the 16-byte chunk q of voxel (r, col) holds source chunk q ^ ((col >> 1) & 3): fragment reads (lane = voxel l % 16 + dw,
+    chunk l / 16) are conflict-free, a tap row is an immediate offset, and an LDS-DMA instruction moves 16 voxels x 64 contiguous bytes (16
+    cache lines; a chunk-planar layout with 64 lines per instruction cost 6.7-9 k cycles of VMEM issue for a tile's first loads against 4-4.7 k).
+    Spatial / causal padding = the buffer descriptors' range check (out-of-range lanes and whole padding frames read zeros).
+  * FRAME-SLOT RING: 5 slots for the 4 frames of a slice.  Taps run dt-major, so frame 0 of a slice is released after a third of the taps,
+    frame 1 after two thirds: the next slice's frames are requested into the slots as they free up, 9-18 taps before their first use -- the
+    patch load of a slice never stalls the MFMAs (a load-then-compute version: 1023 / 1170 / 1214 TF/s; the ring: 1277 / 1432 / 1514).
+  * the W tile of one tap (96 rows x 64 B) arrives by LDS-DMA four taps ahead into a ring of four 8 KB buffers (rows unpadded, 16-byte chunk
     XOR-ed with (row >> 1) & 3 on the source address: conflict-free A-fragment reads); one s_barrier per tap.
-  * per tap: 48 MFMAs || the 14 fragment reads of the next tap || 2 W-tile DMA pieces; 27 taps unrolled, a loop over the slices.
+  * TAP ORDER (dt, dw, dh) with dh innermost: the 10 patch rows of a group (dt, dw) are read once into registers and serve 3 taps (9.3 instead
+    of 14 ds_read_b128 per tap); fragment sets rotate modulo 3 (27 taps and 9 groups per slice: the sets line up across slices).
+  * per tap: 48 MFMAs || ~10 fragment reads of the next tap / group || 2 W-tile DMA pieces || 1 patch piece; 27 taps unrolled, a loop over
+    the slices; counted s_waitcnt vmcnt(n) at the top of every tap, computed from the DMA issue order and each DMA's deadline.
+  * EPILOGUE through LDS: a row block (16 voxels x 96 channels) is written in accumulator layout and read back in memory layout, so every global
+    store (and residual load) instruction moves 64 x 16 contiguous bytes instead of 64 x 8 scattered ones (48 partial-line stores cost 7-10 k
+    cycles per tile, 24 whole-line ones 2.6 k); the stores are non-temporal and drain behind the next tile's taps.  The bias is the
+    accumulators' initial value.
+Measured (profiles/r03_conv4_*.log, 21 x 512 x 896 x 96 / 256 x 448 x 192 / 128 x 224 x 384): 1350 / 1500 / 1560 TF/s against 960 / 1070 /
+1100 for the hipcc halo kernel; s_memtime phase timers: 800 cycles per tap of the 768 the MFMAs need, ~12 k cycles between tiles, shader clock
+1.4-1.7 GHz under this load (the "_prof" variant of the measurement build).
+Negative results kept as notes: splitting the DMA work by kind (waves 0, 1 the W tiles, waves 2, 3 the patch) -1..2 %; staggered workgroup
+starts neutral (the per-tile cost is per-CU VMEM issue, not an HBM burst).
 """
 from __future__ import annotations
 
@@ -36,7 +52,7 @@ KERNARG_FMT = "<5Q4i4i3iI2I2iii2q2i"
 
 TH, TW, NF = 16, 16, 2
 PR, PC = TH + 2, TW + 2                 # patch rows / columns
-FVOX = 384                              # voxels reserved per patch frame (324 used; 6 DMA pieces of 64)
+FVOX = 384                              # voxels reserved per patch frame slot (18 rows x 20 = 360 used; 24 DMA pieces of 16)
 PCL = 20                                # voxels per patch row in LDS (18 used: a multiple of 4 keeps the chunk swizzle a function of the column)
 ROWB = PCL * 64                         # bytes per patch row in LDS: a voxel's 32-channel slice is 64 contiguous bytes (4 chunks of 16)
 FSLOT = FVOX * 64                       # one patch frame of a 32-channel slice: 24576 (18 x 20 voxels = 23040 used; 24 DMA pieces of 16 voxels)
@@ -86,6 +102,7 @@ class Cfg:
     dma_step: float = 20.0
     p_at: float = 12.0      # gap of the tap's patch DMA piece
     stagger: int = 0        # (A/B) workgroup i of an XCD starts i * 64 * stagger cycles late; measured neutral to -1 %: the per-tile cost is VMEM issue, not an HBM burst
+    nt: bool = True         # non-temporal output stores: the output does not displace the patch lines whose second 64-byte half the next slice wants (-1..3 %)
     prof: bool = False      # measurement variant: s_memtime stamps around the phases of a tile; wave 0 of every workgroup writes the sums to `resid`
     abl: str = ""
 
@@ -587,8 +604,10 @@ class Gen:
                 pm = mb - 1
                 e += row_sgprs(pm, ST[11], ST[7], ldc2)
                 for i in range(3):
-                    e += masked(ST[11], i, [isa.vop("v_add_u32", voff, ST[7], E_Y[i]),
-                                            isa.global_store(4, voff, RQ(pm % 2, i), 0, saddr=S_YF, extra_reads=[EXEC])])
+                    st = isa.global_store(4, voff, RQ(pm % 2, i), 0, saddr=S_YF, extra_reads=[EXEC])
+                    if c.nt:
+                        st.text += " nt"
+                    e += masked(ST[11], i, [isa.vop("v_add_u32", voff, ST[7], E_Y[i]), st])
         e += self.stamp(4)                                        # phase 4: stores
         e += [isa.sop("s_bitcmp1_b32", None, self.HAVE_PREV, I32(1)), isa.branch("s_cbranch_scc1", "L_done" if c.prof else "L_exit"), isa.branch("s_branch", "L_start")]
         return sched.pad_hazards(sched.insert_lgkm_waits(e))
@@ -698,6 +717,7 @@ def variant_cfgs():
     out.append(Cfg(epi=0, cap=2, name="scail_conv4_e0_c2"))
     out.append(Cfg(epi=0, prof=True, name="scail_conv4_e0_prof"))
     out.append(Cfg(epi=0, stagger=14, name="scail_conv4_e0_s14"))
+    out.append(Cfg(epi=0, nt=False, name="scail_conv4_e0_t"))
     out.append(Cfg(epi=0, rd_step=2.0, name="scail_conv4_e0_rd2"))
     out.append(Cfg(epi=0, rd_at=6.0, rd_step=2.5, name="scail_conv4_e0_rd6"))
     out.append(Cfg(epi=0, p_at=30.0, dma_at=10.0, name="scail_conv4_e0_p30"))

@@ -14,8 +14,10 @@ from scail_amd import lib, ops as O  # noqa: E402
 which = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 lib.load()
-if len(sys.argv) > 3 and sys.argv[3] == "conv4":
+if len(sys.argv) > 3 and sys.argv[3].startswith("conv4"):
     lib.tune_set("conv_halo", 11)
+    if ":" in sys.argv[3]:
+        lib.tune_set("conv4_kernel:" + sys.argv[3].split(":")[1], 0)
 g = torch.Generator(device="cuda").manual_seed(0)
 T = 21
 for C, H, W in ((96, 512, 896), (192, 256, 448), (384, 128, 224)):

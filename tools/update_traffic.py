@@ -59,6 +59,21 @@ def main():
                 "traffic_bytes": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, "algorithmic_bytes": alg,
                 "kernel": "conv_halo_kernel<0, 32, 1, false, 96, 2, 3, false> (3x3x3 causal convolution, two output frames per workgroup)",
                 "source": "conv.hip", "source_blob": blob(os.path.join(ROOT, "scail_amd", "csrc", "conv.hip")), "measured": note}
+    # the generated convolution kernel on the same shapes (lines "conv4 C=<C> <counter> <value>")
+    conv4 = {}
+    for line in open(src):
+        m = re.match(r"conv4 C=(\d+)\s+(\S+)\s+(\S+)", line)
+        if m:
+            conv4.setdefault(int(m.group(1)), {})[m.group(2)] = float(m.group(3))
+    for C, v in conv4.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            H, W = {96: (512, 896), 192: (256, 448), 384: (128, 224)}[C]
+            alg = 2.0 * 21 * H * W * C * 2 + 27 * C * C * 2
+            tr[f"conv4_c{C}"] = {
+                "shape": {"T": 21, "H": H, "W": W, "C": C}, "fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"],
+                "traffic_bytes": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, "algorithmic_bytes": alg,
+                "kernel": "scail_conv4_e0 (generated 3x3x3 causal convolution: persistent workgroups, 2 frames x 16 x 16 voxels x 96 channels per tile)",
+                "source": "conv4.s", "source_blob": blob(os.path.join(ROOT, "scail_amd", "csrc", "conv4.s")), "measured": note}
     json.dump(tr, open(path, "w"), indent=1)
     print(json.dumps({k: tr[k] for k in ("flash_attn_self", "gemm4_step")}, indent=1))
 
