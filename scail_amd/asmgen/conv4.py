@@ -47,7 +47,7 @@ from . import isa, sched
 from .isa import A, S, V, I32, F32, VCC, EXEC, M0, Instr
 
 KERNARG_SIZE = 136
-# x w bias y resid | Ti To H W | Cin N Kpad pt | tiles_h tiles_w tiles_n magic_n | magic_w magic_h n_slices ot_mul | ot_off per_xcd | ldc ldr | wgs_per_xcd tiles
+# x w bias y resid | Ti To H W | Cin N Kpad pt | tiles_t tiles_w tiles_n magic_n | magic_w magic_t n_slices ot_mul | ot_off tiles_per_wg | ldc ldr | wgs_per_xcd tiles
 KERNARG_FMT = "<5Q4i4i3iI2I2iii2q2i"
 
 TH, TW, NF = 16, 16, 2
@@ -71,10 +71,10 @@ def magic31(d: int) -> int:
 
 def pack_args(x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt=2, ot_mul=1, ot_off=0, ldc=0, ldr=0, cus=256) -> bytes:
     """ldc / ldr: output / residual row strides in elements (0 = N); cus: compute units (one persistent workgroup each)."""
-    th, tw, tn = (H + TH - 1) // TH, (W + TW - 1) // TW, (N + 95) // 96
-    b = struct.pack(KERNARG_FMT, x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt, th, tw, tn, magic31(tn), magic31(tw), magic31(th),
-                    Cin // 32, ot_mul, ot_off, (grid_tiles(To, H, W, N) + 7) // 8, ldc or N, ldr or N,
-                    grid_blocks(To, H, W, N, cus) // 8, grid_tiles(To, H, W, N))
+    tp, tw, tn = (To + NF - 1) // NF, (W + TW - 1) // TW, (N + 95) // 96
+    tiles, grid = grid_tiles(To, H, W, N), grid_blocks(To, H, W, N, cus)
+    b = struct.pack(KERNARG_FMT, x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt, tp, tw, tn, magic31(tn), magic31(tw), magic31(tp),
+                    Cin // 32, ot_mul, ot_off, tiles // grid, ldc or N, ldr or N, grid // 8, tiles)
     assert len(b) == KERNARG_SIZE, len(b)
     return b
 
@@ -84,8 +84,11 @@ def grid_tiles(T, H, W, N) -> int:
 
 
 def grid_blocks(T, H, W, N, cus=256) -> int:
-    """workgroups launched: persistent, at most one per compute unit, a multiple of 8.  Workgroup b runs on XCD b % 8 and walks the tiles
-    (b % 8) * per_xcd + b / 8 + i * (grid / 8) of that XCD's contiguous range (the n tiles of a patch and neighbouring patches share an L2)."""
+    """workgroups launched: persistent, at most one per compute unit, a multiple of 8.  Tiles are numbered with the N TILE fastest, then the FRAME
+    PAIR (then the tile column, the tile row); workgroup b (XCD b % 8) is number (b % 8) * (grid / 8) + b / 8 of the grid and takes the next
+    tiles // grid (+ 1 for the first tiles % grid workgroups) tiles of that order: a workgroup walks the n tiles of a patch, then the next frame
+    pair of the same spatial tile (the patch lines come back from its XCD's L2, the two input frames consecutive pairs share from L2 / the
+    Infinity Cache, the per-lane patch offsets stay), the workgroups of an XCD work on neighbouring spatial tiles."""
     per = (grid_tiles(T, H, W, N) + 7) // 8
     return 8 * min(per, max(cus // 8, 1))
 
@@ -131,15 +134,15 @@ EPI_BQ, EPI_RP, EPI_F = 184, 208, 220                       # epilogue: bias qua
 
 S_KARG = S(0, 2)
 S_WG = S(2)
-S_TILE, S_G, S_TEND = S(3), S(4), S(5)                      # this workgroup's current tile, its stride (workgroups per XCD), end of the XCD's range
+S_TILE, S_G, S_TEND = S(3), S(4), S(5)                      # this workgroup's current tile, workgroups per XCD (entry only), end of its tile range
 S_ET0, S_EH0, S_EW0, S_EN0 = S(6), S(7), S(18), S(19)       # coordinates of the tile whose accumulators wait for the epilogue
 S_X, S_Wp, S_BIAS, S_Y, S_RES = S(8, 2), S(10, 2), S(12, 2), S(14, 2), S(16, 2)
 S_TI, S_T, S_H, S_Wd = S(20), S(21), S(22), S(23)            # input frames, output frames, rows, columns
 S_CIN, S_N, S_KPAD, S_PT = S(24), S(25), S(26), S(27)
-S_TLH, S_TLW, S_TLN, S_MGN = S(28), S(29), S(30), S(31)
-S_MGW, S_MGH, S_NSL, S_OTM = S(32), S(33), S(34), S(35)
+S_TLT, S_TLW, S_TLN, S_MGN = S(28), S(29), S(30), S(31)     # frame pairs, tile columns, n tiles; magic numbers of the divisions
+S_MGW, S_MGT, S_NSL, S_OTM = S(32), S(33), S(34), S(35)
 S_OTO, S_PER = S(36), S(37)
-S_KP2 = S(37)                                               # 2 Kpad (takes the place of per_xcd once the tile range is known)
+S_KP2 = S(37)                                               # 2 Kpad (takes the place of tiles_per_wg once the tile range is known)
 S_SAVE = S(38, 2)                                           # epilogue: saved exec
 S_LDC, S_LDR = S(40, 2), S(42, 2)
 S_XR = [S(44 + 4 * j, 4) for j in range(4)]                 # buffer descriptors of the 4 input frames of the patch (num_records = 0: a padding frame)
@@ -343,10 +346,16 @@ class Gen:
               isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", t[0], I32(6), V(0)),
               isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, t[0]),
               isa.sop("s_lshr_b32", S_F, S_WAVE, I32(1)), isa.sop("s_and_b32", S_RH, S_WAVE, I32(1))]
-        # ---- this workgroup's tiles: XCD x = b % 8 owns [x per_xcd, min((x + 1) per_xcd, tiles)); start at x per_xcd + b / 8, stride S_G ----
-        o += [isa.sop("s_and_b32", ST[0], S_WG, I32(7)), isa.sop("s_mul_i32", ST[1], ST[0], S_PER), isa.sop("s_lshr_b32", S_TILE, S_WG, I32(3)),
-              isa.sop("s_add_u32", S_TILE, S_TILE, ST[1]), isa.sop("s_add_u32", ST[1], ST[1], S_PER), isa.sop("s_min_u32", S_TEND, S_TEND, ST[1]),
-              isa.sop("s_cmp_ge_u32", None, S_TILE, S_TEND), isa.branch("s_cbranch_scc1", "L_exit")]
+        # ---- this workgroup's tiles: number w = (b % 8) * G + b / 8 of the 8 G workgroups takes base (+ 1 if w < rem) consecutive tiles ----
+        wn, rem = ST[0], ST[1]
+        o += [isa.sop("s_and_b32", wn, S_WG, I32(7)), isa.sop("s_mul_i32", wn, wn, S_G), isa.sop("s_lshr_b32", ST[2], S_WG, I32(3)),
+              isa.sop("s_add_u32", wn, wn, ST[2]),
+              isa.sop("s_lshl_b32", ST[2], S_G, I32(3)), isa.sop("s_mul_i32", ST[2], ST[2], S_PER), isa.sop("s_sub_u32", rem, S_TEND, ST[2]),   # tiles - base * grid
+              isa.sop("s_mul_i32", S_TILE, wn, S_PER), isa.sop("s_min_u32", ST[2], wn, rem), isa.sop("s_add_u32", S_TILE, S_TILE, ST[2]),
+              isa.sop("s_cmp_lt_u32", None, wn, rem), isa.sop("s_cselect_b32", ST[2], I32(1), I32(0)), isa.sop("s_add_u32", ST[2], ST[2], S_PER),
+              isa.sop("s_add_u32", S_TEND, S_TILE, ST[2]),
+              isa.sop("s_cmp_ge_u32", None, S_TILE, S_TEND), isa.branch("s_cbranch_scc1", "L_exit"),
+              isa.sop("s_mov_b32", S_H0, I32(-1)), isa.sop("s_mov_b32", S_N0, I32(-1))]                          # no spatial / n tile yet
         # ---- constants ----
         o += [isa.sop("s_lshl_b32", S_KP2, S_KPAD, I32(1)),
               isa.sop("s_mul_i32", ST[8], S_H, S_Wd), isa.sop("s_lshl_b32", S_CIN2, S_CIN, I32(1)),
@@ -410,13 +419,20 @@ class Gen:
         o += [isa.sop("s_bitcmp1_b32", None, self.HAVE_PREV, I32(1)), isa.branch("s_cbranch_scc1", "L_epilogue")]     # nothing follows: only the epilogue
         tt = ST[4]
         q1, q2, q3 = ST[5], ST[6], ST[7]
+        nh0, nw0, nn0, same, same_n = ST[8], ST[11], ST[12], ST[14], ST[15]
         o += [isa.sop("s_lshl_b32", tt, S_TILE, I32(1)), isa.sop("s_mul_hi_u32", q1, tt, S_MGN),                # q1 = tile / tiles_n
-              isa.sop("s_mul_i32", tt, q1, S_TLN), isa.sop("s_sub_u32", tt, S_TILE, tt), isa.sop("s_mul_i32", S_N0, tt, I32(96)),
-              isa.sop("s_lshl_b32", tt, q1, I32(1)), isa.sop("s_mul_hi_u32", q2, tt, S_MGW),                   # q2 = q1 / tiles_w
-              isa.sop("s_mul_i32", tt, q2, S_TLW), isa.sop("s_sub_u32", tt, q1, tt), isa.sop("s_lshl_b32", S_W0, tt, I32(4)),
-              isa.sop("s_lshl_b32", tt, q2, I32(1)), isa.sop("s_mul_hi_u32", q3, tt, S_MGH),                   # q3 = q2 / tiles_h
-              isa.sop("s_mul_i32", tt, q3, S_TLH), isa.sop("s_sub_u32", tt, q2, tt), isa.sop("s_lshl_b32", S_H0, tt, I32(4)),
-              isa.sop("s_lshl_b32", S_T0, q3, I32(1))]
+              isa.sop("s_mul_i32", tt, q1, S_TLN), isa.sop("s_sub_u32", tt, S_TILE, tt), isa.sop("s_mul_i32", nn0, tt, I32(96)),
+              isa.sop("s_lshl_b32", tt, q1, I32(1)), isa.sop("s_mul_hi_u32", q2, tt, S_MGT),                   # q2 = q1 / frame pairs
+              isa.sop("s_mul_i32", tt, q2, S_TLT), isa.sop("s_sub_u32", tt, q1, tt), isa.sop("s_lshl_b32", S_T0, tt, I32(1)),
+              isa.sop("s_lshl_b32", tt, q2, I32(1)), isa.sop("s_mul_hi_u32", q3, tt, S_MGW),                   # q3 = q2 / tiles_w = tile row
+              isa.sop("s_mul_i32", tt, q3, S_TLW), isa.sop("s_sub_u32", tt, q2, tt), isa.sop("s_lshl_b32", nw0, tt, I32(4)),
+              isa.sop("s_lshl_b32", nh0, q3, I32(4)),
+              # the same spatial tile as before (another n tile / the next frame pair): the per-lane patch offsets stay; the same n tile: the
+              # W descriptor and the bias quads stay
+              isa.sop("s_xor_b32", ST[0], nh0, S_H0), isa.sop("s_xor_b32", ST[1], nw0, S_W0), isa.sop("s_or_b32", ST[0], ST[0], ST[1]),
+              isa.sop("s_cmp_eq_u32", None, ST[0], I32(0)), isa.sop("s_cselect_b32", same, I32(1), I32(0)),
+              isa.sop("s_cmp_eq_u32", None, nn0, S_N0), isa.sop("s_cselect_b32", same_n, I32(1), I32(0)),
+              isa.sop("s_mov_b32", S_H0, nh0), isa.sop("s_mov_b32", S_W0, nw0), isa.sop("s_mov_b32", S_N0, nn0)]
         # ---- patch frame j: input frame t = t0 - pt + j; descriptor base = x + t * FB, num_records = FB (0 when t is outside [0, Ti)) ----
         tfr = ST[9]
         for j in range(4):
@@ -428,18 +444,30 @@ class Gen:
                   isa.sop("s_add_u32", S_XR[j].sub(0), S_X.sub(0), ST[0]), isa.sop("s_addc_u32", ST[1], S_X.sub(1), ST[1]),
                   isa.sop("s_and_b32", S_XR[j].sub(1), ST[1], I32(0xFFFF)), isa.sop("s_mov_b32", S_XR[j].sub(2), ST[10]),
                   isa.sop("s_mov_b32", S_XR[j].sub(3), I32(0x00020000))]
+        # ---- ring positions: slice 0's frame j -> slot j; W buffer 0 ----
+        o += [isa.sop("s_lshl_b32", S_WM0, S_WAVE, I32(10)), isa.sop("s_add_u32", ST[0], S_WM0, I32(PBASE0))]
+        for j in range(4):
+            o.append(isa.sop("s_add_u32", S_SLOT[j], ST[0], I32(j * FSLOT)))
+        o += [isa.vop("v_mov_b32", PBASE[0], PBL), isa.vop("v_add_u32", PBASE[1], I32(FSLOT), PBL), isa.vop("v_add_u32", PBASE[2], I32(2 * FSLOT), PBL),
+              isa.vop("v_mov_b32", WB, WBL),
+              isa.sop("s_cmp_eq_u32", None, same_n, I32(1)), isa.branch("s_cbranch_scc1", "L_same_n")]
         # ---- W descriptor: base = w + n0 * Kpad * 2, num_records = min(96, N - n0) * Kpad * 2 ----
         o += [isa.sop("s_mul_i32", ST[0], S_N0, S_KP2), isa.sop("s_mul_hi_u32", ST[1], S_N0, S_KP2),
               isa.sop("s_add_u32", S_WR.sub(0), S_Wp.sub(0), ST[0]), isa.sop("s_addc_u32", ST[1], S_Wp.sub(1), ST[1]),
               isa.sop("s_and_b32", S_WR.sub(1), ST[1], I32(0xFFFF)),
               isa.sop("s_sub_u32", ST[2], S_N, S_N0), isa.sop("s_min_u32", ST[2], ST[2], I32(96)), isa.sop("s_mul_i32", S_WR.sub(2), ST[2], S_KP2),
               isa.sop("s_mov_b32", S_WR.sub(3), I32(0x00020000))]
-        # ---- ring positions: slice 0's frame j -> slot j; W buffer 0 ----
-        o += [isa.sop("s_lshl_b32", S_WM0, S_WAVE, I32(10)), isa.sop("s_add_u32", ST[0], S_WM0, I32(PBASE0))]
-        for j in range(4):
-            o.append(isa.sop("s_add_u32", S_SLOT[j], ST[0], I32(j * FSLOT)))
-        o += [isa.vop("v_mov_b32", PBASE[0], PBL), isa.vop("v_add_u32", PBASE[1], I32(FSLOT), PBL), isa.vop("v_add_u32", PBASE[2], I32(2 * FSLOT), PBL),
-              isa.vop("v_mov_b32", WB, WBL)]
+        # ---- bias quads of this lane's channels n0 + 16 nb + 4 (l / 16) + e (zeros when bias == NULL): the accumulators start from them ----
+        g = t[11]
+        for i in range(24):
+            o.append(isa.vop("v_mov_b32", V(EPI_BQ + i), I32(0)))
+        o += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias"),
+              isa.sop("s_lshl_b32", ST[7], S_N0, I32(2)), isa.sop("s_add_u32", ST[2], S_BIAS.sub(0), ST[7]),
+              isa.sop("s_addc_u32", ST[3], S_BIAS.sub(1), I32(0)), isa.vop("v_lshlrev_b32", t[1], I32(4), g)]
+        for nb in range(6):
+            o.append(isa.global_load(4, V(EPI_BQ + 4 * nb, 4), t[1], 64 * nb, saddr=S(ST[2].idx, 2)))
+        o += [isa.label("L_nobias"), isa.nop(7), isa.label("L_same_n"), isa.nop(7),
+              isa.sop("s_cmp_eq_u32", None, same, I32(1)), isa.branch("s_cbranch_scc1", "L_same")]
         # ---- patch pieces of this wave: piece wave + 4 i = patch voxels p = 16 (wave + 4 i) + l / 4 = (r, col) of the 18 x 20 LDS grid; LDS
         # position q = l % 4 of a voxel holds source chunk q ^ ((col >> 1) & 3) (conflict-free fragment reads, like the W tile); source offset
         # inside the frame, or OOB (padding columns 18, 19, voxels past 360, rows / columns outside the tensor) ----
@@ -462,6 +490,7 @@ class Gen:
                   isa.vop("v_lshl_add_u32", t[7], t[8], I32(4), t[7]),
                   isa.v_cmp("v_cmp_ne_u32", I32(0), ok), isa.vop("v_mov_b32", t[9], I32(OOB)),
                   isa.v_cndmask(PDMA[k], t[9], t[7])]
+        o += [isa.label("L_same"), isa.nop(7)]
         o += self.stamp(0)                                        # phase 0: tile decode, descriptors, lane offsets
         # ---- streams: patch frames 0, 1, 2 of slice 0, W taps 0 .. 3 ----
         o += [isa.sop("s_mov_b32", S_SL, I32(0)), isa.sop("s_mov_b32", S_XOFF, I32(0)), isa.sop("s_mov_b32", S_WNEXT, I32(0)),
@@ -474,16 +503,7 @@ class Gen:
             o += self.slot_next(j, 0)
         for b in range(NWB):
             o += self.w_dma(0, 0, 0) + self.w_next(b, 0)
-        # ---- bias quads of this lane's channels n0 + 16 nb + 4 (l / 16) + e (zeros when bias == NULL): the accumulators start from them ----
-        g = t[11]
-        for i in range(24):
-            o.append(isa.vop("v_mov_b32", V(EPI_BQ + i), I32(0)))
-        o += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias"),
-              isa.sop("s_lshl_b32", ST[7], S_N0, I32(2)), isa.sop("s_add_u32", ST[2], S_BIAS.sub(0), ST[7]),
-              isa.sop("s_addc_u32", ST[3], S_BIAS.sub(1), I32(0)), isa.vop("v_lshlrev_b32", t[1], I32(4), g)]
-        for nb in range(6):
-            o.append(isa.global_load(4, V(EPI_BQ + 4 * nb, 4), t[1], 64 * nb, saddr=S(ST[2].idx, 2)))
-        o += [isa.label("L_nobias"), isa.nop(7)] + self.stamp(1) + [                                             # phase 1: DMA + bias issue
+        o += self.stamp(1) + [                                             # phase 1: DMA + bias issue
               isa.sop("s_cmp_eq_u32", None, self.HAVE_PREV, I32(0)), isa.branch("s_cbranch_scc1", "L_first")]
         return sched.pad_hazards(o)
 
@@ -503,7 +523,7 @@ class Gen:
         """after the last slice: every wave is done with the LDS contents; remember the tile for the epilogue; next tile (or none)."""
         o = self.stamp(6) + [isa.waitcnt(lgkmcnt=0), isa.barrier()] + self.stamp(7) + [       # phase 6: the slices; 7: the closing barrier
              isa.sop("s_mov_b32", S_ET0, S_T0), isa.sop("s_mov_b32", S_EH0, S_H0), isa.sop("s_mov_b32", S_EW0, S_W0), isa.sop("s_mov_b32", S_EN0, S_N0),
-             isa.sop("s_add_u32", S_TILE, S_TILE, S_G), isa.sop("s_cmp_lt_u32", None, S_TILE, S_TEND),
+             isa.sop("s_add_u32", S_TILE, S_TILE, I32(1)), isa.sop("s_cmp_lt_u32", None, S_TILE, S_TEND),
              isa.sop("s_cselect_b32", self.HAVE_PREV, I32(1), I32(3)), isa.branch("s_branch", "L_tile")]
         return sched.pad_hazards(o)
 

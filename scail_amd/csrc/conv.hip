@@ -619,9 +619,9 @@ struct Conv4Args {
     const void* x; const void* w; const void* bias; void* y; const void* resid;
     int32_t Ti, To, H, W;
     int32_t Cin, N, Kpad, pt;
-    int32_t tiles_h, tiles_w, tiles_n; uint32_t magic_n;
-    uint32_t magic_w, magic_h; int32_t n_slices, ot_mul;
-    int32_t ot_off, per_xcd;
+    int32_t tiles_t, tiles_w, tiles_n; uint32_t magic_n;      // frame pairs, tile columns, n tiles (digits of the tile number: n tile fastest, then frame pair, column, row)
+    uint32_t magic_w, magic_t; int32_t n_slices, ot_mul;
+    int32_t ot_off, tiles_per_wg;
     int64_t ldc, ldr;
     int32_t wgs_per_xcd, tiles;      // persistent workgroups per XCD (the tile stride of a workgroup), tiles in all
 };
@@ -725,18 +725,19 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         Conv4Args a;
         a.x = x; a.w = w; a.bias = bias; a.y = y; a.resid = resid;
         a.Ti = p.Ti; a.To = p.To; a.H = p.Ho; a.W = p.Wo; a.Cin = p.Cin; a.N = p.N; a.Kpad = p.Kpad; a.pt = p.pt;
-        a.tiles_h = (p.Ho + 15) / 16; a.tiles_w = (p.Wo + 15) / 16; a.tiles_n = p.N / 96;
+        a.tiles_t = (p.To + 1) / 2; a.tiles_w = (p.Wo + 15) / 16; a.tiles_n = p.N / 96;
         auto magic31 = [](int d) { return (uint32_t)(((1ull << 31) + (uint64_t)d - 1) / (uint64_t)d); };
-        a.magic_n = magic31(a.tiles_n); a.magic_w = magic31(a.tiles_w); a.magic_h = magic31(a.tiles_h);
+        a.magic_n = magic31(a.tiles_n); a.magic_w = magic31(a.tiles_w); a.magic_t = magic31(a.tiles_t);
         a.n_slices = p.Cin / 32; a.ot_mul = p.ot_mul; a.ot_off = p.ot_off; a.ldc = ldc; a.ldr = resid ? ldr : ldc;
-        const int64_t tiles = (int64_t)((p.To + 1) / 2) * a.tiles_h * a.tiles_w * a.tiles_n;
+        const int64_t tiles = (int64_t)a.tiles_t * ((p.Ho + 15) / 16) * a.tiles_w * a.tiles_n;
         SCAIL_REQUIRE(tiles < (1ll << 24), "too many tiles");        // the kernel's magic-number divisions are exact below 2^31 / divisor
-        // persistent workgroups, one per compute unit: workgroup b runs on XCD b % 8 and walks the tiles (b % 8) * per_xcd + b / 8 + i * wgs_per_xcd
-        // of that XCD's contiguous range (the n tiles of a patch and its neighbours share an L2)
-        a.per_xcd = (int32_t)((tiles + 7) / 8);
+        // persistent workgroups, one per compute unit; tiles are numbered n tile fastest, then frame pair, and workgroup number (b % 8) *
+        // wgs_per_xcd + b / 8 takes the next tiles_per_wg (+ 1) of them: a workgroup walks the n tiles and frame pairs of one spatial tile, the
+        // workgroups of an XCD (b % 8) work on neighbouring ones
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-        a.wgs_per_xcd = std::min<int32_t>(a.per_xcd, cus / 8);
+        a.wgs_per_xcd = (int32_t)std::min<int64_t>((tiles + 7) / 8, cus / 8);
+        a.tiles_per_wg = (int32_t)(tiles / (8 * a.wgs_per_xcd));
         a.tiles = (int32_t)tiles;
         hipFunction_t fn;
         // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)

@@ -31,7 +31,8 @@ def test_conv4_static_hazards():
 @pytest.mark.parametrize("name,shape,cus", [("scail_conv4_e0", (2, 16, 16, 32, 96), 256),         # one tile, one slice
                                             ("scail_conv4_e3", (2, 16, 16, 224, 96), 256),        # 7 slices: the 5-slot frame ring wraps
                                             ("scail_conv4_e3", (3, 18, 20, 64, 192), 8),          # ragged tiles, odd frame count, 2 n tiles, 2 tiles per workgroup
-                                            ("scail_conv4_e0", (5, 16, 40, 32, 96), 8)])          # 9 tiles on 8 workgroups: one walks two, a frame pair past the end
+                                            ("scail_conv4_e0", (5, 16, 40, 32, 96), 8),           # 9 tiles on 8 workgroups: one walks two, a frame pair past the end
+                                            ("scail_conv4_e0", (5, 16, 96, 32, 96), 8)])          # 18 tiles: runs of 2-3 tiles, within a spatial tile (offsets kept) and across
 def test_conv4_emulated(name, shape, cus):
     cfg = _cfg(name)
     x, w, b, r = _case(*shape, resid=cfg.epi == 3)

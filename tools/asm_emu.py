@@ -506,6 +506,8 @@ class Emu:
             r = a & b; self._wrs(w, d, r); w.scc = int(r != 0)
         elif op == "s_or_b32":
             r = a | b; self._wrs(w, d, r); w.scc = int(r != 0)
+        elif op == "s_xor_b32":
+            r = a ^ b; self._wrs(w, d, r); w.scc = int(r != 0)
         elif op == "s_min_u32":
             r = min(a, b); self._wrs(w, d, r); w.scc = int(a <= b)
         elif op == "s_max_u32":
