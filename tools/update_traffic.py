@@ -27,8 +27,9 @@ def main():
             d[(m.group(1), m.group(2))] = float(m.group(3))
     path = os.path.join(ROOT, "profiles", "traffic.json")
     tr = json.load(open(path))
-    f, w = d[("scail_attn4_m16f", "FETCH_SIZE")], d[("scail_attn4_m16f", "WRITE_SIZE")]
-    tr["flash_attn_self"] = {
+    if ("scail_attn4_m16f", "FETCH_SIZE") in d:      # (a summary may hold only some of the kernels: the other entries stay)
+      f, w = d[("scail_attn4_m16f", "FETCH_SIZE")], d[("scail_attn4_m16f", "WRITE_SIZE")]
+      tr["flash_attn_self"] = {
         "shape": {"B": 2, "heads": 40, "Lq": 48832, "Lk": 48832}, "fetch_kib": f, "write_kib": w,
         "traffic_bytes": (2 * f + w) * 1024,
         "kernel": "scail_attn4_m16f (16x16x32 MFMAs, queries in log2 units, optimistic hot loop, XCD-aware workgroup ids)",
@@ -36,9 +37,10 @@ def main():
         "measured": note + "; algorithmic bytes per launch = Q + K + V^T + O of 80 (batch, head) slices = 4.0 GB"}
     # the six per-token GEMMs of a block: launches per layer e0 x 2 (qkv, cross q), e3 x 2 (attention out, MLP down), e1 (MLP up), e4 (cross out)
     n = {"e0": 2, "e1": 1, "e3": 2, "e4": 1}
-    tf = sum(d[("scail_gemm4_" + k, "FETCH_SIZE")] * c for k, c in n.items())
-    tw = sum(d[("scail_gemm4_" + k, "WRITE_SIZE")] * c for k, c in n.items())
-    tr["gemm4_step"] = {
+    if all(("scail_gemm4_" + k, "FETCH_SIZE") in d for k in n):
+      tf = sum(d[("scail_gemm4_" + k, "FETCH_SIZE")] * c for k, c in n.items())
+      tw = sum(d[("scail_gemm4_" + k, "WRITE_SIZE")] * c for k, c in n.items())
+      tr["gemm4_step"] = {
         "shape": {"M": 97664, "D": 5120, "FF": 13824}, "fetch_kib_per_layer": tf, "write_kib_per_layer": tw,
         "traffic_bytes_per_layer": (2 * tf + tw) * 1024, "traffic_bytes_per_launch_mean": (2 * tf + tw) * 1024 / 6,
         "algorithmic_bytes_per_layer": 21.0e9,
@@ -75,7 +77,8 @@ def main():
                 "kernel": "scail_conv4_e0 (generated 3x3x3 causal convolution: persistent workgroups, 2 frames x 16 x 16 voxels x 96 channels per tile)",
                 "source": "conv4.s", "source_blob": blob(os.path.join(ROOT, "scail_amd", "csrc", "conv4.s")), "measured": note}
     json.dump(tr, open(path, "w"), indent=1)
-    print(json.dumps({k: tr[k] for k in ("flash_attn_self", "gemm4_step")}, indent=1))
+    print(json.dumps({k: {kk: vv for kk, vv in tr[k].items() if kk in ("traffic_bytes", "traffic_bytes_per_layer", "algorithmic_bytes", "source_blob")}
+                      for k in tr if isinstance(tr[k], dict)}, indent=1))
 
 
 if __name__ == "__main__":
