@@ -23,7 +23,9 @@ extern "C" {
  *   "gemm_group_m"         q8 tile-group height
  *   "gemm4" (0 / 4 / 8), "gemm4_kernel[:suffix]"   generated GEMM kernels: off / gemm4 (the product default) / gemm8 (two waves per
  *                          SIMD, this build only); variant of asmgen/gemm4.py, gemm8.py variant_cfgs() for the bias epilogue
- *   "conv_halo"            halo-convolution layout 0-4
+ *   "conv_halo"            halo-convolution layout 0-5; 10 / 11: generated conv4 kernels off / on (the product's option "conv4")
+ *   "conv4_kernel[:suffix]"   variant of asmgen/conv4.py variant_cfgs() for the bias epilogue (timing ablations abl_*: wrong results;
+ *                          "prof": phase timers (s_memtime) written through the residual pointer, 8 uint32 per workgroup)
  */
 int scail_tune_set(const char* knob, int value);
 

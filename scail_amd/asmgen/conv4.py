@@ -74,7 +74,7 @@ def pack_args(x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt=2, ot_mul=1, 
     tp, tw, tn = (To + NF - 1) // NF, (W + TW - 1) // TW, (N + 95) // 96
     tiles, grid = grid_tiles(To, H, W, N), grid_blocks(To, H, W, N, cus)
     b = struct.pack(KERNARG_FMT, x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt, tp, tw, tn, magic31(tn), magic31(tw), magic31(tp),
-                    Cin // 32, ot_mul, ot_off, tiles // grid, ldc or N, ldr or N, grid // 8, tiles)
+                    Cin // 32, ot_mul, ot_off, tiles // grid if tn == 1 else 0, ldc or N, ldr or N, grid // 8, tiles)
     assert len(b) == KERNARG_SIZE, len(b)
     return b
 
@@ -85,10 +85,12 @@ def grid_tiles(T, H, W, N) -> int:
 
 def grid_blocks(T, H, W, N, cus=256) -> int:
     """workgroups launched: persistent, at most one per compute unit, a multiple of 8.  Tiles are numbered with the N TILE fastest, then the FRAME
-    PAIR (then the tile column, the tile row); workgroup b (XCD b % 8) is number (b % 8) * (grid / 8) + b / 8 of the grid and takes the next
-    tiles // grid (+ 1 for the first tiles % grid workgroups) tiles of that order: a workgroup walks the n tiles of a patch, then the next frame
-    pair of the same spatial tile (the patch lines come back from its XCD's L2, the two input frames consecutive pairs share from L2 / the
-    Infinity Cache, the per-lane patch offsets stay), the workgroups of an XCD work on neighbouring spatial tiles."""
+    PAIR (then the tile column, the tile row); workgroup b (XCD b % 8) is number w = (b % 8) * (grid / 8) + b / 8 of the grid.
+    One n tile (N = 96): w takes the next tiles // grid (+ 1 for the first tiles % grid workgroups) tiles of that order -- it walks the frame
+    pairs of a spatial tile (the two input frames consecutive pairs share come back from L2 / the Infinity Cache, the per-lane patch offsets
+    stay), the workgroups of an XCD work on neighbouring spatial tiles.  Several n tiles: w takes tiles w, w + grid, ...: an XCD works on
+    grid / 8 consecutive tiles at a time = the n tiles of a few neighbouring frame pairs of one spatial tile, which share their patch through
+    the XCD's L2 (a run per workgroup would fetch the patch once per n tile: 5.7 / 11 x the algorithmic traffic at 192 / 384 channels)."""
     per = (grid_tiles(T, H, W, N) + 7) // 8
     return 8 * min(per, max(cus // 8, 1))
 
@@ -135,6 +137,7 @@ EPI_BQ, EPI_RP, EPI_F = 184, 208, 220                       # epilogue: bias qua
 S_KARG = S(0, 2)
 S_WG = S(2)
 S_TILE, S_G, S_TEND = S(3), S(4), S(5)                      # this workgroup's current tile, workgroups per XCD (entry only), end of its tile range
+S_STEP = S(4)                                               # ... then the tile step (1: a run of consecutive tiles; the grid: strided)
 S_ET0, S_EH0, S_EW0, S_EN0 = S(6), S(7), S(18), S(19)       # coordinates of the tile whose accumulators wait for the epilogue
 S_X, S_Wp, S_BIAS, S_Y, S_RES = S(8, 2), S(10, 2), S(12, 2), S(14, 2), S(16, 2)
 S_TI, S_T, S_H, S_Wd = S(20), S(21), S(22), S(23)            # input frames, output frames, rows, columns
@@ -346,14 +349,20 @@ class Gen:
               isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", t[0], I32(6), V(0)),
               isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, t[0]),
               isa.sop("s_lshr_b32", S_F, S_WAVE, I32(1)), isa.sop("s_and_b32", S_RH, S_WAVE, I32(1))]
-        # ---- this workgroup's tiles: number w = (b % 8) * G + b / 8 of the 8 G workgroups takes base (+ 1 if w < rem) consecutive tiles ----
+        # ---- this workgroup's tiles.  Workgroup number w = (b % 8) * G + b / 8 of the 8 G workgroups (the G workgroups of an XCD are neighbours):
+        #   tiles_per_wg > 0 (one n tile): it takes base (+ 1 if w < rem) CONSECUTIVE tiles -- the frame pairs of a spatial tile;
+        #   tiles_per_wg = 0 (several n tiles): it takes tiles w, w + 8 G, ...: at any time an XCD works on G consecutive tiles = the n tiles of
+        #   a few neighbouring frame pairs of one spatial tile, which share their patch through the XCD's L2 ----
         wn, rem = ST[0], ST[1]
         o += [isa.sop("s_and_b32", wn, S_WG, I32(7)), isa.sop("s_mul_i32", wn, wn, S_G), isa.sop("s_lshr_b32", ST[2], S_WG, I32(3)),
-              isa.sop("s_add_u32", wn, wn, ST[2]),
-              isa.sop("s_lshl_b32", ST[2], S_G, I32(3)), isa.sop("s_mul_i32", ST[2], ST[2], S_PER), isa.sop("s_sub_u32", rem, S_TEND, ST[2]),   # tiles - base * grid
+              isa.sop("s_add_u32", wn, wn, ST[2]), isa.sop("s_lshl_b32", ST[3], S_G, I32(3)),                                          # ST[3] = grid
+              isa.sop("s_cmp_eq_u32", None, S_PER, I32(0)), isa.branch("s_cbranch_scc1", "L_strided"),
+              isa.sop("s_mul_i32", ST[2], ST[3], S_PER), isa.sop("s_sub_u32", rem, S_TEND, ST[2]),                                     # tiles - base * grid
               isa.sop("s_mul_i32", S_TILE, wn, S_PER), isa.sop("s_min_u32", ST[2], wn, rem), isa.sop("s_add_u32", S_TILE, S_TILE, ST[2]),
               isa.sop("s_cmp_lt_u32", None, wn, rem), isa.sop("s_cselect_b32", ST[2], I32(1), I32(0)), isa.sop("s_add_u32", ST[2], ST[2], S_PER),
-              isa.sop("s_add_u32", S_TEND, S_TILE, ST[2]),
+              isa.sop("s_add_u32", S_TEND, S_TILE, ST[2]), isa.sop("s_mov_b32", S_STEP, I32(1)), isa.branch("s_branch", "L_ranged"),
+              isa.label("L_strided"), isa.sop("s_mov_b32", S_TILE, wn), isa.sop("s_mov_b32", S_STEP, ST[3]),
+              isa.label("L_ranged"),
               isa.sop("s_cmp_ge_u32", None, S_TILE, S_TEND), isa.branch("s_cbranch_scc1", "L_exit"),
               isa.sop("s_mov_b32", S_H0, I32(-1)), isa.sop("s_mov_b32", S_N0, I32(-1))]                          # no spatial / n tile yet
         # ---- constants ----
@@ -523,7 +532,7 @@ class Gen:
         """after the last slice: every wave is done with the LDS contents; remember the tile for the epilogue; next tile (or none)."""
         o = self.stamp(6) + [isa.waitcnt(lgkmcnt=0), isa.barrier()] + self.stamp(7) + [       # phase 6: the slices; 7: the closing barrier
              isa.sop("s_mov_b32", S_ET0, S_T0), isa.sop("s_mov_b32", S_EH0, S_H0), isa.sop("s_mov_b32", S_EW0, S_W0), isa.sop("s_mov_b32", S_EN0, S_N0),
-             isa.sop("s_add_u32", S_TILE, S_TILE, I32(1)), isa.sop("s_cmp_lt_u32", None, S_TILE, S_TEND),
+             isa.sop("s_add_u32", S_TILE, S_TILE, S_STEP), isa.sop("s_cmp_lt_u32", None, S_TILE, S_TEND),
              isa.sop("s_cselect_b32", self.HAVE_PREV, I32(1), I32(3)), isa.branch("s_branch", "L_tile")]
         return sched.pad_hazards(o)
 

@@ -731,13 +731,14 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         a.n_slices = p.Cin / 32; a.ot_mul = p.ot_mul; a.ot_off = p.ot_off; a.ldc = ldc; a.ldr = resid ? ldr : ldc;
         const int64_t tiles = (int64_t)a.tiles_t * ((p.Ho + 15) / 16) * a.tiles_w * a.tiles_n;
         SCAIL_REQUIRE(tiles < (1ll << 24), "too many tiles");        // the kernel's magic-number divisions are exact below 2^31 / divisor
-        // persistent workgroups, one per compute unit; tiles are numbered n tile fastest, then frame pair, and workgroup number (b % 8) *
-        // wgs_per_xcd + b / 8 takes the next tiles_per_wg (+ 1) of them: a workgroup walks the n tiles and frame pairs of one spatial tile, the
-        // workgroups of an XCD (b % 8) work on neighbouring ones
+        // persistent workgroups, one per compute unit; tiles are numbered n tile fastest, then frame pair; workgroup number w = (b % 8) *
+        // wgs_per_xcd + b / 8.  One n tile: w takes the next tiles_per_wg (+ 1) tiles (the frame pairs of a spatial tile; consecutive pairs
+        // share two input frames, the lane offsets stay).  Several n tiles (tiles_per_wg = 0): w takes tiles w, w + grid, ... so that an XCD
+        // works on the n tiles of a few neighbouring frame pairs at a time and they share the patch through its L2.
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
         a.wgs_per_xcd = (int32_t)std::min<int64_t>((tiles + 7) / 8, cus / 8);
-        a.tiles_per_wg = (int32_t)(tiles / (8 * a.wgs_per_xcd));
+        a.tiles_per_wg = a.tiles_n == 1 ? (int32_t)(tiles / (8 * a.wgs_per_xcd)) : 0;
         a.tiles = (int32_t)tiles;
         hipFunction_t fn;
         // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)
