@@ -79,6 +79,9 @@ class Cfg:
                            # "wpack" / "xpack" TIMING ablations that suggested +6 % re-read the same 32 KB every k-tile: they measure L2
                            # hits, not contiguity.  Kept as an emulator-tested variant of the measurement build only
     nt_store: bool = False # epilogue stores with the non-temporal hint (y is written once and read by a later kernel)
+    stg: bool = False      # (mi = 16) epilogue through LDS: a row block (16 rows x 128 columns of the wave) is written in accumulator layout and read
+                           # back in memory layout, so a global store / residual load instruction moves 4 rows x 256 contiguous bytes (whole cache
+                           # lines) instead of 16 rows x 32 bytes; staging: 4 x 4352 bytes behind the two k-tile slots
     mi: int = 32           # MFMA shape: 32 = v_mfma_f32_32x32x16_bf16 (64 per tile), 16 = v_mfma_f32_16x16x32_bf16 (128 per tile; dma2 only)
     dma_from: float = 48.0  # first gap of the 16 LDS-DMA pieces / LDS writes of tile t+2 (after the barrier at 47.5)
     dma_step: float = 1.0
@@ -517,11 +520,165 @@ class Gen:
         return o
 
     # ---------------------------------------------------------------------------------------------
+    STG_ROW = 272          # bytes per staged row: 256 + 16 (conflict-free 8-byte writes of 16 rows, 16-byte aligned chunks)
+    STG_WAVE = 16 * 272
+
+    def epilogue_staged(self) -> List[Instr]:
+        """mi = 16, whole-line epilogue.  Accumulator layout: lane (v = l % 16, g = l / 16) owns row 16 mb + v, columns 16 nb + 4 g .. + 3 of the
+        wave's 128 x 128 block; memory layout of a row block: chunk j = 64 i + l (i = 0..3) = row j / 16, 16-byte chunk j % 16 of the row's 256 bytes.
+        Per row block: [residual rows: 4 whole-line loads -> LDS -> 8 pairs in accumulator layout] -> bias / GELU / gate / residual in fp32 ->
+        packed pairs -> LDS -> 4 quads in memory layout -> 4 whole-line stores.  Loads of block mb + 1 are requested before block mb is waited
+        for (counted vmcnt: vector-memory operations retire in issue order)."""
+        c = self.cfg
+        assert c.mi == 16
+        e: List[Instr] = []
+        ql, g, t = T_[1], T_[2], T_
+        n_mb = 8
+        BQ = lambda nb: V(nb * 4, 4)
+        LQ = lambda par, i: V(32 + 16 * par + 4 * i, 4)        # residual row block in memory layout, two in flight
+        RB = lambda nb: V(64 + 2 * nb, 2)                       # ... back in accumulator layout
+        OUTP = lambda nb: V(80 + 2 * nb, 2)                     # packed outputs, accumulator layout
+        GQ = lambda par, nb: V(96 + 32 * par + 4 * nb, 4)       # gate quads, two row blocks in flight
+        RQ = lambda i: V(202 + 4 * i, 4)                        # output row block in memory layout
+        ROW = [V(164), V(197)]                                  # accumulator-layout row of the lane, by block parity (gate batch index, e3)
+        GOFF = [V(165), V(198)]
+        TB = V(166)
+        E_W = V(236)
+        E_R = [V(237 + i) for i in range(4)]
+        E_Y = [V(241 + i) for i in range(4)]
+        E_Z = [V(245 + i) for i in range(4)]
+        E_M = [V(249 + i) for i in range(4)]                    # memory-layout row of the lane's chunk (row mask), advanced per block
+        nw = ST[4]            # n0 + 128 wn (first column of the wave)
+        e += [isa.sop("s_lshl_b32", nw, S_WN, I32(7)), isa.sop("s_add_u32", nw, nw, S_N0T)]
+        e += self.addr64_madd(S_Y, nw, I32(1), 1)
+        for i in range(32):
+            e.append(isa.vop("v_mov_b32", V(i), I32(0)))
+        e += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias")]
+        e += self.addr64_madd(S_BIAS, nw, I32(1), 2)
+        e += [isa.vop("v_lshlrev_b32", t[3], I32(4), g)]                       # 4 g floats = 16 g bytes
+        for nb in range(8):
+            e.append(isa.global_load(4, BQ(nb), t[3], nb * 64, saddr=S_BIAS))
+        e += [isa.label("L_nobias")]
+        mw = ST[5]
+        e += [isa.sop("s_lshl_b32", mw, S_WM, I32(7)), isa.sop("s_add_u32", mw, mw, S_M0T)]
+        ldcb, ldrb = ST[6], ST[7]
+        e += [isa.sop("s_lshl_b32", ldcb, S_LDC.sub(0), I32(1))]
+        RCP, KC0, KC1 = V(161), V(162), V(163)
+        if c.epi in (3, 4):
+            e += self.addr64_madd(S_RES, nw, I32(1), 1)
+            e += [isa.sop("s_lshl_b32", ldrb, S_LDR.sub(0), I32(1))]
+        if c.epi == 3:
+            e += self.addr64_madd(S_GATE, nw, I32(1), 2)
+            e += [isa.vop("v_cvt_f32_u32", RCP, S_RPB), isa.vop("v_rcp_f32", RCP, RCP),
+                  isa.sop("s_cmp_eq_u32", None, S_RPB, I32(0)), isa.sop("s_cselect_b32", ST[9], I32(0), I32(0xFFFFFFFF)),
+                  isa.sop("s_lshl_b32", ST[12], S_GS.sub(0), I32(2))]
+        if c.epi == 1:
+            K0, K1 = 0.7978845608028654, 0.044715
+            sc = 2.0 * 1.4426950408889634
+            e += [isa.vop("v_mov_b32", KC0, F32(K0 * sc)), isa.vop("v_mov_b32", KC1, F32(K0 * K1 * sc))]
+        # staging addresses and the lane's place in the memory layout
+        sb = ST[8]
+        e += [isa.sop("s_mul_i32", sb, S_WAVE, I32(self.STG_WAVE)), isa.sop("s_add_u32", sb, sb, I32(131072)),
+              isa.vop("v_mul_u32_u24", t[4], I32(self.STG_ROW), ql), isa.vop("v_lshl_add_u32", t[4], g, I32(3), t[4]), isa.vop("v_add_u32", E_W, sb, t[4]),
+              isa.vop("v_lshlrev_b32", t[5], I32(4), ql)]                                     # chunk l % 16 -> 16 (l % 16) bytes
+        for i in range(4):
+            e += [isa.vop("v_add_u32", t[4], I32(4 * i), g),                                  # row of the block: 4 i + l / 16
+                  isa.vop("v_add_u32", E_M[i], mw, t[4]),
+                  isa.vop("v_mul_u32_u24", t[6], I32(self.STG_ROW), t[4]), isa.vop("v_add_u32", t[6], t[6], t[5]), isa.vop("v_add_u32", E_R[i], sb, t[6]),
+                  isa.vop("v_mul_lo_u32", t[6], E_M[i], ldcb), isa.vop("v_add_u32", E_Y[i], t[6], t[5])]
+            if c.epi in (3, 4):
+                e += [isa.vop("v_mul_lo_u32", t[6], E_M[i], ldrb), isa.vop("v_add_u32", E_Z[i], t[6], t[5])]
+        step_y, step_z = ST[10], ST[11]
+        e += [isa.sop("s_lshl_b32", step_y, ldcb, I32(4)), isa.sop("s_lshl_b32", step_z, ldrb, I32(4))]          # 16 rows on
+
+        def masked(i, ins_list):
+            return ([isa.v_cmp("v_cmp_lt_u32", E_M[i], S_M),
+                     Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)] + ins_list +
+                    [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)])
+
+        def loads(mb):
+            """residual rows (memory layout; E_M / E_Z point at block mb) and the gate quads of the lane's row (accumulator layout)."""
+            o_ = []
+            for i in range(4):
+                o_ += masked(i, [isa.global_load(4, LQ(mb & 1, i), E_Z[i], 0, saddr=S_RES, extra_reads=[EXEC])])
+            if c.epi == 3:
+                row, goff = ROW[mb & 1], GOFF[mb & 1]
+                o_ += [isa.vop("v_add_u32", row, mw, ql)] + ([isa.vop("v_add_u32", row, I32(16 * mb), row)] if mb else [])
+                # batch index of the row: floor((m + 0.5) / rows_per_batch); rows_per_batch == 0 -> 0
+                o_ += [isa.vop("v_cvt_f32_u32", TB, row), isa.vop("v_add_f32", TB, F32(0.5), TB), isa.vop("v_mul_f32", TB, TB, RCP),
+                       isa.vop("v_cvt_u32_f32", TB, TB), isa.vop("v_and_b32", TB, ST[9], TB),
+                       isa.vop("v_mul_lo_u32", goff, TB, ST[12]), isa.vop("v_lshl_add_u32", goff, g, I32(4), goff),
+                       isa.v_cmp("v_cmp_lt_u32", row, S_M),
+                       Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+                for nb in range(8):
+                    o_.append(isa.global_load(4, GQ(mb & 1, nb), goff, nb * 64, saddr=S_GATE, extra_reads=[EXEC]))
+                o_ += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+            return o_
+
+        def advance_z():
+            return [isa.vop("v_add_u32", E_Z[i], step_z, E_Z[i]) for i in range(4)]
+
+        n_loads = {0: 0, 1: 0, 4: 4, 3: 12}[c.epi]
+        # E_M / E_Y follow the block being STORED, E_Z the block being LOADED (one ahead); the load masks of block mb + 1 use E_M + 16
+        if n_loads:
+            e += loads(0) + advance_z()
+        e.append(isa.waitcnt(vmcnt=n_loads))             # the bias quads (older than the first block's loads)
+        for mb in range(n_mb):
+            if n_loads:
+                if mb + 1 < n_mb:
+                    # block mb + 1's loads: rows 16 further (E_M is advanced after block mb's stores: mask with a temporary)
+                    for i in range(4):
+                        e.append(isa.vop("v_add_u32", E_M[i], I32(16), E_M[i]))
+                    e += loads(mb + 1) + advance_z()
+                    for i in range(4):
+                        e.append(isa.vop("v_subrev_u32", E_M[i], I32(16), E_M[i]))
+                # behind the loads of block mb: the stores of block mb - 1 (4) and the loads of block mb + 1
+                n_after = (4 if mb >= 1 else 0) + (n_loads if mb + 1 < n_mb else 0)
+                e.append(isa.waitcnt(vmcnt=n_after))
+                e += [isa.ds_write(16, E_R[i], LQ(mb & 1, i)) for i in range(4)]
+                e += [isa.ds_read(8, RB(nb), E_W, 32 * nb) for nb in range(8)]
+            for nb in range(8):
+                base = 170 + 16 * (nb % 2)         # two rotating register groups
+                f = [V(base + i) for i in range(4)]
+                r_, u2 = V(base + 8), [V(base + 9), V(base + 10)]
+                acc = ACC16(nb, mb)
+                for i in range(4):
+                    e += [isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)), isa.vop("v_add_f32", f[i], f[i], BQ(nb).sub(i))]
+                if c.epi == 1:
+                    for i in range(4):           # gelu_tanh(v) = v - v / (exp2(2 log2e k0 (v + k1 v^3)) + 1)
+                        u = u2[i & 1]
+                        e += [isa.vop("v_mul_f32", u, f[i], f[i]), isa.vop("v_fma_f32", u, u, KC1, KC0),
+                              isa.vop("v_mul_f32", u, u, f[i]), isa.vop("v_exp_f32", u, u), isa.vop("v_add_f32", u, F32(1.0), u),
+                              isa.vop("v_rcp_f32", u, u), isa.vop("v_fma_f32", f[i], Neg(f[i]), u, f[i])]
+                if c.epi in (3, 4):
+                    if c.epi == 3:
+                        for i in range(4):
+                            e.append(isa.vop("v_mul_f32", f[i], f[i], GQ(mb & 1, nb).sub(i)))
+                    for i in range(4):           # + residual (bf16 pairs: low half << 16, high half & 0xffff0000)
+                        src = RB(nb).sub(i >> 1)
+                        e += [isa.vop("v_lshlrev_b32", r_, I32(16), src) if (i & 1) == 0 else isa.vop("v_and_b32", r_, I32(0xFFFF0000), src),
+                              isa.vop("v_add_f32", f[i], f[i], r_)]
+                e += [isa.vop("v_cvt_pk_bf16_f32", OUTP(nb).sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", OUTP(nb).sub(1), f[2], f[3])]
+            e += [isa.ds_write(8, E_W, OUTP(nb), 32 * nb) for nb in range(8)]
+            e += [isa.ds_read_b128(RQ(i), E_R[i]) for i in range(4)]
+            for i in range(4):
+                st = isa.global_store(4, E_Y[i], RQ(i), 0, saddr=S_Y, extra_reads=[EXEC])
+                if c.nt_store:
+                    st.text += " nt"
+                e += masked(i, [st])
+            if mb + 1 < n_mb:
+                for i in range(4):
+                    e += [isa.vop("v_add_u32", E_M[i], I32(16), E_M[i]), isa.vop("v_add_u32", E_Y[i], step_y, E_Y[i])]
+        e += [isa.label("L_exit"), Instr("s_endpgm", cls=isa.BRANCH)]       # (stores may still be in flight: the hardware drains them)
+        return sched.pad_hazards(sched.insert_lgkm_waits(e))
+
     def epilogue(self) -> List[Instr]:
         """mi = 32: y[m][n .. n+3] for the lane's rows m = m0 + 128 wm + 32 mb + (lane & 31), n = n0 + 128 wn + 32 nb + 8 rr + 4 g;
         mi = 16: rows m = m0 + 128 wm + 16 mb + (lane & 15), n = n0 + 128 wn + 16 nb + 4 (lane >> 4) -- in both layouts a lane owns
         quads of 4 consecutive n, `quads` below lists them as (n offset, accumulator quad of row block mb, bias quad)."""
         c = self.cfg
+        if c.stg:
+            return self.epilogue_staged()
         e: List[Instr] = []
         ql, g, t = T_[1], T_[2], T_
         if c.mi == 16:
@@ -915,7 +1072,7 @@ def kernel_text(c: Cfg) -> str:
 \t.section\t.rodata,"a",@progbits
 \t.p2align\t6, 0x0
 \t.amdhsa_kernel {c.name}
-\t\t.amdhsa_group_segment_fixed_size 131072
+\t\t.amdhsa_group_segment_fixed_size {131072 + 4 * Gen.STG_WAVE if c.stg else 131072}
 \t\t.amdhsa_private_segment_fixed_size 0
 \t\t.amdhsa_kernarg_size {KERNARG_SIZE}
 \t\t.amdhsa_user_sgpr_count 2
@@ -944,7 +1101,7 @@ def metadata(cfgs) -> str:
       - .offset:         0
         .size:           {KERNARG_SIZE}
         .value_kind:     by_value
-    .group_segment_fixed_size: 131072
+    .group_segment_fixed_size: {131072 + 4 * Gen.STG_WAVE if c.stg else 131072}
     .kernarg_segment_align: 8
     .kernarg_segment_size: {KERNARG_SIZE}
     .max_flat_workgroup_size: 256
@@ -977,7 +1134,9 @@ def assembly(cfgs) -> str:
 
 # the shipped kernels: LDS-DMA two tiles deep, v_mfma_f32_16x16x32_bf16, <= 1 filler per 16-cycle MFMA gap, slot released at gap 11,
 # one DMA piece per 7 gaps (measured best of the sweep in profiles/r02_gemm4_mi16.log: 1467 TFLOP/s where q8 does 1309, the vendor 1495)
-SHIPPED = dict(stage="dma2", mi=16, cap=1, rd2_step=0.25, b1_at=5.5, dma_step=1.75)
+# Round 3: the epilogue goes through LDS so that every global store / residual load moves whole cache lines (stg): +3.1 % qkv, +6.6 % out-projection,
+# +3.5 / +5.2 % cross q / out, +0.3 % MLP up (GELU: VALU-bound), +2.8 % MLP down, bit-identical (profiles/r03_gemm_staged_epilogue_ab.log)
+SHIPPED = dict(stage="dma2", mi=16, cap=1, rd2_step=0.25, b1_at=5.5, dma_step=1.75, stg=True)
 DEFAULTS = [Cfg(epi=e, name=f"scail_gemm4_e{e}", **SHIPPED) for e in (0, 1, 3, 4)]
 
 
@@ -1001,7 +1160,10 @@ def pack_w(w_bits, N: int, K: int):
 
 def variant_cfgs():
     out = [Cfg(epi=e, name=f"scail_gemm4_e{e}_reg") for e in (0, 1, 3, 4)]       # round-2 first version: register staging, 32x32x16
-    out += [Cfg(epi=e, name=f"scail_gemm4_e{e}_pst", persist=True, **SHIPPED) for e in (0, 1, 3, 4)]      # round 3: persistent workgroups
+    PART = {**SHIPPED, "stg": False}
+    out += [Cfg(epi=e, name=f"scail_gemm4_e{e}_pst", persist=True, **PART) for e in (0, 1, 3, 4)]         # round 3: persistent workgroups (partial-line epilogue)
+    out += [Cfg(epi=e, name=f"scail_gemm4_e{e}_part", **PART) for e in (0, 1, 3, 4)]                      # the epilogue before the LDS staging: 64 stores of 16 rows x 32 bytes per lane
+    out += [Cfg(epi=e, name=f"scail_gemm4_e{e}_stgnt", nt_store=True, **SHIPPED) for e in (0, 1, 3, 4)]   # staged + non-temporal stores (measured: no gain)
     for cap in (2, 4):
         out.append(Cfg(epi=0, cap=cap, name=f"scail_gemm4_e0_c{cap}"))
     out.append(Cfg(epi=0, stage="dma", name="scail_gemm4_e0_lds_dma"))

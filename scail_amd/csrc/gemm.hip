@@ -787,7 +787,7 @@ extern "C" int scail_gemm_bf16(const scail_bf16* x, int64_t lda, const scail_bf1
         const int epi4 = epilogue == SCAIL_EPI_RESID ? (gate != nullptr ? 3 : 4) : epilogue;
         const bool is8 = g_gemm4_mode == 8;
         std::string name = std::string(is8 ? "scail_gemm8_e" : "scail_gemm4_e") + std::to_string(epi4);
-        if (epi4 == 0 || g_gemm4_suffix == "_pst") name += g_gemm4_suffix;      // A/B variants: bias epilogue only, except the persistent set (ablation build)
+        if (epi4 == 0 || g_gemm4_suffix == "_pst" || g_gemm4_suffix == "_part" || g_gemm4_suffix == "_stgnt") name += g_gemm4_suffix;      // A/B variants: bias epilogue only, except the persistent set (ablation build)
         hipFunction_t fn;
         if (int rc = gemm4_function(name, &fn)) return rc;
         uint32_t* table;

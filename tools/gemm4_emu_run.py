@@ -43,7 +43,7 @@ def run(cfg: gemm4.Cfg, x, w, bias=None, resid=None, gate=None, rows_per_batch=0
     args = gemm4.pack_args(px, pw, pb, py, pr, pg, pt, lda, N, N, N if gate is not None else 0, M, N, K, rows_per_batch, grid, len(table))
     stats = None
     for wg in range(grid):
-        emu = E.Emu(prog, mem, n_waves=4, lds_bytes=131072, lazy=lazy)
+        emu = E.Emu(prog, mem, n_waves=4, lds_bytes=163840, lazy=lazy)
         emu.launch(args, block_id=(wg, 0, 0))
         stats = emu.waves[0].stats
     return from_bf16_bits(mem.read_back("y")), stats

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Measurement build: the persistent form of the generated GEMM (scail_gemm4_e*_pst: workgroup b walks entries b, b + grid, ...; the next
-tile's first DMA pieces are issued before the epilogue of the current tile) against the shipped one-workgroup-per-tile kernels, same
-process, on the six per-token GEMMs of a config-2 block and on rank-sized ones; outputs compared bit for bit.  One JSON line per case."""
+"""Measurement build: a variant set of the generated GEMM that exists for all four epilogues (argv[1]: "pst" = persistent workgroups, "part" = the
+partial-line epilogue the kernels had before the LDS staging, "stgnt" = staged epilogue with non-temporal stores) against the shipped kernels, same process, on the six per-token GEMMs
+of a config-2 block and on rank-sized ones; outputs compared bit for bit.  One JSON line per case."""
 import json
 import os
 import sys
@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scail_amd import lib as L, ops  # noqa: E402
 
 DEV = "cuda"
+VAR = sys.argv[1] if len(sys.argv) > 1 else "pst"
 
 
 def timeit(fn, iters=9):
@@ -36,7 +37,7 @@ for M in (97664, 6104, 2048 + 136):
         h0 = rn(M, N).to(torch.bfloat16)
         gate = rn(2, N)
         outs, res = {}, {"M": M, "shape": [M, N, K], "what": tag}
-        for suffix in ("", "pst", "", "pst"):
+        for suffix in ("", VAR, "", VAR):
             L.tune_set("gemm4_kernel" + (":" + suffix if suffix else ""), 0)
             y = h0.clone()
             kw = {}
@@ -52,8 +53,9 @@ for M in (97664, 6104, 2048 + 136):
             key = (suffix or "shipped")
             res[key + "_TFLOPs"] = max(res.get(key + "_TFLOPs", 0.0), 2.0 * M * N * K / ms / 1e9)
         L.tune_set("gemm4_kernel", 0)
-        res["bit_identical"] = bool(torch.equal(outs["shipped"], outs["pst"]))
-        res["finite"] = bool(torch.isfinite(outs["pst"].float()).all())
-        res["gain_pct"] = 100.0 * (res["pst_TFLOPs"] / res["shipped_TFLOPs"] - 1.0)
+        res["variant"] = VAR
+        res["bit_identical"] = bool(torch.equal(outs["shipped"], outs[VAR]))
+        res["finite"] = bool(torch.isfinite(outs[VAR].float()).all())
+        res["gain_pct"] = 100.0 * (res[VAR + "_TFLOPs"] / res["shipped_TFLOPs"] - 1.0)
         print(json.dumps(res), flush=True)
         del x, w, h0, y
