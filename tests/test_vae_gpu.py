@@ -279,3 +279,45 @@ def test_c_executor_equals_layerwise_path():
     z1 = m.encode(img)
     m.use_c_exec = False
     assert torch.equal(z1, m.encode(img))
+
+
+@pytest.mark.parametrize("C,thw", [(96, (9, 512, 896)), (96, (5, 720, 1280)), (192, (9, 256, 448)), (384, (7, 128, 224))])
+def test_conv4_at_vae_resolutions(C, thw):
+    """the generated convolution kernels at the sizes BASELINE config 4 runs them (512 x 896 full / half / quarter resolution; 720 x 1280: 3 600
+    spatial tiles, 32-bit offsets up to 177 MB per frame), odd frame counts: sampled output voxels (corners, tile seams, interior, first / last
+    frame) against an fp32 convolution of the 3 x 3 x 3 neighbourhood, plain and with the residual; the whole tensor against the hipcc halo
+    kernel (summation order only)."""
+    from scail_amd import lib as L, ops
+    T, H, W = thw
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(T, H, W, C, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(C, C, 3, 3, 3, device=DEV, generator=g) / (27 * C) ** 0.5)
+    b = torch.randn(C, device=DEV, generator=g)
+    r = torch.randn(T, H, W, C, device=DEV, generator=g).to(torch.bfloat16)
+    wp = ops.prep_conv_weight(w, b)
+    assert ops.conv_generated(wp, x.shape)
+    y = ops.conv3d_cl(x, wp, (T, H, W))
+    y2 = ops.conv3d_cl(x, wp, (T, H, W), resid=r)
+    L.set_option("conv4", 0)
+    try:
+        y_old = ops.conv3d_cl(x, wp, (T, H, W))
+    finally:
+        L.set_option("conv4", 1)
+    assert torch.isfinite(y.float()).all() and torch.isfinite(y2.float()).all()
+    scale = float(y_old.float().abs().max())
+    assert float((y.float() - y_old.float()).abs().max()) <= 2.0 ** -6 * scale
+    assert float((y2.float() - (y_old.float() + r.float())).abs().max()) <= 2.0 ** -5 * scale + 2.0 ** -7 * float(r.float().abs().max())
+    # sampled voxels against fp32 (bf16-rounded operands): frames / rows / columns at the tensor's edges, across tile seams, inside
+    wr = w.to(torch.bfloat16).float()
+    ts = sorted({0, 1, T // 2, T - 1})
+    hs = sorted({0, 1, 15, 16, 17, H // 2, H - 17, H - 16, H - 1})
+    ws_ = sorted({0, 1, 15, 16, 31, 32, W // 2 + 5, W - 16, W - 1})
+    xp = torch.zeros(T + 2, H + 2, W + 2, C, device=DEV)
+    xp[2:, 1:-1, 1:-1] = x.float()
+    for t in ts:
+        for h in hs:
+            patch = xp[t:t + 3, h:h + 3][:, :, [c for wv in ws_ for c in (wv, wv + 1, wv + 2)]]          # (3, 3, 3 * n, C)
+            patch = patch.view(3, 3, len(ws_), 3, C).permute(2, 0, 1, 3, 4)                              # (n, dt, dh, dw, C)
+            ref = torch.einsum("vtabc,nctab->vn", patch, wr) + b
+            got = y[t, h, ws_].float()
+            torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
