@@ -22,8 +22,8 @@ The JSON line also carries
                launch stream inside the timed region; peak 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md);
   roofline_gemm  the same for the six per-token GEMMs of a block taken together (36 % of the step's FLOPs);
   cpu_baseline the CPU oracle (fp32 port of the reference block) timed on this box's host cores after a warm-up: the per-token
-               part at three sequence lengths, the self-attention (the L^2 term) separately on 2 of the 80 (batch, head)
-               pairs up to L = 24 416; fitted and
+               part at three sequence lengths, the self-attention (the L^2 term) separately on 4 of the 80 (batch, head)
+               pairs up to L = 36 624 (0.75 x the bench length); fitted (with a standard error) and
                evaluated at the bench length (rank 0, N = 1; "kind": "port, extrapolated");
   config.vae   BASELINE config 4 (Wan2.1 VAE encode + decode at 81 x 512 x 896) run once after the timed region,
                with both roofline fractions (rank 0, N = 1 only).
@@ -147,10 +147,10 @@ def cpu_baseline(p, L_bench):
          and the fastest is used (all SMT threads of the GPU box's host are NOT the fastest for torch CPU);
       2. per-token part (projections, MLP, norms, RoPE, the short-key cross attention): the whole block at L = 1008 / 2128 /
          3248 with the time of its self-attention call taken out -> fit  c + a L  (exactly linear in L by construction);
-      3. self-attention (62 % of the step's FLOPs at the bench length, the L^2 term): O.sdpa alone on 2 of the 80 (batch,
-         head) pairs (same head-view call shape as in the block) at L = 3052 / 6104 / 12 208 / 24 416 (as many as fit ~25 s), scaled
-         to 80 pairs (the pairs are independent and each saturates the threads) -> fit  a2 L + b L^2; the bench length is
-         2x-4x the longest timed one (round 2 extrapolated the L^2 term 9x beyond its last sample);
+      3. self-attention (62 % of the step's FLOPs at the bench length, the L^2 term): O.sdpa alone on 4 of the 80 (batch,
+         head) pairs (two calls of the block's own head-view call shape) at L = 6104 / 12 208 / 24 416 / 36 624 (as many as fit ~30 s),
+         scaled to 80 pairs (the pairs are independent and each saturates the threads) -> fit  a2 L + b L^2; the bench length is
+         1.33x the longest timed one (round 3: 2x, round 2: 9x); the fits' standard errors at the bench length go into the line;
     Returns a dict with the fits, their rms residuals, the samples and t_block(L_bench)."""
     from oracle import scail_oracle as O
     import torch.nn.functional as F
@@ -203,27 +203,46 @@ def cpu_baseline(p, L_bench):
     run_block(1)                              # warm-up: thread pool, allocator, BLAS kernel selection
     blocks = [run_block(T) for T in (1, 3, 5)]            # L = 1008, 2128, 3248
     (c0, a1), res_tok = _nnls([[1.0] * len(blocks), [q[0] for q in blocks]], [q[1] - q[2] for q in blocks])
-    pairs_all, pairs = 2 * nh, 2
+    pairs_all, pairs, call_pairs = 2 * nh, 4, 2
     att = []                                  # (L, pairs, seconds for these pairs)
     spent = 0.0
-    for La in ((3052, 6104, 12208, 24416) if D >= 1024 else (1024, 2048)):      # toy widths (tests): two short samples
-        # bounded sample: stop before a length whose predicted cost (4x the previous one) would push the attention samples past ~25 s
-        if len(att) >= 2 and spent + 4.0 * att[-1][2] > 25.0:
+    # lengths up to 0.75 x the bench length: the L^2 term is extrapolated 1.33x (round 3: 2x, round 2: 9x); 4 of the 80 (batch, head) pairs per
+    # length, as two calls of the block's own call shape
+    for La in ((6104, 12208, 24416, 36624) if D >= 1024 else (1024, 2048)):      # toy widths (tests): two short samples
+        # bounded sample: stop before a length whose predicted cost ((L / L_prev)^2 x the previous one) would push the attention samples past ~30 s
+        if len(att) >= 2 and spent + (La / att[-1][0]) ** 2 * att[-1][2] > 30.0:
             break
-        # the call shape the block uses: (1, pairs, L, 128) head views of token-major (1, L, pairs * 128) tensors
-        q, k, v = (O._heads(torch.randn(1, La, pairs * 128, generator=g), pairs) for _ in range(3))
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            plain(q, k, v)
-            att.append((La, pairs, time.perf_counter() - t0))
-        spent += att[-1][2]
-        del q, k, v
+        dt = 0.0
+        for _ in range(pairs // call_pairs):
+            # the call shape the block uses: (1, pairs, L, 128) head views of token-major (1, L, pairs * 128) tensors
+            q, k, v = (O._heads(torch.randn(1, La, call_pairs * 128, generator=g), call_pairs) for _ in range(3))
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                plain(q, k, v)
+                dt += time.perf_counter() - t0
+            del q, k, v
+        att.append((La, pairs, dt))
+        spent += dt
     pts = [(La, dt * pairs_all / pr) for La, pr, dt in att]
     (a2, b2), res_att = _nnls([[q[0] for q in pts], [q[0] ** 2 for q in pts]], [q[1] for q in pts])
+    # standard error of the two fitted predictions at the bench length (ordinary least-squares formula on the active terms:
+    # s^2 x0^T (X^T X)^-1 x0 with s^2 = RSS / max(n - p, 1))
+    import numpy as np
+
+    def pred_sigma(cols, coef, rms, n, x0):
+        act = [i for i, cf in enumerate(coef) if cf > 0.0] or [0]
+        X = np.stack([np.asarray(cols[i], dtype=np.float64) for i in act], 1)
+        x = np.asarray([x0[i] for i in act], dtype=np.float64)
+        s2 = rms * rms * n / max(n - len(act), 1)
+        return float(np.sqrt(max(s2 * x @ np.linalg.pinv(X.T @ X) @ x, 0.0)))
+
+    sig_tok = pred_sigma([[1.0] * len(blocks), [q[0] for q in blocks]], (c0, a1), res_tok, len(blocks), (1.0, L_bench))
+    sig_att = pred_sigma([[q[0] for q in pts], [q[0] ** 2 for q in pts]], (a2, b2), res_att, len(pts), (L_bench, L_bench * L_bench))
     t_tok = c0 + a1 * L_bench
     t_att = a2 * L_bench + b2 * L_bench * L_bench
     return dict(threads=n_threads, probe=probe, blocks=blocks, att=att, c=c0, a=a1, a2=a2, b=b2, res_tok=res_tok, res_att=res_att,
-                t_tok=t_tok, t_att=t_att, t_block=t_tok + t_att, max_timed_L=max(q[0] for q in pts))
+                t_tok=t_tok, t_att=t_att, t_block=t_tok + t_att, max_timed_L=max(q[0] for q in pts), pairs_timed=pairs,
+                sigma_block=(sig_tok ** 2 + sig_att ** 2) ** 0.5)
 
 
 def _git_blob_sha1(path):
@@ -329,10 +348,12 @@ def main():
     net.cache_conditioning = False          # recompute text/CLIP K,V every step like the reference
     net.sp = sp
     n_char = 2 if args.config == "14b-2char" else 1
-    # N = 1, one character: the product default -- every network evaluation is ONE scail_dit_step call and the kernel times come from
-    # the executor's own event pairs.  Sequence-parallel ranks (exchange in the host) and the multi-character extension run the
-    # per-op host path (same kernels, same order), timed by bracketing the tagged launches.
-    use_c = sp is None and n_char == 1 and net.use_c_step
+    # The product default at every N: a network evaluation is ONE call of the C executor -- scail_dit_step on one rank, scail_dit_step_sp on
+    # a sequence-parallel rank (same kernels; only the collectives of the per-layer exchange come back to the host through the exchange
+    # callback) -- and the kernel times come from the executor's own event pairs.  The multi-character extension assembles its tokens in the
+    # host and runs every block as one executor call (scail_dit_block / scail_dit_block_sp).  SCAIL_C_STEP=0: the per-op host path
+    # (cross-check), timed by bracketing the tagged launches.
+    use_c = net.use_c_step
     timer = KernelTimer()
     net.kernel_timer = None if use_c else timer
 
@@ -410,9 +431,16 @@ def main():
     attn_heads = nh // world if sp_mode == "ulysses" else nh
     attn_B = 2 if sp is None else 1          # the sequence-parallel path launches per CFG batch element (comm / compute overlap)
     attn_Lq = L if sp_mode == "ulysses" else L // world      # ulysses: all ranks' query rows of this rank's heads
-    attn_flops = 4.0 * attn_Lq * L * 128 * attn_heads * attn_B
+    # scail_dit_step runs the LAST layer's queries / out-projection / cross attention / MLP on the noise tokens only (its other rows never
+    # reach the final layer; csrc/dit_step.hip): that launch has Lnoise / L of the FLOPs, and the means below are over all launches
+    pruned = use_c and sp is None and n_char == 1
+    nl_ = p["num_layers"]
+    attn_flops = 4.0 * attn_Lq * L * 128 * attn_heads * attn_B * ((nl_ - 1 + Lnoise / L) / nl_ if pruned else 1.0)
     ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms else None
     fl = step_flops(p, L, Lt, Lc)
+    D0, FF0 = p["hidden_size"], p["inner_hidden_size"]
+    # FLOPs the step actually executes: the reference's algorithmic count minus the last layer's skipped ref / pose rows
+    fl_exec = fl - (2 * (L - Lnoise) * (4 * L * D0 + 4 * (Lt + Lc) * D0 + 2 * D0 * (3 * D0 + 2 * FF0)) if pruned else 0.0)
     # HBM/fabric bytes per launch of the dominant kernel: measured offline with rocprofv3 --pmc (separate passes, guide
     # corrections; profiles/), committed with the git blob id of the kernel source it was measured on -- dropped (null)
     # when the kernel source (the generated csrc/attn4.s, or attn.hip for shapes the 8-wave kernel serves) has changed since
@@ -444,7 +472,7 @@ def main():
                                f"({T},16,{H},{W}), L={L} tokens (ref+noise+pose), text {Lt}, clip {Lc}, "
                                f"{p['num_layers']} layers, random-init bf16 weights",
                    "parallelism": f"sp{world}" + (f"-{sp_mode}" if sp is not None else ""), "cond_cache": False, "noise_tokens": Lnoise, "all_tokens_x_batch": 2 * L,
-                   "step_tflop": fl / 1e12, "step_mfma_frac": fl / t_step / (world * PEAK_BF16_TFLOPS * 1e12),
+                   "step_tflop": fl / 1e12, "step_tflop_executed": fl_exec / 1e12, "step_mfma_frac": fl_exec / t_step / (world * PEAK_BF16_TFLOPS * 1e12),
                    "finite": finite, "x_abs_mean": x_abs_mean, "sp_check": sp_check},
         "roofline": {"bound": "mfma", "kernel": kname + " (self-attention)", "achieved": ach,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
@@ -452,16 +480,24 @@ def main():
                      "launches_timed": n_att,
                      "timed_by": "scail_dit_profile (event pairs inside the C executor)" if use_c else "HIP events around the tagged host launches"},
     }
-    out["config"]["path"] = "scail_dit_step (C executor, product default)" if use_c else "per-op host path (scail_amd.dit._run)"
+    if not use_c:
+        out["config"]["path"] = "per-op host path (scail_amd.dit._run)"
+    elif n_char > 1:
+        out["config"]["path"] = ("scail_dit_block_sp" if sp is not None else "scail_dit_block") + " per layer (C executor) + token assembly in the host"
+    else:
+        out["config"]["path"] = ("scail_dit_step_sp (C executor; collectives through the exchange callback)" if sp is not None
+                                 else "scail_dit_step (C executor, product default)")
     if gemm_ms:
         # the six per-token GEMMs of a block (qkv, attention out, cross q, cross out, MLP up, MLP down), all launches of the timed region
         D_, FF_ = p["hidden_size"], p["inner_hidden_size"]
-        gflop = 2.0 * (2 * L) * D_ * (3 * D_ + 3 * D_ + 2 * FF_) * p["num_layers"] * args.steps
+        gflop = 2.0 * (2 * L // world) * D_ * (3 * D_ + 3 * D_ + 2 * FF_) * p["num_layers"] * args.steps      # this rank's token rows
+        if pruned:
+            gflop -= 2.0 * (2 * (L - Lnoise)) * D_ * (3 * D_ + 2 * FF_) * args.steps
         g_ach = gflop / (gemm_ms * 1e-3) / 1e12
         g_traffic = None
         try:
             trg = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["gemm4_step"]
-            if trg.get("source_blob") == _git_blob_sha1(os.path.join(ROOT, "scail_amd", "csrc", "gemm4.s")) and trg["shape"] == {"M": 2 * L, "D": D_, "FF": FF_}:
+            if trg.get("source_blob") == _git_blob_sha1(os.path.join(ROOT, "scail_amd", "csrc", "gemm4.s")) and trg["shape"] == {"M": 2 * L // world, "D": D_, "FF": FF_}:
                 g_traffic = trg["traffic_bytes_per_launch_mean"]
         except Exception:
             pass
@@ -486,8 +522,12 @@ def main():
             "hardware_threads": os.cpu_count(), "kind": "port, extrapolated",
             "fit": {"per_token_s": {"c": cb["c"], "a_per_token": cb["a"], "rms_residual_s": cb["res_tok"]},
                     "self_attention_s": {"a_per_token": cb["a2"], "b_per_token2": cb["b"], "rms_residual_s": cb["res_att"]},
-                    "longest_timed_L": cb["max_timed_L"], "extrapolation_in_L": L / cb["max_timed_L"],
-                    "attention_share_at_bench_L": cb["t_att"] / cb["t_block"]},
+                    "longest_timed_L": cb["max_timed_L"], "extrapolation_in_L": L / cb["max_timed_L"], "pairs_timed_of_80": cb["pairs_timed"],
+                    "attention_share_at_bench_L": cb["t_att"] / cb["t_block"],
+                    # one standard error of the fitted block time at the bench length, carried to the value (the fit's own uncertainty;
+                    # box-to-box spread of the host is larger: quote the baseline as "about 2-2.5 tokens/s")
+                    "block_s_at_bench_L": cb["t_block"], "block_s_sigma": cb["sigma_block"],
+                    "value_plus_minus": Lnoise / t_cpu * cb["sigma_block"] / cb["t_block"]},
             "sample": f"oracle block (fp32, torch CPU, {cb['threads']} threads = fastest of "
                       + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in sorted(cb["probe"].items())) + " on the 2016x5120x15360 projection) at full "
                       f"width D={p['hidden_size']}, B=2, after one warm-up call: whole block at L = "

@@ -7,8 +7,10 @@
  * Ownership: the caller owns every buffer (weights, inputs, outputs, workspace, conditioning cache); the handle
  * only keeps the configuration and COPIES OF THE POINTER TABLES (not of the weights).  All work is enqueued on the
  * hipStream_t passed last; there is no host synchronisation, so a step can be stream-captured into a hipGraph after
- * one warm-up call.  Return 0 / non-zero + scail_last_error().  Single sequence-parallel rank only: the per-layer
- * exchange of the multi-GPU path lives in the host (scail_amd/parallel.py, RCCL through torch.distributed).
+ * one warm-up call.  Return 0 / non-zero + scail_last_error().  Sequence-parallel ranks run the SAME executor through
+ * scail_dit_step_sp / scail_dit_block_sp below: the kernels of a block are enqueued here and only the collectives of the per-layer
+ * exchange are handed to the host through a callback (RCCL through torch.distributed in scail_amd/parallel.py; a C host calls
+ * ncclAllToAll / ncclAllGather there).
  */
 #ifndef SCAIL_DIT_H
 #define SCAIL_DIT_H
@@ -94,6 +96,65 @@ int64_t scail_dit_block_workspace_bytes(const scail_dit* h, int64_t B, int64_t L
 int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, const float* mod, const scail_dit_cond* cond,
                     const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok,
                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * ---- sequence-parallel execution (reference: DeepSpeed-Ulysses, sat/mpu/ulysses_attn_layer.py:41-110, all_to_all.py:15-108,
+ * with the latent split and rank-shifted RoPE of diffusion_video.py:495-585 and dit...:1578-1585) ----------------------------------------
+ * Each rank holds an aligned token slab (B, Ltok, D) of [ref | noise | pose] tokens.  A block is per-token except for the self-attention,
+ * whose exchange comes in two modes:
+ *   SCAIL_SP_ULYSSES    q, k, v head <-> sequence all-to-alls after norm + RoPE, attention over the FULL sequence for heads / ranks heads,
+ *                       one all-to-all back (heads % ranks == 0).  Buffers (bf16, caller-owned, contiguous):
+ *                         send, recv  [B][3][ranks][Ltok][D / ranks]   (q | k | v; send: one slab per destination rank; recv: per source rank,
+ *                                                                       i.e. one (ranks * Ltok, D / ranks) matrix in rank-major token order)
+ *                         ofull, back [B][ranks][Ltok][D / ranks]      (attention output of all tokens for my heads; my tokens for all head groups)
+ *   SCAIL_SP_ALLGATHER  ONE exchange: all-gather of the post-RoPE K rows and of the V rows.  Buffers:
+ *                         send [B][2][Ltok][D] (k rows | v rows),  recv [B][2][ranks][Ltok][D];  ofull / back unused (NULL).
+ * The executor enqueues every kernel and calls `exchange` where a collective has to be started or awaited:
+ *   SCAIL_SP_FWD_START   element b's send buffers are complete on `stream` (stream order): start its forward collectives
+ *                        (ulysses: send[b][j] -> recv[b][j] for j = 0..2, all-to-all with equal splits; allgather: send[b][j] -> recv[b][j], j = 0, 1)
+ *   SCAIL_SP_FWD_WAIT    make `stream` wait for them (the kernels enqueued next read recv[b])
+ *   SCAIL_SP_BACK_START  ulysses: ofull[b] is complete on `stream`: start the all-to-all ofull[b] -> back[b]
+ *   SCAIL_SP_BACK_WAIT   make `stream` wait for it
+ * Per layer the order of the calls is START(0), START(1), .., WAIT(0), [BACK_START(0)], WAIT(1), [BACK_START(1)], .., [BACK_WAIT(0), ..] on every
+ * rank, so collectives are enqueued in the same order everywhere.  A non-zero return aborts the step (status 3).  The callback runs on the
+ * calling thread, between launches; it must not synchronise the device if the step is to stay asynchronous.
+ * side_stream: both NULL = everything on `stream`.  Two streams: the two CFG elements' launches of the ulysses exchange section go to
+ * side_stream[b & 1] (forked from / joined to `stream` with events inside the call): an element's rank-sized launches leave a partial last
+ * round of the chip that the other element's kernels fill (pays up to 4 ranks).
+ */
+#define SCAIL_SP_ALLGATHER 0
+#define SCAIL_SP_ULYSSES 1
+#define SCAIL_SP_FWD_START 0
+#define SCAIL_SP_FWD_WAIT 1
+#define SCAIL_SP_BACK_START 2
+#define SCAIL_SP_BACK_WAIT 3
+typedef int (*scail_sp_exchange_fn)(void* user, int32_t op, int32_t layer, int32_t element, void* stream);
+typedef struct scail_dit_sp {
+    int32_t ranks;              /* group size, >= 2 */
+    int32_t mode;               /* SCAIL_SP_ALLGATHER | SCAIL_SP_ULYSSES */
+    scail_bf16* send;
+    scail_bf16* recv;
+    scail_bf16* ofull;
+    scail_bf16* back;
+    scail_sp_exchange_fn exchange;
+    void* user;
+    void* side_stream[2];
+} scail_dit_sp;
+
+/* One network evaluation on this rank's latent slab x [B,T,16,H,W] (H or W = the full extent / ranks; ref / pose sliced alike; rope tables
+ * of the slab's tokens with the rank's window shift, scail_amd/rope.py): scail_dit_step with the self-attention exchanged as above.
+ * out = this rank's slab of the result.  workspace >= scail_dit_sp_workspace_bytes (the V^T staging buffer holds ALL ranks' keys). */
+int64_t scail_dit_sp_workspace_bytes(const scail_dit* h, int32_t mode, int32_t ranks, int64_t B, int64_t T, int64_t H, int64_t W);
+int scail_dit_step_sp(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
+                      const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
+                      const float* rope_cos, const float* rope_sin, float* out,
+                      int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Seam B2 for a sequence-parallel rank: ONE transformer block in place on this rank's hidden [B, Ltok, D] (scail_dit_block + the exchange). */
+int64_t scail_dit_block_sp_workspace_bytes(const scail_dit* h, int32_t mode, int32_t ranks, int64_t B, int64_t Ltok);
+int scail_dit_block_sp(scail_dit* h, int64_t layer, scail_bf16* hidden, const float* mod, const scail_dit_cond* cond,
+                       const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok, const scail_dit_sp* sp,
+                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * Timing of the executor's own launches with HIP events recorded on the launch stream (what bench.py's `roofline` objects are computed

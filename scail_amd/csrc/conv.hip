@@ -662,6 +662,22 @@ static int conv4_function(const std::string& name, hipFunction_t* fn) {
     return 0;
 }
 
+// compute units of the current device, cached per HIP device id (like gemm4_cu_count)
+static int conv4_cu_count() {
+    static std::map<int, int> cache;
+    static std::mutex mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(dev);
+    if (it == cache.end()) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        it = cache.emplace(dev, n).first;
+    }
+    return it->second;
+}
+
 static int g_conv4 = 1;                                        // option "conv4": the generated kernels where scail_conv3d_kernel_for says 4
 int scail_conv4_enable(int v) { g_conv4 = v != 0; return 0; }
 #ifdef SCAIL_ABLATIONS
@@ -673,8 +689,13 @@ static constexpr int g_conv_halo = 4;
 #endif
 
 // the shapes the generated kernels cover: 3x3x3, stride 1, 'same' spatial extent, 0..2 padding frames in front, whole 32-channel slices and
-// 96-channel output tiles, at least one frame pair, 32-bit byte offsets inside a frame
+// 96-channel output tiles, at least one frame pair, 32-bit byte offsets inside a frame, and a tile grid whose id decode is exact: the kernel
+// divides a tile id by tiles_n, tiles_t and tiles_w with 31-bit magic numbers, exact while dividend x divisor < 2^31
+static int64_t conv4_tiles(const ConvParams& p) { return (int64_t)((p.To + 1) / 2) * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * (p.N / 96); }
 static bool conv4_eligible(const ConvParams& p, int64_t ldc, int64_t ldr) {
+    if (p.N <= 0 || p.N % 96 != 0 || p.To < 2 || p.Ho <= 0 || p.Wo <= 0) return false;
+    const int64_t max_div = std::max<int64_t>({p.N / 96, (p.To + 1) / 2, (p.Wo + 15) / 16});
+    if (conv4_tiles(p) * max_div >= (1ll << 31)) return false;
     return p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups && p.ph == 1 && p.pw == 1 &&
            p.Ho == p.Hi && p.Wo == p.Wi && p.Cin % 32 == 0 && p.N % 96 == 0 && p.To >= 2 && p.pt >= 0 && p.pt <= 2 &&
            ldc % 8 == 0 && ldr % 8 == 0 && ldc < (1 << 20) && ldr < (1 << 20) && (int64_t)p.Hi * p.Wi * p.Cin * 2 < (1ll << 31) &&
@@ -729,14 +750,12 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         auto magic31 = [](int d) { return (uint32_t)(((1ull << 31) + (uint64_t)d - 1) / (uint64_t)d); };
         a.magic_n = magic31(a.tiles_n); a.magic_w = magic31(a.tiles_w); a.magic_t = magic31(a.tiles_t);
         a.n_slices = p.Cin / 32; a.ot_mul = p.ot_mul; a.ot_off = p.ot_off; a.ldc = ldc; a.ldr = resid ? ldr : ldc;
-        const int64_t tiles = (int64_t)a.tiles_t * ((p.Ho + 15) / 16) * a.tiles_w * a.tiles_n;
-        SCAIL_REQUIRE(tiles < (1ll << 24), "too many tiles");        // the kernel's magic-number divisions are exact below 2^31 / divisor
+        const int64_t tiles = conv4_tiles(p);        // conv4_eligible: tiles x the largest divisor < 2^31, so the magic-number divisions are exact
         // persistent workgroups, one per compute unit; tiles are numbered n tile fastest, then frame pair; workgroup number w = (b % 8) *
         // wgs_per_xcd + b / 8.  One n tile: w takes the next tiles_per_wg (+ 1) tiles (the frame pairs of a spatial tile; consecutive pairs
         // share two input frames, the lane offsets stay).  Several n tiles (tiles_per_wg = 0): w takes tiles w, w + grid, ... so that an XCD
         // works on the n tiles of a few neighbouring frame pairs at a time and they share the patch through its L2.
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+        const int cus = conv4_cu_count();
         a.wgs_per_xcd = (int32_t)std::min<int64_t>((tiles + 7) / 8, cus / 8);
         a.tiles_per_wg = a.tiles_n == 1 ? (int32_t)(tiles / (8 * a.wgs_per_xcd)) : 0;
         a.tiles = (int32_t)tiles;

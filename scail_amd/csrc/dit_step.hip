@@ -1,8 +1,9 @@
 // Network-level entry points (include/scail_dit.h): one DiT evaluation of the sampler step composed from the
 // operator entry points of this library -- the C++ statement of DiffusionTransformer.forward ->
 // BaseTransformer.forward -> AdaLNMixin.layer_forward (dit_video_crossattn_sc_xc.py:1452-1587, :1009-1051;
-// sat/model/transformer.py:572-746) for a single sequence-parallel rank.  Host code only: every line below
-// enqueues kernels on the caller's stream; nothing synchronises, so a step is hipGraph-capturable.
+// sat/model/transformer.py:572-746), for one rank or for a sequence-parallel rank (the collectives of the per-layer exchange go to
+// the host through a callback).  Host code only: every line below enqueues kernels on the caller's stream; nothing synchronises, so
+// a single-rank step is hipGraph-capturable.
 #include <vector>
 
 #include "common.h"
@@ -24,6 +25,7 @@ struct scail_dit {
     std::vector<scail_dit_layer> layers;
     bool prof = false;
     ProfPool pool[PROF_CATS];
+    hipEvent_t sp_ev[3] = {nullptr, nullptr, nullptr};   // fork / join events of the sequence-parallel block's side streams (created on first use)
 };
 
 namespace {
@@ -37,11 +39,19 @@ struct Ws {
     int64_t tok, h, xn, qkv, att, ff, vt, xf, tokout, temb, e1, emb, adaln, mod, emb2, fin, total;
 };
 
-Ws layout(const scail_dit_config& c, int64_t B, int64_t T, int64_t H, int64_t W) {
-    const int64_t D = c.hidden_size, FF = c.inner_hidden_size, nh = c.num_heads;
+// elements of the V^T staging buffer of a (B, Ltok) block: one rank (sp_mode < 0): all heads x the local keys; ulysses: heads / ranks
+// heads x ALL ranks' keys; all-gather: all heads x all ranks' keys
+int64_t vt_elems(const scail_dit_config& c, int64_t B, int64_t Ltok, int sp_mode, int64_t ranks) {
+    const int64_t nh = c.num_heads;
+    if (sp_mode < 0) return B * nh * 128 * ((Ltok + 63) / 64 * 64);
+    const int64_t Lfp = (ranks * Ltok + 63) / 64 * 64;
+    return B * (sp_mode == SCAIL_SP_ULYSSES ? nh / ranks : nh) * 128 * Lfp;
+}
+
+Ws layout(const scail_dit_config& c, int64_t B, int64_t T, int64_t H, int64_t W, int sp_mode = -1, int64_t ranks = 1) {
+    const int64_t D = c.hidden_size, FF = c.inner_hidden_size;
     const int64_t hp = H / 2, wp = W / 2;
     const int64_t Lnoise = T * hp * wp, Ltok = hp * wp + Lnoise + T * (H / 4) * (W / 4);
-    const int64_t Lp = (Ltok + 63) / 64 * 64;
     Ws s;
     int64_t off = 0;
     auto take = [&](int64_t bytes) { const int64_t o = off; off += align256(bytes); return o; };
@@ -51,7 +61,7 @@ Ws layout(const scail_dit_config& c, int64_t B, int64_t T, int64_t H, int64_t W)
     s.qkv = take(B * Ltok * 3 * D * 2);
     s.att = take(B * Ltok * D * 2);
     s.ff = take(B * Ltok * FF * 2);
-    s.vt = take(B * nh * 128 * Lp * 2);
+    s.vt = take(vt_elems(c, B, Ltok, sp_mode, ranks) * 2);
     s.xf = take(B * Lnoise * D * 2);
     s.tokout = take(B * Lnoise * 64 * 2);
     s.temb = take(B * c.time_freq_dim * 4);
@@ -107,61 +117,238 @@ static int prof_mark(scail_dit* h, int cat, void* stream) {
         if (h->prof) DIT_TRY(prof_mark(h, cat_, stream));       \
     }
 
-// One transformer block in place on hid (B, Ltok, D): AdaLNMixin.layer_forward, dit...:1009-1051.
-//   m (B, 6D) fp32 = shift_a | scale_a | gate_a | shift_m | scale_m | gate_m of THIS layer (adaLN emb + table)
-static int dit_block(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, const scail_dit_cond* cond,
-                     const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok,
-                     scail_bf16* xn, scail_bf16* qkv, scail_bf16* att, scail_bf16* ff, scail_bf16* vt, void* stream) {
+// one launch of category cat_ on stream st_, bracketed by an event pair when profiling is on
+#define DIT_PROF_S(cat_, st_, call_)                            \
+    {                                                           \
+        if (h->prof) DIT_TRY(prof_mark(h, cat_, st_));          \
+        DIT_TRY(call_);                                         \
+        if (h->prof) DIT_TRY(prof_mark(h, cat_, st_));          \
+    }
+
+struct BlockBufs {
+    scail_bf16 *xn, *qkv, *att, *ff, *vt;
+};
+
+constexpr float ATTN_SCALE = 0.08838834764831845f;              // 1 / sqrt(128)
+constexpr float ATTN_LOG2_SCALE = ATTN_SCALE * 1.4426950408889634f;   // queries in log2 units (scail_flash_attn_bf16 SCAIL_ATTN_Q_PRESCALED)
+
+// Everything of a block AFTER its self-attention, for `nb` batch elements starting at element b0 whose rows lie `rpb` apart in every
+// buffer (hid / att: row stride D; q3: the first column third of a row-stride-3D buffer; xn / ff: scratch of nb * rpb rows):
+// out-projection + gated residual, cross attention (text + CLIP, ungated residual), MLP (dit...:1036-1050, :1107-1203;
+// sat/transformer_defaults.py:163-176).  m = the (6D) modulation row of element b0 (rows of later elements 6D apart).
+static int block_post(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16* att, scail_bf16* q3, scail_bf16* xn, scail_bf16* ff,
+                      const float* m, const scail_dit_cond* cond, int64_t Btot, int64_t b0, int64_t nb, int64_t rpb, void* stream) {
     const scail_dit_config& c = h->cfg;
     const int64_t D = c.hidden_size, FF = c.inner_hidden_size, nh = c.num_heads;
     const float eps = c.layernorm_epsilon;
-    const int64_t Lp = (Ltok + 63) / 64 * 64;
     const int64_t Ltp = (cond->Lt + 63) / 64 * 64, Lcp = (cond->Lc + 63) / 64 * 64;
-    const float scale = 0.08838834764831845f;   // 1 / sqrt(128)
-    const int64_t M = B * Ltok;
-    scail_bf16 *q = qkv, *k = qkv + D, *v = qkv + 2 * D;   // column thirds of the fused projection, row stride 3D
+    const int64_t M = nb * rpb;
     const scail_dit_layer& lw = h->layers[i];
-    // -- self attention (dit...:1031-1036, :1058-1105) --
-    DIT_TRY(scail_ln_modulate(hid, D, xn, D, m, m + D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
-    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xn, D, lw.qkv_w, lw.qkv_b, qkv, 3 * D, M, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
-    DIT_TRY(scail_rmsnorm_rope(k, 3 * D, k, 3 * D, lw.kn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
-    DIT_TRY(scail_transpose_v(v, 3 * D, Ltok * 3 * D, vt, B, nh, 128, Ltok, stream));
-    // the queries go to the attention in log2 units (q * scale * log2 e, one rounding): its exp2 then needs no scale / shift per score
-    DIT_TRY(scail_rmsnorm_rope_scaled(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, M, Ltok, D, 128, eps, scale * 1.4426950408889634f, stream));
-    DIT_PROF(SCAIL_DIT_PROF_SELF_ATTN, scail_flash_attn_bf16(q, Ltok * 3 * D, 3 * D, k, 0, Ltok * 3 * D, 3 * D, vt, 0, nh * 128 * Lp, att, Ltok * D, D,
-                                                             B, nh, Ltok, Ltok, 1, SCAIL_ATTN_Q_PRESCALED, 0, stream));
-    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(att, D, lw.o_w, lw.o_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, m + 2 * D, 6 * D, Ltok, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(att, D, lw.o_w, lw.o_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, m + 2 * D, 6 * D, rpb, stream));
     // -- cross attention: text + CLIP, ungated residual (dit...:1039-1042, :1107-1203) --
     DIT_TRY(scail_layernorm_affine(hid, D, xn, D, lw.ln_w, lw.ln_b, M, D, eps, stream));
-    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xn, D, lw.cq_w, lw.cq_b, q, 3 * D, M, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
-    DIT_TRY(scail_rmsnorm_rope(q, 3 * D, q, 3 * D, lw.cqn, nullptr, nullptr, M, M, D, 128, eps, stream));
-    const scail_bf16* kt = cond->k_text + i * B * cond->Lt * D;
-    const scail_bf16* vtt = cond->vt_text + i * B * nh * 128 * Ltp;
-    const scail_bf16* kc = cond->k_clip + i * cond->Bc * cond->Lc * D;
-    const scail_bf16* vtc = cond->vt_clip + i * cond->Bc * nh * 128 * Lcp;
-    DIT_PROF(SCAIL_DIT_PROF_CROSS_ATTN, scail_cross_attn2_bf16(q, Ltok * 3 * D, 3 * D, kt, cond->Lt * D, D, vtt, nh * 128 * Ltp, cond->Lt,
-                                                               kc, cond->Bc == 1 ? 0 : cond->Lc * D, D, vtc, cond->Bc == 1 ? 0 : nh * 128 * Lcp, cond->Lc,
-                                                               att, Ltok * D, D, B, nh, Ltok, scale, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xn, D, lw.cq_w, lw.cq_b, q3, 3 * D, M, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+    DIT_TRY(scail_rmsnorm_rope(q3, 3 * D, q3, 3 * D, lw.cqn, nullptr, nullptr, M, M, D, 128, eps, stream));
+    const bool shared_clip = cond->Bc == 1;
+    const scail_bf16* kt = cond->k_text + (i * Btot + b0) * cond->Lt * D;
+    const scail_bf16* vtt = cond->vt_text + (i * Btot + b0) * nh * 128 * Ltp;
+    const scail_bf16* kc = cond->k_clip + (i * cond->Bc + (shared_clip ? 0 : b0)) * cond->Lc * D;
+    const scail_bf16* vtc = cond->vt_clip + (i * cond->Bc + (shared_clip ? 0 : b0)) * nh * 128 * Lcp;
+    DIT_PROF(SCAIL_DIT_PROF_CROSS_ATTN, scail_cross_attn2_bf16(q3, rpb * 3 * D, 3 * D, kt, cond->Lt * D, D, vtt, nh * 128 * Ltp, cond->Lt,
+                                                               kc, shared_clip ? 0 : cond->Lc * D, D, vtc, shared_clip ? 0 : nh * 128 * Lcp, cond->Lc,
+                                                               att, rpb * D, D, nb, nh, rpb, ATTN_SCALE, stream));
     DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(att, D, lw.co_w, lw.co_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, nullptr, 0, 0, stream));
     // -- MLP (dit...:1045-1050; sat/transformer_defaults.py:163-176) --
-    DIT_TRY(scail_ln_modulate(hid, D, xn, D, m + 3 * D, m + 4 * D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
+    DIT_TRY(scail_ln_modulate(hid, D, xn, D, m + 3 * D, m + 4 * D, 6 * D, nb, rpb, rpb, 0, D, eps, stream));
     DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xn, D, lw.w1, lw.b1, ff, FF, M, FF, D, SCAIL_EPI_GELU_TANH, nullptr, 0, nullptr, 0, 0, stream));
-    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(ff, FF, lw.w2, lw.b2, hid, D, M, D, FF, SCAIL_EPI_RESID, hid, D, m + 5 * D, 6 * D, Ltok, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(ff, FF, lw.w2, lw.b2, hid, D, M, D, FF, SCAIL_EPI_RESID, hid, D, m + 5 * D, 6 * D, rpb, stream));
     return 0;
 }
 
+// One transformer block in place on hid (B, Ltok, D): AdaLNMixin.layer_forward, dit...:1009-1051.
+//   m (B, 6D) fp32 = shift_a | scale_a | gate_a | shift_m | scale_m | gate_m of THIS layer (adaLN emb + table)
+//   [row0, row0 + rows): the token rows of every batch element whose OUTPUT is wanted.  rows == Ltok: the whole block.  rows < Ltok
+//   (the LAST layer of a step: only the noise tokens reach the final layer, dit...:771, :825-826): every token still contributes its
+//   key and value, but the queries, the out-projection, the cross attention and the MLP run on the wanted rows only -- the other
+//   rows of hid are left as they were.  Result-preserving: every kernel computes a row of its output from that row alone.
+static int dit_block(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, const scail_dit_cond* cond,
+                     const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok, const BlockBufs& bf,
+                     int64_t row0, int64_t rows, void* stream) {
+    const scail_dit_config& c = h->cfg;
+    const int64_t D = c.hidden_size, nh = c.num_heads;
+    const float eps = c.layernorm_epsilon;
+    const int64_t Lp = (Ltok + 63) / 64 * 64;
+    const int64_t M = B * Ltok;
+    scail_bf16 *qkv = bf.qkv, *q = qkv, *k = qkv + D, *v = qkv + 2 * D;   // column thirds of the fused projection, row stride 3D
+    const scail_dit_layer& lw = h->layers[i];
+    // -- self attention (dit...:1031-1036, :1058-1105) --
+    DIT_TRY(scail_ln_modulate(hid, D, bf.xn, D, m, m + D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(bf.xn, D, lw.qkv_w, lw.qkv_b, qkv, 3 * D, M, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+    DIT_TRY(scail_rmsnorm_rope(k, 3 * D, k, 3 * D, lw.kn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
+    DIT_TRY(scail_transpose_v(v, 3 * D, Ltok * 3 * D, bf.vt, B, nh, 128, Ltok, stream));
+    // the queries go to the attention in log2 units (q * scale * log2 e, one rounding): its exp2 then needs no scale / shift per score
+    DIT_TRY(scail_rmsnorm_rope_scaled(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, M, Ltok, D, 128, eps, ATTN_LOG2_SCALE, stream));
+    DIT_PROF(SCAIL_DIT_PROF_SELF_ATTN, scail_flash_attn_bf16(q + row0 * 3 * D, Ltok * 3 * D, 3 * D, k, 0, Ltok * 3 * D, 3 * D, bf.vt, 0, nh * 128 * Lp,
+                                                             bf.att + row0 * D, Ltok * D, D, B, nh, rows, Ltok, 1, SCAIL_ATTN_Q_PRESCALED, 0, stream));
+    if (rows == Ltok) return block_post(h, i, hid, bf.att, q, bf.xn, bf.ff, m, cond, B, 0, B, Ltok, stream);
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t r = b * Ltok + row0;
+        DIT_TRY(block_post(h, i, hid + r * D, bf.att + r * D, q + r * 3 * D, bf.xn, bf.ff, m + b * 6 * D, cond, B, b, 1, rows, stream));
+    }
+    return 0;
+}
+
+// ---- the sequence-parallel block (include/scail_dit.h "sequence-parallel execution") ----
+static int sp_exchange(const scail_dit_sp* sp, int op, int64_t layer, int64_t b, void* stream) {
+    const int rc = sp->exchange(sp->user, (int32_t)op, (int32_t)layer, (int32_t)b, stream);
+    if (rc != 0) {
+        scail_set_error("scail_dit (sequence parallel): the host's exchange callback failed (op " + std::to_string(op) + ", layer " +
+                        std::to_string(layer) + ", element " + std::to_string(b) + ", status " + std::to_string(rc) + ")");
+        return 3;
+    }
+    return 0;
+}
+
+static int sp_check(const scail_dit* h, const scail_dit_sp* sp) {
+    SCAIL_REQUIRE(sp != nullptr && sp->exchange != nullptr, "null sequence-parallel descriptor / exchange callback");
+    SCAIL_REQUIRE(sp->ranks >= 2 && sp->ranks <= 64, "ranks must be 2..64");
+    SCAIL_REQUIRE(sp->mode == SCAIL_SP_ALLGATHER || sp->mode == SCAIL_SP_ULYSSES, "unknown exchange mode");
+    SCAIL_REQUIRE(sp->send != nullptr && sp->recv != nullptr, "null send / recv buffer");
+    if (sp->mode == SCAIL_SP_ULYSSES) {
+        SCAIL_REQUIRE(h->cfg.num_heads % sp->ranks == 0, "ulysses needs heads divisible by the group size");
+        SCAIL_REQUIRE(sp->ofull != nullptr && sp->back != nullptr, "ulysses needs the ofull / back buffers");
+    }
+    SCAIL_REQUIRE((sp->side_stream[0] == nullptr) == (sp->side_stream[1] == nullptr), "give both side streams or none");
+    return 0;
+}
+
+// hid (B, Ltok, D) = this rank's token slab.  Kernel sequence and results are those of scail_amd.parallel's per-op path (kept as the
+// cross-check: tests/test_dit_gpu.py); only the host side differs: one call per layer instead of ~30 launches through the binding.
+static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, const scail_dit_cond* cond,
+                        const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok, const BlockBufs& bf,
+                        const scail_dit_sp* sp, void* stream) {
+    const scail_dit_config& c = h->cfg;
+    const int64_t D = c.hidden_size, nh = c.num_heads, N = sp->ranks;
+    const float eps = c.layernorm_epsilon;
+    const int64_t Lf = N * Ltok, Lfp = (Lf + 63) / 64 * 64;
+    scail_bf16 *qkv = bf.qkv, *q = qkv;
+    const scail_dit_layer& lw = h->layers[i];
+    DIT_TRY(scail_ln_modulate(hid, D, bf.xn, D, m, m + D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
+    if (sp->mode == SCAIL_SP_ULYSSES) {
+        // head <-> sequence all-to-all of q, k, v after norm + RoPE (sat/mpu/ulysses_attn_layer.py:65-107), full-length attention on
+        // heads / N heads, all-to-all back.  The CFG elements are independent sequences: element b + 1's projection runs under
+        // element b's exchange, element b's attention under element b + 1's exchange, the ways back under the other's attention.
+        const int64_t Hn = nh / N, Dn = Hn * 128, slab = Ltok * Dn;
+        const bool side = sp->side_stream[0] != nullptr;
+        auto st = [&](int64_t b) { return side ? sp->side_stream[b & 1] : stream; };
+        if (side) {
+            // one side stream per element (up to 4 ranks: an element's launches leave a partial last round of the chip which the other
+            // element's kernels fill).  The collectives are still enqueued in the order fwd(0), fwd(1), back(0), back(1).
+            for (hipEvent_t& e : h->sp_ev)
+                if (e == nullptr && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                    scail_set_error("scail_dit (sequence parallel): hipEventCreate failed");
+                    return 2;
+                }
+            if (hipEventRecord(h->sp_ev[0], (hipStream_t)stream) != hipSuccess) { scail_set_error("hipEventRecord failed"); return 2; }
+            for (int j = 0; j < (B < 2 ? (int)B : 2); ++j)
+                if (hipStreamWaitEvent((hipStream_t)sp->side_stream[j], h->sp_ev[0], 0) != hipSuccess) { scail_set_error("hipStreamWaitEvent failed"); return 2; }
+        }
+        for (int64_t b = 0; b < B; ++b) {
+            void* s = st(b);
+            scail_bf16* qb = qkv + b * Ltok * 3 * D;
+            scail_bf16* send = sp->send + b * 3 * N * slab;             // [3][N][Ltok][Dn]: q | k | v, one slab per destination rank
+            DIT_PROF_S(SCAIL_DIT_PROF_GEMM, s, scail_gemm_bf16(bf.xn + b * Ltok * D, D, lw.qkv_w, lw.qkv_b, qb, 3 * D, Ltok, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
+            // the norm + RoPE kernels write the send layout themselves; v is a plain copy into it
+            DIT_TRY(scail_rmsnorm_rope_slabs(qb + D, 3 * D, send + N * slab, Dn, slab, lw.kn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, 1.0f, s));
+            DIT_TRY(scail_rmsnorm_rope_slabs(qb, 3 * D, send, Dn, slab, lw.qn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, ATTN_LOG2_SCALE, s));
+            DIT_TRY(scail_rmsnorm_rope_slabs(qb + 2 * D, 3 * D, send + 2 * N * slab, Dn, slab, nullptr, nullptr, nullptr, Ltok, Ltok, D, 128, eps, 1.0f, s));
+            DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_START, i, b, s));
+        }
+        for (int64_t b = 0; b < B; ++b) {
+            void* s = st(b);
+            DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_WAIT, i, b, s));
+            const scail_bf16* recv = sp->recv + b * 3 * N * slab;       // [3][N * Ltok][Dn]: all ranks' tokens (rank-major), my heads
+            scail_bf16* vt = bf.vt + b * Hn * 128 * Lfp;
+            scail_bf16* of = sp->ofull + b * N * slab;
+            DIT_TRY(scail_transpose_v(recv + 2 * N * slab, Dn, 0, vt, 1, Hn, 128, Lf, s));
+            DIT_PROF_S(SCAIL_DIT_PROF_SELF_ATTN, s, scail_flash_attn_bf16(recv, 0, Dn, recv + N * slab, 0, 0, Dn, vt, 0, 0, of, 0, Dn, 1, Hn, Lf, Lf, 1,
+                                                                          SCAIL_ATTN_Q_PRESCALED, 0, s));
+            DIT_TRY(sp_exchange(sp, SCAIL_SP_BACK_START, i, b, s));
+        }
+        for (int64_t b = 0; b < B; ++b) {
+            void* s = st(b);
+            DIT_TRY(sp_exchange(sp, SCAIL_SP_BACK_WAIT, i, b, s));
+            // back[b][g] = my tokens, head group g  ->  att rows (token, all columns)
+            DIT_TRY(scail_slabs_to_rows(sp->back + b * N * slab, Dn, slab, bf.att + b * Ltok * D, D, Ltok, D, s));
+        }
+        if (side)
+            for (int j = 0; j < (B < 2 ? (int)B : 2); ++j) {
+                if (hipEventRecord(h->sp_ev[1 + j], (hipStream_t)sp->side_stream[j]) != hipSuccess ||
+                    hipStreamWaitEvent((hipStream_t)stream, h->sp_ev[1 + j], 0) != hipSuccess) {
+                    scail_set_error("scail_dit (sequence parallel): joining the side streams failed");
+                    return 2;
+                }
+            }
+    } else {
+        // ONE exchange per layer: all-gather of the post-norm, post-RoPE K rows and of the V rows; K / V projection per element first
+        // so that element b's gather runs under element b + 1's projection and the Q projection of all elements.
+        const int64_t rowsD = Ltok * D;
+        for (int64_t b = 0; b < B; ++b) {
+            scail_bf16* qb = qkv + b * Ltok * 3 * D;
+            scail_bf16* send = sp->send + b * 2 * rowsD;                // [2][Ltok][D]: k rows | v rows
+            const scail_bf16* xb = bf.xn + b * rowsD;
+            DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xb, D, lw.qkv_w + D * D, lw.qkv_b + D, qb + D, 3 * D, Ltok, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+            DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xb, D, lw.qkv_w + 2 * D * D, lw.qkv_b + 2 * D, send + rowsD, D, Ltok, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+            DIT_TRY(scail_rmsnorm_rope(qb + D, 3 * D, send, D, lw.kn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, stream));
+            DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_START, i, b, stream));
+        }
+        DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(bf.xn, D, lw.qkv_w, lw.qkv_b, q, 3 * D, B * Ltok, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+        DIT_TRY(scail_rmsnorm_rope_scaled(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, B * Ltok, Ltok, D, 128, eps, ATTN_LOG2_SCALE, stream));
+        for (int64_t b = 0; b < B; ++b) {
+            DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_WAIT, i, b, stream));
+            const scail_bf16* recv = sp->recv + b * 2 * N * rowsD;      // [2][N * Ltok][D]: gathered k rows | v rows, rank-major
+            scail_bf16* vt = bf.vt + b * nh * 128 * Lfp;
+            DIT_TRY(scail_transpose_v(recv + N * rowsD, D, 0, vt, 1, nh, 128, Lf, stream));
+            DIT_PROF(SCAIL_DIT_PROF_SELF_ATTN, scail_flash_attn_bf16(q + b * Ltok * 3 * D, 0, 3 * D, recv, 0, 0, D, vt, 0, 0, bf.att + b * rowsD, 0, D, 1, nh, Ltok, Lf, 1,
+                                                                     SCAIL_ATTN_Q_PRESCALED, 0, stream));
+        }
+    }
+    return block_post(h, i, hid, bf.att, q, bf.xn, bf.ff, m, cond, B, 0, B, Ltok, stream);
+}
+
 // Seam B2 (SAT hook layer_forward): one block on caller-owned hidden states.  Workspace: scail_dit_block_workspace_bytes.
-static int64_t block_ws(const scail_dit_config& c, int64_t B, int64_t Ltok, int64_t* off) {
-    const int64_t D = c.hidden_size, FF = c.inner_hidden_size, nh = c.num_heads, Lp = (Ltok + 63) / 64 * 64;
+static int64_t block_ws(const scail_dit_config& c, int64_t B, int64_t Ltok, int sp_mode, int64_t ranks, int64_t* off) {
+    const int64_t D = c.hidden_size, FF = c.inner_hidden_size;
     int64_t o = 0;
-    const int64_t sizes[5] = {B * Ltok * D * 2, B * Ltok * 3 * D * 2, B * Ltok * D * 2, B * Ltok * FF * 2, B * nh * 128 * Lp * 2};
+    const int64_t sizes[5] = {B * Ltok * D * 2, B * Ltok * 3 * D * 2, B * Ltok * D * 2, B * Ltok * FF * 2, vt_elems(c, B, Ltok, sp_mode, ranks) * 2};
     for (int j = 0; j < 5; ++j) { off[j] = o; o += align256(sizes[j]); }
     return o;
 }
 extern "C" int64_t scail_dit_block_workspace_bytes(const scail_dit* h, int64_t B, int64_t Ltok) {
     if (h == nullptr || B <= 0 || Ltok <= 0) return -1;
     int64_t off[5];
-    return block_ws(h->cfg, B, Ltok, off);
+    return block_ws(h->cfg, B, Ltok, -1, 1, off);
+}
+extern "C" int64_t scail_dit_block_sp_workspace_bytes(const scail_dit* h, int32_t mode, int32_t ranks, int64_t B, int64_t Ltok) {
+    if (h == nullptr || B <= 0 || Ltok <= 0 || ranks < 2 || (mode != SCAIL_SP_ALLGATHER && mode != SCAIL_SP_ULYSSES)) return -1;
+    if (mode == SCAIL_SP_ULYSSES && h->cfg.num_heads % ranks != 0) return -1;
+    int64_t off[5];
+    return block_ws(h->cfg, B, Ltok, mode, ranks, off);
+}
+extern "C" int scail_dit_block_sp(scail_dit* h, int64_t layer, scail_bf16* hidden, const float* mod, const scail_dit_cond* cond,
+                                  const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok, const scail_dit_sp* sp,
+                                  void* workspace, int64_t workspace_bytes, void* stream) {
+    SCAIL_REQUIRE(h != nullptr && hidden != nullptr && mod != nullptr && cond != nullptr, "null argument");
+    SCAIL_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && B > 0 && Ltok > 0, "bad layer / shape");
+    DIT_TRY(sp_check(h, sp));
+    int64_t off[5];
+    const int64_t need = block_ws(h->cfg, B, Ltok, sp->mode, sp->ranks, off);
+    SCAIL_REQUIRE(workspace != nullptr && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
+                  "workspace too small or not 256-byte aligned (scail_dit_block_sp_workspace_bytes)");
+    char* base = static_cast<char*>(workspace);
+    auto P = [&](int j) { return reinterpret_cast<scail_bf16*>(base + off[j]); };
+    const BlockBufs bf{P(0), P(1), P(2), P(3), P(4)};
+    return dit_block_sp(h, layer, hidden, mod, cond, rope_cos, rope_sin, B, Ltok, bf, sp, stream);
 }
 extern "C" int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, const float* mod, const scail_dit_cond* cond,
                                const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok,
@@ -169,12 +356,13 @@ extern "C" int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, 
     SCAIL_REQUIRE(h != nullptr && hidden != nullptr && mod != nullptr && cond != nullptr, "null argument");
     SCAIL_REQUIRE(layer >= 0 && layer < h->cfg.num_layers && B > 0 && Ltok > 0, "bad layer / shape");
     int64_t off[5];
-    const int64_t need = block_ws(h->cfg, B, Ltok, off);
+    const int64_t need = block_ws(h->cfg, B, Ltok, -1, 1, off);
     SCAIL_REQUIRE(workspace != nullptr && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
                   "workspace too small or not 256-byte aligned (scail_dit_block_workspace_bytes)");
     char* base = static_cast<char*>(workspace);
     auto P = [&](int j) { return reinterpret_cast<scail_bf16*>(base + off[j]); };
-    return dit_block(h, layer, hidden, mod, cond, rope_cos, rope_sin, B, Ltok, P(0), P(1), P(2), P(3), P(4), stream);
+    const BlockBufs bf{P(0), P(1), P(2), P(3), P(4)};
+    return dit_block(h, layer, hidden, mod, cond, rope_cos, rope_sin, B, Ltok, bf, 0, Ltok, stream);
 }
 
 extern "C" int scail_dit_create(const scail_dit_config* cfg, const scail_dit_weights* w, scail_dit** out) {
@@ -198,9 +386,12 @@ extern "C" int scail_dit_create(const scail_dit_config* cfg, const scail_dit_wei
 }
 
 extern "C" void scail_dit_destroy(scail_dit* h) {
-    if (h != nullptr)
+    if (h != nullptr) {
         for (ProfPool& p : h->pool)
             for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->sp_ev)
+            if (e != nullptr) (void)hipEventDestroy(e);
+    }
     delete h;
 }
 
@@ -239,29 +430,58 @@ extern "C" int64_t scail_dit_workspace_bytes(const scail_dit* h, int64_t B, int6
     if (h == nullptr || B <= 0 || T <= 0 || H <= 0 || W <= 0 || H % 4 != 0 || W % 4 != 0) return -1;
     return layout(h->cfg, B, T, H, W).total;
 }
+extern "C" int64_t scail_dit_sp_workspace_bytes(const scail_dit* h, int32_t mode, int32_t ranks, int64_t B, int64_t T, int64_t H, int64_t W) {
+    if (h == nullptr || B <= 0 || T <= 0 || H <= 0 || W <= 0 || H % 4 != 0 || W % 4 != 0 || ranks < 2) return -1;
+    if (mode != SCAIL_SP_ALLGATHER && mode != SCAIL_SP_ULYSSES) return -1;
+    if (mode == SCAIL_SP_ULYSSES && h->cfg.num_heads % ranks != 0) return -1;
+    return layout(h->cfg, B, T, H, W, mode, ranks).total;
+}
+
+static int dit_step_impl(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
+                         const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
+                         const float* rope_cos, const float* rope_sin, float* out,
+                         int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, void* workspace, int64_t workspace_bytes,
+                         void* stream);
 
 extern "C" int scail_dit_step(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
                               const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
                               const float* rope_cos, const float* rope_sin, float* out,
                               int64_t B, int64_t T, int64_t H, int64_t W, void* workspace, int64_t workspace_bytes,
                               void* stream) {
+    return dit_step_impl(h, x, timesteps, cond, ref, n_ref, pose, n_pose, rope_cos, rope_sin, out, B, T, H, W, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int scail_dit_step_sp(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
+                                 const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
+                                 const float* rope_cos, const float* rope_sin, float* out,
+                                 int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+    SCAIL_REQUIRE(h != nullptr, "null handle");
+    DIT_TRY(sp_check(h, sp));
+    return dit_step_impl(h, x, timesteps, cond, ref, n_ref, pose, n_pose, rope_cos, rope_sin, out, B, T, H, W, sp, workspace, workspace_bytes, stream);
+}
+
+// x (B, T, 16, H, W): the whole latent (sp == nullptr) or this rank's H- or W-slab of it (rope tables rank-shifted by the host)
+static int dit_step_impl(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
+                         const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
+                         const float* rope_cos, const float* rope_sin, float* out,
+                         int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
     SCAIL_REQUIRE(h != nullptr && cond != nullptr, "null handle / conditioning");
     SCAIL_REQUIRE(B > 0 && B <= 8 && T > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "latent batch must be 1..8, H and W multiples of 4");
     SCAIL_REQUIRE((n_ref == 1 || n_ref == B) && (n_pose == 1 || n_pose == B), "ref / pose batch must be 1 or B");
     SCAIL_REQUIRE(cond->Bc == 1 || cond->Bc == B, "clip batch must be 1 or B");
     const scail_dit_config& c = h->cfg;
-    const Ws s = layout(c, B, T, H, W);
+    const Ws s = sp ? layout(c, B, T, H, W, sp->mode, sp->ranks) : layout(c, B, T, H, W);
     SCAIL_REQUIRE(c.time_embed_dim == c.hidden_size, "final-layer table add needs time_embed_dim == hidden_size");
     SCAIL_REQUIRE(workspace != nullptr && workspace_bytes >= s.total, "workspace too small (scail_dit_workspace_bytes)");
     SCAIL_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
 
-    const int64_t D = c.hidden_size, FF = c.inner_hidden_size, nh = c.num_heads, nl = c.num_layers;
+    const int64_t D = c.hidden_size, nl = c.num_layers;
     const float eps = c.layernorm_epsilon;
     const int64_t hp = H / 2, wp = W / 2;
     const int64_t Lref = hp * wp, Lnoise = T * hp * wp, Lpose = T * (H / 4) * (W / 4);
     const int64_t Ltok = Lref + Lnoise + Lpose, Lrn = Lref + Lnoise;
-    const int64_t Lp = (Ltok + 63) / 64 * 64;
-    const int64_t Ltp = (cond->Lt + 63) / 64 * 64, Lcp = (cond->Lc + 63) / 64 * 64;
     char* base = static_cast<char*>(workspace);
     auto B16 = [&](int64_t off) { return reinterpret_cast<scail_bf16*>(base + off); };
     auto F32 = [&](int64_t off) { return reinterpret_cast<float*>(base + off); };
@@ -270,7 +490,6 @@ extern "C" int scail_dit_step(scail_dit* h, const float* x, const float* timeste
     float *temb = F32(s.temb), *e1 = F32(s.e1), *emb = F32(s.emb), *adaln = F32(s.adaln), *mod = F32(s.mod);
     float *emb2 = F32(s.emb2), *fin = F32(s.fin);
     const scail_dit_weights& w = h->w;
-    const float scale = 0.08838834764831845f;   // 1 / sqrt(128)
 
     // ---- time / AdaLN tables (dit...:1521-1555, :1025-1028, :823) ----
     DIT_TRY(scail_timestep_embedding(timesteps, temb, B, c.time_freq_dim, stream));
@@ -294,8 +513,17 @@ extern "C" int scail_dit_step(scail_dit* h, const float* x, const float* timeste
                                 KPAD, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
     }
 
-    for (int64_t i = 0; i < nl; ++i)
-        DIT_TRY(dit_block(h, i, hid, mod + i * B * 6 * D, cond, rope_cos, rope_sin, B, Ltok, xn, qkv, att, ff, vt, stream));
+    const BlockBufs bf{xn, qkv, att, ff, vt};
+    for (int64_t i = 0; i < nl; ++i) {
+        if (sp != nullptr) {
+            DIT_TRY(dit_block_sp(h, i, hid, mod + i * B * 6 * D, cond, rope_cos, rope_sin, B, Ltok, bf, sp, stream));
+        } else {
+            // the last layer's output is only read at the noise tokens (final layer below): queries / out-projection / cross attention /
+            // MLP of its ref and pose rows are skipped (23 % of that layer's post-K/V work; same result)
+            const bool last = i == nl - 1;
+            DIT_TRY(dit_block(h, i, hid, mod + i * B * 6 * D, cond, rope_cos, rope_sin, B, Ltok, bf, last ? Lref : 0, last ? Lnoise : Ltok, stream));
+        }
+    }
 
     // ---- final layer on the noise tokens only + unpatchify (dit...:818-835, :764-784) ----
     DIT_TRY(scail_ln_modulate(hid, D, xf, D, fin, fin + D, 2 * D, B, Lnoise, Ltok, Lref, D, eps, stream));

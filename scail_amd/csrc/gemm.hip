@@ -591,7 +591,7 @@ static_assert(sizeof(Gemm4Args) == 112, "Gemm4Args must match asmgen/gemm4.py KE
 // per-device caches (a code object / a hipMalloc'd table belongs to the device that was current when it was created)
 static std::map<std::pair<int, int>, hipModule_t> g_gemm4_modules;          // (device, 4 | 8) -> loaded code object
 static std::map<std::pair<int, std::string>, hipFunction_t> g_gemm4_fn;     // (device, kernel name)
-static std::map<std::tuple<int, int, int>, std::pair<uint32_t*, int>> g_gemm4_tables;   // (device, m tiles * 8 + group, n tiles) -> device order table, entries
+static std::map<std::tuple<int, int, int, int, int>, std::pair<uint32_t*, int>> g_gemm4_tables;   // (device, m tiles, n tiles, group height, table mode) -> device order table, entries
 static std::mutex g_gemm4_mutex;
 static int g_gemm4_mode = 4;               // generated kernels where eligible: 4 = gemm4 (default), 0 = never (csrc/gemm.hip only), 8 = gemm8 (measurement build)
 static std::string g_gemm4_suffix;         // A/B variants of the measurement build ("gemm4_kernel:<suffix>")
@@ -643,14 +643,15 @@ static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev_table, int* e
         scail_set_error("gemm4: hipGetDevice failed");
         return 2;
     }
-    auto key = std::make_tuple(dev, (tm * 8 + (group_m & 7)) * 4 + g_gemm4_table_mode, tn);
+    const int table_mode = g_gemm4_table_mode;      // read once, under the mutex (scail_tune_set writes it under the same mutex)
+    auto key = std::make_tuple(dev, tm, tn, group_m, table_mode);
     auto it = g_gemm4_tables.find(key);
     if (it == g_gemm4_tables.end()) {
         // per-XCD tile sequences (workgroup b runs on XCD b % 8 and takes entry b >> 3 of that XCD's sequence)
         std::vector<std::vector<uint32_t>> seq(8);
         auto tile = [](int m, int n) { return (uint32_t)m | ((uint32_t)n << 16); };
         const int n_groups = (tm + group_m - 1) / group_m;
-        if (g_gemm4_table_mode == 0) {
+        if (table_mode == 0) {
             // (round 1 / 2, measurement build) every XCD walks a contiguous range of the grouped order: 8 distant m-regions
             std::vector<uint32_t> order;
             for (int g0 = 0; g0 < tm; g0 += group_m)
@@ -659,7 +660,7 @@ static int gemm4_table(int tm, int tn, int group_m, uint32_t** dev_table, int* e
             const int T = (int)order.size(), per = (T + 7) / 8;
             for (int x = 0; x < 8; ++x)
                 for (int i = x * per; i < std::min((x + 1) * per, T); ++i) seq[x].push_back(order[i]);
-        } else if (g_gemm4_table_mode == 1) {
+        } else if (table_mode == 1) {
             // default (round 3): m-groups dealt round-robin: the 8 XCDs work on 8 ADJACENT m-groups and sweep n together, so a W
             // panel is wanted by all XCDs at about the same time (one HBM fetch, seven Infinity-Cache hits): +1.0-1.8 % on the qkv /
             // MLP shapes over the contiguous ranges (profiles/r03_gemm_table_modes.log), neutral on the N = 5120 ones.
@@ -715,7 +716,9 @@ static int gemm4_cu_count() {
     return it->second;
 }
 
-// Frees the tile-order tables of EVERY device (scail_release_caches, include/scail_hip.h): call with no launch in flight.
+// Frees the tile-order tables of EVERY device (scail_release_caches, include/scail_hip.h): call with no launch in flight.  A table's
+// device pointer is a kernel argument of every gemm4 launch, so it is baked into any hipGraph captured from such launches: graphs
+// captured before this call must be destroyed or re-captured, never replayed.
 int scail_gemm4_release_tables() {
     std::lock_guard<std::mutex> lk(g_gemm4_mutex);
     int cur = 0;
@@ -755,6 +758,7 @@ int scail_gemm4_enable(int on) { g_gemm4_mode = on ? 4 : 0; return 0; }
 #ifdef SCAIL_ABLATIONS
 int scail_gemm4_knob(const char* knob, int value) {
     std::string k(knob);
+    std::lock_guard<std::mutex> lk(g_gemm4_mutex);      // gemm4_table / the launch read these under the same mutex
     if (k == "gemm4") { g_gemm4_mode = (value == 4 || value == 8) ? value : (value ? 4 : 0); return 0; }
     if (k == "gemm4_table") { g_gemm4_table_mode = (value >= 0 && value <= 2) ? value : 1; return 0; }
     if (k.rfind("gemm4_kernel", 0) == 0) { g_gemm4_suffix = k.size() > 13 ? "_" + k.substr(13) : ""; return 0; }

@@ -410,6 +410,32 @@ extern "C" int scail_rmsnorm_rope_slabs(const scail_bf16* x, int64_t ldx, scail_
     return rmsnorm_rope_launch(x, ldx, y, 0, w, cos_tab, sin_tab, rows, rows_per_batch, D, head_dim, eps, out_scale, slab_w, slab_stride, stream);
 }
 
+// slabs -> rows: the way back of the Ulysses exchange (the inverse layout of scail_rmsnorm_rope_slabs): slab g is a dense [rows, slab_w]
+// matrix at x + g * slab_stride; row r of y gets slab g's row r at columns [g * slab_w, (g + 1) * slab_w).  One 16-byte chunk per thread,
+// chunk index fastest along the OUTPUT row (whole-line stores; the loads of a slab row are contiguous too).
+__global__ void slabs_to_rows_kernel(const u16* __restrict__ x, int64_t slab_stride, int slab_chunks, u16* __restrict__ y, int64_t ldy,
+                                     int row_chunks, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int64_t r = i / row_chunks;
+    const int c = (int)(i - r * row_chunks);
+    const int g = c / slab_chunks, j = c - g * slab_chunks;
+    const uint4 v = *reinterpret_cast<const uint4*>(x + g * slab_stride + (r * slab_chunks + j) * 8);
+    *reinterpret_cast<uint4*>(y + r * ldy + (int64_t)c * 8) = v;
+}
+
+extern "C" int scail_slabs_to_rows(const scail_bf16* x, int64_t slab_w, int64_t slab_stride, scail_bf16* y, int64_t ldy,
+                                   int64_t rows, int64_t D, void* stream) {
+    SCAIL_REQUIRE(slab_w > 0 && slab_w % 8 == 0 && D % slab_w == 0, "slab width must be a multiple of 8 that divides D");
+    SCAIL_REQUIRE(ldy % 8 == 0 && slab_stride % 8 == 0 && slab_stride >= rows * slab_w && aligned16(x) && aligned16(y), "16-byte alignment / slab stride");
+    const int64_t total = rows * (D / 8);
+    if (total == 0) return 0;
+    SCAIL_REQUIRE(total / 256 + 1 < (1ll << 31), "too many rows");
+    hipLaunchKernelGGL(slabs_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, slab_stride,
+                       (int)(slab_w / 8), y, ldy, (int)(D / 8), total);
+    return scail_check_launch("slabs_to_rows");
+}
+
 extern "C" int scail_transpose_v(const scail_bf16* v, int64_t ldv, int64_t v_batch_stride,
                                  scail_bf16* vt, int64_t n_batch, int64_t heads, int64_t head_dim,
                                  int64_t Lk, void* stream) {

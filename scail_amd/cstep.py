@@ -39,6 +39,23 @@ class DitCond(C.Structure):
     _fields_ = [("k_text", _p), ("vt_text", _p), ("k_clip", _p), ("vt_clip", _p), ("Lt", _i64), ("Lc", _i64), ("Bc", _i64)]
 
 
+# include/scail_dit.h "sequence-parallel execution": the exchange callback and its descriptor
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p)
+SP_ALLGATHER, SP_ULYSSES = 0, 1
+SP_FWD_START, SP_FWD_WAIT, SP_BACK_START, SP_BACK_WAIT = 0, 1, 2, 3
+
+
+class DitSp(C.Structure):
+    _fields_ = [("ranks", C.c_int32), ("mode", C.c_int32), ("send", _p), ("recv", _p), ("ofull", _p), ("back", _p),
+                ("exchange", EXCHANGE_FN), ("user", _p), ("side_stream", _p * 2)]
+
+
+def _cond_struct(cond: Dict) -> "DitCond":
+    k_text, k_clip = cond["k_text"], cond["k_clip"]
+    return DitCond(k_text.data_ptr(), cond["vt_text"].data_ptr(), k_clip.data_ptr(), cond["vt_clip"].data_ptr(),
+                   k_text.shape[2], k_clip.shape[2], k_clip.shape[1])
+
+
 class CStep:
     """Handle around scail_dit_create / scail_dit_step for one prepared network (``net.prepare()`` dict)."""
 
@@ -144,4 +161,45 @@ class CStep:
         assert hidden.is_contiguous() and mod.is_contiguous() and mod.dtype == torch.float32
         L.call("scail_dit_block", self._h, layer, hidden.data_ptr(), mod.data_ptr(), C.byref(cc), cos.data_ptr(), sin.data_ptr(),
                B, Ltok, self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
+        return hidden
+
+    # ---- sequence-parallel rank (include/scail_dit.h: scail_dit_step_sp / scail_dit_block_sp) ----
+    def _sp_call(self, name, xch, *args):
+        """Run one executor call whose collectives go through ``xch`` (scail_amd.parallel.CExchange); an exception raised inside the
+        callback is re-raised here (the executor only sees a non-zero status)."""
+        xch.error = None
+        try:
+            L.call(name, *args)
+        except L.ScailHipError:
+            if xch.error is not None:
+                raise xch.error
+            raise
+
+    def _ws_for(self, need, device):
+        if need < 0:
+            raise L.ScailHipError("sequence-parallel workspace: bad shape / mode")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, device=device, dtype=torch.uint8)
+        return self._ws
+
+    def step_sp(self, x32, t32, cond: Dict, ref, pose, cos, sin, xch) -> torch.Tensor:
+        """One network evaluation on this rank's latent slab (scail_dit_step_sp); ``xch`` owns the exchange buffers and issues the
+        collectives from the executor's callback."""
+        B, T, _, H, W = x32.shape
+        ws = self._ws_for(L.load().scail_dit_sp_workspace_bytes(self._h, xch.mode_code, xch.size, B, T, H, W), x32.device)
+        cc, sp = _cond_struct(cond), xch.descriptor()
+        out = torch.empty(B, T, 16, H, W, device=x32.device, dtype=torch.float32)
+        self._sp_call("scail_dit_step_sp", xch, self._h, x32.data_ptr(), t32.data_ptr(), C.byref(cc), ref.data_ptr(), ref.shape[0],
+                      pose.data_ptr(), pose.shape[0], cos.data_ptr(), sin.data_ptr(), out.data_ptr(), B, T, H, W, C.byref(sp),
+                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def block_sp(self, layer: int, hidden: torch.Tensor, mod: torch.Tensor, cond: Dict, cos, sin, xch) -> torch.Tensor:
+        """Seam B2 for a sequence-parallel rank: one block in place on this rank's ``hidden`` (B, Ltok, D)."""
+        B, Ltok, _ = hidden.shape
+        ws = self._ws_for(L.load().scail_dit_block_sp_workspace_bytes(self._h, xch.mode_code, xch.size, B, Ltok), hidden.device)
+        cc, sp = _cond_struct(cond), xch.descriptor()
+        assert hidden.is_contiguous() and mod.is_contiguous() and mod.dtype == torch.float32
+        self._sp_call("scail_dit_block_sp", xch, self._h, layer, hidden.data_ptr(), mod.data_ptr(), C.byref(cc), cos.data_ptr(), sin.data_ptr(),
+                      B, Ltok, C.byref(sp), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         return hidden

@@ -457,13 +457,18 @@ class DiffusionTransformer(nn.Module):
             raise L.ScailHipError("context batch must equal the (CFG-doubled) input batch")
         cond = self._conditioning(ctx, clip, cond_key)
         cos, sin = self._rope(T, hp, wp, H_shift, W_shift, dev, n_char)
-        if (n_char == 1 and self.use_c_step and self._tap is None and self.kernel_timer is None
-                and not (self.sp is not None and self.sp.size > 1)):
-            # the whole evaluation as ONE call into the library (include/scail_dit.h); same kernels, same order
-            if self._cstep is None:
-                from .cstep import CStep
-                self._cstep = CStep(self, W)
-            return self._cstep.step(x32, t32, cond, ref.contiguous(), pose.contiguous(), cos, sin)
+        sp = self.sp if (self.sp is not None and self.sp.size > 1) else None
+        use_c = self.use_c_step and self._tap is None and self.kernel_timer is None
+        if use_c and self._cstep is None:
+            from .cstep import CStep
+            self._cstep = CStep(self, W)
+        xch = sp.c_exchange(nh, D, B, Ltok, dev) if (use_c and sp is not None) else None
+        if use_c and n_char == 1:
+            # the whole evaluation as ONE call into the library (include/scail_dit.h); same kernels, same order.  A sequence-parallel
+            # rank runs the same executor: only the collectives of the per-layer exchange come back to the host (xch)
+            if sp is None:
+                return self._cstep.step(x32, t32, cond, ref.contiguous(), pose.contiguous(), cos, sin)
+            return self._cstep.step_sp(x32, t32, cond, ref.contiguous(), pose.contiguous(), cos, sin, xch)
         ws = self._workspace(B, Ltok, Lnoise, dev)
 
         # ---- time / AdaLN tables (reference :1521-1555, :1025-1028, :823) ----
@@ -495,9 +500,15 @@ class DiffusionTransformer(nn.Module):
 
         xn, qkv, att, ff, vt = ws["xn"], ws["qkv"], ws["att"], ws["ff"], ws["vt"]
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
-        sp = self.sp if (self.sp is not None and self.sp.size > 1) else None
         for i, lw in enumerate(W["layers"]):
             m = mod[i]                                                        # (B, 6D)
+            if use_c:
+                # (multi-character extension: token assembly above in the host, every block as one executor call)
+                if sp is None:
+                    self._cstep.block(i, h, m, cond, cos, sin)
+                else:
+                    self._cstep.block_sp(i, h, m, cond, cos, sin, xch)
+                continue
             sh_a, sc_a, g_a = m[:, 0:D], m[:, D:2 * D], m[:, 2 * D:3 * D]
             sh_m, sc_m, g_m = m[:, 3 * D:4 * D], m[:, 4 * D:5 * D], m[:, 5 * D:6 * D]
             # -- self attention (:1031-1036, :1058-1105) --

@@ -23,6 +23,7 @@ SIGNATURES = {
     "scail_rmsnorm_rope": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _p],
     "scail_rmsnorm_rope_scaled": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
     "scail_rmsnorm_rope_slabs": [_p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
+    "scail_slabs_to_rows": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p],
     "scail_transpose_v": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "scail_flash_attn_bf16": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
@@ -60,6 +61,10 @@ SIGNATURES = {
     "scail_dit_profile_read": [_p, _i, _p, _p],
     "scail_dit_block_workspace_bytes": [_p, _i64, _i64],
     "scail_dit_block": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _i64, _p],
+    "scail_dit_sp_workspace_bytes": [_p, C.c_int32, C.c_int32, _i64, _i64, _i64, _i64],
+    "scail_dit_step_sp": [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p],
+    "scail_dit_block_sp_workspace_bytes": [_p, C.c_int32, C.c_int32, _i64, _i64],
+    "scail_dit_block_sp": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _i64, _p],
     "scail_dit_sample_workspace_bytes": [_p, _i64, _i64, _i64],
     "scail_dit_sample": [_p, _p, _p, _p, _i64, _f, _p, _p, _p, _p, _p, _i64, _i64, _i64, _p, _i64, _p],
     # include/scail_vae.h (scail_amd/cvae.py builds the structs)
@@ -71,7 +76,7 @@ SIGNATURES = {
 }
 # return types other than the int status
 RESTYPES = {"scail_dit_destroy": None, "scail_vae_destroy": None, "scail_vae_workspace_bytes": _i64, "scail_dit_workspace_bytes": _i64, "scail_dit_sample_workspace_bytes": _i64,
-            "scail_dit_block_workspace_bytes": _i64}
+            "scail_dit_block_workspace_bytes": _i64, "scail_dit_sp_workspace_bytes": _i64, "scail_dit_block_sp_workspace_bytes": _i64}
 
 # include/scail_hip_ablation.h: only libscail_hip_abl.so (SCAIL_ABLATIONS=1) exports these
 ABLATION_SIGNATURES = {
@@ -82,7 +87,7 @@ ABLATIONS = LIB_PATH.endswith("_abl.so")
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2          # include/scail_hip.h scail_abi_version: 2 = negative SCAIL_ATTN_Q_PRESCALED sentinel + the SP executor entry points
 
 _lib = None
 

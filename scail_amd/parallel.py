@@ -157,6 +157,77 @@ class ThreadBackend:
         return res
 
 
+class CExchange:
+    """Host side of the C executor's exchange callback (include/scail_dit.h "sequence-parallel execution"): owns the send / recv /
+    ofull / back buffers of one (B, Ltok) shape and starts / awaits the collectives through the group's backend when the executor
+    asks for them.  The executor enqueues every kernel of a block itself; per layer this object only sees 4 (all-gather) or 8
+    (ulysses) callbacks."""
+
+    def __init__(self, sp: "SequenceParallel", heads: int, D: int, B: int, Ltok: int, device):
+        from . import cstep
+        self._cs = cstep
+        self.backend, self.size = sp.backend, sp.size
+        self.mode = sp.resolve_mode(heads)
+        self.mode_code = cstep.SP_ULYSSES if self.mode == "ulysses" else cstep.SP_ALLGATHER
+        N = self.size
+        e = lambda *sh: torch.empty(*sh, device=device, dtype=torch.bfloat16)
+        if self.mode == "ulysses":
+            Dn = D // N
+            self.send, self.recv = e(B, 3, N, Ltok, Dn), e(B, 3, N, Ltok, Dn)
+            self.ofull, self.back = e(B, N, Ltok, Dn), e(B, N, Ltok, Dn)
+        else:
+            self.send, self.recv = e(B, 2, Ltok, D), e(B, 2, N, Ltok, D)
+            self.ofull = self.back = None
+        # two side streams for the two CFG elements up to 4 ranks (DESIGN.md section 6: 4 ranks 91.4 -> 93.9 % compute-side
+        # efficiency, 8 ranks 90.7 -> 89.4 %), none beyond
+        self.side = [torch.cuda.Stream(device=device) for _ in range(2)] if (self.mode == "ulysses" and N <= 4 and torch.device(device).type == "cuda") else None
+        self.device = torch.device(device)
+        self.handles = {}
+        self.error = None
+        self._ext = {}
+        self._cb = cstep.EXCHANGE_FN(self._callback)            # must outlive every call that uses it
+
+    def descriptor(self):
+        cs = self._cs
+        p = lambda t: t.data_ptr() if t is not None else None
+        side = (cs._p * 2)(*( [s.cuda_stream for s in self.side] if self.side else [None, None]))
+        return cs.DitSp(self.size, self.mode_code, p(self.send), p(self.recv), p(self.ofull), p(self.back), self._cb, None, side)
+
+    def _on(self, stream):
+        """context that makes ``stream`` (a hipStream_t value) torch's current stream, so that the collective orders itself
+        against the kernels the executor enqueued there"""
+        ptr = stream or 0
+        if ptr == torch.cuda.current_stream(self.device).cuda_stream:
+            return contextlib.nullcontext()
+        if ptr not in self._ext:
+            self._ext[ptr] = torch.cuda.ExternalStream(ptr, device=self.device)
+        return torch.cuda.stream(self._ext[ptr])
+
+    def _callback(self, user, op, layer, b, stream):
+        cs = self._cs
+        try:
+            with self._on(stream):
+                if op == cs.SP_FWD_START:
+                    if self.mode == "ulysses":
+                        self.handles["f", b] = [self.backend.all_to_all(self.recv[b, j], self.send[b, j], async_op=True) for j in range(3)]
+                    else:
+                        self.handles["f", b] = [self.backend.all_gather_into(self.recv[b, j], self.send[b, j]) for j in range(2)]
+                elif op == cs.SP_FWD_WAIT:
+                    for h in self.handles.pop(("f", b)):
+                        h.wait()
+                elif op == cs.SP_BACK_START:
+                    self.handles["b", b] = [self.backend.all_to_all(self.back[b], self.ofull[b], async_op=True)]
+                elif op == cs.SP_BACK_WAIT:
+                    for h in self.handles.pop(("b", b)):
+                        h.wait()
+                else:
+                    raise L.ScailHipError(f"unknown exchange op {op}")
+            return 0
+        except BaseException as e:              # never let an exception cross the C frame: hand it to CStep._sp_call
+            self.error = e
+            return 1
+
+
 class SequenceParallel:
     """What the engine and the DiT need from a sequence-parallel group."""
 
@@ -170,6 +241,14 @@ class SequenceParallel:
         self.mode = mode
         self._buf = {}
         self._streams = None
+        self._xch = {}
+
+    def c_exchange(self, heads: int, D: int, B: int, Ltok: int, device) -> CExchange:
+        """The exchange object the C executor calls back into (one per (B, Ltok) shape; one shape is kept)."""
+        key = (heads, D, B, Ltok, str(device))
+        if key not in self._xch:
+            self._xch = {key: CExchange(self, heads, D, B, Ltok, device)}
+        return self._xch[key]
 
     def resolve_mode(self, heads: int) -> str:
         if self.mode != "auto":
@@ -315,8 +394,9 @@ class SequenceParallel:
     @staticmethod
     def pack_rows(x, out, w, cos, sin, Ltok, eps, out_scale):
         """x (Ltok, D) view -> out (N, Ltok, D / N): RMSNorm + RoPE (w given) or plain copy (w None) straight into the send layout
-        of the head <-> sequence all-to-all.  On the GPU one kernel (scail_rmsnorm_rope_slabs); the CPU branch serves the gloo /
-        oracle-compute tests of the exchange logic and states what the kernel computes."""
+        of the head <-> sequence all-to-all: one kernel (scail_rmsnorm_rope_slabs).  GPU tensors only -- there is no CPU path; the layout
+        is pinned by tests/test_kernels_gpu.py::test_rmsnorm_rope_slabs: out == rows.view(Ltok, N, D / N).permute(1, 0, 2) of the
+        row-major kernel's result, bit for bit."""
         if x.is_cuda:
             return ops.rmsnorm_rope_slabs(x, w, out, cos, sin, rows_per_batch=Ltok, eps=eps, out_scale=out_scale)
         raise L.ScailHipError("sequence-parallel self-attention needs GPU tensors (scail_amd has no CPU path)")

@@ -52,6 +52,20 @@ def test_bench_two_ranks_one_gpu(mode):
     assert abs(two["config"]["x_abs_mean"] - one["config"]["x_abs_mean"]) < 2e-3 * one["config"]["x_abs_mean"]
 
 
+def test_bench_config5_line_reduced_layers():
+    """BASELINE config 5 (2 reference frames + 2 pose streams in one token sequence, L = 60 032: the long-sequence self-attention stress) through
+    `bench.py --config 14b-2char` at full width and full length with 2 of the 40 layers, so that GPUTEST exercises the code path behind the
+    builder's config-5 number.  The line must say what it is: an EXTENSION (the reference has one reference frame and one pose stream,
+    dit...:1559) whose parity is unpinned by construction, and a debug layer count."""
+    o = _run([sys.executable, "bench.py", "--config", "14b-2char", "--layers", "2", "--steps", "1", "--warmup", "1", "--no-vae", "--no-cpu-baseline"],
+             timeout=900)
+    cfg = o["config"]
+    assert "EXTENSION_not_in_reference" in cfg and "unpinned by construction" in cfg["EXTENSION_not_in_reference"]
+    assert cfg["INVALID_debug_layers"] == 2 and cfg["finite"] and "L=60032" in cfg["workload"]
+    assert cfg["path"].startswith("scail_dit_block per layer (C executor)")
+    assert o["roofline"]["launches_timed"] == 2 and o["roofline"]["achieved"] > 500.0        # the 4-wave kernel at L = 60 032 (measured 1 646 TFLOP/s)
+
+
 def test_fullsize_request_two_steps():
     """BASELINE config-2 SIZES end to end through the driver (SCAIL-14B shapes, 512x896x81f, random-init weights, 2 of the 50
     sampler steps): VAE encode of the reference frame and the pose clip, the C-level sampler loop, VAE decode.  Guards the

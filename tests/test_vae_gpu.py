@@ -321,3 +321,68 @@ def test_conv4_at_vae_resolutions(C, thw):
             ref = torch.einsum("vtabc,nctab->vn", patch, wr) + b
             got = y[t, h, ws_].float()
             torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
+
+
+def _tile_stats(err, th, tw):
+    """err (..., H, W) -> per-(th x tw)-tile max and mean over the trailing two axes (ragged edges ignored: H, W are multiples here)."""
+    *lead, H, W = err.shape
+    t = err.reshape(*lead, H // th, th, W // tw, tw)
+    return t.amax(dim=(-3, -1)), t.mean(dim=(-3, -1))
+
+
+@pytest.mark.parametrize("direction", ["encode", "decode"])
+def test_vae_fullsize_vs_fp32(direction):
+    """BASELINE config 4 at its OWN size through the C executor (scail_vae_encode / scail_vae_decode: video (1,3,81,512,896), latent
+    (1,16,21,64,112)) against oracle/wan_vae_oracle.py evaluated in fp32 ON THE GPU (CONV_IMPL = "taps": every convolution as fp32 matmuls
+    per tap, pinned to the real chunked reference by tests/test_vae_oracle_golden.py): the whole 26 / 33-convolution chain with its temporal
+    rules, the stride-2 / upsample convolutions, whole-sequence (unchunked) execution and the 7 168-token mid attention
+    (reference wan_vae.py:516-568).
+    Criterion (bf16 activations through ~30 layers vs fp32; same form as the DiT's full-size test): cosine >= 0.999; at most 1e-4 of the
+    elements beyond rtol / atol 3e-2 and none beyond 4x that bound; and PER TILE (16 x 16 output pixels per frame for the decoder -- the
+    convolution kernels' own tile; one latent pixel = 8 x 8 video pixels per frame for the encoder) the worst error inside the same 4x bound
+    and the tile's mean error <= 5x the global mean error + 1e-3, so a wrong halo / seam / frame-slot cannot hide in the statistics."""
+    from scail_amd.wan_vae import WanVAE_
+    cfg = V.VAEConfig(dim=96, z_dim=16)
+    sd = V.make_state_dict(cfg, seed=4321)
+    m = WanVAE_(dim=96, z_dim=16, device=DEV)
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected and m.use_c_exec
+    g = torch.Generator(device=DEV).manual_seed(5)
+    if direction == "encode":
+        inp = (torch.rand(1, 3, 81, 512, 896, device=DEV, generator=g) * 2 - 1).to(torch.bfloat16).float()
+        got = m.encode(inp)
+    else:
+        inp = torch.randn(1, 16, 21, 64, 112, device=DEV, generator=g).to(torch.bfloat16).float()
+        got = m.decode(inp)
+    torch.cuda.synchronize()
+    assert m._cvae is not None, "the C executor (include/scail_vae.h) must have run"
+    m._cvae = None                                       # release the executor's arena before the fp32 oracle allocates
+    torch.cuda.empty_cache()
+    sdg = {k: v.to(DEV) for k, v in sd.items()}
+    old = V.CONV_IMPL
+    V.CONV_IMPL = "taps"
+    try:
+        with torch.no_grad():
+            want = V.encode(cfg, sdg, inp) if direction == "encode" else V.decode(cfg, sdg, inp, clamp=False)
+    finally:
+        V.CONV_IMPL = old
+    assert got.shape == want.shape == ((1, 16, 21, 64, 112) if direction == "encode" else (1, 3, 81, 512, 896))
+    assert torch.isfinite(got).all()
+    tol, frac, hard = 3e-2, 1e-4, 4.0
+    err = (got - want).abs()
+    lim = tol + tol * want.abs()
+    rel = err / lim
+    n_bad = int((rel > 1).sum())
+    worst = float(rel.max())
+    gmean = float(err.mean())
+    cos = _cos(got, want)
+    th, tw = (1, 1) if direction == "encode" else (16, 16)
+    tmax, tmean = _tile_stats(rel, th, tw)[0], _tile_stats(err, th, tw)[1]
+    print(f"VAE {direction} 81x512x896 vs fp32 oracle: cosine {cos:.6f}, {n_bad} of {err.numel()} beyond rtol/atol {tol} ({n_bad / err.numel():.2e}), "
+          f"worst {worst:.2f}x the bound, max abs err {float(err.max()):.3e}, mean {gmean:.3e}, |ref| max {float(want.abs().max()):.2f} rms "
+          f"{float(want.pow(2).mean().sqrt()):.3f}; worst tile: max {float(tmax.max()):.2f}x, mean err {float(tmean.max()):.3e}")
+    assert cos >= 0.999
+    assert n_bad <= frac * err.numel(), f"{n_bad} elements beyond tolerance"
+    assert worst <= hard
+    assert float(tmax.max()) <= hard
+    assert float(tmean.max()) <= 5.0 * gmean + 1e-3, "a tile whose mean error stands out: wrong halo / seam / frame slot"

@@ -41,3 +41,19 @@ def test_decode_matches_reference(golden_dir, name):
     with torch.no_grad():
         rec = V.decode(cfg, sd, g["z_in"])
     torch.testing.assert_close(rec, g["rec"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["vae_tiny.npz", "vae_tiny2.npz"])
+def test_tap_matmul_convolutions_match_reference(golden_dir, name, monkeypatch):
+    """CONV_IMPL = "taps" (every convolution as one fp32 matmul per kernel tap over a zero-padded channels-last copy: what lets the oracle
+    run in fp32 on the GPU at config 4's own size, tests/test_vae_gpu.py::test_vae_fullsize_vs_fp32) is the same function: pinned to the
+    real chunked reference's golden like the F.conv3d form, including the stride-2 / upsample / temporal convolutions."""
+    g = _load(golden_dir, name)
+    cfg = V.VAEConfig(dim=int(g["dim"]), z_dim=16)
+    sd = V.make_state_dict(cfg, seed=int(g["seed"]))
+    monkeypatch.setattr(V, "CONV_IMPL", "taps")
+    with torch.no_grad():
+        mu = V.encode(cfg, sd, g["video"])
+        rec = V.decode(cfg, sd, g["z_in"])
+    torch.testing.assert_close(mu, g["mu"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rec, g["rec"], rtol=1e-4, atol=1e-4)

@@ -2,7 +2,9 @@
 replaced by local copies (results are meaningless, the launch sequence and every kernel shape are those of rank 0 in an
 N-rank run).  Gives the compute part of the strong-scaling efficiency -- (T_1 / N) / T_N -- without an N-GPU node; the
 exchange time comes on top.
-usage: sp_rank_compute.py [N ...]      e.g. 1 2 4 8"""
+The timed path is the product's: one scail_dit_step / scail_dit_step_sp call of the C executor per network evaluation, the exchange
+callback served by local copies.  `--host` times the per-op host path (scail_amd.parallel, ~30 binding calls per layer) beside it.
+usage: sp_rank_compute.py [--host] [N ...]      e.g. 1 2 4 8"""
 import json
 import os
 import sys
@@ -48,7 +50,8 @@ T, H, W = 21, 64, 112
 ctx = torch.randn(2, 512, 4096, generator=g).to(dev).to(torch.bfloat16)
 clip = torch.randn(1, 257, 1280, generator=g).to(dev).to(torch.bfloat16)
 base = None
-for N in [int(a) for a in (sys.argv[1:] or ["1", "2", "4", "8"])]:
+HOST = "--host" in sys.argv
+for N in [int(a) for a in ([a for a in sys.argv[1:] if a != "--host"] or ["1", "2", "4", "8"])]:
     sp = SequenceParallel(LocalCopyBackend(N)) if N > 1 else None
     net.sp = sp
     h = H // N
@@ -62,13 +65,21 @@ for N in [int(a) for a in (sys.argv[1:] or ["1", "2", "4", "8"])]:
         v = net.forward_f32(torch.cat([x, x], 0), torch.tensor([700.0, 700.0], device=dev), ctx, None, **kw)
         ops.cfg_euler_(x, v, 4.0, -0.01)
 
-    step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(2):
+    def timed():
         step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 2
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 2
+
+    net.use_c_step = True
+    dt = timed()
     base = base or dt * N
-    print(json.dumps(dict(ranks=N, mode=(sp.resolve_mode(40) if sp else "-"), s_per_step_one_rank=dt,
-                          compute_only_efficiency=(base / N) / dt)), flush=True)
+    rec = dict(ranks=N, mode=(sp.resolve_mode(40) if sp else "-"), path="C executor", s_per_step_one_rank=dt, compute_only_efficiency=(base / N) / dt)
+    if HOST and N > 1:
+        net.use_c_step = False
+        rec["s_per_step_one_rank_host_path"] = timed()
+        rec["compute_only_efficiency_host_path"] = (base / N) / rec["s_per_step_one_rank_host_path"]
+    print(json.dumps(rec), flush=True)
