@@ -72,6 +72,15 @@ typedef struct scail_vae scail_vae;
 int scail_vae_create(const scail_vae_weights* w, scail_vae** out);
 void scail_vae_destroy(scail_vae* h);
 
+/* Debug seam (what a forward hook on the reference's modules gives its maintainers): after every operator launch that completes a whole
+ * activation -- convolutions, RMS_norm(+SiLU) passes, the mid-block attention -- `fn(user, index, op, data, T, H, W, C)` is called on the
+ * host with the channels-last bf16 tensor [T][H][W][C] inside the workspace that the launch writes.  The launch is only ENQUEUED at that
+ * point: the callback must order itself after the stream (enqueue its own work on the same stream, or synchronise) before reading, and
+ * must not write.  The call sequence is the launch order of scail_amd/wan_vae.py's layer-by-layer path (tools/vae_exec_vs_layers.py
+ * walks both).  fn == NULL switches it off (the default; nothing is called, nothing synchronises). */
+typedef void (*scail_vae_trace_fn)(void* user, int index, const char* op, const void* data, int64_t T, int64_t H, int64_t W, int64_t C);
+int scail_vae_set_trace(scail_vae* h, scail_vae_trace_fn fn, void* user);
+
 /* Device workspace for a clip of T frames of H x W pixels (T = 1 + 4n, H and W multiples of 8); the same size serves decode. */
 int64_t scail_vae_workspace_bytes(const scail_vae* h, int64_t T, int64_t H, int64_t W);
 

@@ -10,6 +10,8 @@
 struct scail_vae {
     scail_vae_weights w;
     std::vector<scail_vae_stage> enc, dec;
+    scail_vae_trace_fn trace = nullptr;
+    void* trace_user = nullptr;
 };
 
 namespace {
@@ -31,6 +33,13 @@ struct Arena {
     bool used[NSLOT] = {false, false, false, false, false, false};
     void* stream;
     int err = 0;
+    scail_vae_trace_fn trace = nullptr;     // scail_vae_set_trace: called after every operator launch whose output is a whole activation
+    void* trace_user = nullptr;
+    int trace_n = 0;
+    void emit(const char* op, const Tens& t) {
+        if (trace) trace(trace_user, trace_n, op, t.p, t.T, t.H, t.W, t.C);
+        ++trace_n;
+    }
     Tens get(int64_t T, int64_t H, int64_t W, int64_t C) {
         Tens t;
         t.T = T; t.H = H; t.W = W; t.C = C;
@@ -60,7 +69,9 @@ int conv(Arena& a, const Tens& x, const scail_conv_w& cw, Tens& out, int64_t To,
     SCAIL_REQUIRE(x.C == cw.Cin, "scail_vae: channel mismatch between an activation and its convolution");
     int32_t geom[21] = {(int32_t)x.T, (int32_t)x.H, (int32_t)x.W, (int32_t)x.C, (int32_t)To, (int32_t)Ho, (int32_t)Wo,
                         cw.kt, cw.kh, cw.kw, st, sh, sw, pt, ph, pw, ups, ot_mul, ot_off, cw.N, cw.Kpad};
-    return scail_conv3d_cl(x.p, cw.w, cw.b, out.p, out.C, resid ? resid->p : nullptr, resid ? resid->C : 0, geom, a.stream);
+    VAE_TRY(scail_conv3d_cl(x.p, cw.w, cw.b, out.p, out.C, resid ? resid->p : nullptr, resid ? resid->C : 0, geom, a.stream));
+    if (ot_mul == 1) a.emit("conv", out);         // (the two interleaved halves of an upsample3d time_conv are seen through the resample conv)
+    return 0;
 }
 
 // ResidualBlock (wan_vae.py:180-218); consumes x
@@ -70,6 +81,7 @@ int res_block(Arena& a, const scail_vae_res& r, Tens& x) {
     if (sc) VAE_TRY(conv(a, x, r.shortcut, h, x.T, x.H, x.W));
     y = a.get(x.T, x.H, x.W, x.C); VAE_CHK(a)
     VAE_TRY(scail_rms_silu(x.p, y.p, r.gamma0, x.vox(), x.C, 1, a.stream));
+    a.emit("rms_silu", y);
     int32_t geom[21] = {(int32_t)y.T, (int32_t)y.H, (int32_t)y.W, (int32_t)y.C, (int32_t)x.T, (int32_t)x.H, (int32_t)x.W,
                         3, 3, 3, 1, 1, 1, 2, 1, 1, 0, 1, 0, r.conv2.N, r.conv2.Kpad};
     if (r.conv2.kt == 3 && r.conv2.kh == 3 && r.conv2.kw == 3 && y.C % 32 == 0 && r.conv2.N <= 96 &&
@@ -79,11 +91,13 @@ int res_block(Arena& a, const scail_vae_res& r, Tens& x) {
         // on the 96-channel full-resolution shape).
         y2 = a.get(x.T, x.H, x.W, r.conv2.N); VAE_CHK(a)
         VAE_TRY(scail_conv3d_cl_norm(y.p, r.conv2.w, r.conv2.b, y2.p, y2.C, r.gamma3, geom, a.stream));
+        a.emit("conv_norm", y2);
         a.put(y);
     } else {
         VAE_TRY(conv(a, y, r.conv2, y2, x.T, x.H, x.W));
         a.put(y);
         VAE_TRY(scail_rms_silu(y2.p, y2.p, r.gamma3, y2.vox(), y2.C, 1, a.stream));
+        a.emit("rms_silu", y2);
     }
     VAE_TRY(conv(a, y2, r.conv6, out, x.T, x.H, x.W, 1, 1, 1, -1, -1, -1, 0, 1, 0, &h));
     a.put(y2);
@@ -99,6 +113,7 @@ int attn_block(Arena& a, const scail_vae_attn& at, Tens& x) {
     SCAIL_REQUIRE(C == at.C && nt <= 32768, "scail_vae: mid-block attention handles up to 32768 tokens per frame ((H/8)*(W/8))");
     Tens y = a.get(x.T, x.H, x.W, C); VAE_CHK(a)
     VAE_TRY(scail_rms_silu(x.p, y.p, at.gamma, x.vox(), C, 0, a.stream));
+    a.emit("rms_silu", y);
     Tens tmp = a.get(1, 1, 1, 0); VAE_CHK(a)          // one slot, carved up below
     const int64_t act = align256((T * nt + 8) * C * 2);       // + 8 rows: the score GEMM reads k rows up to ceil8(nt) of the last frame
     SCAIL_REQUIRE(4 * act + align256(nt * npad * 2) + align256(C * npad * 2) <= a.slot_bytes, "scail_vae: attention temporaries exceed a slot");
@@ -115,7 +130,9 @@ int attn_block(Arena& a, const scail_vae_attn& at, Tens& x) {
         scail_set_error("scail_vae: hipMemsetAsync failed");
         return 2;
     }
-    const float scale = 1.0f / std::sqrt((float)C);
+    // in double, then rounded once: what Python's 1.0 / math.sqrt(C) hands the operator seam (and SDPA's default scale in the reference); the
+    // float expression 1.0f / sqrtf(C) is one ulp off at C = 384, which made this executor differ from the layer path in the last bit
+    const float scale = (float)(1.0 / std::sqrt((double)C));
     for (int64_t f = 0; f < T; ++f) {
         const scail_bf16 *qf = q + f * nt * C, *kf = k + f * nt * C, *vf = v + f * nt * C;
         // N = ceil8(nt): the up to 7 extra score columns come from the next frame's keys (or the pad rows) and are zeroed by the softmax
@@ -126,6 +143,7 @@ int attn_block(Arena& a, const scail_vae_attn& at, Tens& x) {
     }
     Tens out = a.get(x.T, x.H, x.W, C); VAE_CHK(a)
     VAE_TRY(scail_gemm_bf16(o, C, at.proj_w, at.proj_b, out.p, C, M, C, C, SCAIL_EPI_RESID, x.p, C, nullptr, 0, 0, a.stream));
+    a.emit("attn", out);
     a.put(tmp); a.put(y); a.put(x);
     x = out;
     return 0;
@@ -205,6 +223,13 @@ extern "C" int scail_vae_create(const scail_vae_weights* w, scail_vae** out) {
 
 extern "C" void scail_vae_destroy(scail_vae* h) { delete h; }
 
+extern "C" int scail_vae_set_trace(scail_vae* h, scail_vae_trace_fn fn, void* user) {
+    SCAIL_REQUIRE(h != nullptr, "null handle");
+    h->trace = fn;
+    h->trace_user = user;
+    return 0;
+}
+
 extern "C" int64_t scail_vae_workspace_bytes(const scail_vae* h, int64_t T, int64_t H, int64_t W) {
     if (h == nullptr || T <= 0 || (T - 1) % 4 != 0 || H <= 0 || W <= 0 || H % 8 != 0 || W % 8 != 0) return -1;
     return NSLOT * slot_bytes_for(h->w, T, H, W);
@@ -219,6 +244,7 @@ extern "C" int scail_vae_encode(scail_vae* h, const float* video, float* latent,
     a.base = static_cast<char*>(workspace);
     a.slot_bytes = slot_bytes_for(w, T, H, W);
     a.stream = stream;
+    a.trace = h->trace; a.trace_user = h->trace_user;
     SCAIL_REQUIRE(workspace != nullptr && workspace_bytes >= NSLOT * a.slot_bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
                   "workspace too small or not 256-byte aligned (scail_vae_workspace_bytes)");
     Tens x = a.get(T, H, W, 8); VAE_CHK(a)
@@ -236,6 +262,7 @@ extern "C" int scail_vae_encode(scail_vae* h, const float* video, float* latent,
     VAE_TRY(attn_block(a, w.enc_attn, x));
     VAE_TRY(res_block(a, w.enc_mid2, x));
     VAE_TRY(scail_rms_silu(x.p, x.p, w.enc_head_gamma, x.vox(), x.C, 1, stream));
+    a.emit("rms_silu", x);
     VAE_TRY(conv(a, x, w.enc_head, y, x.T, x.H, x.W));
     a.put(x);
     x = y;
@@ -256,6 +283,7 @@ extern "C" int scail_vae_decode(scail_vae* h, const float* latent, float* video,
     a.base = static_cast<char*>(workspace);
     a.slot_bytes = slot_bytes_for(w, T, H, W);
     a.stream = stream;
+    a.trace = h->trace; a.trace_user = h->trace_user;
     SCAIL_REQUIRE(workspace != nullptr && workspace_bytes >= NSLOT * a.slot_bytes && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0,
                   "workspace too small or not 256-byte aligned (scail_vae_workspace_bytes)");
     Tens x = a.get(Tl, hl, wl, w.z_dim); VAE_CHK(a)
@@ -276,6 +304,7 @@ extern "C" int scail_vae_decode(scail_vae* h, const float* latent, float* video,
         else { scail_set_error("scail_vae_decode: downsampling stage in the decoder table"); return 1; }
     }
     VAE_TRY(scail_rms_silu(x.p, x.p, w.dec_head_gamma, x.vox(), x.C, 1, stream));
+    a.emit("rms_silu", x);
     VAE_TRY(conv(a, x, w.dec_head, y, x.T, x.H, x.W));
     a.put(x);
     x = y;

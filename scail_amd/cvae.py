@@ -59,6 +59,9 @@ def _attn(W: Dict, n: str) -> Attn:
                 qb.data_ptr(), kb.data_ptr(), vb.data_ptr(), pb.data_ptr(), qw.shape[0])
 
 
+_TRACE_FN = C.CFUNCTYPE(None, _p, C.c_int, C.c_char_p, _p, _i64, _i64, _i64, _i64)
+
+
 class CVae:
     def __init__(self, model, W: Dict):
         L.load()
@@ -97,6 +100,23 @@ class CVae:
         h = _p()
         L.call("scail_vae_create", C.byref(w), C.byref(h))
         self._h, self._ws, self._dev, self.z = h, None, dev, model.z_dim
+
+    def set_trace(self, fn):
+        """include/scail_vae.h ``scail_vae_set_trace``: ``fn(index, op, tensor)`` after every launch that completes an activation; ``tensor`` is
+        a (T, H, W, C) bf16 VIEW into the workspace, ordered on torch's current stream (the one encode / decode enqueue on): read or copy
+        it with torch ops inside the callback, do not keep it.  ``None`` switches tracing off."""
+        if fn is None:
+            self._trace_c = None
+            L.call("scail_vae_set_trace", self._h, None, None)
+            return
+
+        def thunk(_user, index, op, data, T, H, W, Cc):
+            off = data - self._ws.data_ptr()
+            view = self._ws[off:off + T * H * W * Cc * 2].view(torch.bfloat16).view(T, H, W, Cc)
+            fn(index, op.decode(), view)
+
+        self._trace_c = _TRACE_FN(thunk)
+        L.call("scail_vae_set_trace", self._h, C.cast(self._trace_c, _p), None)
 
     def close(self):
         if self._h is not None:

@@ -70,6 +70,7 @@ SIGNATURES = {
     # include/scail_vae.h (scail_amd/cvae.py builds the structs)
     "scail_vae_create": [_p, _p],
     "scail_vae_destroy": [_p],
+    "scail_vae_set_trace": [_p, _p, _p],
     "scail_vae_workspace_bytes": [_p, _i64, _i64, _i64],
     "scail_vae_encode": [_p, _p, _p, _i64, _i64, _i64, _p, _i64, _p],
     "scail_vae_decode": [_p, _p, _p, _i64, _i64, _i64, _p, _i64, _p],

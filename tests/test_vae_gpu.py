@@ -5,6 +5,7 @@ cosine >= 0.999."""
 import os
 
 import numpy as np
+import math
 import pytest
 import torch
 import torch.nn.functional as F
@@ -274,6 +275,24 @@ def test_c_executor_equals_layerwise_path():
     with pytest.raises(ValueError):
         m.use_c_exec = True
         m.encode(vid[:, :, :8])
+    # the shipped width: 384 attention channels, where 1 / sqrt(C) rounds differently in float and in double (the C executor computed it
+    # in float until round 4 and so differed from the layer path in the last bit -- found at 81 x 512 x 896 by tools/vae_exec_vs_layers.py);
+    # the launch-by-launch trace of include/scail_vae.h sees the same tensors as the layer path's launches
+    m96 = WanVAE_(dim=96, z_dim=16, device=DEV)
+    v96 = (torch.rand(1, 3, 9, 32, 48, generator=g) * 2 - 1).to(DEV)
+    seen = []
+    m96.prepare()
+    m96._c().set_trace(lambda i, op, t: seen.append((i, op, tuple(t.shape), float(t.float().abs().sum()))))
+    z96 = m96.encode(v96)
+    n_enc = len(seen)
+    x96 = m96.decode(z96)
+    m96._c().set_trace(None)
+    m96.decode(z96)
+    assert [s_[0] for s_ in seen[:n_enc]] == list(range(n_enc)) and len(seen) > n_enc + 30, "trace indices count the launches of one call"
+    assert {s_[1] for s_ in seen} == {"conv", "rms_silu", "attn", "conv_norm"} or {s_[1] for s_ in seen} == {"conv", "rms_silu", "attn"}
+    assert seen[0][2] == (9, 32, 48, 96) and seen[n_enc - 1][2] == (3, 4, 6, 32) and all(math.isfinite(s_[3]) for s_ in seen)
+    m96.use_c_exec = False
+    assert torch.equal(z96, m96.encode(v96)) and torch.equal(x96, m96.decode(z96))
     # a single large frame: the attention score matrix (4096 x 4096), not an activation, sizes the workspace slots
     img = (torch.rand(1, 3, 1, 512, 512, generator=g) * 2 - 1).to(DEV)
     z1 = m.encode(img)
@@ -339,7 +358,7 @@ def test_vae_fullsize_vs_fp32(direction):
     (reference wan_vae.py:516-568).
     Criterion (bf16 activations through ~30 layers vs fp32; same form as the DiT's full-size test): cosine >= 0.999; at most 1e-4 of the
     elements beyond rtol / atol 3e-2 and none beyond 4x that bound; and PER TILE (16 x 16 output pixels per frame for the decoder -- the
-    convolution kernels' own tile; one latent pixel = 8 x 8 video pixels per frame for the encoder) the worst error inside the same 4x bound
+    convolution kernels' own tile; 4 x 4 latent pixels = 32 x 32 video pixels per frame for the encoder) the worst error inside the same 4x bound
     and the tile's mean error <= 5x the global mean error + 1e-3, so a wrong halo / seam / frame-slot cannot hide in the statistics."""
     from scail_amd.wan_vae import WanVAE_
     cfg = V.VAEConfig(dim=96, z_dim=16)
@@ -376,7 +395,7 @@ def test_vae_fullsize_vs_fp32(direction):
     worst = float(rel.max())
     gmean = float(err.mean())
     cos = _cos(got, want)
-    th, tw = (1, 1) if direction == "encode" else (16, 16)
+    th, tw = (4, 4) if direction == "encode" else (16, 16)
     tmax, tmean = _tile_stats(rel, th, tw)[0], _tile_stats(err, th, tw)[1]
     print(f"VAE {direction} 81x512x896 vs fp32 oracle: cosine {cos:.6f}, {n_bad} of {err.numel()} beyond rtol/atol {tol} ({n_bad / err.numel():.2e}), "
           f"worst {worst:.2f}x the bound, max abs err {float(err.max()):.3e}, mean {gmean:.3e}, |ref| max {float(want.abs().max()):.2f} rms "
