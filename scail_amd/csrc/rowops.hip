@@ -149,6 +149,154 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// ONE WAVE PER ROW forms of the two norm kernels (round 4): D = 512 * CPL columns, lane l holds the 16-byte chunks l, l + 64, ... of its
+// row (each wave-instruction moves 1 KB of contiguous bytes), all CPL loads in flight before the first use, wave-level reductions only
+// (no LDS, no barrier), four independent rows per 256-thread workgroup.  Same arithmetic as the block kernels above up to the order of
+// the fp32 sums.  The block kernels had every thread wait at two (LayerNorm: four) barriers per row and left the third pass half empty
+// at D = 5120 (640 chunks on 256 threads): 4.3 TB/s; see DESIGN.md section 4.3 for the measured A/B.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int CPL>
+__global__ __launch_bounds__(256) void ln_wave_kernel(
+    const u16* __restrict__ x, int64_t ldx, u16* __restrict__ y, int64_t ldy,
+    const float* __restrict__ p0, const float* __restrict__ p1, int64_t mod_stride,
+    int64_t rows_out, int64_t src_rows_per_batch, int64_t src_row_offset, int wgs_per_batch, float eps) {
+    constexpr int D = 512 * CPL;
+    // the row parameters of this workgroup's batch element in LDS: [D] multiplier (1 + scale | weight), [D] addend (shift | bias).  From
+    // global memory they are 8 bytes per element against the 2 + 2 of x and y (40 KB per row through L2 at D = 5120).
+    extern __shared__ __attribute__((aligned(16))) float prm[];
+    const int64_t b = blockIdx.x / wgs_per_batch;
+    const int g = blockIdx.x - (int)b * wgs_per_batch;
+    {
+        const float* a0 = (MODE == 0) ? p0 + b * mod_stride : p0;  // shift | weight
+        const float* a1 = (MODE == 0) ? p1 + b * mod_stride : p1;  // scale | bias
+        for (int i4 = threadIdx.x; i4 < D / 4; i4 += 256) {
+            float4 m = *reinterpret_cast<const float4*>((MODE == 0 ? a1 : a0) + i4 * 4);
+            const float4 ad = *reinterpret_cast<const float4*>((MODE == 0 ? a0 : a1) + i4 * 4);
+            if (MODE == 0) { m.x += 1.0f; m.y += 1.0f; m.z += 1.0f; m.w += 1.0f; }
+            *reinterpret_cast<float4*>(prm + i4 * 4) = m;
+            *reinterpret_cast<float4*>(prm + D + i4 * 4) = ad;
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)g * 4 + (threadIdx.x >> 6); i < rows_out; i += (int64_t)wgs_per_batch * 4) {
+        const u16* xr = x + (b * src_rows_per_batch + src_row_offset + i) * ldx;
+        u16* yr = y + (b * rows_out + i) * ldy;
+        uint4 u[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) u[j] = *reinterpret_cast<const uint4*>(xr + (j * 64 + lane) * 8);
+        float v[CPL][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            unpack8(u[j], v[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[j][e];
+        }
+        const float mean = wave_sum(s) * (1.0f / (float)D);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[j][e] - mean;
+                q += d * d;
+            }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / (float)D) + eps);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = j * 64 + lane;
+            const float4 m0 = *reinterpret_cast<const float4*>(prm + c * 8);
+            const float4 m1 = *reinterpret_cast<const float4*>(prm + c * 8 + 4);
+            const float4 t0 = *reinterpret_cast<const float4*>(prm + D + c * 8);
+            const float4 t1 = *reinterpret_cast<const float4*>(prm + D + c * 8 + 4);
+            const float Mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            const float Ad[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[j][e] - mean) * rstd * Mu[e] + Ad[e];
+            *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+        }
+    }
+}
+
+template <int CPL, bool HD128>
+__global__ __launch_bounds__(256) void rmsnorm_rope_wave_kernel(
+    const u16* __restrict__ x, int64_t ldx, u16* __restrict__ y, int64_t ldy,
+    const float* __restrict__ w, const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+    int64_t rows, int64_t rows_per_batch, int head_dim, float eps, float out_scale, int slab_w, int64_t slab_stride) {
+    constexpr int D = 512 * CPL;
+    extern __shared__ __attribute__((aligned(16))) float prm[];       // the norm weight times out_scale: [D]
+    for (int i4 = threadIdx.x; i4 < D / 4; i4 += 256) *reinterpret_cast<float4*>(prm + i4 * 4) = *reinterpret_cast<const float4*>(w + i4 * 4);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int half = head_dim >> 1;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const u16* xr = x + r * ldx;
+        u16* yr = y + r * ldy;
+        uint4 u[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) u[j] = *reinterpret_cast<const uint4*>(xr + (j * 64 + lane) * 8);
+        // head_dim == 128: chunk j * 64 + lane starts at column (lane % 16) * 8 of its head for every j, so the lane's four (cos, sin)
+        // pairs are the same for all its chunks: two 16-byte loads per row, requested with the row itself (the block kernel asks for them
+        // per chunk, after the reduction: 20 loads per lane at D = 5120)
+        const int64_t tok = r % rows_per_batch;
+        float4 cs1 = make_float4(0.f, 0.f, 0.f, 0.f), sn1 = cs1;
+        if (HD128 && cos_tab != nullptr) {
+            cs1 = *reinterpret_cast<const float4*>(cos_tab + tok * 64 + (lane & 15) * 4);
+            sn1 = *reinterpret_cast<const float4*>(sin_tab + tok * 64 + (lane & 15) * 4);
+        }
+        float v[CPL][8];
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            unpack8(u[j], v[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q += v[j][e] * v[j][e];
+        }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / (float)D) + eps);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = j * 64 + lane;
+            float n[8], o[8];
+            const float4 w0 = *reinterpret_cast<const float4*>(prm + c * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(prm + c * 8 + 4);
+            const float W[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) n[e] = W[e] * (v[j][e] * rstd);
+            if (cos_tab != nullptr) {
+                float4 cs = cs1, sn = sn1;
+                if (!HD128) {
+                    const int p0 = ((c * 8) % head_dim) >> 1;
+                    cs = *reinterpret_cast<const float4*>(cos_tab + tok * half + p0);
+                    sn = *reinterpret_cast<const float4*>(sin_tab + tok * half + p0);
+                }
+                const float C[4] = {cs.x, cs.y, cs.z, cs.w};
+                const float S[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[2 * e] = n[2 * e] * C[e] - n[2 * e + 1] * S[e];
+                    o[2 * e + 1] = n[2 * e + 1] * C[e] + n[2 * e] * S[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = n[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= out_scale;
+            u16* dst;
+            if (slab_w == 0) {
+                dst = yr + c * 8;
+            } else {
+                const int col = c * 8, gsl = col / slab_w;
+                dst = y + (int64_t)gsl * slab_stride + r * slab_w + (col - gsl * slab_w);
+            }
+            *reinterpret_cast<uint4*>(dst) = pack8(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // V -> V^T staging (64 keys x head_dim tile through LDS)
 // ------------------------------------------------------------------------------------------------
 #define TV_KEYS 64
@@ -341,6 +489,51 @@ __global__ void bf16_to_f32_kernel(const u16* __restrict__ x, float* __restrict_
 // ================================================================================================
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// option "row_wave" (scail_set_option): 1 (default) = the one-wave-per-row norm kernels where D is 1536 / 2048 / 4096 / 5120 / 6144,
+// 0 = the block-per-row kernels for every D (same-process A/B; the results agree up to the order of the fp32 sums)
+static int g_row_wave = 1;
+int scail_row_wave_enable(int on) { g_row_wave = on != 0; return 0; }
+static int row_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
+
+// returns -1 when the wave kernels do not cover this D (the caller launches the block kernel), else the launch status
+template <int MODE>
+static int ln_wave_launch(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t ldy, const float* p0, const float* p1, int64_t mod_stride,
+                          int64_t rows_out, int64_t src_rows_per_batch, int64_t src_row_offset, int64_t rows, int64_t D, float eps, void* stream) {
+    if (!g_row_wave || D % 512 != 0 || rows_out <= 0 || rows % rows_out != 0) return -1;
+#define LN_WAVE(CPL_)                                                                                                                  \
+    case CPL_: {                                                                                                                       \
+        constexpr int lds_ = 2 * 512 * CPL_ * 4;                                                                                       \
+        static bool attr_ = false;                                                                                                     \
+        if (!attr_) {                                                                                                                  \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_wave_kernel<MODE, CPL_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) { \
+                scail_set_error("ln_wave: hipFuncSetAttribute failed");                                                                \
+                return 2;                                                                                                              \
+            }                                                                                                                          \
+            attr_ = true;                                                                                                              \
+        }                                                                                                                              \
+        hipLaunchKernelGGL((ln_wave_kernel<MODE, CPL_>), dim3((unsigned)(n_batch * wpb)), dim3(256), lds_, (hipStream_t)stream, x, ldx, y, ldy, \
+                           p0, p1, mod_stride, rows_out, src_rows_per_batch, src_row_offset, (int)wpb, eps);                           \
+        return scail_check_launch("ln_wave");                                                                                          \
+    }
+    // persistent workgroups: about three per compute unit (157 VGPRs, 40 KB of LDS), dealt evenly to the batch elements
+    const int64_t n_batch = rows / rows_out;
+    const int64_t wpb = std::max<int64_t>(1, std::min<int64_t>((rows_out + 3) / 4, (3 * row_cu_count() + n_batch - 1) / n_batch));
+    switch (D / 512) {
+        LN_WAVE(3) LN_WAVE(4) LN_WAVE(8) LN_WAVE(10) LN_WAVE(12)
+        default: return -1;
+    }
+#undef LN_WAVE
+}
+
 extern "C" int scail_ln_modulate(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t ldy,
                                  const float* shift, const float* scale, int64_t mod_stride,
                                  int64_t n_batch, int64_t rows_out, int64_t src_rows_per_batch,
@@ -350,6 +543,8 @@ extern "C" int scail_ln_modulate(const scail_bf16* x, int64_t ldx, scail_bf16* y
     SCAIL_REQUIRE(aligned16(x) && aligned16(y) && aligned16(shift) && aligned16(scale), "pointers must be 16-byte aligned");
     const int64_t rows = n_batch * rows_out;
     if (rows == 0) return 0;
+    if (int rc = ln_wave_launch<0>(x, ldx, y, ldy, shift, scale, mod_stride, rows_out, src_rows_per_batch, src_row_offset, rows, D, eps, stream); rc >= 0)
+        return rc;
     hipLaunchKernelGGL(ln_kernel<0>, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream, x, ldx,
                        y, ldy, shift, scale, mod_stride, rows_out, src_rows_per_batch, src_row_offset,
                        (int)D, eps);
@@ -363,6 +558,7 @@ extern "C" int scail_layernorm_affine(const scail_bf16* x, int64_t ldx, scail_bf
     SCAIL_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "strides must keep 16-byte alignment");
     SCAIL_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && aligned16(b), "pointers must be 16-byte aligned");
     if (rows == 0) return 0;
+    if (int rc = ln_wave_launch<1>(x, ldx, y, ldy, w, b, 0, rows, rows, 0, rows, D, eps, stream); rc >= 0) return rc;
     hipLaunchKernelGGL(ln_kernel<1>, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream, x, ldx,
                        y, ldy, w, b, (int64_t)0, rows, rows, (int64_t)0, (int)D, eps);
     return scail_check_launch("layernorm_affine");
@@ -388,6 +584,27 @@ static int rmsnorm_rope_launch(const scail_bf16* x, int64_t ldx, scail_bf16* y, 
     SCAIL_REQUIRE(slab_w == 0 || (slab_w % 8 == 0 && D % slab_w == 0 && slab_stride % 8 == 0 && slab_stride >= rows * slab_w),
                   "slab width must be a multiple of 8 dividing D, slab stride a multiple of 8 and >= rows * slab_w");
     if (rows == 0) return 0;
+    // with RoPE the wave form wins (0.455 -> 0.41 ms at config 2: the (cos, sin) pairs once per row instead of per chunk); without, the block
+    // kernel is already at the pass's plateau (0.367 against 0.383 ms; profiles/r04_row_pass_probe.log)
+    if (g_row_wave && w != nullptr && cos_tab != nullptr && D % 512 == 0) {
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((rows + 3) / 4, 3 * (int64_t)row_cu_count()));
+#define RR_WAVE(CPL_)                                                                                                                \
+    case CPL_: {                                                                                                                     \
+        constexpr int lds_ = 512 * CPL_ * 4;                                                                                         \
+        if (head_dim == 128)                                                                                                         \
+            hipLaunchKernelGGL((rmsnorm_rope_wave_kernel<CPL_, true>), dim3(grid), dim3(256), lds_, (hipStream_t)stream, x, ldx, y,  \
+                               ldy, w, cos_tab, sin_tab, rows, rows_per_batch, (int)head_dim, eps, out_scale, (int)slab_w, slab_stride); \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((rmsnorm_rope_wave_kernel<CPL_, false>), dim3(grid), dim3(256), lds_, (hipStream_t)stream, x, ldx, y, \
+                               ldy, w, cos_tab, sin_tab, rows, rows_per_batch, (int)head_dim, eps, out_scale, (int)slab_w, slab_stride); \
+        return scail_check_launch("rmsnorm_rope");                                                                                   \
+    }
+        switch (D / 512) {
+            RR_WAVE(3) RR_WAVE(4) RR_WAVE(8) RR_WAVE(10) RR_WAVE(12)
+            default: break;
+        }
+#undef RR_WAVE
+    }
     hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((unsigned)rows), dim3(ROW_THREADS), 0, (hipStream_t)stream,
                        x, ldx, y, ldy, w, cos_tab, sin_tab, rows_per_batch, (int)D, (int)head_dim, eps, out_scale, (int)slab_w, slab_stride);
     return scail_check_launch("rmsnorm_rope");
