@@ -98,6 +98,8 @@ def grid_blocks(T, H, W, N, cus=256) -> int:
 @dataclass
 class Cfg:
     epi: int = 0            # 0: y = conv + bias;  3: y = resid + conv + bias
+    kt: int = 3             # temporal taps: 3 = CausalConv3d 3x3x3;  1 = the 1x3x3 convolution of Resample (behind the nearest 2x upsample when the
+                            # kernel argument `pt` -- no padding frames exist for kt = 1 -- is 1: patch voxel (h, w) reads input (h >> 1, w >> 1))
     cap: int = 1
     lookahead: float = 2.0
     name: str = "scail_conv4_e0"
@@ -153,7 +155,8 @@ S_WR = S(60, 4)                                             # W descriptor of th
 S_WAVE, S_F, S_RH = S(64), S(65), S(66)
 S_T0, S_H0, S_W0, S_N0 = S(67), S(68), S(69), S(70)
 S_SL, S_XOFF, S_XOFFN = S(71), S(72), S(73)                 # slice counter, channel byte offset of this / the next slice
-S_WNEXT, S_CIN2, S_C26 = S(74), S(75), S(76)                # W source offset of the next DMA tap, 2 Cin, 26 * 2 Cin - 64
+S_WNEXT, S_CIN2, S_C26 = S(74), S(75), S(76)                # W source offset of the next DMA tap, 2 Cin, (taps per slice - 1) * 2 Cin - 64
+S_WI = S(81)                                                # (kt = 1) columns of an input frame: W >> ups (S_SLOT[3] is unused there)
 S_WM0 = S(77)                                               # LDS offset of this wave's first piece in the W buffer of the current tap
 S_SLOT = [S(78 + j) for j in range(4)]                      # LDS offset (plane of this wave) of the slot the next load of patch frame j goes to
 ST = [S(82 + i) for i in range(16)]                         # s82..s97 temporaries
@@ -179,6 +182,22 @@ E_Z = [V(218 + i) for i in range(3)]                        # ... in a residual 
 class Gen:
     def __init__(self, cfg: Cfg):
         self.cfg = cfg
+        assert cfg.kt in (1, 3)
+        self.kt1 = cfg.kt == 1
+        self.TAPS = 9 * cfg.kt                  # taps of a 32-channel slice
+        self.NGRP = self.TAPS // 3              # tap groups (dt, dw) of a slice: the 10 patch rows of a group serve its 3 taps dh
+        self.NFR = NF + cfg.kt - 1              # patch frames of a slice
+        # kt = 3: which patch piece a position issues: (frame, voxel group, next slice?, needed at the top of relative position).  Frame 2 is first
+        # read (wave frame 1, dt = 1: group 3) during positions 6..8, frame 3 (group 6) during 15..17, frames 0 / 1 of the next slice during
+        # 24..26; their slots were released by frames 1 (after the top of 15), 2 (24), 3 (24) of the slice before and 0 (6) of this one.
+        # kt = 1: two frames per slice in two alternating slot pairs.  Group 0 of slice s + 1 is read during positions 6..8 of slice s, so both
+        # frames of the next slice are requested during positions 0..2 (four pieces each) into the pair slice s - 1 released at the top of its
+        # position 6, and are due at the top of position 6.
+        if self.kt1:
+            self.PIECES = {t: [(j, 2 * t + h, True, 6) for j in range(2) for h in range(2)] for t in range(3)}
+        else:
+            self.PIECES = {**{i: [(3, i, False, 15)] for i in range(6)}, **{6 + i: [(0, i, True, 24)] for i in range(6)},
+                           **{12 + i: [(1, i, True, 24)] for i in range(6)}, **{18 + i: [(2, i, True, 27 + 6)] for i in range(6)}}
 
     # ---- building blocks -------------------------------------------------------------------------------------------------------
     N_PHASE = 8
@@ -214,7 +233,7 @@ class Gen:
     # Tap order: position i = (dt 3 + dw) 3 + dh -- dh innermost: the 10 patch rows of a group (dt, dw) are read once and serve 3 taps.
     @staticmethod
     def tap_id(i: int) -> int:
-        """weight tap (dt 3 + dh) 3 + dw of position i."""
+        """weight tap (dt 3 + dh) 3 + dw of position i (kt = 1: dt = 0, positions 0..8)."""
         dt, dw, dh = i // 9, (i // 3) % 3, i % 3
         return (dt * 3 + dh) * 3 + dw
 
@@ -234,7 +253,7 @@ class Gen:
 
     def xb_set(self, grp: int, tg: float) -> List[Instr]:
         """fragment base of tap group grp = dt 3 + dw: slot of frame f + dt (+ this wave's first row) + the lane's place in a row shifted by dw."""
-        return [isa.vop("v_add_u32", XB, PBASE[grp // 3], LP[grp % 3], target_gap=tg)]
+        return [isa.vop("v_add_u32", XB, PBASE[grp // 3], LP[grp % 3], target_gap=tg)]      # (kt = 1: groups 0..2 = dw, all in frame f)
 
     def w_dma(self, t0: float, step: float, need: int) -> List[Instr]:
         """this wave's 2 pieces (of 8: pieces w and w + 4; rows >= 96 fail the range check = zeros) of the W tile at S_WNEXT -> the buffer
@@ -252,7 +271,7 @@ class Gen:
 
     def w_next(self, pos: int, tg: float) -> List[Instr]:
         """advance S_WNEXT from the weight tap of position ``pos`` (0..26) to that of the next position."""
-        if pos == 26:             # position 0 of the following slice: back 26 taps, forward one slice (64 bytes)
+        if pos == self.TAPS - 1:  # position 0 of the following slice: back TAPS - 1 taps, forward one slice (64 bytes)
             return [isa.sop("s_sub_u32", S_WNEXT, S_WNEXT, S_C26, target_gap=tg)]
         d = self.tap_id(pos + 1) - self.tap_id(pos)
         return [isa.sop("s_add_u32", S_WNEXT, S_WNEXT, {3: S_C3, 1: S_CIN2}[d], target_gap=tg) if d > 0 else
@@ -265,21 +284,22 @@ class Gen:
         return [isa.sop("s_add_u32", M0, S_SLOT[j], I32(k * 4096), target_gap=tg - 0.5), d]
 
     def slot_next(self, j: int, tg: float) -> List[Instr]:
-        """the next load of frame j goes one slot down the ring (4 frames per slice, 5 slots: -1 mod 5)."""
+        """the next load of frame j goes one slot down the ring (4 frames per slice, 5 slots: -1 mod 5); kt = 1: to the other slot pair."""
         t = ST[0]
+        if self.kt1:
+            return [isa.sop("s_add_u32", t, S_SLOT[j], I32(2 * FSLOT), target_gap=tg), isa.sop("s_cmp_ge_u32", None, t, I32(PBASE0 + 4 * FSLOT), target_gap=tg + 0.1),
+                    isa.sop("s_cselect_b32", ST[1], I32(4 * FSLOT), I32(0), target_gap=tg + 0.2), isa.sop("s_sub_u32", S_SLOT[j], t, ST[1], target_gap=tg + 0.3)]
         return [isa.sop("s_sub_u32", t, S_SLOT[j], I32(FSLOT), target_gap=tg), isa.sop("s_cmp_lt_u32", None, t, I32(PBASE0), target_gap=tg + 0.1),
                 isa.sop("s_cselect_b32", ST[1], I32(NSLOT * FSLOT), I32(0), target_gap=tg + 0.2), isa.sop("s_add_u32", S_SLOT[j], t, ST[1], target_gap=tg + 0.3)]
 
     def pbase_next(self, dt: int, tg: float) -> List[Instr]:
         t0, t1 = T_[0], T_[1]
+        if self.kt1:
+            return [isa.vop("v_add_u32", t0, I32(2 * FSLOT), PBASE[dt], target_gap=tg), isa.v_cmp("v_cmp_le_u32", I32(PBASE0 + 4 * FSLOT), t0, target_gap=tg + 0.1),
+                    isa.vop("v_subrev_u32", t1, I32(4 * FSLOT), t0, target_gap=tg + 0.2), isa.v_cndmask(PBASE[dt], t0, t1, target_gap=tg + 0.3)]
         return [isa.vop("v_subrev_u32", t0, I32(FSLOT), PBASE[dt], target_gap=tg), isa.v_cmp("v_cmp_gt_u32", I32(PBASE0), t0, target_gap=tg + 0.1),
                 isa.vop("v_add_u32", t1, I32(NSLOT * FSLOT), t0, target_gap=tg + 0.2), isa.v_cndmask(PBASE[dt], t0, t1, target_gap=tg + 0.3)]
 
-    # which patch piece a position issues: (frame, voxel group, next slice?, needed at the top of relative position).  Frame 2 is first read
-    # (wave frame 1, dt = 1: group 3) during positions 6..8, frame 3 (group 6) during 15..17, frames 0 / 1 of the next slice during 24..26;
-    # their slots were released by frames 1 (after the top of 15), 2 (24), 3 (24) of the slice before and 0 (6) of this one.
-    PIECES = {**{i: (3, i, False, 15) for i in range(6)}, **{6 + i: (0, i, True, 24) for i in range(6)},
-              **{12 + i: (1, i, True, 24) for i in range(6)}, **{18 + i: (2, i, True, 27 + 6) for i in range(6)}}
     XSPLIT = ((0, 1, 2, 3), (4, 5, 6), (7, 8, 9))          # rows of the next group read during dh = 0, 1, 2 of this one
 
     def tap_fillers(self, i: int) -> List[Instr]:
@@ -290,19 +310,22 @@ class Gen:
             blk += [isa.vop("v_add_u32", WB, I32(WBUF), WB, target_gap=0.0), isa.vop("v_and_b32", WB, I32(WREG - 1), WB, target_gap=0.1)]
             rows = self.XSPLIT[i % 3]
             if i % 3 == 0:
-                blk += self.xb_set((i // 3 + 1) % 9, 0.2)
-            blk += self.w_reads((i + 1) % 27, c.rd_at, c.rd_step)
-            blk += self.x_reads((i // 3 + 1) % 9, rows, c.rd_at + 6 * c.rd_step, c.rd_step)
+                blk += self.xb_set((i // 3 + 1) % self.NGRP, 0.2)
+            blk += self.w_reads((i + 1) % self.TAPS, c.rd_at, c.rd_step)
+            blk += self.x_reads((i // 3 + 1) % self.NGRP, rows, c.rd_at + 6 * c.rd_step, c.rd_step)
         if "dma" not in abl:
             blk += self.w_dma(c.dma_at, c.dma_step, need=i + NWB - 1)
-            blk += self.w_next((i + NWB) % 27, c.dma_at + c.dma_step + 1.5)
-            if i in self.PIECES and "patch" not in abl:
-                j, k, nxt, need = self.PIECES[i]
-                blk += self.patch_piece(j, k, S_XOFFN if nxt else S_XOFF, c.p_at, need)
-                if k == 5:
-                    blk += self.slot_next(j, c.p_at + 1.0)
-        if i in (10, 19, 26):
-            blk += self.pbase_next({10: 0, 19: 1, 26: 2}[i], 40.0)
+            blk += self.w_next((i + NWB) % self.TAPS, c.dma_at + c.dma_step + 1.5)
+            if "patch" not in abl:
+                for n, (j, k, nxt, need) in enumerate(self.PIECES.get(i, ())):
+                    blk += self.patch_piece(j, k, S_XOFFN if nxt else S_XOFF, c.p_at + 8.0 * n, need)
+                    if k == 5:
+                        blk += self.slot_next(j, c.p_at + 8.0 * n + 1.0)
+        # the fragment base of frame f + dt moves to the next slice's slot once the last group that reads through it has been requested
+        # (kt = 3: groups 3 dt .. 3 dt + 2 are read during positions 9 dt - 3 .. 9 dt + 5; kt = 1: group 2 during positions 3..5)
+        nxt_base = {5: 0} if self.kt1 else {10: 0, 19: 1, 26: 2}
+        if i in nxt_base:
+            blk += self.pbase_next(nxt_base[i], 40.0)
         return blk
 
     def tap_block(self, tap: int) -> List[Instr]:
@@ -312,16 +335,17 @@ class Gen:
         return sched.schedule(self.tap_fillers(tap) + self.mfmas(tap), cap=c.cap, lookahead=c.lookahead)
 
     def slice_body(self) -> List[Instr]:
-        """One 32-channel slice = 27 taps.  At the top of tap i: this tap's fragments are in registers (lgkmcnt 0), every DMA whose data
+        """One 32-channel slice = 27 taps (kt = 1: 9).  At the top of tap i: this tap's fragments are in registers (lgkmcnt 0), every DMA whose data
         the reads issued during tap i need has landed (counted vmcnt: DMAs retire in order) -- in every wave (barrier)."""
         c = self.cfg
         abl = c.abl.split(",")
-        blocks = [self.tap_block(t) for t in range(27)]
+        TAPS = self.TAPS
+        blocks = [self.tap_block(t) for t in range(TAPS)]
         dmas = [[i for i in blk if i.cls == isa.LDS_DMA] for blk in blocks]
         o: List[Instr] = [isa.label("L_slice"), isa.nop(7)]
-        for tap in range(27):
-            # DMAs in issue order up to here: the previous slice's (their deadlines are 27 taps earlier) + this slice's before tap
-            hist = [d.need - 27 for blk in dmas for d in blk] + [d.need for blk in dmas[:tap] for d in blk]
+        for tap in range(TAPS):
+            # DMAs in issue order up to here: the previous slice's (their deadlines are TAPS positions earlier) + this slice's before tap
+            hist = [d.need - TAPS for blk in dmas for d in blk] + [d.need for blk in dmas[:tap] for d in blk]
             due = [k for k, need in enumerate(hist) if need <= tap]
             top = [isa.waitcnt(lgkmcnt=0)]
             if due:
@@ -366,10 +390,14 @@ class Gen:
               isa.sop("s_cmp_ge_u32", None, S_TILE, S_TEND), isa.branch("s_cbranch_scc1", "L_exit"),
               isa.sop("s_mov_b32", S_H0, I32(-1)), isa.sop("s_mov_b32", S_N0, I32(-1))]                          # no spatial / n tile yet
         # ---- constants ----
-        o += [isa.sop("s_lshl_b32", S_KP2, S_KPAD, I32(1)),
-              isa.sop("s_mul_i32", ST[8], S_H, S_Wd), isa.sop("s_lshl_b32", S_CIN2, S_CIN, I32(1)),
+        o += [isa.sop("s_lshl_b32", S_KP2, S_KPAD, I32(1))]
+        if self.kt1:       # input frame = (H >> ups) x (W >> ups) voxels (ups = the `pt` argument: no padding frames exist for kt = 1)
+            o += [isa.sop("s_lshr_b32", ST[8], S_H, S_PT), isa.sop("s_lshr_b32", S_WI, S_Wd, S_PT), isa.sop("s_mul_i32", ST[8], ST[8], S_WI)]
+        else:
+            o += [isa.sop("s_mul_i32", ST[8], S_H, S_Wd)]
+        o += [isa.sop("s_lshl_b32", S_CIN2, S_CIN, I32(1)),
               isa.sop("s_mul_i32", S_FB.sub(0), ST[8], S_CIN2), isa.sop("s_mul_hi_u32", S_FB.sub(1), ST[8], S_CIN2),
-              isa.sop("s_mul_i32", S_C26, S_CIN2, I32(26)), isa.sop("s_sub_u32", S_C26, S_C26, I32(64)),
+              isa.sop("s_mul_i32", S_C26, S_CIN2, I32(self.TAPS - 1)), isa.sop("s_sub_u32", S_C26, S_C26, I32(64)),
               isa.sop("s_mul_i32", S_C3, S_CIN2, I32(3)), isa.sop("s_mul_i32", S_C5, S_CIN2, I32(5))]
         # ---- W pieces of this wave: piece w + 4 i = rows 16 (w + 4 i) + l / 4, LDS position q = l % 4 holds source chunk q ^ ((row >> 1) & 3) ----
         o += [isa.vop("v_lshrrev_b32", t[1], I32(2), LANE), isa.vop("v_and_b32", t[2], I32(3), LANE)]
@@ -393,7 +421,8 @@ class Gen:
               isa.vop("v_lshlrev_b32", t[2], I32(6), ql), isa.vop("v_lshl_add_u32", WBL, t[1], I32(4), t[2])]
         # ---- epilogue staging addresses ----
         sb = ST[2]
-        o += [isa.sop("s_mul_i32", sb, S_WAVE, I32(STG_WAVE)), isa.sop("s_add_u32", sb, sb, I32(PBASE0 + 3 * FSLOT)),
+        # (kt = 1: slot 4 -- its four patch frames of two consecutive slices live in slots 0..3, and the next tile's first frames arrive in 0, 1)
+        o += [isa.sop("s_mul_i32", sb, S_WAVE, I32(STG_WAVE)), isa.sop("s_add_u32", sb, sb, I32(PBASE0 + (4 if self.kt1 else 3) * FSLOT)),
               isa.sop("s_lshl_b32", ST[3], S_LDC.sub(0), I32(1)), isa.sop("s_lshl_b32", ST[4], S_LDR.sub(0), I32(1)),
               isa.vop("v_mul_u32_u24", t[1], I32(STG_VOX), ql), isa.vop("v_lshl_add_u32", t[1], g, I32(3), t[1]), isa.vop("v_add_u32", E_W, sb, t[1])]
         for i in range(3):
@@ -444,8 +473,8 @@ class Gen:
               isa.sop("s_mov_b32", S_H0, nh0), isa.sop("s_mov_b32", S_W0, nw0), isa.sop("s_mov_b32", S_N0, nn0)]
         # ---- patch frame j: input frame t = t0 - pt + j; descriptor base = x + t * FB, num_records = FB (0 when t is outside [0, Ti)) ----
         tfr = ST[9]
-        for j in range(4):
-            o += [isa.sop("s_add_u32", tfr, S_T0, I32(j)), isa.sop("s_sub_u32", tfr, tfr, S_PT),                 # may wrap below 0 -> huge unsigned
+        for j in range(self.NFR):
+            o += [isa.sop("s_add_u32", tfr, S_T0, I32(j))] + ([] if self.kt1 else [isa.sop("s_sub_u32", tfr, tfr, S_PT)]) + [   # may wrap below 0 -> huge unsigned
                   isa.sop("s_cmp_lt_u32", None, tfr, S_TI), isa.sop("s_cselect_b32", ST[10], S_FB.sub(0), I32(0)),   # num_records
                   isa.sop("s_cselect_b32", tfr, tfr, I32(0)),
                   isa.sop("s_mul_i32", ST[0], S_FB.sub(0), tfr), isa.sop("s_mul_hi_u32", ST[1], S_FB.sub(0), tfr),
@@ -455,7 +484,7 @@ class Gen:
                   isa.sop("s_mov_b32", S_XR[j].sub(3), I32(0x00020000))]
         # ---- ring positions: slice 0's frame j -> slot j; W buffer 0 ----
         o += [isa.sop("s_lshl_b32", S_WM0, S_WAVE, I32(10)), isa.sop("s_add_u32", ST[0], S_WM0, I32(PBASE0))]
-        for j in range(4):
+        for j in range(self.NFR):
             o.append(isa.sop("s_add_u32", S_SLOT[j], ST[0], I32(j * FSLOT)))
         o += [isa.vop("v_mov_b32", PBASE[0], PBL), isa.vop("v_add_u32", PBASE[1], I32(FSLOT), PBL), isa.vop("v_add_u32", PBASE[2], I32(2 * FSLOT), PBL),
               isa.vop("v_mov_b32", WB, WBL),
@@ -489,12 +518,14 @@ class Gen:
                   isa.vop("v_mul_u32_u24", r, I32(3277), pv), isa.vop("v_lshrrev_b32", r, I32(16), r),             # r = pv / 20 (pv < 384)
                   isa.vop("v_mul_u32_u24", col, I32(PCL), r), isa.vop("v_sub_u32", col, pv, col),
                   isa.vop("v_add_u32", hi, hm1, r), isa.vop("v_add_u32", wi, wm1, col),                             # wraps below 0 -> huge unsigned
-                  isa.v_cmp("v_cmp_gt_u32", S_H, hi), isa.vop("v_mul_lo_u32", t[7], hi, S_Wd),
+                  isa.v_cmp("v_cmp_gt_u32", S_H, hi)] + ([isa.vop("v_lshrrev_b32", t[14], S_PT, hi), isa.vop("v_mul_lo_u32", t[7], t[14], S_WI)] if self.kt1 else
+                                                           [isa.vop("v_mul_lo_u32", t[7], hi, S_Wd)]) + [
                   isa.v_cndmask(ok, I32(0), I32(1)),
                   isa.v_cmp("v_cmp_gt_u32", S_Wd, wi), isa.v_cndmask(t[8], I32(0), I32(1)), isa.vop("v_and_b32", ok, ok, t[8]),
                   isa.v_cmp("v_cmp_gt_u32", I32(PC), col), isa.v_cndmask(t[8], I32(0), I32(1)), isa.vop("v_and_b32", ok, ok, t[8]),
                   isa.v_cmp("v_cmp_gt_u32", I32(PR * PCL), pv), isa.v_cndmask(t[8], I32(0), I32(1)), isa.vop("v_and_b32", ok, ok, t[8]),
-                  isa.vop("v_add_u32", t[7], t[7], wi), isa.vop("v_mul_lo_u32", t[7], t[7], S_CIN2),
+                  ] + ([isa.vop("v_lshrrev_b32", t[14], S_PT, wi), isa.vop("v_add_u32", t[7], t[7], t[14])] if self.kt1 else [isa.vop("v_add_u32", t[7], t[7], wi)]) + [
+                  isa.vop("v_mul_lo_u32", t[7], t[7], S_CIN2),
                   isa.vop("v_lshrrev_b32", t[8], I32(1), col), isa.vop("v_and_b32", t[8], I32(3), t[8]), isa.vop("v_xor_b32", t[8], t[13], t[8]),
                   isa.vop("v_lshl_add_u32", t[7], t[8], I32(4), t[7]),
                   isa.v_cmp("v_cmp_ne_u32", I32(0), ok), isa.vop("v_mov_b32", t[9], I32(OOB)),
@@ -504,11 +535,12 @@ class Gen:
         # ---- streams: patch frames 0, 1, 2 of slice 0, W taps 0 .. 3 ----
         o += [isa.sop("s_mov_b32", S_SL, I32(0)), isa.sop("s_mov_b32", S_XOFF, I32(0)), isa.sop("s_mov_b32", S_WNEXT, I32(0)),
               isa.sop("s_cmp_lt_u32", None, I32(1), S_NSL), isa.sop("s_cselect_b32", S_XOFFN, I32(64), I32(0))]
-        for j in range(3):
+        first = 2 if self.kt1 else 3
+        for j in range(first):
             for k in range(6):
                 o += self.patch_piece(j, k, S_XOFF, 0, 0)
-        # where the body's loads go: frame 3 of slice 0 -> slot 3; frames 0, 1, 2 of slice 1 -> slots 4, 0, 1
-        for j in range(3):
+        # where the body's loads go: frame 3 of slice 0 -> slot 3; frames 0, 1, 2 of slice 1 -> slots 4, 0, 1  (kt = 1: slice 1 -> slots 2, 3)
+        for j in range(first):
             o += self.slot_next(j, 0)
         for b in range(NWB):
             o += self.w_dma(0, 0, 0) + self.w_next(b, 0)
@@ -737,6 +769,9 @@ def assembly(cfgs) -> str:
 
 
 DEFAULTS = [Cfg(epi=0, name="scail_conv4_e0"), Cfg(epi=3, name="scail_conv4_e3")]
+# the 1x3x3 convolution of Resample (wan_vae.py:76-85: nearest-exact 2x upsample, then Conv2d(dim, dim / 2, 3, padding 1) per frame): its own
+# code object (csrc/conv4u.s), so that csrc/conv4.s -- and the traffic measurements stamped with its blob id -- stay as they are
+UPSAMPLE = [Cfg(epi=0, kt=1, name="scail_conv4u_e0")]
 
 
 def variant_cfgs():

@@ -615,6 +615,10 @@ __global__ void from_channels_last_kernel(const u16* __restrict__ x, int64_t ldx
 static const unsigned char k_conv4_hsaco[] = {
 #include "conv4_hsaco.inc"
 };
+// the kt = 1 kernels (scail_conv4u_*: the 1x3x3 convolution of Resample, optionally behind the nearest 2x upsample; csrc/conv4u.s, Cfg.kt = 1)
+static const unsigned char k_conv4u_hsaco[] = {
+#include "conv4u_hsaco.inc"
+};
 struct Conv4Args {
     const void* x; const void* w; const void* bias; void* y; const void* resid;
     int32_t Ti, To, H, W;
@@ -626,7 +630,7 @@ struct Conv4Args {
     int32_t wgs_per_xcd, tiles;      // persistent workgroups per XCD (the tile stride of a workgroup), tiles in all
 };
 static_assert(sizeof(Conv4Args) == 136, "Conv4Args must match asmgen/conv4.py KERNARG_SIZE");
-static std::map<int, hipModule_t> g_conv4_modules;                          // device -> loaded code object
+static std::map<std::pair<int, int>, hipModule_t> g_conv4_modules;          // (device, code object: 0 conv4.s, 1 conv4u.s) -> loaded module
 static std::map<std::pair<int, std::string>, hipFunction_t> g_conv4_fn;     // (device, kernel name)
 static std::mutex g_conv4_mutex;
 static std::string g_conv4_suffix;                                          // measurement build: "conv4_kernel:<suffix>"
@@ -638,15 +642,16 @@ static int conv4_function(const std::string& name, hipFunction_t* fn) {
         scail_set_error("conv4: hipGetDevice failed");
         return 2;
     }
-    auto mit = g_conv4_modules.find(dev);
+    const int which = name.rfind("scail_conv4u", 0) == 0 ? 1 : 0;
+    auto mit = g_conv4_modules.find(std::make_pair(dev, which));
     if (mit == g_conv4_modules.end()) {
         hipModule_t mod = nullptr;
-        hipError_t e = hipModuleLoadData(&mod, k_conv4_hsaco);
+        hipError_t e = hipModuleLoadData(&mod, which ? k_conv4u_hsaco : k_conv4_hsaco);
         if (e != hipSuccess) {
             scail_set_error(std::string("conv4: hipModuleLoadData failed: ") + hipGetErrorString(e));
             return 2;
         }
-        mit = g_conv4_modules.emplace(dev, mod).first;
+        mit = g_conv4_modules.emplace(std::make_pair(dev, which), mod).first;
     }
     auto it = g_conv4_fn.find(std::make_pair(dev, name));
     if (it == g_conv4_fn.end()) {
@@ -702,6 +707,18 @@ static bool conv4_eligible(const ConvParams& p, int64_t ldc, int64_t ldr) {
            (int64_t)p.Ho * p.Wo * std::max(ldc, ldr) * 2 < (1ll << 32);
 }
 
+// the kt = 1 kernels: 1 x 3 x 3, stride 1, padding (0, 1, 1), every output frame from the input frame of the same index, same extent or
+// (ups) exactly twice the input's; otherwise the limits above (32-bit byte offsets inside an INPUT frame)
+static bool conv4u_eligible(const ConvParams& p, int64_t ldc) {
+    if (p.N <= 0 || p.N % 96 != 0 || p.To < 2 || p.Ho <= 0 || p.Wo <= 0) return false;
+    const int64_t max_div = std::max<int64_t>({p.N / 96, (p.To + 1) / 2, (p.Wo + 15) / 16});
+    if (conv4_tiles(p) * max_div >= (1ll << 31)) return false;
+    const bool extent = p.ups ? (p.Ho == 2 * p.Hi && p.Wo == 2 * p.Wi) : (p.Ho == p.Hi && p.Wo == p.Wi);
+    return p.kt == 1 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.pt == 0 && p.ph == 1 && p.pw == 1 && extent &&
+           p.Ti == p.To && p.Cin % 32 == 0 && ldc % 8 == 0 && ldc < (1 << 20) && (int64_t)p.Hi * p.Wi * p.Cin * 2 < (1ll << 31) &&
+           (int64_t)p.Ho * p.Wo * ldc * 2 < (1ll << 32);
+}
+
 static void conv_params(ConvParams& p, const int32_t* geom) {
     p.Ti = geom[0]; p.Hi = geom[1]; p.Wi = geom[2]; p.Cin = geom[3];
     p.To = geom[4]; p.Ho = geom[5]; p.Wo = geom[6];
@@ -718,7 +735,7 @@ extern "C" int scail_conv3d_kernel_for(const int32_t* geom, int64_t ldc, int64_t
     if (geom == nullptr) return 0;
     ConvParams p;
     conv_params(p, geom);
-    return (g_conv4 && !fused_norm && conv4_eligible(p, ldc, ldr > 0 ? ldr : ldc)) ? 4 : 0;
+    return (g_conv4 && !fused_norm && (conv4_eligible(p, ldc, ldr > 0 ? ldr : ldc) || (ldr == 0 && conv4u_eligible(p, ldc)))) ? 4 : 0;
 }
 
 static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
@@ -741,11 +758,13 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
     // 2 = 32-channel slices, swizzled unpadded layout with two W buffers (one barrier per tap row), 2 workgroups per CU --
     // measured equal (283 / 490 ms vs 281 / 487 ms encode / decode): the barrier is not what bounds the kernel
     const bool fuse = gamma != nullptr;       // conv + RMS_norm + SiLU: always the halo kernel, whatever the knob says
-    if (g_conv4 && !fuse && conv4_eligible(p, ldc, resid ? ldr : ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
-        (reinterpret_cast<uintptr_t>(resid) & 15) == 0) {      // (16-byte row chunks; the arena's tensors always are)
+    const bool k1 = g_conv4 && !fuse && resid == nullptr && conv4u_eligible(p, ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    if (k1 || (g_conv4 && !fuse && conv4_eligible(p, ldc, resid ? ldr : ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(resid) & 15) == 0)) {      // (16-byte row chunks; the arena's tensors always are)
         Conv4Args a;
         a.x = x; a.w = w; a.bias = bias; a.y = y; a.resid = resid;
-        a.Ti = p.Ti; a.To = p.To; a.H = p.Ho; a.W = p.Wo; a.Cin = p.Cin; a.N = p.N; a.Kpad = p.Kpad; a.pt = p.pt;
+        // (kt = 1 kernels: H, W are the OUTPUT extent, the `pt` argument carries the upsample shift -- there are no padding frames)
+        a.Ti = p.Ti; a.To = p.To; a.H = p.Ho; a.W = p.Wo; a.Cin = p.Cin; a.N = p.N; a.Kpad = p.Kpad; a.pt = k1 ? (p.ups ? 1 : 0) : p.pt;
         a.tiles_t = (p.To + 1) / 2; a.tiles_w = (p.Wo + 15) / 16; a.tiles_n = p.N / 96;
         auto magic31 = [](int d) { return (uint32_t)(((1ull << 31) + (uint64_t)d - 1) / (uint64_t)d); };
         a.magic_n = magic31(a.tiles_n); a.magic_w = magic31(a.tiles_w); a.magic_t = magic31(a.tiles_t);
@@ -762,7 +781,8 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         hipFunction_t fn;
         // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)
         const bool prof = g_conv4_suffix.find("prof") != std::string::npos;
-        if (int rc = conv4_function(std::string(resid && !prof ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
+        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn)
+                        : conv4_function(std::string(resid && !prof ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
         hipError_t e = hipModuleLaunchKernel(fn, (unsigned)a.wgs_per_xcd * 8u, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);

@@ -24,8 +24,27 @@ def _cfg(name):
 
 
 def test_conv4_static_hazards():
-    for cfg in conv4.DEFAULTS:
+    for cfg in conv4.DEFAULTS + conv4.UPSAMPLE:
         assert R.check_static(cfg) == [], cfg.name
+
+
+@pytest.mark.parametrize("ups,shape,cus", [(1, (2, 8, 8, 224, 96), 256),      # 7 slices of 9 taps: the two slot pairs alternate
+                                           (1, (3, 9, 10, 64, 192), 8),       # odd frame count, ragged 18 x 20 output, 2 n tiles, several tiles per workgroup
+                                           (0, (5, 16, 40, 32, 96), 8),       # no upsample: a plain per-frame 3 x 3 convolution, 9 tiles on 8 workgroups
+                                           (1, (4, 8, 24, 96, 96), 8)])       # runs of tiles within a spatial tile and across
+def test_conv4u_emulated(ups, shape, cus):
+    """scail_conv4u_e0 (Cfg.kt = 1): the 3 x 3 convolution of Resample behind the nearest 2x upsample (reference wan_vae.py:76-85), folded into
+    the patch gather -- patch voxel (h, w) reads input (h >> 1, w >> 1)."""
+    cfg = conv4.UPSAMPLE[0]
+    T, Hi, Wi, Cin, N = shape
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((T, Hi, Wi, Cin)).astype(np.float32)
+    w = (rng.standard_normal((N, Cin, 1, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    y, _ = R.run_k1(cfg, x, w, b, ups, cus=cus)
+    ref = R.reference_k1(x, w, b, ups)
+    assert not np.isnan(y).any(), "every output voxel is written"
+    assert np.abs(y - ref).max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("name,shape,cus", [("scail_conv4_e0", (2, 16, 16, 32, 96), 256),         # one tile, one slice

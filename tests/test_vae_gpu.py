@@ -148,6 +148,44 @@ def test_resample_convs(C, T, H, W, conv_halo):
     torch.testing.assert_close(_pl(yu), refu, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("cin,cout,thw,ups", [(192, 96, (3, 24, 40), True),       # decoder stage 11's widths: 6 slices, one n tile, odd frame count
+                                              (384, 192, (4, 17, 23), True),      # stage 3 / 7's widths: 12 slices, 2 n tiles, ragged 34 x 46 output
+                                              (96, 96, (2, 32, 48), False),       # the same kernel without the upsample (a per-frame 3 x 3 convolution)
+                                              (192, 96, (5, 128, 224), True)])    # 256 x 448 output: 224 spatial tiles x 3 frame pairs, runs of tiles per workgroup
+def test_conv4u_generated_upsample_conv(cin, cout, thw, ups):
+    """scail_conv4u_e0 (csrc/conv4u.s, asmgen Cfg.kt = 1) behind scail_conv3d_cl: Resample's nearest-exact 2x upsample + Conv2d(dim, dim / 2, 3,
+    padding 1) per frame (reference wan_vae.py:76-85) against torch's fp32 convolution of the bf16-rounded operands on the GPU, against the
+    hipcc halo kernel it replaces (summation order only), into interleaved output frames of a wider tensor (ot_mul / ot_off, ldc > N)."""
+    import ctypes as C
+    from scail_amd import lib as L, ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    T, H, W = thw
+    x = torch.randn(T, H, W, cin, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (9 * cin) ** 0.5).to(torch.bfloat16).float()
+    b = torch.randn(cout, device=DEV, generator=g)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    wp = ops.prep_conv_weight(w, b)
+    geom = (C.c_int32 * 21)(T, H, W, cin, T, Ho, Wo, 1, 3, 3, 1, 1, 1, 0, 1, 1, 1 if ups else 0, 1, 0, wp["N"], wp["Kpad"])
+    assert L.load().scail_conv3d_kernel_for(C.cast(geom, C.c_void_p), cout, 0, 0) == 4
+    y = torch.full((T, Ho, Wo, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.conv3d_cl(x, wp, (T, Ho, Wo), pad=(0, 1, 1), ups=ups, out=y)
+    xf = x.float().permute(0, 3, 1, 2)
+    if ups:
+        xf = F.interpolate(xf, scale_factor=(2.0, 2.0), mode="nearest-exact")
+    ref = F.conv2d(xf, w, b, padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+    L.set_option("conv4", 0)
+    try:
+        y_old = ops.conv3d_cl(x, wp, (T, Ho, Wo), pad=(0, 1, 1), ups=ups)
+    finally:
+        L.set_option("conv4", 1)
+    assert float((y.float() - y_old.float()).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
+    out = torch.full((2 * T + 1, Ho, Wo, cout + 32), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.conv3d_cl(x, wp, (T, Ho, Wo), pad=(0, 1, 1), ups=ups, out=out, ot_mul=2, ot_off=1)
+    assert torch.equal(out[1::2, :, :, :cout], y)
+    assert torch.isnan(out[0::2].float()).all() and torch.isnan(out[:, :, :, cout:].float()).all(), "nothing else is written"
+
+
 @pytest.mark.parametrize("cin,cout,thw", [(96, 96, (5, 10, 12)), (32, 32, (4, 9, 17)), (64, 64, (2, 8, 16)), (96, 96, (1, 16, 16)),
                                           (192, 96, (3, 11, 21)), (32, 40, (3, 8, 16))])
 def test_conv_with_fused_rms_silu(cin, cout, thw):

@@ -16,9 +16,9 @@ from tools.attn4_emu_run import from_bf16_bits, to_bf16_bits  # noqa: E402
 
 
 def pack_weight(w, kpad=None):
-    """(N, Cin, 3, 3, 3) -> (N, Kpad) with k = ((dt 3 + dh) 3 + dw) Cin + c   (scail_amd.ops.prep_conv_weight)."""
+    """(N, Cin, kt, 3, 3) -> (N, Kpad) with k = ((dt 3 + dh) 3 + dw) Cin + c   (scail_amd.ops.prep_conv_weight)."""
     N, Cin = w.shape[:2]
-    k = 27 * Cin
+    k = w.shape[2] * 9 * Cin
     kpad = kpad or (k + 63) // 64 * 64
     out = np.zeros((N, kpad), dtype=np.float32)
     out[:, :k] = w.transpose(0, 2, 3, 4, 1).reshape(N, k)
@@ -76,6 +76,48 @@ def check_static(cfg):
             + sched.check_hazards(body + g.tile_end() + g.tile_setup()))
 
 
+def run_k1(cfg: conv4.Cfg, x, w, bias=None, ups=0, ldc=None, lazy=True, wgs=None, cus=256):
+    """the kt = 1 kernels: x (T, Hi, Wi, Cin), w (N, Cin, 1, 3, 3); output (T, Hi << ups, Wi << ups, N)."""
+    T, Hi, Wi, Cin = x.shape
+    N = w.shape[0]
+    H, W = Hi << ups, Wi << ups
+    ldc = ldc or N
+    wp = pack_weight(w)
+    mem = E.Memory(size=1 << 27)
+    px = mem.alloc("x", to_bf16_bits(x))
+    pw = mem.alloc("w", to_bf16_bits(wp))
+    pb = mem.alloc("bias", bias.astype(np.float32)) if bias is not None else 0
+    py = mem.alloc("y", np.full((T, H, W, ldc), 0x7FC0, dtype=np.uint16))
+    prog = conv4.Gen(cfg).program()
+    args = conv4.pack_args(px, pw, pb, py, 0, T, T, H, W, Cin, N, wp.shape[1], ups, 1, 0, ldc, 0, cus)
+    stats = None
+    for wg in (range(conv4.grid_blocks(T, H, W, N, cus)) if wgs is None else wgs):
+        emu = E.Emu(prog, mem, n_waves=4, lds_bytes=conv4.LDS_BYTES, lazy=lazy)
+        emu.launch(args, block_id=(wg, 0, 0))
+        stats = emu.waves[0].stats
+    return from_bf16_bits(mem.read_back("y")).reshape(T, H, W, ldc), stats
+
+
+def reference_k1(x, w, bias=None, ups=0):
+    """per frame: nearest 2x upsample (ups) then the 3x3 'same' convolution (reference Resample, wan_vae.py:76-85)."""
+    rt = lambda a: from_bf16_bits(to_bf16_bits(a)).astype(np.float64)
+    xr = rt(x)
+    if ups:
+        xr = xr.repeat(2, axis=1).repeat(2, axis=2)
+    T, H, W, Cin = xr.shape
+    N = w.shape[0]
+    xp = np.zeros((T, H + 2, W + 2, Cin))
+    xp[:, 1:-1, 1:-1] = xr
+    wr = rt(w)
+    y = np.zeros((T, H, W, N))
+    for dh in range(3):
+        for dw in range(3):
+            y += np.einsum("thwc,nc->thwn", xp[:, dh:dh + H, dw:dw + W], wr[:, :, 0, dh, dw])
+    if bias is not None:
+        y = y + bias.astype(np.float64)
+    return y
+
+
 if __name__ == "__main__":
     rng = np.random.default_rng(0)
     for cfg in conv4.DEFAULTS:
@@ -88,3 +130,12 @@ if __name__ == "__main__":
         y, st = run(cfg, x, w, bias, resid)
         ref = reference(x, w, bias, resid)
         print("   max abs err", np.abs(y - ref).max(), "ref absmax", np.abs(ref).max(), st)
+    for cfg in conv4.UPSAMPLE:
+        for ups, (T, Hi, Wi, Cin, N) in ((1, (2, 8, 8, 64, 96)), (0, (3, 18, 20, 96, 96))):
+            x = rng.standard_normal((T, Hi, Wi, Cin)).astype(np.float32)
+            w = (rng.standard_normal((N, Cin, 1, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+            bias = rng.standard_normal(N).astype(np.float32)
+            print(cfg.name, "ups", ups, "static", check_static(cfg)[:3])
+            y, st = run_k1(cfg, x, w, bias, ups)
+            ref = reference_k1(x, w, bias, ups)
+            print("   max abs err", np.abs(y - ref).max(), "ref absmax", np.abs(ref).max(), "nan", int(np.isnan(y).sum()), st)
