@@ -100,6 +100,8 @@ class Cfg:
     epi: int = 0            # 0: y = conv + bias;  3: y = resid + conv + bias
     kt: int = 3             # temporal taps: 3 = CausalConv3d 3x3x3;  1 = the 1x3x3 convolution of Resample (behind the nearest 2x upsample when the
                             # kernel argument `pt` -- no padding frames exist for kt = 1 -- is 1: patch voxel (h, w) reads input (h >> 1, w >> 1))
+    nb: int = 6             # 16-channel output blocks of the tile: 6 = 96 channels;  1 = a NARROW output (N <= 16: the decoder's RGB head, 96 -> 3):
+                            # 8 MFMAs per (tap, slice) instead of 48, the W rows past N read zeros, 8-byte stores straight from the accumulator layout
     cap: int = 1
     lookahead: float = 2.0
     name: str = "scail_conv4_e0"
@@ -187,6 +189,9 @@ class Gen:
         self.TAPS = 9 * cfg.kt                  # taps of a 32-channel slice
         self.NGRP = self.TAPS // 3              # tap groups (dt, dw) of a slice: the 10 patch rows of a group serve its 3 taps dh
         self.NFR = NF + cfg.kt - 1              # patch frames of a slice
+        assert cfg.nb in (1, 6) and not (cfg.nb == 1 and (cfg.epi != 0 or cfg.kt != 3))
+        self.NB = cfg.nb
+        self.gs = cfg.nb / 6.0                  # the fillers' target gaps scale with the MFMAs of a tap (48 -> 8)
         # kt = 3: which patch piece a position issues: (frame, voxel group, next slice?, needed at the top of relative position).  Frame 2 is first
         # read (wave frame 1, dt = 1: group 3) during positions 6..8, frame 3 (group 6) during 15..17, frames 0 / 1 of the next slice during
         # 24..26; their slots were released by frames 1 (after the top of 15), 2 (24), 3 (24) of the slice before and 0 (6) of this one.
@@ -240,11 +245,11 @@ class Gen:
     def mfmas(self, i: int) -> List[Instr]:
         # n-block major: the A fragment (W) stays for 8 consecutive MFMAs
         ws, xs, dh = i % 3, (i // 3) % 3, i % 3
-        return [isa.mfma16(ACC(nb, mb), WF(ws, nb), XF(xs, mb + dh), ACC(nb, mb), tag="mm") for nb in range(6) for mb in range(8)]
+        return [isa.mfma16(ACC(nb, mb), WF(ws, nb), XF(xs, mb + dh), ACC(nb, mb), tag="mm") for nb in range(self.NB) for mb in range(8)]
 
     def w_reads(self, i: int, t0: float, step: float) -> List[Instr]:
         """the 6 W quads of position i from the W buffer WB points at."""
-        return [isa.ds_read_b128(WF(i % 3, nb), WB, nb * 1024, target_gap=t0 + step * nb) for nb in range(6)]
+        return [isa.ds_read_b128(WF(i % 3, nb), WB, nb * 1024, target_gap=t0 + step * nb) for nb in range(self.NB)]
 
     def x_reads(self, grp: int, rows, t0: float, step: float) -> List[Instr]:
         """patch rows ``rows`` of tap group grp = dt 3 + dw (of the slice the PBASE registers point into) -> set grp % 3."""
@@ -304,6 +309,7 @@ class Gen:
 
     def tap_fillers(self, i: int) -> List[Instr]:
         c = self.cfg
+        g = self.gs
         abl = c.abl.split(",")
         blk: List[Instr] = []
         if "lds" not in abl:
@@ -311,28 +317,29 @@ class Gen:
             rows = self.XSPLIT[i % 3]
             if i % 3 == 0:
                 blk += self.xb_set((i // 3 + 1) % self.NGRP, 0.2)
-            blk += self.w_reads((i + 1) % self.TAPS, c.rd_at, c.rd_step)
-            blk += self.x_reads((i // 3 + 1) % self.NGRP, rows, c.rd_at + 6 * c.rd_step, c.rd_step)
+            blk += self.w_reads((i + 1) % self.TAPS, c.rd_at * g, c.rd_step * g)
+            blk += self.x_reads((i // 3 + 1) % self.NGRP, rows, (c.rd_at + 6 * c.rd_step) * g, c.rd_step * g)
         if "dma" not in abl:
-            blk += self.w_dma(c.dma_at, c.dma_step, need=i + NWB - 1)
-            blk += self.w_next((i + NWB) % self.TAPS, c.dma_at + c.dma_step + 1.5)
+            blk += self.w_dma(c.dma_at * g, c.dma_step * g, need=i + NWB - 1)
+            blk += self.w_next((i + NWB) % self.TAPS, (c.dma_at + c.dma_step) * g + 1.5)
             if "patch" not in abl:
                 for n, (j, k, nxt, need) in enumerate(self.PIECES.get(i, ())):
-                    blk += self.patch_piece(j, k, S_XOFFN if nxt else S_XOFF, c.p_at + 8.0 * n, need)
+                    blk += self.patch_piece(j, k, S_XOFFN if nxt else S_XOFF, (c.p_at + 8.0 * n) * g, need)
                     if k == 5:
-                        blk += self.slot_next(j, c.p_at + 8.0 * n + 1.0)
+                        blk += self.slot_next(j, (c.p_at + 8.0 * n) * g + 1.0)
         # the fragment base of frame f + dt moves to the next slice's slot once the last group that reads through it has been requested
         # (kt = 3: groups 3 dt .. 3 dt + 2 are read during positions 9 dt - 3 .. 9 dt + 5; kt = 1: group 2 during positions 3..5)
         nxt_base = {5: 0} if self.kt1 else {10: 0, 19: 1, 26: 2}
         if i in nxt_base:
-            blk += self.pbase_next(nxt_base[i], 40.0)
+            blk += self.pbase_next(nxt_base[i], 40.0 * g)
         return blk
 
     def tap_block(self, tap: int) -> List[Instr]:
         """One tap of the unrolled slice body, scheduled: 48 MFMAs with the next tap's fragment reads, the W DMA of tap + 4 and a patch
         piece of the frames that are due in their gaps.  (The top -- waits + barrier -- is added by slice_body, which knows the DMA order.)"""
         c = self.cfg
-        return sched.schedule(self.tap_fillers(tap) + self.mfmas(tap), cap=c.cap, lookahead=c.lookahead)
+        # (narrow tile: ~40 fillers for 8 MFMAs -- the tap is bound by instruction issue and the fragment reads, several fillers per gap)
+        return sched.schedule(self.tap_fillers(tap) + self.mfmas(tap), cap=c.cap if self.NB == 6 else 6, lookahead=c.lookahead)
 
     def slice_body(self) -> List[Instr]:
         """One 32-channel slice = 27 taps (kt = 1: 9).  At the top of tap i: this tap's fragments are in registers (lgkmcnt 0), every DMA whose data
@@ -497,13 +504,18 @@ class Gen:
               isa.sop("s_mov_b32", S_WR.sub(3), I32(0x00020000))]
         # ---- bias quads of this lane's channels n0 + 16 nb + 4 (l / 16) + e (zeros when bias == NULL): the accumulators start from them ----
         g = t[11]
-        for i in range(24):
+        for i in range(4 * self.NB):
             o.append(isa.vop("v_mov_b32", V(EPI_BQ + i), I32(0)))
         o += [isa.sop("s_cmp_eq_u64", None, S_BIAS, I32(0)), isa.branch("s_cbranch_scc1", "L_nobias"),
               isa.sop("s_lshl_b32", ST[7], S_N0, I32(2)), isa.sop("s_add_u32", ST[2], S_BIAS.sub(0), ST[7]),
               isa.sop("s_addc_u32", ST[3], S_BIAS.sub(1), I32(0)), isa.vop("v_lshlrev_b32", t[1], I32(4), g)]
-        for nb in range(6):
-            o.append(isa.global_load(4, V(EPI_BQ + 4 * nb, 4), t[1], 64 * nb, saddr=S(ST[2].idx, 2)))
+        if self.NB == 6:
+            for nb in range(6):
+                o.append(isa.global_load(4, V(EPI_BQ + 4 * nb, 4), t[1], 64 * nb, saddr=S(ST[2].idx, 2)))
+        else:       # N may be 8: a range-checked load (the quads of lanes 32..63 lie past the bias array and read zeros)
+            bd = S(ST[6].idx, 4)       # s88..s91: a 4-aligned quad of temporaries that are free here
+            o += [isa.sop("s_mov_b32", bd.sub(0), ST[2]), isa.sop("s_and_b32", bd.sub(1), ST[3], I32(0xFFFF)), isa.sop("s_lshl_b32", bd.sub(2), S_N, I32(2)),
+                  isa.sop("s_mov_b32", bd.sub(3), I32(0x00020000)), isa.buffer_load(4, V(EPI_BQ, 4), t[1], bd, I32(0))]
         o += [isa.label("L_nobias"), isa.nop(7), isa.label("L_same_n"), isa.nop(7),
               isa.sop("s_cmp_eq_u32", None, same, I32(1)), isa.branch("s_cbranch_scc1", "L_same")]
         # ---- patch pieces of this wave: piece wave + 4 i = patch voxels p = 16 (wave + 4 i) + l / 4 = (r, col) of the 18 x 20 LDS grid; LDS
@@ -551,7 +563,7 @@ class Gen:
     def tile_start(self) -> List[Instr]:
         """accumulators = bias, first DMAs landed (every wave), first fragments."""
         o: List[Instr] = [isa.label("L_first"), isa.waitcnt(vmcnt=0), isa.label("L_start"), isa.nop(7)]
-        for nb in range(6):
+        for nb in range(self.NB):
             for mb in range(8):
                 for i in range(4):
                     o.append(isa.vop("v_accvgpr_write_b32", ACC(nb, mb).sub(i), V(EPI_BQ + 4 * nb + i)))
@@ -568,10 +580,59 @@ class Gen:
              isa.sop("s_cselect_b32", self.HAVE_PREV, I32(1), I32(3)), isa.branch("s_branch", "L_tile")]
         return sched.pad_hazards(o)
 
+    def epilogue_narrow(self) -> List[Instr]:
+        """Cfg.nb = 1 (N <= 16, one n tile, no residual): lane = voxel (frame t0 + f, row h0 + 8 rh + mb, column w0 + l % 16), channels
+        4 (l / 16) + e.  A voxel's <= 16 channels are <= 32 contiguous bytes and the 16 voxels of a row block are neighbours in memory, so the
+        8-byte stores of a wave instruction already fill whole runs (16 x ldc x 2 bytes): no staging through LDS.  Lanes whose channels lie
+        past N do not store (N = 8: lanes 32..63)."""
+        t = T_
+        e: List[Instr] = [isa.label("L_epilogue"), isa.nop(15), isa.nop(15)]
+        tf, tfo, hw = ST[4], ST[5], ST[6]
+        ldc2 = ST[13]
+        e += [isa.sop("s_add_u32", tf, S_ET0, S_F), isa.sop("s_mul_i32", tfo, tf, S_OTM), isa.sop("s_add_u32", tfo, tfo, S_OTO),
+              isa.sop("s_mul_i32", hw, S_H, S_Wd), isa.sop("s_lshl_b32", ldc2, S_LDC.sub(0), I32(1)),
+              isa.sop("s_mul_i32", ST[0], hw, ldc2), isa.sop("s_mul_hi_u32", ST[1], hw, ldc2),                 # frame bytes (64 bit)
+              isa.sop("s_mul_i32", ST[2], ST[0], tfo), isa.sop("s_mul_hi_u32", ST[3], ST[0], tfo), isa.sop("s_mul_i32", ST[7], ST[1], tfo),
+              isa.sop("s_add_u32", ST[3], ST[3], ST[7]),
+              isa.sop("s_add_u32", S_YF.sub(0), S_Y.sub(0), ST[2]), isa.sop("s_addc_u32", S_YF.sub(1), S_Y.sub(1), ST[3]),
+              isa.sop("s_cmp_lt_u32", None, tf, S_T), isa.sop("s_cselect_b32", ST[8], S_Wd, I32(0))]           # frame outside [0, To): no column is valid
+        row0 = ST[9]
+        e += [isa.sop("s_lshl_b32", row0, S_RH, I32(3)), isa.sop("s_add_u32", row0, row0, S_EH0)]
+        ql, g, vcol, loff, voff = t[10], t[11], t[12], t[13], t[4]
+        e += [isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE),
+              isa.vop("v_add_u32", vcol, S_EW0, ql), isa.vop("v_lshlrev_b32", t[14], I32(2), g),
+              isa.v_cmp("v_cmp_gt_u32", S_N, t[14]), isa.vop("v_mov_b32", t[15], I32(0x7FFFFFFF)), isa.v_cndmask(vcol, t[15], vcol),   # channels past N: never valid
+              isa.vop("v_mul_lo_u32", loff, ql, ldc2), isa.vop("v_lshl_add_u32", loff, g, I32(3), loff)]
+        OUT = lambda mb: V(2 * mb, 2)
+        f = [V(120 + i) for i in range(4)]
+        for mb in range(8):
+            for i in range(4):
+                e.append(isa.vop("v_accvgpr_read_b32", f[i], ACC(0, mb).sub(i)))
+            e += [isa.vop("v_cvt_pk_bf16_f32", OUT(mb).sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", OUT(mb).sub(1), f[2], f[3])]
+        e += self.stamp(2)
+        e.append(isa.waitcnt(vmcnt=0))        # the next tile's first loads have landed (see epilogue)
+        e += self.stamp(3)
+        for mb in range(8):
+            hrow = ST[10]
+            e += [isa.sop("s_add_u32", hrow, row0, I32(mb)),
+                  isa.sop("s_cmp_lt_u32", None, hrow, S_H), isa.sop("s_cselect_b32", ST[11], ST[8], I32(0)),
+                  isa.sop("s_mul_i32", ST[12], hrow, S_Wd), isa.sop("s_add_u32", ST[12], ST[12], S_EW0), isa.sop("s_mul_i32", ST[7], ST[12], ldc2)]
+            st = isa.global_store(2, voff, OUT(mb), 0, saddr=S_YF, extra_reads=[EXEC])
+            if self.cfg.nt:
+                st.text += " nt"
+            e += [isa.v_cmp("v_cmp_gt_u32", ST[11], vcol),
+                  Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU),
+                  isa.vop("v_add_u32", voff, ST[7], loff), st, Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+        e += self.stamp(4)
+        e += [isa.sop("s_bitcmp1_b32", None, self.HAVE_PREV, I32(1)), isa.branch("s_cbranch_scc1", "L_done" if self.cfg.prof else "L_exit"), isa.branch("s_branch", "L_start")]
+        return sched.pad_hazards(sched.insert_lgkm_waits(e))
+
     def epilogue(self) -> List[Instr]:
         """lane: voxel (frame t0 + f, row h0 + 8 rh + mb, column w0 + l % 16), channels n0 + 16 nb + 4 (l / 16) + e of tile (S_ET0, ...);
         y / resid rows: voxel index ((frame * ot_mul + ot_off) * H + row) * W + column, strides ldc / ldr elements.  The bias is in the
         accumulators already."""
+        if self.NB == 1:
+            return self.epilogue_narrow()
         c = self.cfg
         t = T_
         e: List[Instr] = [isa.label("L_epilogue"), isa.nop(15), isa.nop(15)]
@@ -772,6 +833,8 @@ DEFAULTS = [Cfg(epi=0, name="scail_conv4_e0"), Cfg(epi=3, name="scail_conv4_e3")
 # the 1x3x3 convolution of Resample (wan_vae.py:76-85: nearest-exact 2x upsample, then Conv2d(dim, dim / 2, 3, padding 1) per frame): its own
 # code object (csrc/conv4u.s), so that csrc/conv4.s -- and the traffic measurements stamped with its blob id -- stay as they are
 UPSAMPLE = [Cfg(epi=0, kt=1, name="scail_conv4u_e0")]
+# narrow outputs (N <= 16): the decoder's RGB head (CausalConv3d(96, 3, 3), wan_vae.py:417-419); same code object as the kt = 1 kernel
+NARROW = [Cfg(epi=0, nb=1, name="scail_conv4n_e0")]
 
 
 def variant_cfgs():

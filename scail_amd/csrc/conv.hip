@@ -615,7 +615,8 @@ __global__ void from_channels_last_kernel(const u16* __restrict__ x, int64_t ldx
 static const unsigned char k_conv4_hsaco[] = {
 #include "conv4_hsaco.inc"
 };
-// the kt = 1 kernels (scail_conv4u_*: the 1x3x3 convolution of Resample, optionally behind the nearest 2x upsample; csrc/conv4u.s, Cfg.kt = 1)
+// the kt = 1 kernels (scail_conv4u_*: the 1x3x3 convolution of Resample, optionally behind the nearest 2x upsample; Cfg.kt = 1) and the narrow-output
+// 3x3x3 kernel (scail_conv4n_*: N <= 16, the RGB head; Cfg.nb = 1): csrc/conv4u.s
 static const unsigned char k_conv4u_hsaco[] = {
 #include "conv4u_hsaco.inc"
 };
@@ -642,7 +643,7 @@ static int conv4_function(const std::string& name, hipFunction_t* fn) {
         scail_set_error("conv4: hipGetDevice failed");
         return 2;
     }
-    const int which = name.rfind("scail_conv4u", 0) == 0 ? 1 : 0;
+    const int which = (name.rfind("scail_conv4u", 0) == 0 || name.rfind("scail_conv4n", 0) == 0) ? 1 : 0;
     auto mit = g_conv4_modules.find(std::make_pair(dev, which));
     if (mit == g_conv4_modules.end()) {
         hipModule_t mod = nullptr;
@@ -696,7 +697,7 @@ static constexpr int g_conv_halo = 4;
 // the shapes the generated kernels cover: 3x3x3, stride 1, 'same' spatial extent, 0..2 padding frames in front, whole 32-channel slices and
 // 96-channel output tiles, at least one frame pair, 32-bit byte offsets inside a frame, and a tile grid whose id decode is exact: the kernel
 // divides a tile id by tiles_n, tiles_t and tiles_w with 31-bit magic numbers, exact while dividend x divisor < 2^31
-static int64_t conv4_tiles(const ConvParams& p) { return (int64_t)((p.To + 1) / 2) * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * (p.N / 96); }
+static int64_t conv4_tiles(const ConvParams& p) { return (int64_t)((p.To + 1) / 2) * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) * std::max(p.N / 96, 1); }
 static bool conv4_eligible(const ConvParams& p, int64_t ldc, int64_t ldr) {
     if (p.N <= 0 || p.N % 96 != 0 || p.To < 2 || p.Ho <= 0 || p.Wo <= 0) return false;
     const int64_t max_div = std::max<int64_t>({p.N / 96, (p.To + 1) / 2, (p.Wo + 15) / 16});
@@ -719,6 +720,18 @@ static bool conv4u_eligible(const ConvParams& p, int64_t ldc) {
            (int64_t)p.Ho * p.Wo * ldc * 2 < (1ll << 32);
 }
 
+// the narrow-output kernel: the 3x3x3 shapes of conv4_eligible with N = 8 or 16 output channels (one n tile, W rows past N read zeros), no
+// residual; 8-byte stores (ldc % 4 == 0)
+static bool conv4n_eligible(const ConvParams& p, int64_t ldc) {
+    if (p.N != 8 && p.N != 16) return false;
+    if (p.To < 2 || p.Ho <= 0 || p.Wo <= 0) return false;
+    const int64_t max_div = std::max<int64_t>((p.To + 1) / 2, (p.Wo + 15) / 16);
+    if (conv4_tiles(p) * max_div >= (1ll << 31)) return false;
+    return p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups && p.ph == 1 && p.pw == 1 &&
+           p.Ho == p.Hi && p.Wo == p.Wi && p.Cin % 32 == 0 && p.pt >= 0 && p.pt <= 2 && ldc % 4 == 0 && ldc >= p.N && ldc < (1 << 20) &&
+           (int64_t)p.Hi * p.Wi * p.Cin * 2 < (1ll << 31) && (int64_t)p.Ho * p.Wo * ldc * 2 < (1ll << 32);
+}
+
 static void conv_params(ConvParams& p, const int32_t* geom) {
     p.Ti = geom[0]; p.Hi = geom[1]; p.Wi = geom[2]; p.Cin = geom[3];
     p.To = geom[4]; p.Ho = geom[5]; p.Wo = geom[6];
@@ -735,7 +748,7 @@ extern "C" int scail_conv3d_kernel_for(const int32_t* geom, int64_t ldc, int64_t
     if (geom == nullptr) return 0;
     ConvParams p;
     conv_params(p, geom);
-    return (g_conv4 && !fused_norm && (conv4_eligible(p, ldc, ldr > 0 ? ldr : ldc) || (ldr == 0 && conv4u_eligible(p, ldc)))) ? 4 : 0;
+    return (g_conv4 && !fused_norm && (conv4_eligible(p, ldc, ldr > 0 ? ldr : ldc) || (ldr == 0 && (conv4u_eligible(p, ldc) || conv4n_eligible(p, ldc))))) ? 4 : 0;
 }
 
 static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
@@ -759,13 +772,14 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
     // measured equal (283 / 490 ms vs 281 / 487 ms encode / decode): the barrier is not what bounds the kernel
     const bool fuse = gamma != nullptr;       // conv + RMS_norm + SiLU: always the halo kernel, whatever the knob says
     const bool k1 = g_conv4 && !fuse && resid == nullptr && conv4u_eligible(p, ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-    if (k1 || (g_conv4 && !fuse && conv4_eligible(p, ldc, resid ? ldr : ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+    const bool nar = g_conv4 && !fuse && resid == nullptr && conv4n_eligible(p, ldc);
+    if (k1 || nar || (g_conv4 && !fuse && conv4_eligible(p, ldc, resid ? ldr : ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(resid) & 15) == 0)) {      // (16-byte row chunks; the arena's tensors always are)
         Conv4Args a;
         a.x = x; a.w = w; a.bias = bias; a.y = y; a.resid = resid;
         // (kt = 1 kernels: H, W are the OUTPUT extent, the `pt` argument carries the upsample shift -- there are no padding frames)
         a.Ti = p.Ti; a.To = p.To; a.H = p.Ho; a.W = p.Wo; a.Cin = p.Cin; a.N = p.N; a.Kpad = p.Kpad; a.pt = k1 ? (p.ups ? 1 : 0) : p.pt;
-        a.tiles_t = (p.To + 1) / 2; a.tiles_w = (p.Wo + 15) / 16; a.tiles_n = p.N / 96;
+        a.tiles_t = (p.To + 1) / 2; a.tiles_w = (p.Wo + 15) / 16; a.tiles_n = std::max(p.N / 96, 1);
         auto magic31 = [](int d) { return (uint32_t)(((1ull << 31) + (uint64_t)d - 1) / (uint64_t)d); };
         a.magic_n = magic31(a.tiles_n); a.magic_w = magic31(a.tiles_w); a.magic_t = magic31(a.tiles_t);
         a.n_slices = p.Cin / 32; a.ot_mul = p.ot_mul; a.ot_off = p.ot_off; a.ldc = ldc; a.ldr = resid ? ldr : ldc;
@@ -781,7 +795,7 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         hipFunction_t fn;
         // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)
         const bool prof = g_conv4_suffix.find("prof") != std::string::npos;
-        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn)
+        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function("scail_conv4n_e0", &fn)
                         : conv4_function(std::string(resid && !prof ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};

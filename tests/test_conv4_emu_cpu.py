@@ -24,8 +24,24 @@ def _cfg(name):
 
 
 def test_conv4_static_hazards():
-    for cfg in conv4.DEFAULTS + conv4.UPSAMPLE:
+    for cfg in conv4.DEFAULTS + conv4.UPSAMPLE + conv4.NARROW:
         assert R.check_static(cfg) == [], cfg.name
+
+
+@pytest.mark.parametrize("shape,cus,ldc", [((2, 16, 16, 96, 8), 256, None),        # the RGB head's widths (3 channels padded to 8): lanes 32..63 store nothing
+                                           ((3, 18, 20, 64, 16), 8, None),         # 16 channels, ragged tiles, odd frame count, several tiles per workgroup
+                                           ((5, 16, 40, 32, 8), 8, 16)])           # output rows wider than N
+def test_conv4n_emulated(shape, cus, ldc):
+    """scail_conv4n_e0 (Cfg.nb = 1): 3x3x3 causal convolution with N <= 16 output channels (the decoder head CausalConv3d(96, 3, 3),
+    reference wan_vae.py:417-419): one 16-channel block per tile, range-checked bias / W rows, 8-byte stores from the accumulator layout."""
+    cfg = conv4.NARROW[0]
+    Ti, H, W, Cin, N = shape
+    x, w, b, _ = _case(Ti, H, W, Cin, N, False, seed=2)
+    y, _ = R.run(cfg, x, w, b, None, cus=cus, ldc=ldc)
+    ref = R.reference(x, w, b, None)
+    assert not np.isnan(y[..., :N]).any(), "every output voxel is written"
+    assert np.isnan(y[..., N:]).all(), "nothing past the N channels is written"
+    assert np.abs(y[..., :N] - ref).max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("ups,shape,cus", [(1, (2, 8, 8, 224, 96), 256),      # 7 slices of 9 taps: the two slot pairs alternate

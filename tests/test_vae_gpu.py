@@ -148,6 +148,34 @@ def test_resample_convs(C, T, H, W, conv_halo):
     torch.testing.assert_close(_pl(yu), refu, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("cin,cout,thw", [(96, 3, (5, 40, 56)), (96, 3, (4, 128, 224)), (64, 16, (3, 19, 33)), (32, 12, (2, 16, 16))])
+def test_conv4n_generated_narrow_conv(cin, cout, thw):
+    """scail_conv4n_e0 (csrc/conv4u.s, asmgen Cfg.nb = 1) behind scail_conv3d_cl: 3x3x3 causal convolutions with at most 16 output channels --
+    the decoder head CausalConv3d(96, 3, 3) (reference wan_vae.py:417-419) -- against torch's fp32 convolution of the bf16-rounded operands
+    and against the hipcc halo kernel it replaces; the padding channels of the output (3 -> 8) hold zeros like before."""
+    import ctypes as C
+    from scail_amd import lib as L, ops
+    g = torch.Generator(device=DEV).manual_seed(8)
+    T, H, W = thw
+    x = torch.randn(T, H, W, cin, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=g) / (27 * cin) ** 0.5).to(torch.bfloat16).float()
+    b = torch.randn(cout, device=DEV, generator=g)
+    wp = ops.prep_conv_weight(w, b)
+    N = wp["N"]
+    assert N in (8, 16) and L.load().scail_conv3d_kernel_for(C.cast(_geom(T, H, W, cin, T, N, wp["Kpad"]), C.c_void_p), N, 0, 0) == 4
+    y = torch.full((T, H, W, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.conv3d_cl(x, wp, (T, H, W), out=y)
+    ref = F.conv3d(F.pad(x.float().permute(3, 0, 1, 2)[None], (1, 1, 1, 1, 2, 0)), w, b)[0].permute(1, 2, 3, 0)
+    torch.testing.assert_close(y[..., :cout].float(), ref, rtol=2e-2, atol=2e-2)
+    assert float(y[..., cout:].float().abs().max() if cout < N else 0.0) == 0.0, "padding channels: zero weights, zero bias"
+    L.set_option("conv4", 0)
+    try:
+        y_old = ops.conv3d_cl(x, wp, (T, H, W))
+    finally:
+        L.set_option("conv4", 1)
+    assert float((y.float() - y_old.float()).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("cin,cout,thw,ups", [(192, 96, (3, 24, 40), True),       # decoder stage 11's widths: 6 slices, one n tile, odd frame count
                                               (384, 192, (4, 17, 23), True),      # stage 3 / 7's widths: 12 slices, 2 n tiles, ragged 34 x 46 output
                                               (96, 96, (2, 32, 48), False),       # the same kernel without the upsample (a per-frame 3 x 3 convolution)

@@ -417,11 +417,12 @@ class Emu:
             base = rs[0] | ((rs[1] & 0xFFFF) << 32)
             voff = self._rd(w, s[0]).astype(np.int64)
             addr = base + voff + self._rds(w, s[2]) + ins.offset
-            def commit(addr=addr, d=d, nb=nb, mask=w.exec.copy()):
+            inrange = (voff + ins.offset + nb) <= rs[2]            # raw buffer: offsets past num_records read zeros
+            def commit(addr=addr, d=d, nb=nb, mask=w.exec.copy(), inrange=inrange):
                 bank = w.v if d.kind == "v" else w.a
                 for l in range(64):
                     if mask[l]:
-                        data = self.mem.load(int(addr[l]), nb).view(np.uint32)
+                        data = self.mem.load(int(addr[l]), nb).view(np.uint32) if inrange[l] else np.zeros(nb // 4, np.uint32)
                         for i in range(d.n):
                             bank[d.idx + i][l] = data[i]
             self._queue(w, "vm", commit)

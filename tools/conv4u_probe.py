@@ -45,3 +45,21 @@ for (T, H, W, cin) in ((41, 64, 112, 384), (81, 128, 224, 384), (81, 256, 448, 1
         rec[name + "_TFLOPs"] = round(fl / min(rec[name + "_ms"]) / 1e9, 0)
     rec["max_abs_diff"] = float((outs["halo"].float() - outs["conv4u"].float()).abs().max())
     print(json.dumps(rec), flush=True)
+    del x, y, outs
+
+# the decoder head CausalConv3d(96, 3, 3) at full resolution: the narrow-output kernel (scail_conv4n_e0) against the halo kernel (32-wide N tile)
+T, H, W, cin, cout = 81, 512, 896, 96, 3
+x = torch.randn(T, H, W, cin, device=DEV, generator=g).to(torch.bfloat16)
+wp = ops.prep_conv_weight(torch.randn(cout, cin, 3, 3, 3, device=DEV, generator=g) / (27 * cin) ** 0.5, torch.randn(cout, device=DEV, generator=g))
+y = torch.empty(T, H, W, wp["N"], device=DEV, dtype=torch.bfloat16)
+rec = {"head": [T, H, W, cin, cout], "algorithmic_GB": round((x.numel() + y.numel()) * 2 / 1e9, 2)}
+outs = {}
+for rnd in range(2):
+    for mode, name in ((0, "halo"), (1, "conv4n")):
+        L.set_option("conv4", mode)
+        ms = timeit(lambda: ops.conv3d_cl(x, wp, (T, H, W), out=y))
+        rec.setdefault(name + "_ms", []).append(round(ms, 3))
+        outs[name] = y.clone()
+L.set_option("conv4", 1)
+rec["max_abs_diff"] = float((outs["halo"].float() - outs["conv4n"].float()).abs().max())
+print(json.dumps(rec), flush=True)
