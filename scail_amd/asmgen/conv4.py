@@ -97,7 +97,9 @@ def grid_blocks(T, H, W, N, cus=256) -> int:
 
 @dataclass
 class Cfg:
-    epi: int = 0            # 0: y = conv + bias;  3: y = resid + conv + bias
+    epi: int = 0            # 0: y = conv + bias;  3: y = resid + conv + bias;  4: y = SiLU(RMS_norm(bf16(conv + bias)) * gamma) -- the first
+                            # convolution of a ResidualBlock with its RMS_norm and SiLU (wan_vae.py:190-196); one n tile (N = 96), gamma (fp32 [96])
+                            # arrives in the `resid` argument
     kt: int = 3             # temporal taps: 3 = CausalConv3d 3x3x3;  1 = the 1x3x3 convolution of Resample (behind the nearest 2x upsample when the
                             # kernel argument `pt` -- no padding frames exist for kt = 1 -- is 1: patch voxel (h, w) reads input (h >> 1, w >> 1))
     nb: int = 6             # 16-channel output blocks of the tile: 6 = 96 channels;  1 = a NARROW output (N <= 16: the decoder's RGB head, 96 -> 3):
@@ -137,6 +139,7 @@ WDMA = [V(138 + i) for i in range(2)]                       # per-lane source of
 LANE = V(141)
 T_ = [V(144 + i) for i in range(40)]                        # v144..v183 temporaries
 EPI_BQ, EPI_RP, EPI_F = 184, 208, 220                       # epilogue: bias quads v184..207, residual pairs v208..219, staging v220..235
+EPI_GQ = 228                                                # (epi 4) gamma quads v228..251 of this lane's channels 16 nb + 4 (l / 16) + e, loaded once at entry
 
 S_KARG = S(0, 2)
 S_WG = S(2)
@@ -189,7 +192,7 @@ class Gen:
         self.TAPS = 9 * cfg.kt                  # taps of a 32-channel slice
         self.NGRP = self.TAPS // 3              # tap groups (dt, dw) of a slice: the 10 patch rows of a group serve its 3 taps dh
         self.NFR = NF + cfg.kt - 1              # patch frames of a slice
-        assert cfg.nb in (1, 6) and not (cfg.nb == 1 and (cfg.epi != 0 or cfg.kt != 3))
+        assert cfg.nb in (1, 6) and not (cfg.nb == 1 and (cfg.epi != 0 or cfg.kt != 3)) and cfg.epi in (0, 3, 4)
         self.NB = cfg.nb
         self.gs = cfg.nb / 6.0                  # the fillers' target gaps scale with the MFMAs of a tap (48 -> 8)
         # kt = 3: which patch piece a position issues: (frame, voxel group, next slice?, needed at the top of relative position).  Frame 2 is first
@@ -416,6 +419,9 @@ class Gen:
         # ---- per-lane parts of the fragment bases ----
         ql, g = t[10], t[11]
         o += [isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
+        if c.epi == 4:      # gamma quads (one n tile: the same 96 channels for every tile of the launch); landed long before the first epilogue
+            assert not c.prof
+            o += [isa.vop("v_lshlrev_b32", t[1], I32(4), g)] + [isa.global_load(4, V(EPI_GQ + 4 * nb, 4), t[1], 64 * nb, saddr=S_RES) for nb in range(6)]
         # patch: row 8 rh of the slot of frame f (+ dt slots, + the ring position: tile_setup); the lane's place in a row per column shift
         o += [isa.sop("s_mul_i32", ST[0], S_RH, I32(8 * ROWB)), isa.sop("s_mul_i32", ST[1], S_F, I32(FSLOT)), isa.sop("s_add_u32", ST[1], ST[1], ST[0]),
               isa.sop("s_add_u32", ST[1], ST[1], I32(PBASE0)), isa.vop("v_mov_b32", PBL, ST[1])]
@@ -694,6 +700,40 @@ class Gen:
                 r += [isa.vop("v_cvt_pk_bf16_f32", OUT(mb, nb).sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", OUT(mb, nb).sub(1), f[2], f[3])]
             return r
 
+        def norm_silu(mb):
+            """(epi 4) OUT(mb, .) holds the bf16-rounded conv + bias of the lane's 24 channels of one voxel (lanes l, l ^ 16, l ^ 32, l ^ 48 hold the
+            same voxel's other channels): x * sqrt(96) / max(||x||, 1e-12) * gamma, SiLU, packed back in place -- the arithmetic of
+            rms_silu_kernel (csrc/conv.hip) on what scail_conv4_e0 would have stored (reference RMS_norm = F.normalize * sqrt(C) * gamma,
+            wan_vae.py:39-54)."""
+            ss, tt = t[18], t[19]
+            f0, f1, u0, u1 = F(0)
+            r = []
+            first = True
+            for nb in range(6):
+                for h in range(2):
+                    src = OUT(mb, nb).sub(h)
+                    r += [isa.vop("v_lshlrev_b32", f0, I32(16), src), isa.vop("v_and_b32", f1, I32(0xFFFF0000), src),
+                          isa.vop("v_mul_f32", ss, f0, f0) if first else isa.vop("v_fma_f32", ss, f0, f0, ss), isa.vop("v_fma_f32", ss, f1, f1, ss)]
+                    first = False
+            r += [isa.vop("v_mov_b32", tt, ss), isa.permlane32_swap(ss, tt), isa.vop("v_add_f32", ss, ss, tt),
+                  isa.vop("v_mov_b32", tt, ss), isa.permlane16_swap(ss, tt), isa.vop("v_add_f32", ss, ss, tt),
+                  isa.vop("v_sqrt_f32", ss, ss), isa.vop("v_max_f32", ss, F32(1e-12), ss), isa.vop("v_rcp_f32", ss, ss),
+                  isa.vop("v_mul_f32", ss, F32(96.0 ** 0.5), ss)]
+            for nb in range(6):
+                for h in range(2):
+                    src = OUT(mb, nb).sub(h)
+                    g0, g1 = V(EPI_GQ + 4 * nb + 2 * h), V(EPI_GQ + 4 * nb + 2 * h + 1)
+                    r += [isa.vop("v_lshlrev_b32", f0, I32(16), src), isa.vop("v_and_b32", f1, I32(0xFFFF0000), src),
+                          isa.vop("v_mul_f32", f0, f0, ss), isa.vop("v_mul_f32", f1, f1, ss),
+                          isa.vop("v_mul_f32", f0, f0, g0), isa.vop("v_mul_f32", f1, f1, g1),
+                          isa.vop("v_mul_f32", u0, F32(-1.4426950408889634), f0), isa.vop("v_mul_f32", u1, F32(-1.4426950408889634), f1),
+                          isa.vop("v_exp_f32", u0, u0), isa.vop("v_exp_f32", u1, u1),
+                          isa.vop("v_add_f32", u0, F32(1.0), u0), isa.vop("v_add_f32", u1, F32(1.0), u1),
+                          isa.vop("v_rcp_f32", u0, u0), isa.vop("v_rcp_f32", u1, u1),
+                          isa.vop("v_mul_f32", f0, f0, u0), isa.vop("v_mul_f32", f1, f1, u1),
+                          isa.vop("v_cvt_pk_bf16_f32", src, f0, f1)]
+            return r
+
         if c.epi == 3:
             # residual rows: whole lines from memory (3 x 16 bytes per lane and row block, everything requested first), through LDS into the
             # accumulator layout
@@ -712,6 +752,8 @@ class Gen:
         else:
             for mb in range(8):
                 e += to_packed(mb, 0)
+                if c.epi == 4:
+                    e += norm_silu(mb)
         e += self.stamp(2)                                        # phase 2: accumulators -> packed outputs
         # the next tile's first loads have landed by now (the stores of the tile before were issued a whole tile ago): the accumulators can
         # take the next tile's bias as soon as the stores are issued -- these drain behind the next tile's taps
@@ -835,6 +877,8 @@ DEFAULTS = [Cfg(epi=0, name="scail_conv4_e0"), Cfg(epi=3, name="scail_conv4_e3")
 UPSAMPLE = [Cfg(epi=0, kt=1, name="scail_conv4u_e0")]
 # narrow outputs (N <= 16): the decoder's RGB head (CausalConv3d(96, 3, 3), wan_vae.py:417-419); same code object as the kt = 1 kernel
 NARROW = [Cfg(epi=0, nb=1, name="scail_conv4n_e0")]
+# conv -> RMS_norm -> SiLU in one kernel (96 output channels): ResidualBlock.residual[2..4]; also in csrc/conv4u.s
+FUSED = [Cfg(epi=4, name="scail_conv4f_e4")]
 
 
 def variant_cfgs():

@@ -616,7 +616,7 @@ static const unsigned char k_conv4_hsaco[] = {
 #include "conv4_hsaco.inc"
 };
 // the kt = 1 kernels (scail_conv4u_*: the 1x3x3 convolution of Resample, optionally behind the nearest 2x upsample; Cfg.kt = 1) and the narrow-output
-// 3x3x3 kernel (scail_conv4n_*: N <= 16, the RGB head; Cfg.nb = 1): csrc/conv4u.s
+// 3x3x3 kernel (scail_conv4n_*: N <= 16, the RGB head; Cfg.nb = 1) and conv + RMS_norm + SiLU in one kernel (scail_conv4f_e4: N = 96): csrc/conv4u.s
 static const unsigned char k_conv4u_hsaco[] = {
 #include "conv4u_hsaco.inc"
 };
@@ -643,7 +643,7 @@ static int conv4_function(const std::string& name, hipFunction_t* fn) {
         scail_set_error("conv4: hipGetDevice failed");
         return 2;
     }
-    const int which = (name.rfind("scail_conv4u", 0) == 0 || name.rfind("scail_conv4n", 0) == 0) ? 1 : 0;
+    const int which = (name.rfind("scail_conv4u", 0) == 0 || name.rfind("scail_conv4n", 0) == 0 || name.rfind("scail_conv4f", 0) == 0) ? 1 : 0;
     auto mit = g_conv4_modules.find(std::make_pair(dev, which));
     if (mit == g_conv4_modules.end()) {
         hipModule_t mod = nullptr;
@@ -748,7 +748,9 @@ extern "C" int scail_conv3d_kernel_for(const int32_t* geom, int64_t ldc, int64_t
     if (geom == nullptr) return 0;
     ConvParams p;
     conv_params(p, geom);
-    return (g_conv4 && !fused_norm && (conv4_eligible(p, ldc, ldr > 0 ? ldr : ldc) || (ldr == 0 && (conv4u_eligible(p, ldc) || conv4n_eligible(p, ldc))))) ? 4 : 0;
+    if (fused_norm)      // conv + RMS_norm + SiLU: the generated kernel where one n tile holds a voxel's 96 channels, no residual
+        return (g_conv4 && ldr == 0 && p.N == 96 && conv4_eligible(p, ldc, ldc)) ? 4 : 0;
+    return (g_conv4 && (conv4_eligible(p, ldc, ldr > 0 ? ldr : ldc) || (ldr == 0 && (conv4u_eligible(p, ldc) || conv4n_eligible(p, ldc))))) ? 4 : 0;
 }
 
 static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
@@ -773,10 +775,13 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
     const bool fuse = gamma != nullptr;       // conv + RMS_norm + SiLU: always the halo kernel, whatever the knob says
     const bool k1 = g_conv4 && !fuse && resid == nullptr && conv4u_eligible(p, ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     const bool nar = g_conv4 && !fuse && resid == nullptr && conv4n_eligible(p, ldc);
-    if (k1 || nar || (g_conv4 && !fuse && conv4_eligible(p, ldc, resid ? ldr : ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+    // conv -> RMS_norm -> SiLU (scail_conv3d_cl_norm) on the generated kernel: one n tile of 96 channels; gamma travels in the residual argument
+    const bool fnorm = g_conv4 && fuse && resid == nullptr && p.N == 96 && conv4_eligible(p, ldc, ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(gamma) & 15) == 0;
+    if (k1 || nar || fnorm || (g_conv4 && !fuse && conv4_eligible(p, ldc, resid ? ldr : ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(resid) & 15) == 0)) {      // (16-byte row chunks; the arena's tensors always are)
         Conv4Args a;
-        a.x = x; a.w = w; a.bias = bias; a.y = y; a.resid = resid;
+        a.x = x; a.w = w; a.bias = bias; a.y = y; a.resid = fnorm ? static_cast<const void*>(gamma) : static_cast<const void*>(resid);
         // (kt = 1 kernels: H, W are the OUTPUT extent, the `pt` argument carries the upsample shift -- there are no padding frames)
         a.Ti = p.Ti; a.To = p.To; a.H = p.Ho; a.W = p.Wo; a.Cin = p.Cin; a.N = p.N; a.Kpad = p.Kpad; a.pt = k1 ? (p.ups ? 1 : 0) : p.pt;
         a.tiles_t = (p.To + 1) / 2; a.tiles_w = (p.Wo + 15) / 16; a.tiles_n = std::max(p.N / 96, 1);
@@ -795,7 +800,7 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         hipFunction_t fn;
         // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)
         const bool prof = g_conv4_suffix.find("prof") != std::string::npos;
-        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function("scail_conv4n_e0", &fn)
+        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function("scail_conv4n_e0", &fn) : fnorm ? conv4_function("scail_conv4f_e4", &fn)
                         : conv4_function(std::string(resid && !prof ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};

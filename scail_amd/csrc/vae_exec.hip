@@ -85,10 +85,11 @@ int res_block(Arena& a, const scail_vae_res& r, Tens& x) {
     int32_t geom[21] = {(int32_t)y.T, (int32_t)y.H, (int32_t)y.W, (int32_t)y.C, (int32_t)x.T, (int32_t)x.H, (int32_t)x.W,
                         3, 3, 3, 1, 1, 1, 2, 1, 1, 0, 1, 0, r.conv2.N, r.conv2.Kpad};
     if (r.conv2.kt == 3 && r.conv2.kh == 3 && r.conv2.kw == 3 && y.C % 32 == 0 && r.conv2.N <= 96 &&
-        scail_conv3d_kernel_for(geom, r.conv2.N, 0, 0) != 4) {
-        // conv -> RMS_norm -> SiLU in one kernel: the raw conv output never goes to HBM (same rule as ops.conv_norm_fusable).  Where the
-        // generated convolution kernels apply, conv + a separate rms_silu pass is faster than the fused hipcc kernel (13.9 + 2.8 vs 21.0 ms
-        // on the 96-channel full-resolution shape).
+        (scail_conv3d_kernel_for(geom, r.conv2.N, 0, 1) == 4 || scail_conv3d_kernel_for(geom, r.conv2.N, 0, 0) != 4)) {
+        // conv -> RMS_norm -> SiLU in one kernel: the raw conv output never goes to HBM (same rule as ops.conv_norm_fusable): the generated
+        // kernel's norm epilogue where it applies (N = 96: scail_conv4f_e4), else the hipcc halo kernel's -- except where the plain generated
+        // kernel runs but its norm epilogue does not: there conv + a separate rms_silu pass beats the fused hipcc kernel (13.9 + 2.8 vs 21.0 ms
+        // on the 96-channel full-resolution shape, round 3).
         y2 = a.get(x.T, x.H, x.W, r.conv2.N); VAE_CHK(a)
         VAE_TRY(scail_conv3d_cl_norm(y.p, r.conv2.w, r.conv2.b, y2.p, y2.C, r.gamma3, geom, a.stream));
         a.emit("conv_norm", y2);

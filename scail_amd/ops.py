@@ -353,6 +353,16 @@ def conv_norm_fusable(wp, x_channels: int) -> bool:
     return tuple(wp["k"]) == (3, 3, 3) and x_channels % 32 == 0 and wp["N"] <= 96
 
 
+def conv_norm_generated(wp, x_shape) -> bool:
+    """Whether conv3d_cl_norm of an activation of shape (T, H, W, Cin) runs the generated kernel's norm epilogue (scail_conv4f_e4: 96 output
+    channels; scail_conv3d_kernel_for(..., fused_norm = 1) == 4)."""
+    import ctypes as C
+    T, H, W, Cin = x_shape
+    kt, kh, kw = wp["k"]
+    geom = (C.c_int32 * 21)(T, H, W, Cin, T, H, W, kt, kh, kw, 1, 1, 1, kt - 1, kh // 2, kw // 2, 0, 1, 0, wp["N"], wp["Kpad"])
+    return L.load().scail_conv3d_kernel_for(C.cast(geom, C.c_void_p), wp["N"], 0, 1) == 4
+
+
 def conv_generated(wp, x_shape) -> bool:
     """Whether the causal 'same' conv3d_cl of an activation of shape (T, H, W, Cin) runs the generated kernels (scail_conv3d_kernel_for == 4).
     The VAE then prefers conv3d_cl + rms_silu over the fused conv3d_cl_norm of the hipcc halo kernel: 13.9 + 2.8 ms against 21.0 ms on the

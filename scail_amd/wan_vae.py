@@ -188,8 +188,10 @@ class WanVAE_(nn.Module):
         T, H, Wd, _ = x.shape
         h = ops.conv3d_cl(x, W[n + ".shortcut"], (T, H, Wd)) if (n + ".shortcut") in W else x
         y = ops.rms_silu(x, W[n + ".residual.0.gamma"])
-        if ops.conv_norm_fusable(W[n + ".residual.2"], y.shape[3]) and not ops.conv_generated(W[n + ".residual.2"], y.shape):
-            # conv -> RMS_norm -> SiLU in one kernel (shapes the generated convolution kernels do not cover)
+        if ops.conv_norm_fusable(W[n + ".residual.2"], y.shape[3]) and (ops.conv_norm_generated(W[n + ".residual.2"], y.shape) or
+                                                                         not ops.conv_generated(W[n + ".residual.2"], y.shape)):
+            # conv -> RMS_norm -> SiLU in one kernel: the generated kernel's norm epilogue (96 channels), or the hipcc halo kernel's for the
+            # shapes the generated kernels do not cover (same rule as csrc/vae_exec.hip res_block)
             y = ops.conv3d_cl_norm(y, W[n + ".residual.2"], W[n + ".residual.3.gamma"])
         else:
             y = ops.conv3d_cl(y, W[n + ".residual.2"], (T, H, Wd))

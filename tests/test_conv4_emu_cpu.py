@@ -24,7 +24,7 @@ def _cfg(name):
 
 
 def test_conv4_static_hazards():
-    for cfg in conv4.DEFAULTS + conv4.UPSAMPLE + conv4.NARROW:
+    for cfg in conv4.DEFAULTS + conv4.UPSAMPLE + conv4.NARROW + conv4.FUSED:
         assert R.check_static(cfg) == [], cfg.name
 
 
@@ -90,3 +90,19 @@ def test_conv4_emulated_row_stride_frame_mapping_no_bias():
     assert np.isnan(y[0::2]).all() and np.isnan(y[:, :, :, N:]).all(), "nothing outside the addressed frames / channels is written"
     err = np.abs(y[1::2, :, :, :N] - ref)
     assert err.max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max()), float(err.max())
+
+
+@pytest.mark.parametrize("shape,cus", [((2, 16, 16, 32, 96), 256), ((3, 18, 20, 96, 96), 8)])
+def test_conv4f_emulated_norm_epilogue(shape, cus):
+    """scail_conv4f_e4 (Cfg.epi = 4): conv -> RMS_norm -> SiLU in the epilogue (ResidualBlock.residual[2..4], reference wan_vae.py:190-196 with
+    RMS_norm :39-54): the sum of squares over a voxel's 96 channels = 24 in-lane terms + two permlane swaps, applied to the bf16-rounded
+    convolution output like the separate rms_silu pass."""
+    cfg = conv4.FUSED[0]
+    Ti, H, W, Cin, N = shape
+    x, w, b, _ = _case(Ti, H, W, Cin, N, False, seed=4)
+    gam = (1 + 0.1 * np.random.default_rng(9).standard_normal(N)).astype(np.float32)
+    y, _ = R.run(cfg, x, w, b, None, cus=cus, gamma=gam)
+    ref = R.reference_norm_silu(R.reference(x, w, b, None), gam)
+    assert not np.isnan(y).any()
+    err = np.abs(y - ref)
+    assert err.max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max()) and err.mean() <= 2e-3, (float(err.max()), float(err.mean()))

@@ -103,7 +103,7 @@ def test_conv4_generated_kernels(cin, cout, thw):
     ref = V.causal_conv3d(x[None], w, b)[0]
     wp = ops.prep_conv_weight(w.to(DEV), b.to(DEV))
     assert L.load().scail_conv3d_kernel_for(C.cast(_geom(T, H, W, cin, T, cout, wp["Kpad"]), C.c_void_p), cout, cout, 0) == 4
-    assert L.load().scail_conv3d_kernel_for(C.cast(_geom(T, H, W, cin, T, cout, wp["Kpad"]), C.c_void_p), cout, 0, 1) == 0      # fused norm: csrc/conv.hip
+    assert L.load().scail_conv3d_kernel_for(C.cast(_geom(T, H, W, cin, T, cout, wp["Kpad"]), C.c_void_p), cout, 0, 1) == (4 if cout == 96 else 0)   # fused norm: generated for one n tile
     assert L.load().scail_conv3d_kernel_for(C.cast(_geom(1, H, W, cin, 1, cout, wp["Kpad"]), C.c_void_p), cout, 0, 0) == 0      # a single frame
     y = torch.full((T, H, W, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
     ops.conv3d_cl(_cl(x), wp, (T, H, W), out=y)
@@ -146,6 +146,28 @@ def test_resample_convs(C, T, H, W, conv_halo):
     refu = F.conv2d(F.interpolate(xf, scale_factor=(2.0, 2.0), mode="nearest-exact"), wu, bu, padding=1).permute(1, 0, 2, 3)
     yu = ops.conv3d_cl(_cl(x), ops.prep_conv_weight(wu.to(DEV), bu.to(DEV)), (T, 2 * H, 2 * W), pad=(0, 1, 1), ups=True)
     torch.testing.assert_close(_pl(yu), refu, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("cin,thw", [(96, (5, 33, 40)), (192, (4, 64, 112)), (96, (3, 256, 448))])
+def test_conv4f_generated_norm_epilogue(cin, thw):
+    """scail_conv4f_e4 behind scail_conv3d_cl_norm (96 output channels): equal to scail_conv3d_cl followed by scail_rms_silu up to the order
+    of the norm's sum and the reciprocal (one bf16 step on a few elements), and to the oracle's conv -> RMS_norm -> SiLU on sampled frames."""
+    from scail_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(6)
+    T, H, W = thw
+    x = torch.randn(T, H, W, cin, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(96, cin, 3, 3, 3, device=DEV, generator=g) / (27 * cin) ** 0.5).to(torch.bfloat16).float()
+    b = torch.randn(96, device=DEV, generator=g)
+    gam = 1 + 0.1 * torch.randn(96, device=DEV, generator=g)
+    wp = ops.prep_conv_weight(w, b)
+    assert ops.conv_norm_generated(wp, x.shape)
+    fused = ops.conv3d_cl_norm(x, wp, gam)
+    two = ops.rms_silu(ops.conv3d_cl(x, wp, (T, H, W)), gam)
+    d = (fused.float() - two.float()).abs()
+    assert float(d.max()) <= 2.0 ** -6 * max(1.0, float(two.float().abs().max())) and float(d.mean()) < 2e-4, (float(d.max()), float(d.mean()))
+    conv = F.conv3d(F.pad(x.float().permute(3, 0, 1, 2)[None], (1, 1, 1, 1, 2, 0)), w, b)                        # (1, 96, T, H, W) fp32
+    ref = F.silu(V.rms_norm(conv, gam.cpu().to(conv.device)))[0].permute(1, 2, 3, 0)
+    torch.testing.assert_close(fused.float(), ref, rtol=2e-2, atol=2e-2)
 
 
 @pytest.mark.parametrize("cin,cout,thw", [(96, 3, (5, 40, 56)), (96, 3, (4, 128, 224)), (64, 16, (3, 19, 33)), (32, 12, (2, 16, 16))])

@@ -566,6 +566,8 @@ class Emu:
                 self._wrv(w, d, _u(np.fmax(np.fmax(F(0), F(1)), F(2))))
             elif op == "v_exp_f32":
                 self._wrv(w, d, _u(np.exp2(F(0).astype(np.float64)).astype(np.float32)))
+            elif op == "v_sqrt_f32":
+                self._wrv(w, d, _u(np.sqrt(F(0).astype(np.float64)).astype(np.float32)))
             elif op == "v_rcp_f32":
                 self._wrv(w, d, _u((1.0 / F(0).astype(np.float64)).astype(np.float32)))
             elif op == "v_cvt_f32_u32":

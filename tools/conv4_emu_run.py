@@ -25,7 +25,7 @@ def pack_weight(w, kpad=None):
     return out
 
 
-def run(cfg: conv4.Cfg, x, w, bias=None, resid=None, pt=2, To=None, ot_mul=1, ot_off=0, y_frames=None, ldc=None, lazy=True, wgs=None, cus=256):
+def run(cfg: conv4.Cfg, x, w, bias=None, resid=None, pt=2, To=None, ot_mul=1, ot_off=0, y_frames=None, ldc=None, lazy=True, wgs=None, cus=256, gamma=None):
     """x (Ti, H, W, Cin), w (N, Cin, 3, 3, 3), bias (N) | None, resid (frames, H, W, N) | None; fp32 in, bf16 operands."""
     Ti, H, W, Cin = x.shape
     N = w.shape[0]
@@ -39,6 +39,8 @@ def run(cfg: conv4.Cfg, x, w, bias=None, resid=None, pt=2, To=None, ot_mul=1, ot
     pb = mem.alloc("bias", bias.astype(np.float32)) if bias is not None else 0
     py = mem.alloc("y", np.full((y_frames, H, W, ldc), 0x7FC0, dtype=np.uint16))
     pr = mem.alloc("resid", to_bf16_bits(resid)) if resid is not None else 0
+    if gamma is not None:                                      # epi 4: the `resid` argument carries gamma (fp32 [N])
+        pr = mem.alloc("gamma", gamma.astype(np.float32))
     prog = conv4.Gen(cfg).program()
     args = conv4.pack_args(px, pw, pb, py, pr, Ti, To, H, W, Cin, N, wp.shape[1], pt, ot_mul, ot_off, ldc, resid.shape[-1] if resid is not None else 0, cus)
     stats = None
@@ -67,6 +69,14 @@ def reference(x, w, bias=None, resid=None, pt=2, To=None):
     if resid is not None:
         y = y + rt(resid)
     return y
+
+
+def reference_norm_silu(y, gamma):
+    """rms_silu_kernel on the bf16-rounded convolution output: x * sqrt(C) / max(||x||, 1e-12) * gamma, SiLU (reference wan_vae.py:39-54 + SiLU)."""
+    v = from_bf16_bits(to_bf16_bits(y.astype(np.float32))).astype(np.float64)
+    nrm = np.maximum(np.sqrt((v * v).sum(-1, keepdims=True)), 1e-12)
+    t = v * (np.sqrt(v.shape[-1]) / nrm) * gamma.astype(np.float64)
+    return t / (1.0 + np.exp(-t))
 
 
 def check_static(cfg):

@@ -63,3 +63,16 @@ for rnd in range(2):
 L.set_option("conv4", 1)
 rec["max_abs_diff"] = float((outs["halo"].float() - outs["conv4n"].float()).abs().max())
 print(json.dumps(rec), flush=True)
+
+# conv -> RMS_norm -> SiLU at the full-resolution 96-channel stage: scail_conv4f_e4 (one launch) against scail_conv4_e0 + rms_silu (two)
+T, H, W, C = 21, 512, 896, 96
+x = torch.randn(T, H, W, C, device=DEV, generator=g).to(torch.bfloat16)
+wp = ops.prep_conv_weight(torch.randn(C, C, 3, 3, 3, device=DEV, generator=g) / (27 * C) ** 0.5, torch.randn(C, device=DEV, generator=g))
+gam = 1 + 0.1 * torch.randn(C, device=DEV, generator=g)
+y = torch.empty(T, H, W, C, device=DEV, dtype=torch.bfloat16)
+rec = {"conv_norm": [T, H, W, C]}
+for rnd in range(2):
+    rec.setdefault("fused_e4_ms", []).append(round(timeit(lambda: ops.conv3d_cl_norm(x, wp, gam, out=y)), 3))
+    rec.setdefault("conv_e0_ms", []).append(round(timeit(lambda: ops.conv3d_cl(x, wp, (T, H, W), out=y)), 3))
+    rec.setdefault("conv_e0_plus_rms_silu_ms", []).append(round(timeit(lambda: ops.rms_silu(ops.conv3d_cl(x, wp, (T, H, W), out=y), gam, out=y)), 3))
+print(json.dumps(rec), flush=True)
