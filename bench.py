@@ -293,8 +293,8 @@ def vae_leg(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default=os.environ.get("SCAIL_BENCH_CONFIG", "14b"), choices=list(CONFIGS),
                     help="14b = the headline workload (BASELINE config 2); 14b-2char = BASELINE config 5 (2 ref + 2 pose streams, an extension, flagged)")
     ap.add_argument("--layers", type=int, default=None, help="DEBUG ONLY: fewer layers (result flagged invalid)")
