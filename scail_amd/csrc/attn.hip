@@ -339,16 +339,11 @@ struct Cross2Params {
 };
 
 #define X2_THREADS 256
-// KB / VB: LDS buffers of the K / V^T tile.  (2, 2): both double-buffered, 64 KiB, two workgroups per CU (rounds 2-3).  With ONE buffer the
-// next tile is requested as soon as every wave is done with the current one -- K right after the QK^T MFMAs (one more barrier), V^T after
-// the P.V MFMAs -- and the workgroup shrinks to 48 KiB (three per CU) or 32 KiB (four): the kernel is bound by the lock step of its waves
-// (MFMA -> softmax on the VALU -> MFMA), not by LDS or the matrix pipe (30 % busy), so more resident waves per SIMD can buy more than the
-// second buffer (A/B: scail_set_option "cross2_buf", tools/cross_attn_probe.py).
-template <int KB, int VB>
-__global__ __launch_bounds__(X2_THREADS, (KB + VB == 4 ? 2 : KB + VB == 3 ? 3 : 4)) void cross_attn2_kernel(Cross2Params p) {
+#define X2_LDS_BYTES (2 * (KVBLK * HD + HD * KVBLK) * 2)   // 64 KiB: two workgroups per CU
+__global__ __launch_bounds__(X2_THREADS, 2) void cross_attn2_kernel(Cross2Params p) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
-    u16* Ks = smem;                       // [KB][KVBLK][HD]
-    u16* Vs = smem + KB * KVBLK * HD;     // [VB][HD][KVBLK]
+    u16* Ks = smem;                      // [2][KVBLK][HD]
+    u16* Vs = smem + 2 * KVBLK * HD;     // [2][HD][KVBLK]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -375,30 +370,21 @@ __global__ __launch_bounds__(X2_THREADS, (KB + VB == 4 ? 2 : KB + VB == 3 ? 3 : 
     const u16* vb0 = p.vt0 + b * p.vt0_bs + (int64_t)h * HD * p.Lkp0;
     const u16* vb1 = p.vt1 + b * p.vt1_bs + (int64_t)h * HD * p.Lkp1;
     const int n0 = p.Lkp0 / KVBLK, n1 = p.Lkp1 / KVBLK, ntiles = n0 + n1;
-#define X2_SET(tt_)                                                                                         \
-        const bool s1_ = (tt_) >= n0;                                                                       \
-        const int key0_ = ((tt_) - (s1_ ? n0 : 0)) * KVBLK;
-#define X2_ISSUE_K(tt_, buf_)                                                                               \
+#define X2_ISSUE(tt_, buf_)                                                                                 \
     {                                                                                                       \
-        X2_SET(tt_)                                                                                         \
+        const bool s1_ = (tt_) >= n0;                                                                       \
+        const int key0_ = ((tt_) - (s1_ ? n0 : 0)) * KVBLK;                                                 \
         const u16* kp_ = s1_ ? kb1 : kb0;                                                                   \
         const int64_t krs_ = s1_ ? p.k1_rs : p.k0_rs;                                                       \
         const int last_ = (s1_ ? p.Lk1 : p.Lk0) - 1;                                                        \
+        const int lkp_ = s1_ ? p.Lkp1 : p.Lkp0;                                                             \
+        const u16* vp_ = (s1_ ? vb1 : vb0) + key0_;                                                         \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                  \
             const int j_ = wave * 4 + i_;                                                                   \
             const int kr_ = 4 * j_ + dk_row;                                                                \
             const u16* ks_src = kp_ + (int64_t)min(key0_ + kr_, last_) * krs_ + ((dk_c ^ (kr_ & 15)) << 3); \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks_src,          \
                 (__attribute__((address_space(3))) void*)(Ks + ((buf_) * KVBLK + 4 * j_) * HD), 16, 0, 0);   \
-        }                                                                                                   \
-    }
-#define X2_ISSUE_V(tt_, buf_)                                                                               \
-    {                                                                                                       \
-        X2_SET(tt_)                                                                                         \
-        const int lkp_ = s1_ ? p.Lkp1 : p.Lkp0;                                                             \
-        const u16* vp_ = (s1_ ? vb1 : vb0) + key0_;                                                         \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                  \
-            const int j_ = wave * 4 + i_;                                                                   \
             const int vr_ = 8 * j_ + dv_row;                                                                \
             const u16* vs_src = vp_ + (int64_t)vr_ * lkp_ + ((dv_c ^ ((vr_ >> 1) & 7)) << 3);               \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs_src,          \
@@ -421,14 +407,12 @@ __global__ __launch_bounds__(X2_THREADS, (KB + VB == 4 ? 2 : KB + VB == 3 ? 3 : 
     float m_run = -INFINITY, l_run = 0.f;
     const float sl2 = p.sl2;
 
-    X2_ISSUE_K(0, 0)
-    X2_ISSUE_V(0, 0)
+    X2_ISSUE(0, 0)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): tile 0 has landed in LDS, Q fragments in registers
     __syncthreads();
     for (int tt = 0; tt < ntiles; ++tt) {
-        const int kcur = KB == 2 ? (tt & 1) : 0, vcur = VB == 2 ? (tt & 1) : 0;
-        if (KB == 2 && tt + 1 < ntiles) X2_ISSUE_K(tt + 1, kcur ^ 1)
-        if (VB == 2 && tt + 1 < ntiles) X2_ISSUE_V(tt + 1, vcur ^ 1)
+        const int cur = tt & 1;
+        if (tt + 1 < ntiles) X2_ISSUE(tt + 1, cur ^ 1)
         if (tt == n0) {
             // ---- key set 1 is complete: O1 = acc / l, rounded to bf16; fresh softmax state for set 2 ----
             const float inv1 = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
@@ -450,7 +434,7 @@ __global__ __launch_bounds__(X2_THREADS, (KB + VB == 4 ? 2 : KB + VB == 3 ? 3 : 
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[f][e] = 0.f;
-        const u16* ks_ = Ks + (kcur * KVBLK + ql) * HD;
+        const u16* ks_ = Ks + (cur * KVBLK + ql) * HD;
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
 #pragma unroll
@@ -458,10 +442,6 @@ __global__ __launch_bounds__(X2_THREADS, (KB + VB == 4 ? 2 : KB + VB == 3 ? 3 : 
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks_ + f * 32 * HD + koff[ks]);
                 s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[f], 0, 0, 0);
             }
-        }
-        if (KB == 1) {      // one K buffer: every wave has its K fragments -> the next tile's K arrives under the softmax and P.V
-            __syncthreads();
-            if (tt + 1 < ntiles) X2_ISSUE_K(tt + 1, 0)
         }
         // ---- mask the padded keys of each set's last tile ----
         {
@@ -518,7 +498,7 @@ __global__ __launch_bounds__(X2_THREADS, (KB + VB == 4 ? 2 : KB + VB == 3 ? 3 : 
             pf[ks] = __builtin_bit_cast(bf16x8, u);
         }
         // ---- O^T += V^T P^T ----
-        const u16* vs_ = Vs + (vcur * HD + ql) * KVBLK;
+        const u16* vs_ = Vs + (cur * HD + ql) * KVBLK;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -526,10 +506,6 @@ __global__ __launch_bounds__(X2_THREADS, (KB + VB == 4 ? 2 : KB + VB == 3 ? 3 : 
                 const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs_ + d * 32 * KVBLK + voff[ks]);
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[d], 0, 0, 0);
             }
-        }
-        if (VB == 1) {      // one V^T buffer: requested once every wave has read this tile's (the other resident workgroups cover the wait)
-            __syncthreads();
-            if (tt + 1 < ntiles) X2_ISSUE_V(tt + 1, 0)
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of tile tt + 1 are in LDS before the barrier
         __syncthreads();
@@ -857,7 +833,6 @@ static std::string g_attn4_name = k_attn4_default;               // A/B variants
 static std::map<std::pair<int, std::string>, hipFunction_t> g_attn4_fns;
 static std::mutex g_attn4_mutex;
 static float g_attn4_thr_log2 = 8.0f;      // lazy-rescale threshold: P <= 2^thr
-static int g_cross2_buf = 22;              // option "cross2_buf": LDS buffers of the K / V^T tile of cross_attn2_kernel as KB * 10 + VB
 static int g_attn4_xcd = 1;                // XCD-aware workgroup-id decode (A/B knob "attn4_xcd")
 
 static int attn4_function(const std::string& name, hipFunction_t* fn) {
@@ -931,11 +906,6 @@ extern "C" int scail_set_option(const char* name, int value) {
     if (k == "attn4") { g_attn4_mode = value != 0; return 0; }              // 0: 8-wave kernel for every shape
     if (k == "gemm4") return scail_gemm4_enable(value);                     // 0: the kernels of csrc/gemm.hip for every shape
     if (k == "conv4") return scail_conv4_enable(value);                     // 0: the kernels of csrc/conv.hip for every convolution
-    if (k == "cross2_buf") {                                                // 22 / 12 / 21 / 11: K / V^T tile buffers of the fused cross attention
-        SCAIL_REQUIRE(value == 22 || value == 12 || value == 21 || value == 11, "cross2_buf must be 22, 12, 21 or 11");
-        g_cross2_buf = value;
-        return 0;
-    }
     if (k == "row_wave") return scail_row_wave_enable(value);               // 0: block-per-row LayerNorm / RMSNorm kernels for every width
     if (k == "attn4_thr") {                                                 // lazy-rescale threshold of attn4: P <= 2^value
         SCAIL_REQUIRE(value >= 0 && value <= 64, "attn4_thr must be in [0, 64] (log2 units)");
@@ -1146,7 +1116,7 @@ extern "C" int scail_cross_attn2_bf16(const scail_bf16* q, int64_t q_bs, int64_t
     if (n_batch == 0 || Lq == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn2_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KVBLK * HD * 2);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X2_LDS_BYTES);
         if (e != hipSuccess) {
             scail_set_error(std::string("cross_attn2: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
             return 2;
@@ -1161,10 +1131,6 @@ extern "C" int scail_cross_attn2_bf16(const scail_bf16* q, int64_t q_bs, int64_t
     p.heads = (int)heads; p.Lq = (int)Lq;
     p.sl2 = scale * 1.44269504088896340736f;
     dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)heads, (unsigned)n_batch);
-    const hipStream_t st = (hipStream_t)stream;
-    if (g_cross2_buf == 22) hipLaunchKernelGGL((cross_attn2_kernel<2, 2>), grid, dim3(X2_THREADS), 4 * KVBLK * HD * 2, st, p);
-    else if (g_cross2_buf == 12) hipLaunchKernelGGL((cross_attn2_kernel<1, 2>), grid, dim3(X2_THREADS), 3 * KVBLK * HD * 2, st, p);
-    else if (g_cross2_buf == 21) hipLaunchKernelGGL((cross_attn2_kernel<2, 1>), grid, dim3(X2_THREADS), 3 * KVBLK * HD * 2, st, p);
-    else hipLaunchKernelGGL((cross_attn2_kernel<1, 1>), grid, dim3(X2_THREADS), 2 * KVBLK * HD * 2, st, p);
+    hipLaunchKernelGGL(cross_attn2_kernel, grid, dim3(X2_THREADS), X2_LDS_BYTES, (hipStream_t)stream, p);
     return scail_check_launch("cross_attn2");
 }
