@@ -185,6 +185,127 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Direct-gather kernel for the HBM-BOUND convolutions of the VAE (round 4): few k-steps, output or input traffic far above the MFMA
+// time -- the stem CausalConv3d(3 -> 96) (K = 27 x 8: a 7.1 GB store), the temporal stride-2 convolution of downsample3d (3 x 1 x 1,
+// K = 288), the 1 x 1 x 1 shortcuts (K = Cin).  The gather kernel above runs them latency-bound (0.7-2 TB/s: one k-tile in flight per
+// workgroup, a barrier per k-tile, 8-byte partial-line stores).  Here:
+//   * the whole weight matrix (N x Kpad, <= 64 KB) sits in LDS for the lifetime of a PERSISTENT workgroup of 8 waves;
+//   * a wave owns 32 consecutive output voxels x all N channels and needs no barrier: the B operand of v_mfma_f32_32x32x16_bf16 is
+//     8 consecutive k of one voxel = 8 channels of one tap = ONE 16-byte global load per lane and k-step, straight into the fragment
+//     register (Cin % 8 == 0; padding = zero fill) -- every load of a tile is requested before the first MFMA, no staging through LDS;
+//   * the output goes through a per-wave LDS strip (32 voxels x 96 channels) so that every store instruction writes whole 192-byte
+//     voxel rows of neighbouring voxels (1 KB contiguous per wave instruction).
+// KS = k-steps held in registers (16-byte quad each); NB = 32-channel blocks of the output (N = 32 NB <= 192).
+// ------------------------------------------------------------------------------------------------
+#define CD_THREADS 512
+#define CD_STRIP_LD 104            // elements per staged voxel row: 96 channels + 8 (208 bytes: 16-byte aligned, conflict-light 8-byte writes)
+template <int KS, int NB>
+__global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p, int wld) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Ws = smem;                                              // [N][wld]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u16* strip = smem + (int64_t)p.N * wld + wave * 32 * CD_STRIP_LD;      // [32][CD_STRIP_LD] of this wave
+    const int l31 = lane & 31, g = lane >> 5;
+    const int ksteps = (p.Ktrue + 15) >> 4;                      // k-steps that hold real taps (<= KS)
+    // ---- weights -> LDS, once (rows n, k < 16 ksteps; 16-byte chunks) ----
+    {
+        const int cpr = ksteps * 2;                              // chunks per row
+        for (int c = tid; c < p.N * cpr; c += CD_THREADS) {
+            const int n = c / cpr, kc = c - n * cpr;
+            *reinterpret_cast<uint4*>(Ws + n * wld + kc * 8) = *reinterpret_cast<const uint4*>(p.w + (int64_t)n * p.Kpad + kc * 8);
+        }
+    }
+    __syncthreads();
+    // ---- this lane's k chunks: chunk (2 ks + g) = 8 channels c0 .. c0 + 7 of tap (dt, dh, dw), packed c0 | dw << 16 | dh << 21 | dt << 26 ----
+    int tapc[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = (2 * ks + g) * 8;
+        const int tap = k / p.Cin;
+        const int c0 = k - tap * p.Cin;
+        const int khw = p.kh * p.kw;
+        int dt = tap / khw;
+        const int r2 = tap - dt * khw;
+        const int dh = r2 / p.kw;
+        const int dw = r2 - dh * p.kw;
+        if (k >= p.Ktrue) dt = 31;                               // padding columns of the last k-step: a frame that never exists -> zeros
+        tapc[ks] = c0 | (dw << 16) | (dh << 21) | (dt << 26);
+    }
+    const int HWo = p.Ho * p.Wo;
+    const int64_t ntile = (p.M + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntile; tile += (int64_t)gridDim.x * 8) {
+        const int64_t m = tile * 32 + l31;
+        const bool ok = m < p.M;
+        const int64_t mm = ok ? m : 0;
+        const int to = (int)(mm / HWo);
+        const int r = (int)(mm - (int64_t)to * HWo);
+        const int ho = r / p.Wo, wo = r - ho * p.Wo;
+        const int tb = ok ? to * p.st - p.pt : -(1 << 29), hb = ho * p.sh - p.ph, wb = wo * p.sw - p.pw;
+        uint4 xr[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            xr[ks] = make_uint4(0, 0, 0, 0);
+            if (ks < ksteps) {
+                const int tc = tapc[ks];
+                const int ti = tb + (tc >> 26), hi = hb + ((tc >> 21) & 31), wi = wb + ((tc >> 16) & 31);
+                if ((tc >> 26) != 31 && ti >= 0 && ti < p.Ti && hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi)
+                    xr[ks] = *reinterpret_cast<const uint4*>(p.x + (((int64_t)ti * p.Hi + hi) * p.Wi + wi) * p.Cin + (tc & 0xFFFF));
+            }
+        }
+        f32x16 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+        const u16* wrow = Ws + l31 * wld + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks < ksteps) {
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, xr[ks]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + nb * 32 * wld + ks * 16);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: 96 channels at a time through this wave's strip; lane -> (voxel l31, channels 32 nb + 8 rr + 4 g + e) ----
+        const int64_t vox0 = tile * 32;
+#pragma unroll
+        for (int h = 0; h < (NB + 2) / 3; ++h) {
+            const int nbs = (NB - 3 * h) < 3 ? (NB - 3 * h) : 3;                   // 32-channel blocks in this pass
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (q < nbs) {
+                    const int nb = 3 * h + q;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int n = nb * 32 + 8 * rr + 4 * g;
+                        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.bias != nullptr) bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        uint2 o;
+                        o.x = pack_bf16x2(acc[nb][4 * rr + 0] + bb.x, acc[nb][4 * rr + 1] + bb.y);
+                        o.y = pack_bf16x2(acc[nb][4 * rr + 2] + bb.z, acc[nb][4 * rr + 3] + bb.w);
+                        *reinterpret_cast<uint2*>(strip + l31 * CD_STRIP_LD + q * 32 + 8 * rr + 4 * g) = o;
+                    }
+                }
+            }
+            // the strip is private to the wave: LDS operations of one wave complete in order, no barrier
+            const int cpv = nbs * 4;                                               // 16-byte chunks per voxel in this pass
+            for (int j = lane; j < 32 * cpv; j += 64) {
+                const int v = j / cpv, ch = j - v * cpv;
+                const int64_t mv = vox0 + v;
+                if (mv < p.M) {
+                    const int tv = (int)(mv / HWo);
+                    const int64_t vox = ((int64_t)(tv * p.ot_mul + p.ot_off)) * HWo + (mv - (int64_t)tv * HWo);
+                    *reinterpret_cast<uint4*>(p.y + vox * p.ldc + h * 96 + ch * 8) = *reinterpret_cast<const uint4*>(strip + v * CD_STRIP_LD + ch * 8);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Halo-tile kernel for the 3x3x3 stride-1 causal convolutions (all ResidualBlock convs: 26 of the 33 decoder convs).
 // (The 1x3x3 conv behind the 2x upsample uses it too, KT = 1 / UPS below; with ONE output frame per workgroup -- only 3 tap rows per patch
 // load -- that was 8 % slower than the gather kernel, with two frames it is 65 % faster.)
@@ -684,6 +805,8 @@ static int conv4_cu_count() {
     return it->second;
 }
 
+static int g_conv_direct = 1;                                  // option "conv_direct": the direct-gather kernel for the HBM-bound convolutions
+int scail_conv_direct_enable(int v) { g_conv_direct = v != 0; return 0; }
 static int g_conv4 = 1;                                        // option "conv4": the generated kernels where scail_conv3d_kernel_for says 4
 int scail_conv4_enable(int v) { g_conv4 = v != 0; return 0; }
 #ifdef SCAIL_ABLATIONS
@@ -869,6 +992,47 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
         if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96, 2, 1, true) else HALO_LAUNCH(0, 32, 1, false, 96, 2, 1, true)
         return scail_check_launch("conv3d_cl");
+    }
+    // HBM-bound shapes: the direct-gather kernel (comment above conv_direct_kernel); N = 384 as two launches of 192 channels
+    {
+        const int ksteps = (p.Ktrue + 15) / 16;
+        const int nsplit = p.N == 384 ? 2 : 1, nn = p.N / nsplit, nb = nn / 32;
+        const bool shape = ((ksteps <= 6 && (nb == 1 || nb == 2 || nb == 3 || nb == 4 || nb == 6)) || (ksteps <= 14 && (nb == 3 || nb == 6)) ||
+                            (ksteps <= 20 && nb == 3)) && p.kt <= 30 && p.kh <= 31 && p.kw <= 31 && p.Cin < 65536;
+        const int wld = ksteps * 16 + 8;                              // padded W row: 16 consecutive rows start in distinct 16-byte bank groups
+        const int lds = (nn * wld + 8 * 32 * CD_STRIP_LD) * 2;
+        if (g_conv_direct && !p.ups && resid == nullptr && p.Cin % 8 == 0 && nn % 32 == 0 && shape && lds <= 150 * 1024 && ldc % 8 == 0 &&
+            (reinterpret_cast<uintptr_t>(y) & 15) == 0 && p.M >= 4096 && p.M < (1ll << 40) && p.Ho * (int64_t)p.Wo < (1ll << 31)) {
+            const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((p.M + 255) / 256, conv4_cu_count()));
+#define CD_LAUNCH(KS_, NB_)                                                                                                          \
+    {                                                                                                                                \
+        static bool attr_ = false;                                                                                                   \
+        if (!attr_) {                                                                                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_kernel<KS_, NB_>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { \
+                scail_set_error("conv3d: hipFuncSetAttribute failed");                                                               \
+                return 2;                                                                                                            \
+            }                                                                                                                        \
+            attr_ = true;                                                                                                            \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((conv_direct_kernel<KS_, NB_>), dim3(grid), dim3(CD_THREADS), lds, (hipStream_t)stream, q, wld);          \
+    }
+            for (int part = 0; part < nsplit; ++part) {
+                ConvParams q = p;
+                q.N = nn;
+                q.w = p.w + (int64_t)part * nn * p.Kpad;
+                q.bias = p.bias ? p.bias + part * nn : nullptr;
+                q.y = p.y + part * nn;
+                if (ksteps <= 6) {
+                    if (nb == 1) CD_LAUNCH(6, 1) else if (nb == 2) CD_LAUNCH(6, 2) else if (nb == 3) CD_LAUNCH(6, 3) else if (nb == 4) CD_LAUNCH(6, 4) else CD_LAUNCH(6, 6)
+                } else if (ksteps <= 14) {
+                    if (nb == 3) CD_LAUNCH(14, 3) else CD_LAUNCH(14, 6)
+                } else {
+                    CD_LAUNCH(20, 3)
+                }
+            }
+#undef CD_LAUNCH
+            return scail_check_launch("conv3d_cl");
+        }
     }
     // N tile: of 128 / 96 / 64 the one with the fewest padding columns (ties -> the wider tile)
     int bn = 128;

@@ -148,6 +148,45 @@ def test_resample_convs(C, T, H, W, conv_halo):
     torch.testing.assert_close(_pl(yu), refu, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("name,cin,cout,k,stride,pad,thw", [
+    ("stem", 3, 96, (3, 3, 3), (1, 1, 1), None, (5, 40, 56)),                  # CausalConv3d(3, 96, 3): Cin padded to 8, 14 k-steps
+    ("temporal stride 2", 96, 96, (3, 1, 1), (2, 1, 1), (0, 0, 0), (9, 31, 40)),   # downsample3d time_conv: 18 k-steps, ragged M, frame offset
+    ("shortcut", 96, 192, (1, 1, 1), (1, 1, 1), None, (3, 40, 41)),           # ResidualBlock.shortcut 96 -> 192
+    ("shortcut 384", 192, 384, (1, 1, 1), (1, 1, 1), None, (2, 48, 50)),      # 192 -> 384: two launches of 192 channels
+    ("pointwise 64", 32, 64, (1, 1, 1), (1, 1, 1), None, (4, 33, 35))])
+def test_conv_direct_gather_kernel(name, cin, cout, k, stride, pad, thw):
+    """conv_direct_kernel (csrc/conv.hip; option conv_direct): the HBM-bound convolutions of the VAE -- stem (wan_vae.py:283), downsample3d's
+    temporal stride-2 convolution (:143-159), the 1 x 1 x 1 shortcuts (:186-205) -- against torch's fp32 convolution of the bf16-rounded
+    operands and against the gather kernel they ran on before (summation order only)."""
+    from scail_amd import lib as L, ops
+    g = torch.Generator(device=DEV).manual_seed(12)
+    T, H, W = thw
+    cpad = (cin + 7) // 8 * 8
+    x = torch.zeros(T, H, W, cpad, device=DEV, dtype=torch.bfloat16)
+    x[..., :cin] = torch.randn(T, H, W, cin, device=DEV, generator=g).to(torch.bfloat16)
+    fan = cin * k[0] * k[1] * k[2]
+    w = (torch.randn(cout, cin, *k, device=DEV, generator=g) / fan ** 0.5).to(torch.bfloat16).float()
+    b = torch.randn(cout, device=DEV, generator=g)
+    wp = ops.prep_conv_weight(w, b, cin_pad=cpad)
+    xf = x[..., :cin].float().permute(3, 0, 1, 2)[None]
+    if pad is None:                                        # causal 'same'
+        ref = F.conv3d(F.pad(xf, (k[2] // 2, k[2] // 2, k[1] // 2, k[1] // 2, k[0] - 1, 0)), w, b)[0].permute(1, 2, 3, 0)
+        To, kw_ = T, {}
+    else:
+        ref = F.conv3d(xf, w, b, stride=stride)[0].permute(1, 2, 3, 0)
+        To, kw_ = ref.shape[0], dict(stride=stride, pad=pad)
+    out = torch.full((To + 1, H, W, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.conv3d_cl(x, wp, (To, H, W), out=out, ot_off=1, **kw_)
+    assert torch.isnan(out[0].float()).all(), "the frame in front of the offset is not written"
+    torch.testing.assert_close(out[1:].float(), ref, rtol=2e-2, atol=2e-2)
+    L.set_option("conv_direct", 0)
+    try:
+        old = ops.conv3d_cl(x, wp, (To, H, W), **kw_)
+    finally:
+        L.set_option("conv_direct", 1)
+    assert float((out[1:].float() - old.float()).abs().max()) <= 2.0 ** -6 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("cin,thw", [(96, (5, 33, 40)), (192, (4, 64, 112)), (96, (3, 256, 448))])
 def test_conv4f_generated_norm_epilogue(cin, thw):
     """scail_conv4f_e4 behind scail_conv3d_cl_norm (96 output channels): equal to scail_conv3d_cl followed by scail_rms_silu up to the order
