@@ -217,7 +217,7 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
     }
     __syncthreads();
     // ---- this lane's k chunks: chunk (2 ks + g) = 8 channels c0 .. c0 + 7 of tap (dt, dh, dw), packed c0 | dw << 16 | dh << 21 | dt << 26 ----
-    int tapc[KS];
+    int tapc[KS], offk[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int k = (2 * ks + g) * 8;
@@ -230,45 +230,64 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
         const int dw = r2 - dh * p.kw;
         if (k >= p.Ktrue) dt = 31;                               // padding columns of the last k-step: a frame that never exists -> zeros
         tapc[ks] = c0 | (dw << 16) | (dh << 21) | (dt << 26);
+        offk[ks] = ((dt * p.Hi + dh) * p.Wi + dw) * p.Cin + c0;     // element offset of the chunk from the voxel's tap (0, 0, 0), channel 0 (fits: frames < 2^31 bytes)
     }
     const int HWo = p.Ho * p.Wo;
     const int64_t ntile = (p.M + 31) / 32;
-    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntile; tile += (int64_t)gridDim.x * 8) {
-        const int64_t m = tile * 32 + l31;
+    // the fragments of a tile are dead once its MFMAs are issued: the NEXT tile's loads are requested before this tile's epilogue, whose
+    // LDS round trip and stores then run under their latency
+    uint4 xr[KS];
+    auto load_tile = [&](int64_t tile_) {
+        const int64_t m = tile_ * 32 + l31;
         const bool ok = m < p.M;
         const int64_t mm = ok ? m : 0;
         const int to = (int)(mm / HWo);
         const int r = (int)(mm - (int64_t)to * HWo);
         const int ho = r / p.Wo, wo = r - ho * p.Wo;
-        const int tb = ok ? to * p.st - p.pt : -(1 << 29), hb = ho * p.sh - p.ph, wb = wo * p.sw - p.pw;
-        uint4 xr[KS];
+        const int tb = ok ? to * p.st - p.pt : -(1 << 20), hb = ho * p.sh - p.ph, wb = wo * p.sw - p.pw;
+        const u16* xb = p.x + (((int64_t)tb * p.Hi + hb) * p.Wi + wb) * p.Cin;      // the voxel's tap (0, 0, 0); one 64-bit address per tile, 32-bit offsets per chunk
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             xr[ks] = make_uint4(0, 0, 0, 0);
             if (ks < ksteps) {
                 const int tc = tapc[ks];
-                const int ti = tb + (tc >> 26), hi = hb + ((tc >> 21) & 31), wi = wb + ((tc >> 16) & 31);
-                if ((tc >> 26) != 31 && ti >= 0 && ti < p.Ti && hi >= 0 && hi < p.Hi && wi >= 0 && wi < p.Wi)
-                    xr[ks] = *reinterpret_cast<const uint4*>(p.x + (((int64_t)ti * p.Hi + hi) * p.Wi + wi) * p.Cin + (tc & 0xFFFF));
+                const unsigned ti = (unsigned)(tb + (tc >> 26)), hi = (unsigned)(hb + ((tc >> 21) & 31)), wi = (unsigned)(wb + ((tc >> 16) & 31));
+                if ((tc >> 26) != 31 && ti < (unsigned)p.Ti && hi < (unsigned)p.Hi && wi < (unsigned)p.Wi)
+                    xr[ks] = *reinterpret_cast<const uint4*>(xb + offk[ks]);
             }
         }
+    };
+    const int64_t tstep = (int64_t)gridDim.x * 8;
+    int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+    if (tile < ntile) load_tile(tile);
+    for (; tile < ntile; tile += tstep) {
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
         const u16* wrow = Ws + l31 * wld + g * 8;
+        // W fragments two k-steps ahead of their MFMAs (hipcc otherwise issues every ds_read right in front of its MFMA and the LDS
+        // latency of all KS x NB reads lines up on the critical path of a tile)
+        constexpr int PF = KS * NB <= 42 ? 2 : 1;        // (the deeper form spills at KS x NB = 60 / 84 quads)
+        bf16x8 wf[PF + 1][NB];
+#pragma unroll
+        for (int d = 0; d < PF; ++d)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) wf[d][nb] = *reinterpret_cast<const bf16x8*>(wrow + nb * 32 * wld + (d < KS ? d : 0) * 16);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            if (ks + PF < KS) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) wf[(ks + PF) % (PF + 1)][nb] = *reinterpret_cast<const bf16x8*>(wrow + nb * 32 * wld + (ks + PF) * 16);
+            }
             if (ks < ksteps) {
                 const bf16x8 xf = __builtin_bit_cast(bf16x8, xr[ks]);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + nb * 32 * wld + ks * 16);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[nb], 0, 0, 0);
-                }
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks % (PF + 1)][nb], xf, acc[nb], 0, 0, 0);
             }
         }
+        if (tile + tstep < ntile) load_tile(tile + tstep);
         // ---- epilogue: 96 channels at a time through this wave's strip; lane -> (voxel l31, channels 32 nb + 8 rr + 4 g + e) ----
         const int64_t vox0 = tile * 32;
 #pragma unroll
@@ -997,8 +1016,11 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
     {
         const int ksteps = (p.Ktrue + 15) / 16;
         const int nsplit = p.N == 384 ? 2 : 1, nn = p.N / nsplit, nb = nn / 32;
-        const bool shape = ((ksteps <= 6 && (nb == 1 || nb == 2 || nb == 3 || nb == 4 || nb == 6)) || (ksteps <= 14 && (nb == 3 || nb == 6)) ||
-                            (ksteps <= 20 && nb == 3)) && p.kt <= 30 && p.kh <= 31 && p.kw <= 31 && p.Cin < 65536;
+        // (instantiated: up to 6 k-steps with 32 / 64 / 96 / 128 / 192 channels -- the 1x1x1 convolutions of up to 96 input channels --, up to
+        // 14 k-steps with 96 channels -- the stem; 14 x 192 and 20 x 96 were built and spill 46 / 22 registers: those shapes stay on the gather kernel)
+        const bool shape = ((ksteps <= 6 && (nb == 1 || nb == 2 || nb == 3 || nb == 4 || nb == 6)) || (ksteps <= 14 && nb == 3)) &&
+                           p.kt <= 30 && p.kh <= 31 && p.kw <= 31 && p.Cin < 65536 &&
+                           (int64_t)(p.kt + 1) * p.Hi * p.Wi * p.Cin < (1ll << 31);
         const int wld = ksteps * 16 + 8;                              // padded W row: 16 consecutive rows start in distinct 16-byte bank groups
         const int lds = (nn * wld + 8 * 32 * CD_STRIP_LD) * 2;
         if (g_conv_direct && !p.ups && resid == nullptr && p.Cin % 8 == 0 && nn % 32 == 0 && shape && lds <= 150 * 1024 && ldc % 8 == 0 &&
@@ -1024,10 +1046,8 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
                 q.y = p.y + part * nn;
                 if (ksteps <= 6) {
                     if (nb == 1) CD_LAUNCH(6, 1) else if (nb == 2) CD_LAUNCH(6, 2) else if (nb == 3) CD_LAUNCH(6, 3) else if (nb == 4) CD_LAUNCH(6, 4) else CD_LAUNCH(6, 6)
-                } else if (ksteps <= 14) {
-                    if (nb == 3) CD_LAUNCH(14, 3) else CD_LAUNCH(14, 6)
                 } else {
-                    CD_LAUNCH(20, 3)
+                    CD_LAUNCH(14, 3)
                 }
             }
 #undef CD_LAUNCH

@@ -150,10 +150,11 @@ def test_resample_convs(C, T, H, W, conv_halo):
 
 @pytest.mark.parametrize("name,cin,cout,k,stride,pad,thw", [
     ("stem", 3, 96, (3, 3, 3), (1, 1, 1), None, (5, 40, 56)),                  # CausalConv3d(3, 96, 3): Cin padded to 8, 14 k-steps
-    ("temporal stride 2", 96, 96, (3, 1, 1), (2, 1, 1), (0, 0, 0), (9, 31, 40)),   # downsample3d time_conv: 18 k-steps, ragged M, frame offset
+    ("temporal stride 2", 32, 96, (3, 1, 1), (2, 1, 1), (0, 0, 0), (9, 31, 40)),   # a strided, unpadded temporal convolution: 6 k-steps, ragged M, frame offset
     ("shortcut", 96, 192, (1, 1, 1), (1, 1, 1), None, (3, 40, 41)),           # ResidualBlock.shortcut 96 -> 192
-    ("shortcut 384", 192, 384, (1, 1, 1), (1, 1, 1), None, (2, 48, 50)),      # 192 -> 384: two launches of 192 channels
-    ("pointwise 64", 32, 64, (1, 1, 1), (1, 1, 1), None, (4, 33, 35))])
+    ("pointwise 384", 64, 384, (1, 1, 1), (1, 1, 1), None, (2, 48, 50)),      # 384 output channels: two launches of 192
+    ("pointwise 64", 32, 64, (1, 1, 1), (1, 1, 1), None, (4, 33, 35)),
+    ("wide K stays on the gather kernel", 192, 384, (1, 1, 1), (1, 1, 1), None, (2, 33, 40))])
 def test_conv_direct_gather_kernel(name, cin, cout, k, stride, pad, thw):
     """conv_direct_kernel (csrc/conv.hip; option conv_direct): the HBM-bound convolutions of the VAE -- stem (wan_vae.py:283), downsample3d's
     temporal stride-2 convolution (:143-159), the 1 x 1 x 1 shortcuts (:186-205) -- against torch's fp32 convolution of the bf16-rounded
