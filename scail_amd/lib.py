@@ -88,7 +88,8 @@ ABLATIONS = LIB_PATH.endswith("_abl.so")
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 2          # include/scail_hip.h scail_abi_version: 2 = negative SCAIL_ATTN_Q_PRESCALED sentinel + the SP executor entry points
+ABI_VERSION = 3          # include/scail_hip.h scail_abi_version: 2 = negative SCAIL_ATTN_Q_PRESCALED sentinel + the SP executor entry points;
+                         # 3 = scail_vae_set_trace, options "row_wave" / "conv_direct", scail_conv3d_kernel_for = 4 for the kt = 1 / narrow / fused-norm shapes
 
 _lib = None
 
