@@ -206,6 +206,39 @@ def test_rmsnorm_rope(ops, heads):
     assert torch.equal(o2, xg[..., D:2 * D])
 
 
+@pytest.mark.parametrize("D", [1536, 5120])
+def test_row_wave_kernels_agree_with_the_block_kernels(ops, D):
+    """option row_wave (include/scail_hip.h): the one-wave-per-row LayerNorm / RMSNorm + RoPE kernels against the block-per-row kernels on the
+    same inputs -- same arithmetic up to the order of the fp32 sums: at most one bf16 step, on a small fraction of the elements; ragged row
+    counts (rows % 4 != 0), strided input, slab output."""
+    from scail_amd import lib as L
+    heads = D // 128
+    B, Ls = 2, 203
+    x = gpu_bf16(rnd(B, Ls, 3 * D, seed=4, scale=1.5))
+    sh, sc = rnd(B, D, seed=5).to(DEV), rnd(B, D, seed=6, scale=0.3).to(DEV)
+    w, b = (1 + 0.1 * rnd(D, seed=7)).to(DEV), rnd(D, seed=8).to(DEV)
+    ang = torch.rand(Ls, 64, generator=torch.Generator().manual_seed(9)) * 6.28
+    cos, sin = torch.cos(ang).to(DEV).contiguous(), torch.sin(ang).to(DEV).contiguous()
+    xd = x[..., :D].contiguous()
+
+    def run():
+        slabs = torch.empty(heads // 4, B * Ls, 4 * 128, device=DEV, dtype=torch.bfloat16)
+        ops.rmsnorm_rope_slabs(x.view(B * Ls, 3 * D)[:, D:2 * D], w, slabs, cos, sin, rows_per_batch=Ls, out_scale=0.1275)
+        return (ops.ln_modulate(xd, sh, sc), ops.ln_modulate(xd, sh, sc, rows_out=101, src_row_offset=7), ops.layernorm_affine(xd.view(B * Ls, D), w, b),
+                ops.rmsnorm_rope(x[..., D:2 * D], w, cos, sin, out=torch.empty(B, Ls, D, device=DEV, dtype=torch.bfloat16), rows_per_batch=Ls), slabs)
+
+    L.set_option("row_wave", 0)
+    try:
+        old = run()
+    finally:
+        L.set_option("row_wave", 1)
+    new = run()
+    for a, c in zip(old, new):
+        d = (a.float() - c.float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 * max(1.0, float(a.float().abs().max())), float(d.max())
+        assert float((d > 0).float().mean()) < 2e-3
+
+
 @pytest.mark.parametrize("heads,n_slabs", [(4, 2), (8, 8), (4, 1)])
 def test_rmsnorm_rope_slabs(ops, heads, n_slabs):
     """scail_rmsnorm_rope_slabs: the q / k norm + RoPE (and the plain copy of v) written as one dense column slab per destination rank
