@@ -2,7 +2,7 @@
 oracle evaluated on the GPU, at BASELINE config 4's own size.  Written to localise the full-size decode mismatch that
 tests/test_vae_gpu.py::test_vae_fullsize_vs_fp32[decode] reported on its first hardware run (round 4).
 
-  python tools/vae_decode_bisect.py [T h w]        default 21 64 112
+  python tests/debug_vae_decode_bisect.py [T h w]        default 21 64 112      (a checker: lives under tests/ because it evaluates the oracle)
 Per stage: cosine(product bf16, oracle fp32), cosine per frame (first / worst), and -- for the stage where they part -- the oracle op
 re-evaluated on the PRODUCT's input, which tells which side moved.  For 'up' stages torch's nearest-exact interpolate is also checked
 against an index restatement (repeat_interleave) because the tensors pass 2^31 elements there."""
@@ -11,7 +11,7 @@ import os
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from oracle import wan_vae_oracle as V          # noqa: E402  (tools/ is measurement scaffolding, not the product)
+from oracle import wan_vae_oracle as V          # noqa: E402  (test infrastructure: the oracle is the checker here)
 from scail_amd import ops                       # noqa: E402
 from scail_amd.wan_vae import WanVAE_           # noqa: E402
 
