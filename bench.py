@@ -278,12 +278,12 @@ def vae_leg(dev):
         res[name + "_achieved_hbm"] = {"GB/s": by / ms / 1e6, "frac": by / ms / 1e6 / 8000.0}
         res[name + "_finite"] = bool(torch.isfinite(out).all().item())
         del out
-    # fabric traffic of the dominant convolution launches (PMC, measured offline like roofline.traffic; dropped when csrc/conv4.s changed)
+    # fabric traffic of the dominant convolution launches (PMC, measured offline like roofline.traffic; an entry is dropped when the generated source its kernel comes from changed)
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        blob = _git_blob_sha1(os.path.join(ROOT, "scail_amd", "csrc", "conv4.s"))
+        blobs = {f: _git_blob_sha1(os.path.join(ROOT, "scail_amd", "csrc", f)) for f in ("conv4.s", "conv4u.s")}      # an entry names the file its kernel comes from
         conv = {k: {"traffic_bytes": v["traffic_bytes"], "algorithmic_bytes": v["algorithmic_bytes"], "shape": v["shape"], "kernel": v["kernel"].split(" ")[0]}
-                for k, v in tr.items() if k.startswith("conv4_c") and v.get("source_blob") == blob}
+                for k, v in tr.items() if k.startswith("conv4_c") and v.get("source_blob") == blobs.get(v.get("source"))}
         res["conv_traffic"] = conv or None
     except Exception:
         res["conv_traffic"] = None

@@ -102,6 +102,10 @@ class Cfg:
                             # arrives in the `resid` argument
     kt: int = 3             # temporal taps: 3 = CausalConv3d 3x3x3;  1 = the 1x3x3 convolution of Resample (behind the nearest 2x upsample when the
                             # kernel argument `pt` -- no padding frames exist for kt = 1 -- is 1: patch voxel (h, w) reads input (h >> 1, w >> 1))
+    cont: bool = False      # TILE CONTINUATION (one n tile, kt = 3): when the next tile of a workgroup's run is the next frame pair of the same spatial tile,
+                            # the last slice's "next slice" prefetch -- otherwise a wasted re-read of slice 0 -- fetches the NEXT TILE's frames 0, 1, 2 of
+                            # slice 0 (= this tile's frames 2, 3 and one new frame) and its W taps 0..3; the rings just continue, the next tile issues no
+                            # first loads.  Costs a dynamic staging slot for the epilogue (the ring phase differs from tile to tile)
     nb: int = 6             # 16-channel output blocks of the tile: 6 = 96 channels;  1 = a NARROW output (N <= 16: the decoder's RGB head, 96 -> 3):
                             # 8 MFMAs per (tap, slice) instead of 48, the W rows past N read zeros, 8-byte stores straight from the accumulator layout
     cap: int = 1
@@ -171,6 +175,8 @@ S_YF, S_RF = S(0, 2), S(96, 2)                              # epilogue: output /
 S_LDR2 = S(2)                                               # epilogue: residual row stride in bytes (the workgroup id is consumed at entry)
 N_SGPR = 102
 S_PROFWG = S(43)                                            # (prof variant; the unused high word of ldr) workgroup id
+S_CONT = S(43)                                              # (cont variants; same register) bit 0: the tile after this one continues the rings; bit 1: this tile's first loads
+                                                            # were prefetched; bit 2: the running slice is the last one of a tile whose successor continues the rings
 PBL, WBL = V(142), V(143)                                   # tile-independent parts of the fragment bases
 LP = [V(221 + dw) for dw in range(3)]                       # the lane's place in a patch row shifted by dw columns: (u 64 + ((chunk ^ ((u >> 1) & 3)) 16), u = l % 16 + dw
 XB = V(224)                                                 # fragment base of the tap group being read
@@ -195,6 +201,7 @@ class Gen:
         assert cfg.nb in (1, 6) and not (cfg.nb == 1 and (cfg.epi != 0 or cfg.kt != 3)) and cfg.epi in (0, 3, 4)
         self.NB = cfg.nb
         self.gs = cfg.nb / 6.0                  # the fillers' target gaps scale with the MFMAs of a tap (48 -> 8)
+        assert not (cfg.cont and (cfg.kt != 3 or cfg.nb != 6 or cfg.prof))
         # kt = 3: which patch piece a position issues: (frame, voxel group, next slice?, needed at the top of relative position).  Frame 2 is first
         # read (wave frame 1, dt = 1: group 3) during positions 6..8, frame 3 (group 6) during 15..17, frames 0 / 1 of the next slice during
         # 24..26; their slots were released by frames 1 (after the top of 15), 2 (24), 3 (24) of the slice before and 0 (6) of this one.
@@ -362,11 +369,31 @@ class Gen:
                 top.append(isa.waitcnt(vmcnt=len(hist) - 1 - due[-1]))
             if "bar" not in abl:
                 top.append(isa.barrier())
+            if c.cont and tap == 6:
+                # the pieces of the "next slice" (frames 0 / 1 / 2 from positions 6 / 12 / 18 on) belong to the NEXT TILE during the last slice:
+                # its frames 0, 1 are this tile's frames 2, 3; its frame 2 is input frame t0 + 4 - pt (slice 0: S_XOFFN is 0 there anyway)
+                tfr = ST[9]
+                top += [isa.sop("s_add_u32", tfr, S_T0, I32(4)), isa.sop("s_sub_u32", tfr, tfr, S_PT),
+                        isa.sop("s_cmp_lt_u32", None, tfr, S_TI), isa.sop("s_cselect_b32", ST[10], S_FB.sub(0), I32(0)), isa.sop("s_cselect_b32", tfr, tfr, I32(0)),
+                        isa.sop("s_mul_i32", ST[0], S_FB.sub(0), tfr), isa.sop("s_mul_hi_u32", ST[1], S_FB.sub(0), tfr),
+                        isa.sop("s_mul_i32", ST[2], S_FB.sub(1), tfr), isa.sop("s_add_u32", ST[1], ST[1], ST[2]),
+                        isa.sop("s_add_u32", ST[0], S_X.sub(0), ST[0]), isa.sop("s_addc_u32", ST[1], S_X.sub(1), ST[1]), isa.sop("s_and_b32", ST[1], ST[1], I32(0xFFFF)),
+                        isa.sop("s_bitcmp1_b32", None, S_CONT, I32(2))]
+                for k in range(4):
+                    top += [isa.sop("s_cselect_b32", S_XR[0].sub(k), S_XR[2].sub(k), S_XR[0].sub(k)), isa.sop("s_cselect_b32", S_XR[1].sub(k), S_XR[3].sub(k), S_XR[1].sub(k))]
+                top += [isa.sop("s_cselect_b32", S_XR[2].sub(0), ST[0], S_XR[2].sub(0)), isa.sop("s_cselect_b32", S_XR[2].sub(1), ST[1], S_XR[2].sub(1)),
+                        isa.sop("s_cselect_b32", S_XR[2].sub(2), ST[10], S_XR[2].sub(2))]
+            if c.cont and tap == 23:
+                # ... and the W stream wraps to tap 0 of slice 0 (position 26 -> 0 was taken as "the next slice" during tap 22)
+                top += [isa.sop("s_bitcmp1_b32", None, S_CONT, I32(2)), isa.sop("s_cselect_b32", S_WNEXT, I32(0), S_WNEXT)]
             o += top + blocks[tap]
         o += [isa.sop("s_add_u32", S_SL, S_SL, I32(1)), isa.sop("s_mov_b32", S_XOFF, S_XOFFN),
               isa.sop("s_add_u32", ST[0], S_SL, I32(1)), isa.sop("s_add_u32", ST[1], S_XOFF, I32(64)),
-              isa.sop("s_cmp_lt_u32", None, ST[0], S_NSL), isa.sop("s_cselect_b32", S_XOFFN, ST[1], I32(0)),      # no slice after the last: re-read slice 0 (unused)
-              isa.sop("s_cmp_lt_u32", None, S_SL, S_NSL), isa.branch("s_cbranch_scc1", "L_slice")]
+              isa.sop("s_cmp_lt_u32", None, ST[0], S_NSL), isa.sop("s_cselect_b32", S_XOFFN, ST[1], I32(0))]      # no slice after the last: re-read slice 0 (unused; cont: the next tile's)
+        if c.cont:      # the slice that starts now is the last one of a tile whose successor continues the rings?
+            o += [isa.sop("s_and_b32", ST[2], S_CONT, I32(1)), isa.sop("s_cmp_eq_u32", None, ST[0], S_NSL), isa.sop("s_cselect_b32", ST[2], ST[2], I32(0)),
+                  isa.sop("s_lshl_b32", ST[2], ST[2], I32(2)), isa.sop("s_and_b32", S_CONT, S_CONT, I32(3)), isa.sop("s_or_b32", S_CONT, S_CONT, ST[2])]
+        o += [isa.sop("s_cmp_lt_u32", None, S_SL, S_NSL), isa.branch("s_cbranch_scc1", "L_slice")]
         return o
 
     # ---- entry, per-tile setup, epilogue --------------------------------------------------------------------------------------------
@@ -447,6 +474,8 @@ class Gen:
                   isa.vop("v_mul_lo_u32", t[4], vx, ST[3]), isa.vop("v_add_u32", E_Y[i], t[4], c12),
                   isa.vop("v_mul_lo_u32", t[4], vx, ST[4]), isa.vop("v_add_u32", E_Z[i], t[4], c12)]
         o += [isa.sop("s_mov_b32", self.HAVE_PREV, I32(0))]       # no tile waits for its epilogue yet
+        if c.cont:
+            o += [isa.sop("s_mov_b32", S_CONT, I32(0))]
         if c.stagger:
             # All workgroups start together and a tile takes every one of them the same time: unstaggered, the first loads of 256 tiles
             # (27 MB) and the stores of 256 tiles (25 MB) hit HBM at once and each costs ~7-10 k cycles of blocked VMEM issue per tile
@@ -484,6 +513,13 @@ class Gen:
               isa.sop("s_cmp_eq_u32", None, ST[0], I32(0)), isa.sop("s_cselect_b32", same, I32(1), I32(0)),
               isa.sop("s_cmp_eq_u32", None, nn0, S_N0), isa.sop("s_cselect_b32", same_n, I32(1), I32(0)),
               isa.sop("s_mov_b32", S_H0, nh0), isa.sop("s_mov_b32", S_W0, nw0), isa.sop("s_mov_b32", S_N0, nn0)]
+        if self.cfg.cont:
+            # bit 0: the workgroup's NEXT tile is the next frame pair of this spatial tile (a run of consecutive tiles: step 1, one n tile)
+            o += [isa.sop("s_and_b32", S_CONT, S_CONT, I32(2)),
+                  isa.sop("s_add_u32", ST[0], S_TILE, S_STEP), isa.sop("s_cmp_lt_u32", None, ST[0], S_TEND), isa.sop("s_cselect_b32", ST[0], I32(1), I32(0)),
+                  isa.sop("s_cmp_eq_u32", None, S_STEP, I32(1)), isa.sop("s_cselect_b32", ST[0], ST[0], I32(0)),
+                  isa.sop("s_lshr_b32", ST[1], S_T0, I32(1)), isa.sop("s_add_u32", ST[1], ST[1], I32(1)), isa.sop("s_cmp_lt_u32", None, ST[1], S_TLT),
+                  isa.sop("s_cselect_b32", ST[0], ST[0], I32(0)), isa.sop("s_or_b32", S_CONT, S_CONT, ST[0])]
         # ---- patch frame j: input frame t = t0 - pt + j; descriptor base = x + t * FB, num_records = FB (0 when t is outside [0, Ti)) ----
         tfr = ST[9]
         for j in range(self.NFR):
@@ -495,13 +531,17 @@ class Gen:
                   isa.sop("s_add_u32", S_XR[j].sub(0), S_X.sub(0), ST[0]), isa.sop("s_addc_u32", ST[1], S_X.sub(1), ST[1]),
                   isa.sop("s_and_b32", S_XR[j].sub(1), ST[1], I32(0xFFFF)), isa.sop("s_mov_b32", S_XR[j].sub(2), ST[10]),
                   isa.sop("s_mov_b32", S_XR[j].sub(3), I32(0x00020000))]
-        # ---- ring positions: slice 0's frame j -> slot j; W buffer 0 ----
+        # ---- ring positions: slice 0's frame j -> slot j; W buffer 0 ----  (cont: a prefetched tile keeps the rings where its predecessor left them)
+        if self.cfg.cont:
+            o += [isa.sop("s_bitcmp1_b32", None, S_CONT, I32(1)), isa.branch("s_cbranch_scc1", "L_keep_rings")]
         o += [isa.sop("s_lshl_b32", S_WM0, S_WAVE, I32(10)), isa.sop("s_add_u32", ST[0], S_WM0, I32(PBASE0))]
         for j in range(self.NFR):
             o.append(isa.sop("s_add_u32", S_SLOT[j], ST[0], I32(j * FSLOT)))
         o += [isa.vop("v_mov_b32", PBASE[0], PBL), isa.vop("v_add_u32", PBASE[1], I32(FSLOT), PBL), isa.vop("v_add_u32", PBASE[2], I32(2 * FSLOT), PBL),
-              isa.vop("v_mov_b32", WB, WBL),
-              isa.sop("s_cmp_eq_u32", None, same_n, I32(1)), isa.branch("s_cbranch_scc1", "L_same_n")]
+              isa.vop("v_mov_b32", WB, WBL)]
+        if self.cfg.cont:
+            o += [isa.label("L_keep_rings"), isa.nop(7)]
+        o += [isa.sop("s_cmp_eq_u32", None, same_n, I32(1)), isa.branch("s_cbranch_scc1", "L_same_n")]
         # ---- W descriptor: base = w + n0 * Kpad * 2, num_records = min(96, N - n0) * Kpad * 2 ----
         o += [isa.sop("s_mul_i32", ST[0], S_N0, S_KP2), isa.sop("s_mul_hi_u32", ST[1], S_N0, S_KP2),
               isa.sop("s_add_u32", S_WR.sub(0), S_Wp.sub(0), ST[0]), isa.sop("s_addc_u32", ST[1], S_Wp.sub(1), ST[1]),
@@ -551,8 +591,14 @@ class Gen:
         o += [isa.label("L_same"), isa.nop(7)]
         o += self.stamp(0)                                        # phase 0: tile decode, descriptors, lane offsets
         # ---- streams: patch frames 0, 1, 2 of slice 0, W taps 0 .. 3 ----
-        o += [isa.sop("s_mov_b32", S_SL, I32(0)), isa.sop("s_mov_b32", S_XOFF, I32(0)), isa.sop("s_mov_b32", S_WNEXT, I32(0)),
+        o += [isa.sop("s_mov_b32", S_SL, I32(0)), isa.sop("s_mov_b32", S_XOFF, I32(0))] + ([] if self.cfg.cont else [isa.sop("s_mov_b32", S_WNEXT, I32(0))]) + [
               isa.sop("s_cmp_lt_u32", None, I32(1), S_NSL), isa.sop("s_cselect_b32", S_XOFFN, I32(64), I32(0))]
+        if self.cfg.cont:
+            # the last slice of this tile prefetches for the next one?  (one slice: this is the last)
+            o += [isa.sop("s_and_b32", ST[0], S_CONT, I32(1)), isa.sop("s_cmp_eq_u32", None, S_NSL, I32(1)), isa.sop("s_cselect_b32", ST[0], ST[0], I32(0)),
+                  isa.sop("s_lshl_b32", ST[0], ST[0], I32(2)), isa.sop("s_and_b32", S_CONT, S_CONT, I32(3)), isa.sop("s_or_b32", S_CONT, S_CONT, ST[0]),
+                  isa.sop("s_bitcmp1_b32", None, S_CONT, I32(1)), isa.branch("s_cbranch_scc1", "L_prefetched"),
+                  isa.sop("s_mov_b32", S_WNEXT, I32(0))]
         first = 2 if self.kt1 else 3
         for j in range(first):
             for k in range(6):
@@ -562,6 +608,8 @@ class Gen:
             o += self.slot_next(j, 0)
         for b in range(NWB):
             o += self.w_dma(0, 0, 0) + self.w_next(b, 0)
+        if self.cfg.cont:
+            o += [isa.label("L_prefetched"), isa.nop(7)]
         o += self.stamp(1) + [                                             # phase 1: DMA + bias issue
               isa.sop("s_cmp_eq_u32", None, self.HAVE_PREV, I32(0)), isa.branch("s_cbranch_scc1", "L_first")]
         return sched.pad_hazards(o)
@@ -582,7 +630,8 @@ class Gen:
         """after the last slice: every wave is done with the LDS contents; remember the tile for the epilogue; next tile (or none)."""
         o = self.stamp(6) + [isa.waitcnt(lgkmcnt=0), isa.barrier()] + self.stamp(7) + [       # phase 6: the slices; 7: the closing barrier
              isa.sop("s_mov_b32", S_ET0, S_T0), isa.sop("s_mov_b32", S_EH0, S_H0), isa.sop("s_mov_b32", S_EW0, S_W0), isa.sop("s_mov_b32", S_EN0, S_N0),
-             isa.sop("s_add_u32", S_TILE, S_TILE, S_STEP), isa.sop("s_cmp_lt_u32", None, S_TILE, S_TEND),
+             isa.sop("s_add_u32", S_TILE, S_TILE, S_STEP)] + ([isa.sop("s_and_b32", S_CONT, S_CONT, I32(1)), isa.sop("s_lshl_b32", S_CONT, S_CONT, I32(1))] if self.cfg.cont else []) + [
+             isa.sop("s_cmp_lt_u32", None, S_TILE, S_TEND),
              isa.sop("s_cselect_b32", self.HAVE_PREV, I32(1), I32(3)), isa.branch("s_branch", "L_tile")]
         return sched.pad_hazards(o)
 
@@ -664,6 +713,17 @@ class Gen:
         row0 = ST[9]
         e += [isa.sop("s_lshl_b32", row0, S_RH, I32(3)), isa.sop("s_add_u32", row0, row0, S_EH0)]
         voff = t[4]
+        EW, ER = E_W, E_R
+        if c.cont:
+            # The staging strip normally sits in frame slot 3, which is idle between a tile's last tap and the next tile's first loads (these go to
+            # slots 0, 1, 2).  When the next tile was PREFETCHED the ring did not restart and any slot may hold one of its frames: the strip moves to
+            # the slot of this tile's frame 3 of its last slice (dead since the last tap) = one slot above where the next frame 3 will be loaded.
+            EW, ER = t[20], [t[21], t[22], t[23]]
+            e += [isa.sop("s_lshl_b32", ST[0], S_WAVE, I32(10)), isa.sop("s_sub_u32", ST[0], S_SLOT[3], ST[0]), isa.sop("s_add_u32", ST[0], ST[0], I32(FSLOT)),
+                  isa.sop("s_cmp_ge_u32", None, ST[0], I32(PBASE0 + NSLOT * FSLOT)), isa.sop("s_cselect_b32", ST[1], I32(NSLOT * FSLOT), I32(0)),
+                  isa.sop("s_sub_u32", ST[0], ST[0], ST[1]), isa.sop("s_sub_u32", ST[0], ST[0], I32(PBASE0 + 3 * FSLOT)),
+                  isa.sop("s_bitcmp1_b32", None, S_CONT, I32(1)), isa.sop("s_cselect_b32", ST[0], ST[0], I32(0)),
+                  isa.vop("v_add_u32", EW, ST[0], E_W)] + [isa.vop("v_add_u32", ER[i], ST[0], E_R[i]) for i in range(3)]
 
         def row_sgprs(mb, cols, rowoff, ld2):
             """cols = columns allowed in row block mb (0: the row / frame is outside the tensor), rowoff = byte offset of its first voxel."""
@@ -745,8 +805,8 @@ class Gen:
             e.append(isa.waitcnt(vmcnt=0))
             for mb in range(9):
                 if mb < 8:
-                    e += [isa.ds_write(16, E_R[i], LQ(mb, i)) for i in range(3)]
-                    e += [isa.ds_read(8, RB(mb % 2, nb), E_W, 32 * nb) for nb in range(6)]
+                    e += [isa.ds_write(16, ER[i], LQ(mb, i)) for i in range(3)]
+                    e += [isa.ds_read(8, RB(mb % 2, nb), EW, 32 * nb) for nb in range(6)]
                 if mb >= 1:
                     e += to_packed(mb - 1, (mb - 1) % 2)
         else:
@@ -762,8 +822,8 @@ class Gen:
         # row blocks through LDS into the memory layout: 3 stores of 64 x 16 contiguous bytes instead of 6 of 64 x 8 scattered ones
         for mb in range(9):
             if mb < 8:
-                e += [isa.ds_write(8, E_W, OUT(mb, nb), 32 * nb) for nb in range(6)]
-                e += [isa.ds_read_b128(RQ(mb % 2, i), E_R[i]) for i in range(3)]
+                e += [isa.ds_write(8, EW, OUT(mb, nb), 32 * nb) for nb in range(6)]
+                e += [isa.ds_read_b128(RQ(mb % 2, i), ER[i]) for i in range(3)]
             if mb >= 1:
                 pm = mb - 1
                 e += row_sgprs(pm, ST[11], ST[7], ldc2)
@@ -879,6 +939,8 @@ UPSAMPLE = [Cfg(epi=0, kt=1, name="scail_conv4u_e0")]
 NARROW = [Cfg(epi=0, nb=1, name="scail_conv4n_e0")]
 # conv -> RMS_norm -> SiLU in one kernel (96 output channels): ResidualBlock.residual[2..4]; also in csrc/conv4u.s
 FUSED = [Cfg(epi=4, name="scail_conv4f_e4")]
+# tile continuation (Cfg.cont) of the three 96-channel kernels: A/B candidates beside the shipped ones, in csrc/conv4u.s
+CONT = [Cfg(epi=0, cont=True, name="scail_conv4c_e0"), Cfg(epi=3, cont=True, name="scail_conv4c_e3"), Cfg(epi=4, cont=True, name="scail_conv4c_e4")]
 
 
 def variant_cfgs():

@@ -783,7 +783,8 @@ static int conv4_function(const std::string& name, hipFunction_t* fn) {
         scail_set_error("conv4: hipGetDevice failed");
         return 2;
     }
-    const int which = (name.rfind("scail_conv4u", 0) == 0 || name.rfind("scail_conv4n", 0) == 0 || name.rfind("scail_conv4f", 0) == 0) ? 1 : 0;
+    const int which = (name.rfind("scail_conv4u", 0) == 0 || name.rfind("scail_conv4n", 0) == 0 || name.rfind("scail_conv4f", 0) == 0 ||
+                       name.rfind("scail_conv4c", 0) == 0) ? 1 : 0;
     auto mit = g_conv4_modules.find(std::make_pair(dev, which));
     if (mit == g_conv4_modules.end()) {
         hipModule_t mod = nullptr;
@@ -824,6 +825,8 @@ static int conv4_cu_count() {
     return it->second;
 }
 
+static int g_conv4_cont = 1;                                   // option "conv4_cont": the tile-continuation variants (scail_conv4c_e0 / e3 / e4) for the one-n-tile shapes
+int scail_conv4_cont_enable(int v) { g_conv4_cont = v != 0; return 0; }
 static int g_conv_direct = 1;                                  // option "conv_direct": the direct-gather kernel for the HBM-bound convolutions
 int scail_conv_direct_enable(int v) { g_conv_direct = v != 0; return 0; }
 static int g_conv4 = 1;                                        // option "conv4": the generated kernels where scail_conv3d_kernel_for says 4
@@ -942,7 +945,10 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         hipFunction_t fn;
         // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)
         const bool prof = g_conv4_suffix.find("prof") != std::string::npos;
-        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function("scail_conv4n_e0", &fn) : fnorm ? conv4_function("scail_conv4f_e4", &fn)
+        const bool cont = g_conv4_cont && !k1 && !nar && a.tiles_n == 1 && !prof;      // one n tile: runs of frame pairs per workgroup
+        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function("scail_conv4n_e0", &fn)
+                        : fnorm ? conv4_function(cont ? "scail_conv4c_e4" : "scail_conv4f_e4", &fn)
+                        : cont ? conv4_function(resid ? "scail_conv4c_e3" : "scail_conv4c_e0", &fn)
                         : conv4_function(std::string(resid && !prof ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};

@@ -24,7 +24,7 @@ def _cfg(name):
 
 
 def test_conv4_static_hazards():
-    for cfg in conv4.DEFAULTS + conv4.UPSAMPLE + conv4.NARROW + conv4.FUSED:
+    for cfg in conv4.DEFAULTS + conv4.UPSAMPLE + conv4.NARROW + conv4.FUSED + conv4.CONT:
         assert R.check_static(cfg) == [], cfg.name
 
 
@@ -106,3 +106,22 @@ def test_conv4f_emulated_norm_epilogue(shape, cus):
     assert not np.isnan(y).any()
     err = np.abs(y - ref)
     assert err.max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max()) and err.mean() <= 2e-3, (float(err.max()), float(err.mean()))
+
+
+@pytest.mark.parametrize("name,shape", [("scail_conv4c_e0", (13, 32, 32, 32, 96)),      # 28 tiles on 8 workgroups: runs of 3-4 frame pairs, one slice per tile
+                                        ("scail_conv4c_e3", (5, 18, 20, 96, 96)),       # three slices, residual; runs that cross into the next spatial tile
+                                        ("scail_conv4c_e4", (9, 16, 32, 32, 96))])
+def test_conv4c_emulated_tile_continuation(name, shape):
+    """Cfg.cont: when a workgroup's next tile is the next frame pair of the same spatial tile, the last slice prefetches that tile's first
+    frames and W taps and the rings continue (no first loads, the epilogue's staging strip in the slot of the dead frame 3); otherwise the
+    rings restart.  Same results as the shipped kernels."""
+    cfg = [c for c in conv4.CONT if c.name == name][0]
+    Ti, H, W, Cin, N = shape
+    x, w, b, r = _case(Ti, H, W, Cin, N, cfg.epi == 3, seed=6)
+    gam = (1 + 0.1 * np.random.default_rng(3).standard_normal(N)).astype(np.float32) if cfg.epi == 4 else None
+    y, _ = R.run(cfg, x, w, b, r, cus=8, gamma=gam)
+    ref = R.reference(x, w, b, r)
+    if cfg.epi == 4:
+        ref = R.reference_norm_silu(ref, gam)
+    assert not np.isnan(y).any()
+    assert np.abs(y - ref).max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max())

@@ -188,6 +188,28 @@ def test_conv_direct_gather_kernel(name, cin, cout, k, stride, pad, thw):
     assert float((out[1:].float() - old.float()).abs().max()) <= 2.0 ** -6 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("cin,thw", [(96, (9, 40, 56)), (192, (7, 128, 224)), (96, (21, 256, 448)), (32, (5, 512, 896))])
+def test_conv4c_tile_continuation_is_bit_identical(cin, thw):
+    """option conv4_cont (default on): scail_conv4c_e0 / e3 / e4 keep the patch and W rings going across the frame pairs a workgroup walks; the
+    arithmetic is that of scail_conv4_e0 / e3 / scail_conv4f_e4 -- bit-identical outputs on shapes with short and long runs per workgroup."""
+    from scail_amd import lib as L, ops
+    g = torch.Generator(device=DEV).manual_seed(15)
+    T, H, W = thw
+    x = torch.randn(T, H, W, cin, device=DEV, generator=g).to(torch.bfloat16)
+    wp = ops.prep_conv_weight(torch.randn(96, cin, 3, 3, 3, device=DEV, generator=g) / (27 * cin) ** 0.5, torch.randn(96, device=DEV, generator=g))
+    r = torch.randn(T, H, W, 96, device=DEV, generator=g).to(torch.bfloat16)
+    gam = 1 + 0.1 * torch.randn(96, device=DEV, generator=g)
+    res = {}
+    for mode in (0, 1):
+        L.set_option("conv4_cont", mode)
+        try:
+            res[mode] = (ops.conv3d_cl(x, wp, (T, H, W)), ops.conv3d_cl(x, wp, (T, H, W), resid=r), ops.conv3d_cl_norm(x, wp, gam))
+        finally:
+            L.set_option("conv4_cont", 1)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("cin,thw", [(96, (5, 33, 40)), (192, (4, 64, 112)), (96, (3, 256, 448))])
 def test_conv4f_generated_norm_epilogue(cin, thw):
     """scail_conv4f_e4 behind scail_conv3d_cl_norm (96 output channels): equal to scail_conv3d_cl followed by scail_rms_silu up to the order

@@ -71,11 +71,13 @@ def main():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             H, W = {96: (512, 896), 192: (256, 448), 384: (128, 224)}[C]
             alg = 2.0 * 21 * H * W * C * 2 + 27 * C * C * 2
+            # one n tile (C = 96): the tile-continuation variant scail_conv4c_e0 of csrc/conv4u.s (option conv4_cont, default on); else scail_conv4_e0
+            kern, srcf = (("scail_conv4c_e0", "conv4u.s") if C == 96 else ("scail_conv4_e0", "conv4.s"))
             tr[f"conv4_c{C}"] = {
                 "shape": {"T": 21, "H": H, "W": W, "C": C}, "fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"],
                 "traffic_bytes": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, "algorithmic_bytes": alg,
-                "kernel": "scail_conv4_e0 (generated 3x3x3 causal convolution: persistent workgroups, 2 frames x 16 x 16 voxels x 96 channels per tile)",
-                "source": "conv4.s", "source_blob": blob(os.path.join(ROOT, "scail_amd", "csrc", "conv4.s")), "measured": note}
+                "kernel": kern + " (generated 3x3x3 causal convolution: persistent workgroups, 2 frames x 16 x 16 voxels x 96 channels per tile)",
+                "source": srcf, "source_blob": blob(os.path.join(ROOT, "scail_amd", "csrc", srcf)), "measured": note}
     json.dump(tr, open(path, "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in tr[k].items() if kk in ("traffic_bytes", "traffic_bytes_per_layer", "algorithmic_bytes", "source_blob")}
                       for k in tr if isinstance(tr[k], dict)}, indent=1))
