@@ -201,7 +201,7 @@ class Gen:
         assert cfg.nb in (1, 6) and not (cfg.nb == 1 and (cfg.epi != 0 or cfg.kt != 3)) and cfg.epi in (0, 3, 4)
         self.NB = cfg.nb
         self.gs = cfg.nb / 6.0                  # the fillers' target gaps scale with the MFMAs of a tap (48 -> 8)
-        assert not (cfg.cont and (cfg.kt != 3 or cfg.nb != 6 or cfg.prof))
+        assert not (cfg.cont and (cfg.kt != 3 or cfg.prof))
         # kt = 3: which patch piece a position issues: (frame, voxel group, next slice?, needed at the top of relative position).  Frame 2 is first
         # read (wave frame 1, dt = 1: group 3) during positions 6..8, frame 3 (group 6) during 15..17, frames 0 / 1 of the next slice during
         # 24..26; their slots were released by frames 1 (after the top of 15), 2 (24), 3 (24) of the slice before and 0 (6) of this one.
@@ -940,7 +940,8 @@ NARROW = [Cfg(epi=0, nb=1, name="scail_conv4n_e0")]
 # conv -> RMS_norm -> SiLU in one kernel (96 output channels): ResidualBlock.residual[2..4]; also in csrc/conv4u.s
 FUSED = [Cfg(epi=4, name="scail_conv4f_e4")]
 # tile continuation (Cfg.cont) of the three 96-channel kernels: A/B candidates beside the shipped ones, in csrc/conv4u.s
-CONT = [Cfg(epi=0, cont=True, name="scail_conv4c_e0"), Cfg(epi=3, cont=True, name="scail_conv4c_e3"), Cfg(epi=4, cont=True, name="scail_conv4c_e4")]
+CONT = [Cfg(epi=0, cont=True, name="scail_conv4c_e0"), Cfg(epi=3, cont=True, name="scail_conv4c_e3"), Cfg(epi=4, cont=True, name="scail_conv4c_e4"),
+        Cfg(epi=0, nb=1, cont=True, name="scail_conv4cn_e0")]      # the narrow kernel: no staging strip, the rings simply continue
 
 
 def variant_cfgs():

@@ -110,7 +110,8 @@ def test_conv4f_emulated_norm_epilogue(shape, cus):
 
 @pytest.mark.parametrize("name,shape", [("scail_conv4c_e0", (13, 32, 32, 32, 96)),      # 28 tiles on 8 workgroups: runs of 3-4 frame pairs, one slice per tile
                                         ("scail_conv4c_e3", (5, 18, 20, 96, 96)),       # three slices, residual; runs that cross into the next spatial tile
-                                        ("scail_conv4c_e4", (9, 16, 32, 32, 96))])
+                                        ("scail_conv4c_e4", (9, 16, 32, 32, 96)),
+                                        ("scail_conv4cn_e0", (13, 16, 32, 32, 8))])     # the narrow kernel with continuing rings (no staging strip to move)
 def test_conv4c_emulated_tile_continuation(name, shape):
     """Cfg.cont: when a workgroup's next tile is the next frame pair of the same spatial tile, the last slice prefetches that tile's first
     frames and W taps and the rings continue (no first loads, the epilogue's staging strip in the slot of the dead frame 3); otherwise the
@@ -123,5 +124,5 @@ def test_conv4c_emulated_tile_continuation(name, shape):
     ref = R.reference(x, w, b, r)
     if cfg.epi == 4:
         ref = R.reference_norm_silu(ref, gam)
-    assert not np.isnan(y).any()
-    assert np.abs(y - ref).max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max())
+    assert not np.isnan(y[..., :N]).any()
+    assert np.abs(y[..., :N] - ref).max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max())

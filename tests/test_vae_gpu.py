@@ -208,6 +208,16 @@ def test_conv4c_tile_continuation_is_bit_identical(cin, thw):
             L.set_option("conv4_cont", 1)
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+    if cin == 96:       # the narrow kernel (RGB head) with and without continuation
+        wn = ops.prep_conv_weight(torch.randn(3, cin, 3, 3, 3, device=DEV, generator=g) / (27 * cin) ** 0.5, torch.randn(3, device=DEV, generator=g))
+        outs = []
+        for mode in (0, 1):
+            L.set_option("conv4_cont", mode)
+            try:
+                outs.append(ops.conv3d_cl(x, wn, (T, H, W)))
+            finally:
+                L.set_option("conv4_cont", 1)
+        assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize("cin,thw", [(96, (5, 33, 40)), (192, (4, 64, 112)), (96, (3, 256, 448))])

@@ -55,12 +55,13 @@ y = torch.empty(T, H, W, wp["N"], device=DEV, dtype=torch.bfloat16)
 rec = {"head": [T, H, W, cin, cout], "algorithmic_GB": round((x.numel() + y.numel()) * 2 / 1e9, 2)}
 outs = {}
 for rnd in range(2):
-    for mode, name in ((0, "halo"), (1, "conv4n")):
-        L.set_option("conv4", mode)
+    for (c4, cont), name in (((0, 1), "halo"), ((1, 0), "conv4n"), ((1, 1), "conv4n_continuation")):
+        L.set_option("conv4", c4); L.set_option("conv4_cont", cont)
         ms = timeit(lambda: ops.conv3d_cl(x, wp, (T, H, W), out=y))
         rec.setdefault(name + "_ms", []).append(round(ms, 3))
         outs[name] = y.clone()
-L.set_option("conv4", 1)
+L.set_option("conv4", 1); L.set_option("conv4_cont", 1)
+rec["continuation_identical"] = bool(torch.equal(outs["conv4n"], outs["conv4n_continuation"]))
 rec["max_abs_diff"] = float((outs["halo"].float() - outs["conv4n"].float()).abs().max())
 print(json.dumps(rec), flush=True)
 
