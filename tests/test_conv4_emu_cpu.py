@@ -108,8 +108,8 @@ def test_conv4f_emulated_norm_epilogue(shape, cus):
     assert err.max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max()) and err.mean() <= 2e-3, (float(err.max()), float(err.mean()))
 
 
-@pytest.mark.parametrize("name,shape", [("scail_conv4c_e0", (13, 32, 32, 32, 96)),      # 28 tiles on 8 workgroups: runs of 3-4 frame pairs, one slice per tile
-                                        ("scail_conv4c_e3", (5, 18, 20, 96, 96)),       # three slices, residual; runs that cross into the next spatial tile
+@pytest.mark.parametrize("name,shape", [("scail_conv4c_e0", (21, 16, 16, 32, 96)),      # 11 frame pairs of ONE spatial tile on 8 workgroups: runs of 1-2 tiles, one slice per tile
+                                        ("scail_conv4c_e3", (5, 18, 20, 64, 96)),       # two slices, residual; runs that cross into the next spatial tile
                                         ("scail_conv4c_e4", (9, 16, 32, 32, 96)),
                                         ("scail_conv4cn_e0", (13, 16, 32, 32, 8))])     # the narrow kernel with continuing rings (no staging strip to move)
 def test_conv4c_emulated_tile_continuation(name, shape):
