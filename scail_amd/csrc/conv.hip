@@ -945,8 +945,8 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         hipFunction_t fn;
         // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)
         const bool prof = g_conv4_suffix.find("prof") != std::string::npos;
-        const bool cont = g_conv4_cont && !k1 && !nar && a.tiles_n == 1 && !prof;      // one n tile: runs of frame pairs per workgroup
-        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function(g_conv4_cont && !prof ? "scail_conv4cn_e0" : "scail_conv4n_e0", &fn)
+        const bool cont = g_conv4_cont && !k1 && !nar && a.tiles_n == 1 && g_conv4_suffix.empty();      // one n tile: runs of frame pairs per workgroup (a measurement-build kernel variant takes precedence)
+        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function(g_conv4_cont && g_conv4_suffix.empty() ? "scail_conv4cn_e0" : "scail_conv4n_e0", &fn)
                         : fnorm ? conv4_function(cont ? "scail_conv4c_e4" : "scail_conv4f_e4", &fn)
                         : cont ? conv4_function(resid ? "scail_conv4c_e3" : "scail_conv4c_e0", &fn)
                         : conv4_function(std::string(resid && !prof ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
