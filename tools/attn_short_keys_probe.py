@@ -32,12 +32,18 @@ qkv = rn(B, Lq, 3 * D)
 q = qkv[..., :D]
 o = torch.empty(B, Lq, D, device=DEV, dtype=torch.bfloat16)
 out = {}
-for Lk in (512, 768, 1024, 2048, 4096):
+MODES = ((1, "attn4"), (0, "8wave_swp")) if "--both" in sys.argv else ((1, "attn4"),)
+for on, tag in MODES:
+  L.set_option("attn4", on)
+  for Lk in (256, 320, 512, 768, 832, 1024, 2048, 4096):
+    if on and Lk < 512:
+        continue
     k, v = rn(B, Lk, D), rn(B, Lk, D)
     vt = ops.transpose_v(v, H)
     kind = L.load().scail_flash_attn_kernel_for(q.stride(1), k.stride(1), o.stride(1), Lq, Lk, 0, 0)
     ms = timeit(lambda: ops.flash_attn(q, k, vt, out=o))
-    out[f"Lk{Lk}"] = {"kernel": kind, "ms": round(ms, 4), "TFLOPs": round(4.0 * B * H * Lq * Lk * 128 / ms / 1e9, 1)}
+    out[f"{tag}_Lk{Lk}"] = {"kernel": kind, "ms": round(ms, 4), "TFLOPs": round(4.0 * B * H * Lq * Lk * 128 / ms / 1e9, 1)}
+L.set_option("attn4", 1)
 k1, v1, k2, v2 = rn(B, 512, D), rn(B, 512, D), rn(1, 257, D), rn(1, 257, D)
 vt1, vt2 = ops.transpose_v(v1, H), ops.transpose_v(v2, H)
 ms = timeit(lambda: ops.cross_attn2(q, k1, vt1, k2, vt2, out=o))
