@@ -290,6 +290,84 @@ def vae_leg(dev):
     return res
 
 
+def sp_compute_side_leg(net, p, thw, ctx, clip, dev, t1, args):
+    """The launch sequence of rank 0 of a 2 / 4 / 8-rank sequence-parallel step through scail_dit_step_sp ON THIS ONE GPU, the collectives
+    served by local copies (scail_amd.parallel.LocalCopyBackend; results meaningless, every kernel shape real): the compute side of the
+    strong-scaling efficiency, (T_1 / N) / T_N against the step time just measured.  The exchange over xGMI comes on top and is NOT
+    in these numbers (no multi-GPU node in this run).  One warm-up + one timed step per N."""
+    from scail_amd import lib, ops
+    from scail_amd.parallel import LocalCopyBackend, SequenceParallel
+    T, H, W = thw
+    nh = p["num_attention_heads"]
+    g = torch.Generator().manual_seed(99)
+    res = {"what": "rank 0's launches of an N-rank step on one GPU, collectives = local copies (compute side only; exchange time NOT included)",
+           "s_per_step_1_rank": t1, "ranks": {}}
+    old_sp = net.sp
+    try:
+        for N in (2, 4, 8):
+            sp = SequenceParallel(LocalCopyBackend(N))
+            net.sp = sp
+            h = H // N
+            x = torch.randn(1, T, 16, h, W, generator=g).to(dev)
+            ref = torch.randn(1, 1, 16, h, W, generator=g).to(dev).to(torch.bfloat16)
+            pose = torch.randn(1, T, 16, h // 2, W // 2, generator=g).to(dev).to(torch.bfloat16)
+            tt = torch.tensor([700.0, 700.0], device=dev)
+
+            def one():
+                v = net.forward_f32(torch.cat([x, x], 0), tt, ctx, None, concat_images=torch.zeros(1, device=dev), image_clip_features=clip,
+                                    ref_concat=ref, concat_smpl_render=pose, chunk_dim=3, cfg_pair=not args.no_cfg_pair)
+                ops.cfg_euler_(x, v, args.cfg_scale, -0.01)
+
+            one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            mode = sp.resolve_mode(nh)
+            L = (1 + T) * (H // 2) * (W // 2) + T * (H // 4) * (W // 4)
+            rows = lib.load().scail_flash_attn_rows_for(1, nh // N if mode == "ulysses" else nh, L if mode == "ulysses" else L // N)
+            res["ranks"][str(N)] = {"mode": mode, "s_per_step_one_rank": dt, "compute_only_efficiency": (t1 / N) / dt, "attn_query_tile_rows": int(rows)}
+    finally:
+        net.sp = old_sp
+        net._ws = {}
+    return res
+
+
+def multichar_leg(net, p, thw, ctx, clip, dev, Lt, Lc, args):
+    """BASELINE config 5 on one GPU: 2 reference frames + 2 pose streams in one token sequence (L = 60 032), the same 40-layer network, one
+    warm-up + two timed steps.  An EXTENSION of the reference (which has one of each, dit...:1559): parity is against the oracle extended
+    the same way (tests/test_dit_gpu.py), unpinned by construction.  8-GPU sequence parallel of it: unmeasured."""
+    from scail_amd import ops
+    T, H, W = thw
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, T, 16, H, W, generator=g).to(dev)
+    ref = torch.randn(1, 2, 16, H, W, generator=g).to(dev).to(torch.bfloat16)
+    pose = torch.randn(1, 2 * T, 16, H // 2, W // 2, generator=g).to(dev).to(torch.bfloat16)
+    tt = torch.tensor([700.0, 700.0], device=dev)
+
+    def one():
+        v = net.forward_f32(torch.cat([x, x], 0), tt, ctx, None, concat_images=torch.zeros(1, device=dev), image_clip_features=clip,
+                            ref_concat=ref, concat_smpl_render=pose)
+        ops.cfg_euler_(x, v, args.cfg_scale, -0.01)
+
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    one(); one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    hp, wp = H // 2, W // 2
+    Lnoise = T * hp * wp
+    L = 2 * hp * wp + Lnoise + 2 * T * (H // 4) * (W // 4)
+    fl = step_flops(p, L, Lt, Lc)
+    net._ws = {}
+    return {"EXTENSION_not_in_reference": "2 reference frames + 2 pose streams (BASELINE config 5); parity unpinned by construction",
+            "L_tokens": L, "layers": p["num_layers"], "steps_timed": 2, "ms_per_step": dt * 1e3, "latent_tokens_per_s": Lnoise / dt,
+            "step_tflop": fl / 1e12, "step_mfma_frac": fl / dt / (PEAK_BF16_TFLOPS * 1e12), "finite": bool(torch.isfinite(x).all().item()),
+            "path": "scail_dit_block per layer (C executor) + token assembly in the host", "n_gpus": 1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,6 +381,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the config-4 VAE leg after the timed region")
     ap.add_argument("--cfg-scale", type=float, default=4.0)
+    ap.add_argument("--no-cfg-pair", action="store_true", help="A/B: evaluate both CFG elements in layer 0 (no SCAIL_DIT_CFG_PAIR)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip config.sp_compute_side and config.multichar after the timed region")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -379,8 +459,10 @@ def main():
     def step(i):
         xin = torch.cat([x, x], 0)
         t = (sig[i] * 1000.0).repeat(2).to(dev)
+        # cfg_pair: what the sampler's VanillaCFG passes with its [x; x] batch (scail_amd/sampler.py): the executor evaluates layer 0 up to its
+        # first cross attention once (SCAIL_DIT_CFG_PAIR, result-preserving; accounted for in step_tflop_executed below)
         v = net.forward_f32(xin, t, ctx, None, concat_images=dummy, ref_concat=ref, concat_smpl_render=pose,
-                            image_clip_features=clip, chunk_dim=chunk_dim)
+                            image_clip_features=clip, chunk_dim=chunk_dim, cfg_pair=not args.no_cfg_pair)
         ops.cfg_euler_(x, v, args.cfg_scale, float(sig[i + 1] - sig[i]))
 
     def barrier():
@@ -433,14 +515,30 @@ def main():
     attn_Lq = L if sp_mode == "ulysses" else L // world      # ulysses: all ranks' query rows of this rank's heads
     # scail_dit_step runs the LAST layer's queries / out-projection / cross attention / MLP on the noise tokens only (its other rows never
     # reach the final layer; csrc/dit_step.hip): that launch has Lnoise / L of the FLOPs, and the means below are over all launches
-    pruned = use_c and sp is None and n_char == 1
+    # Two result-preserving prunings of the executor (n_char == 1), both accounted for here:
+    #   last layer: its output is read at the noise rows only -> out-projection / cross attention / MLP on those rows; the queries too, except
+    #               in the ulysses exchange (rank-major full sequence); the all-gather rank prunes its Q projection as well;
+    #   cfg pair:   layer 0 up to the first cross attention runs for ONE of the two CFG elements (SCAIL_DIT_CFG_PAIR).
+    pruned = use_c and n_char == 1 and p["num_layers"] > 0
+    pair = pruned and not args.no_cfg_pair and p["num_layers"] > 1
     nl_ = p["num_layers"]
-    attn_flops = 4.0 * attn_Lq * L * 128 * attn_heads * attn_B * ((nl_ - 1 + Lnoise / L) / nl_ if pruned else 1.0)
+    D0, FF0 = p["hidden_size"], p["inner_hidden_size"]
+    frac_noise = Lnoise / L
+    q_pruned = pruned and sp_mode != "ulysses"
+    # self-attention FLOPs of this rank per step, in units of one (element, layer) launch of 4 Lq Lk 128 heads
+    unit = 4.0 * attn_Lq * L * 128 * attn_heads
+    att_units = 2.0 * nl_ - (1.0 if pair else 0.0) - (2.0 * (1.0 - frac_noise) if q_pruned else 0.0)
+    att_launches = nl_ if attn_B == 2 else 2 * nl_ - (1 if pair else 0)      # one rank: a launch covers both elements (layer 0 of a cfg pair: one)
+    attn_flops = unit * att_units / att_launches                  # mean over the launches of a step
     ach = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms else None
     fl = step_flops(p, L, Lt, Lc)
-    D0, FF0 = p["hidden_size"], p["inner_hidden_size"]
-    # FLOPs the step actually executes: the reference's algorithmic count minus the last layer's skipped ref / pose rows
-    fl_exec = fl - (2 * (L - Lnoise) * (4 * L * D0 + 4 * (Lt + Lc) * D0 + 2 * D0 * (3 * D0 + 2 * FF0)) if pruned else 0.0)
+    # FLOPs the step actually executes (whole job): the reference's algorithmic count minus what the two prunings skip
+    fl_exec = fl
+    if pruned:
+        fl_exec -= 2 * (L - Lnoise) * ((4 * L * D0 if q_pruned else 0.0) + 4 * (Lt + Lc) * D0 + 2 * D0 * (3 * D0 + 2 * FF0)
+                                       + (2 * D0 * D0 if sp_mode == "allgather" else 0.0))
+    if pair:
+        fl_exec -= 4.0 * L * L * D0 + 2.0 * L * D0 * 4 * D0
     # HBM/fabric bytes per launch of the dominant kernel: measured offline with rocprofv3 --pmc (separate passes, guide
     # corrections; profiles/), committed with the git blob id of the kernel source it was measured on -- dropped (null)
     # when the kernel source (the generated csrc/attn4.s, or attn.hip for shapes the 8-wave kernel serves) has changed since
@@ -455,7 +553,8 @@ def main():
         strides = (3 * Dm, 3 * Dm, Dm)
     which = lib.load().scail_flash_attn_kernel_for(*strides, attn_Lq, L, 0, 1)
     ksrc = "attn4.s" if which == 4 else "attn.hip"
-    kname = ("scail_attn4_m16f (hand-scheduled 4-wave flash attention, 16x16x32 MFMAs, queries in log2 units; csrc/attn4.s)"
+    kname = ("scail_attn4_m16f" + ("_q3" if lib.load().scail_flash_attn_rows_for(attn_B, attn_heads, attn_Lq) == 192 else "")
+             + " (hand-scheduled 4-wave flash attention, 16x16x32 MFMAs, queries in log2 units; csrc/attn4.s)"
              if which == 4 else "flash_attn_swp_kernel<4, 4, 0, 1>")
     try:
         tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["flash_attn_self"]
@@ -473,7 +572,9 @@ def main():
                                f"{p['num_layers']} layers, random-init bf16 weights",
                    "parallelism": f"sp{world}" + (f"-{sp_mode}" if sp is not None else ""), "cond_cache": False, "noise_tokens": Lnoise, "all_tokens_x_batch": 2 * L,
                    "step_tflop": fl / 1e12, "step_tflop_executed": fl_exec / 1e12, "step_mfma_frac": fl_exec / t_step / (world * PEAK_BF16_TFLOPS * 1e12),
-                   "finite": finite, "x_abs_mean": x_abs_mean, "sp_check": sp_check},
+                   "finite": finite, "x_abs_mean": x_abs_mean, "sp_check": sp_check,
+                   "result_preserving_prunings": {"last_layer_noise_rows_only": bool(pruned), "cfg_pair_layer0_once": bool(pair)},
+                   "attn_query_tile_rows": int(lib.load().scail_flash_attn_rows_for(attn_B, attn_heads, attn_Lq))},
         "roofline": {"bound": "mfma", "kernel": kname + " (self-attention)", "achieved": ach,
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
                      "traffic": traffic, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,
@@ -492,7 +593,9 @@ def main():
         D_, FF_ = p["hidden_size"], p["inner_hidden_size"]
         gflop = 2.0 * (2 * L // world) * D_ * (3 * D_ + 3 * D_ + 2 * FF_) * p["num_layers"] * args.steps      # this rank's token rows
         if pruned:
-            gflop -= 2.0 * (2 * (L - Lnoise)) * D_ * (3 * D_ + 2 * FF_) * args.steps
+            gflop -= 2.0 * (2 * (L - Lnoise) // world) * D_ * (3 * D_ + 2 * FF_ + (D_ if sp_mode == "allgather" else 0)) * args.steps
+        if pair:
+            gflop -= 2.0 * (L // world) * D_ * 4 * D_ * args.steps
         g_ach = gflop / (gemm_ms * 1e-3) / 1e12
         g_traffic = None
         try:
@@ -512,6 +615,9 @@ def main():
         out["config"]["INVALID_debug_layers"] = args.layers
     if args.latent_hw is not None:
         out["config"]["INVALID_other_resolution"] = list(args.latent_hw)
+    if rank == 0 and world == 1 and use_c and args.config == "14b" and args.latent_hw is None and not args.no_extra_legs:
+        out["config"]["sp_compute_side"] = sp_compute_side_leg(net, p, (T, H, W), ctx, clip, dev, t_step, args)
+        out["config"]["multichar"] = multichar_leg(net, p, (T, H, W), ctx, clip, dev, Lt, Lc, args)
     if rank == 0 and world == 1 and not args.no_vae:
         out["config"]["vae"] = vae_leg(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -527,7 +633,10 @@ def main():
                     # one standard error of the fitted block time at the bench length, carried to the value (the fit's own uncertainty;
                     # box-to-box spread of the host is larger: quote the baseline as "about 2-2.5 tokens/s")
                     "block_s_at_bench_L": cb["t_block"], "block_s_sigma": cb["sigma_block"],
-                    "value_plus_minus": Lnoise / t_cpu * cb["sigma_block"] / cb["t_block"]},
+                    "fit_standard_error": Lnoise / t_cpu * cb["sigma_block"] / cb["t_block"]},
+            # spread of this figure over the GPU boxes of the pool (same code, rounds 3-5: host load and NUMA placement differ from box to box);
+            # much wider than the fit's standard error above -- quote the baseline as "about 2-2.5 tokens/s"
+            "box_to_box_range": [1.95, 2.5],
             "sample": f"oracle block (fp32, torch CPU, {cb['threads']} threads = fastest of "
                       + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in sorted(cb["probe"].items())) + " on the 2016x5120x15360 projection) at full "
                       f"width D={p['hidden_size']}, B=2, after one warm-up call: whole block at L = "

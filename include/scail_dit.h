@@ -81,11 +81,19 @@ int64_t scail_dit_workspace_bytes(const scail_dit* h, int64_t B, int64_t T, int6
  *   ref bf16 [n_ref,1,16,H,W], pose bf16 [n_pose,T,16,H/2,W/2] (n_* in {1, B}: CFG repeat, dit...:1479-1495);
  *   rope_cos / rope_sin fp32 [L, 64] per-token pair tables for L = (1+T)(H/2)(W/2) + T(H/4)(W/4) tokens
  *   (scail_amd/rope.py; Rotary3DPositionEmbeddingMixin dit...:382-757);  workspace: scail_dit_workspace_bytes().
+ *   flags: 0, or SCAIL_DIT_CFG_PAIR -- the caller states that this is the classifier-free-guidance pair of a sampler step
+ *   (VanillaCFG.prepare_inputs, guiders.py:41-57: x = cat([x] * 2), s = cat([s] * 2)): B == 2, n_ref == n_pose == 1, and x[1] == x[0],
+ *   timesteps[1] == timesteps[0]; only the conditioning differs.  The two elements' hidden states are then equal until the first cross
+ *   attention of layer 0 (dit...:1009-1042), so the patch embedding and layer 0's LayerNorm -> QKV -> norm / RoPE -> self-attention ->
+ *   out-projection run ONCE and are copied to element 1 (0.94 % of the 14B step).  Results are bit-identical to flags = 0 on such
+ *   inputs (every kernel computes a row from that row alone); x[1] is not read.  The flag is a statement about the inputs, not
+ *   checked on the device.  The last layer likewise evaluates only the rows the final layer reads (the noise tokens) past its K / V.
  */
+#define SCAIL_DIT_CFG_PAIR 1u
 int scail_dit_step(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
                    const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
                    const float* rope_cos, const float* rope_sin, float* out,
-                   int64_t B, int64_t T, int64_t H, int64_t W, void* workspace, int64_t workspace_bytes, void* stream);
+                   int64_t B, int64_t T, int64_t H, int64_t W, uint32_t flags, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * Seam B2 (the SAT hook `layer_forward`, dit...:1009-1051): ONE transformer block, in place on caller-owned hidden states
@@ -116,8 +124,11 @@ int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, const float
  *   SCAIL_SP_BACK_START  ulysses: ofull[b] is complete on `stream`: start the all-to-all ofull[b] -> back[b]
  *   SCAIL_SP_BACK_WAIT   make `stream` wait for it
  * Per layer the order of the calls is START(0), START(1), .., WAIT(0), [BACK_START(0)], WAIT(1), [BACK_START(1)], .., [BACK_WAIT(0), ..] on every
- * rank, so collectives are enqueued in the same order everywhere.  A non-zero return aborts the step (status 3).  The callback runs on the
- * calling thread, between launches; it must not synchronise the device if the step is to stay asynchronous.
+ * rank, so collectives are enqueued in the same order everywhere (with SCAIL_DIT_CFG_PAIR layer 0 exchanges element 0 only).  A non-zero
+ * return aborts the step (status 3): the side streams are still joined back into `stream`, so work already enqueued stays ordered before
+ * whatever the caller enqueues next, but collectives the peers started are left unmatched -- after a status 3 the caller must tear down
+ * (abort) the communicator.  The callback runs on the calling thread, between launches; it must not synchronise the device if the step is
+ * to stay asynchronous.
  * side_stream: both NULL = everything on `stream`.  Two streams: the two CFG elements' launches of the ulysses exchange section go to
  * side_stream[b & 1] (forked from / joined to `stream` with events inside the call): an element's rank-sized launches leave a partial last
  * round of the chip that the other element's kernels fill (pays up to 4 ranks).
@@ -143,12 +154,15 @@ typedef struct scail_dit_sp {
 
 /* One network evaluation on this rank's latent slab x [B,T,16,H,W] (H or W = the full extent / ranks; ref / pose sliced alike; rope tables
  * of the slab's tokens with the rank's window shift, scail_amd/rope.py): scail_dit_step with the self-attention exchanged as above.
- * out = this rank's slab of the result.  workspace >= scail_dit_sp_workspace_bytes (the V^T staging buffer holds ALL ranks' keys). */
+ * out = this rank's slab of the result.  workspace >= scail_dit_sp_workspace_bytes (the V^T staging buffer holds ALL ranks' keys).
+ * flags as for scail_dit_step.  The last layer evaluates the rank's noise rows only past its K / V exchange (all-gather: their queries too;
+ * ulysses: the full-sequence attention keeps every query, its rows are rank-major). */
 int64_t scail_dit_sp_workspace_bytes(const scail_dit* h, int32_t mode, int32_t ranks, int64_t B, int64_t T, int64_t H, int64_t W);
 int scail_dit_step_sp(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
                       const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
                       const float* rope_cos, const float* rope_sin, float* out,
-                      int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, void* workspace, int64_t workspace_bytes, void* stream);
+                      int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, uint32_t flags, void* workspace, int64_t workspace_bytes,
+                      void* stream);
 
 /* Seam B2 for a sequence-parallel rank: ONE transformer block in place on this rank's hidden [B, Ltok, D] (scail_dit_block + the exchange). */
 int64_t scail_dit_block_sp_workspace_bytes(const scail_dit* h, int32_t mode, int32_t ranks, int64_t B, int64_t Ltok);
@@ -161,7 +175,8 @@ int scail_dit_block_sp(scail_dit* h, int64_t layer, scail_bf16* hidden, const fl
  * from: the timed thing is the product path itself, not an instrumented copy).  scail_dit_profile(h, 1): every following scail_dit_step
  * / scail_dit_block / scail_dit_sample brackets each launch of the categories below with an event pair (events are pooled in the
  * handle; counters restart); scail_dit_profile(h, 0) stops.  scail_dit_profile_read waits for the recorded events and returns the summed
- * kernel time in ms and the number of launches of one category since the last enable.  Off by default; do not enable inside a stream
+ * kernel time in ms and the number of launches of one category since the last enable.  With side streams (scail_dit_sp.side_stream) the
+ * two elements' launches overlap, so the sum of a category is NOT wall-exclusive there.  Off by default; do not enable inside a stream
  * capture (event records are not capturable into a replayable graph with readable timings).
  */
 #define SCAIL_DIT_PROF_SELF_ATTN 0   /* scail_flash_attn_bf16 of the self-attention (dit...:1058-1105) */

@@ -47,9 +47,10 @@ from typing import List
 from . import isa, sched
 from .isa import A, S, V, I32, F32, Neg, VCC, EXEC, M0, Instr
 
-KERNARG_SIZE = 152
-# q k vt o | q_bs q_rs k_ss k_bs k_rs vt_ss vt_bs o_bs o_rs | heads Lq Lk Lkp n_seg | sl2 thr | nqb magic_nqb magic_heads xcd_mode pad
-KERNARG_FMT = "<4Q9q5iffiIIi4x"
+KERNARG_SIZE = 160
+# q k vt o | q_bs q_rs k_ss k_bs k_rs vt_ss vt_bs o_bs o_rs | heads Lq Lk Lkp n_seg | sl2 thr | nqb magic_nqb magic_heads xcd_mode |
+# items_per_xcd n_items (xcd_mode 2) pad
+KERNARG_FMT = "<4Q9q5iffiIIiii4x"
 
 
 def magic31(d: int) -> int:
@@ -57,22 +58,28 @@ def magic31(d: int) -> int:
     return -(-(1 << 31) // d)
 
 
-def grid_blocks(n_batch: int, heads: int, Lq: int) -> int:
-    return ((Lq + 255) // 256) * heads * n_batch
+def grid_blocks(n_batch: int, heads: int, Lq: int, rows: int = 256, mode: int = None) -> int:
+    items = ((Lq + rows - 1) // rows) * heads * n_batch
+    mode = xcd_mode(n_batch, heads) if mode is None else mode
+    return 8 * ((items + 7) // 8) if mode == 2 else items
 
 
 def xcd_mode(n_batch: int, heads: int) -> int:
     """1: workgroup id -> (XCD = id % 8 works on (batch, head) pairs = XCD mod 8), so the 32 CUs of an XCD stream the SAME K / V^T
-    through their L2 (the hardware places consecutive workgroup ids on consecutive XCDs); needs pairs % 8 == 0."""
-    return 1 if (n_batch * heads) % 8 == 0 else 0
+    through their L2 (the hardware places consecutive workgroup ids on consecutive XCDs); needs pairs % 8 == 0.
+    2 (any pair count): the (pair, query block) items in pair-major order are cut into 8 equal runs, XCD x walks run x
+    (item = x * ceil(items / 8) + id / 8; ids past the end of a run exit at once), so an XCD streams one pair's K / V^T at a time
+    (two where a run crosses a pair boundary) instead of all 8 XCDs streaming the same pair as the plain decode (0) does."""
+    return 1 if (n_batch * heads) % 8 == 0 else 2
 
 
 def pack_args(q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=1,
-              mode=None) -> bytes:
-    nqb = (Lq + 255) // 256
+              mode=None, rows: int = 256) -> bytes:
+    nqb = (Lq + rows - 1) // rows
     mode = xcd_mode(n_batch, heads) if mode is None else mode
+    items = nqb * heads * n_batch
     b = struct.pack(KERNARG_FMT, q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr,
-                    nqb, magic31(nqb), magic31(heads), mode)
+                    nqb, magic31(nqb), magic31(heads), mode, (items + 7) // 8, items)
     assert len(b) == KERNARG_SIZE
     return b
 
@@ -116,9 +123,14 @@ class Cfg:
     k_at: float = 18.0     # K(t+2) fragment reads: first at this gap unit (after the QK^T MFMAs that still read the old fragments), k_step apart
     k_step: float = 2.0
     late_extra: float = -1.0   # >= 0: sched.schedule(late_extra=...) -- one filler beyond ``cap`` in a gap when the stream is that many gaps late
+    nq: int = 4            # (mi = 16, fold, lsum) 16-row query blocks per wave: 4 = 256-row workgroups; 3 = 192-row workgroups (102 MFMAs
+                           # per tile instead of 136 beside the same K / V^T traffic): the launch shape of a sequence-parallel rank, where
+                           # ceil(workgroups / CUs) x tile cost is lower for the shorter tile (scail_flash_attn_bf16 picks per launch)
     align: int = 0         # .p2align of the hot-loop entry labels (0 = none): code placement A/B (guide: hand-asm streams are
                            # sensitive to a uniform shift of the instruction stream)
 
+    @property
+    def rows(self): return 64 * self.nq        # query rows of a workgroup (4 waves x nq blocks of 16)
     @property
     def unroll(self): return max(2, self.rd)
     @property
@@ -195,6 +207,7 @@ S_KRS, S_VTSS, S_VTBS, S_OBS = S(24, 2), S(26, 2), S(28, 2), S(30, 2)
 S_ORS = S(32, 2)
 S_HEADS, S_LQ, S_LK, S_LKP, S_NSEG, S_C, S_THR, S_NQB = S(36), S(37), S(38), S(39), S(40), S(41), S(42), S(43)
 S_MAGQ, S_MAGH, S_XMODE = S(84), S(85), S(86)
+S_IPX, S_NITEMS = S(87), S(88)     # xcd_mode 2: items per XCD run, items in all (live in the id decode only: s87 / s88 are S_CLAMP / S_FIRST later)
 S_KRSRC, S_VRSRC = S(44, 4), S(48, 4)
 S_KOFF, S_VOFF, S_KSTEP, S_VSTEP, S_KMAX, S_VMAX = S(52), S(53), S(54), S(55), S(56), S(57)
 S_T, S_NT, S_SEG, S_WAVE = S(58), S(59), S(60), S(61)
@@ -335,7 +348,7 @@ class Gen:
         out = []
         for kb in range(4):
             for ks in range(4):
-                for qb in range(4):
+                for qb in range(self.cfg.nq):
                     d = Sb16(nxt, kb, qb)
                     c0 = NEGM[qb] if self.cfg.fold else I32(0)
                     out.append(isa.mfma16(d, Kf16(kb, ks), Qf16(qb, ks), c0 if ks == 0 else d, tag="qk"))
@@ -345,12 +358,13 @@ class Gen:
         """O[db][qb] += V^T[db][ks] x P[qb][ks]; P[qb][ks] = the packed quad built in place from S[2 ks][qb], S[2 ks + 1][qb]."""
         out = []
         for ks in range(2):
-            order = ([(db, qb) for qb in range(4) for db in range(8)] if self.cfg.pv_qb else
-                     [(db, qb) for db in range(8) for qb in range(4)])
+            nq = self.cfg.nq
+            order = ([(db, qb) for qb in range(nq) for db in range(8)] if self.cfg.pv_qb else
+                     [(db, qb) for db in range(8) for qb in range(nq)])
             for db, qb in order:
                 out.append(isa.mfma16(O16(db, qb), Vtf16(db, ks), Pq16(cur, ks, qb), O16(db, qb), tag="pv"))
             if self.cfg.lsum:
-                for qb in range(4):
+                for qb in range(self.cfg.nq):
                     out.append(isa.mfma16(LACC[qb], ONES, Pq16(cur, ks, qb), LACC[qb], tag="pv"))
         return out
 
@@ -358,7 +372,7 @@ class Gen:
         out = []
         nofma = "fma" in self.cfg.abl.split(",")
         for ks in range(2):
-            for qb in range(4):
+            for qb in range(self.cfg.nq):
                 base = Pq16(cur, ks, qb).idx
                 regs = [V(base + j) for j in range(8)]
                 lsum = L16F if self.cfg.fold else L16
@@ -381,7 +395,7 @@ class Gen:
         for kb in range(4):
             grp = []
             T = TMPL if self.cfg.lsum else TMP16
-            for qb in range(4):
+            for qb in range(self.cfg.nq):
                 s = Sb16(nxt, kb, qb)
                 acc = T[qb]
                 if kb == 0:
@@ -391,7 +405,7 @@ class Gen:
                     grp.append(isa.vop("v_max3_f32", acc, acc, s.sub(0), s.sub(1)))
                     grp.append(isa.vop("v_max3_f32", acc, acc, s.sub(2), s.sub(3)))
             grp = grp[0::2] + grp[1::2]                     # the four rows' chains interleaved
-            span = 12.0 / len(grp)
+            span = 12.0 * self.cfg.nq / 4.0 / len(grp)
             for k, ins in enumerate(grp):
                 ins.target_gap = t_kb[kb] + k * span
             out.extend(grp)
@@ -399,13 +413,13 @@ class Gen:
             # S' is already relative to the running maximum: any lane's partial maximum above thr triggers the (rare) subroutine,
             # which does the cross-lane part
             T = TMPL if self.cfg.lsum else TMP16
-            fin = [isa.vop("v_max3_f32", T[4], T[0], T[1], T[2]), isa.vop("v_max_f32", T[4], T[4], T[3]),
+            fin = [isa.vop("v_max3_f32", T[4], T[0], T[1], T[2])] + ([isa.vop("v_max_f32", T[4], T[4], T[3])] if self.cfg.nq == 4 else []) + [
                    isa.v_cmp("v_cmp_gt_f32", T[4], S_THR)]
             for k, ins in enumerate(fin):
                 ins.target_gap = t_fin + 0.5 * k
             return out + fin
         fin = []
-        for qb in range(4):
+        for qb in range(self.cfg.nq):
             acc, cp = TMP16[qb], TMP16[4 + (qb & 1)]
             fin.append(isa.vop("v_mov_b32", cp, acc))
             fin.append(isa.permlane32_swap(acc, cp))                                  # acc = {lo, lo}, cp = {hi, hi}
@@ -442,7 +456,7 @@ class Gen:
                 tg = t_kb[kb] - 1.5 + 0.3 * e
                 out += [isa.sop("s_sub_u32", lim, valid, I32(32 * (kb >> 1) + 8 * (kb & 1) + e), target_gap=tg),
                         isa.v_cmp("v_cmp_gt_i32", lim, G, target_gap=tg + 0.05)]                        # vcc = key is valid
-                for qb in range(4):
+                for qb in range(self.cfg.nq):
                     r = Sb16(nxt, kb, qb).sub(e)
                     out.append(isa.v_cndmask(r, VT1, r, target_gap=tg + 0.1))
         return out
@@ -517,7 +531,7 @@ class Gen:
         cur, nxt = p & 1, (p + 1) & 1
         rd = c.rd
         m16 = c.mi == 16
-        gs = 2.0 if m16 else 1.0
+        gs = (2.0 if m16 else 1.0) * c.nq / 4.0      # nq = 3: 102 MFMAs per tile, every target scales with the spine
         blk: List[Instr] = []
         abl = c.abl.split(",")
         careful = careful and c.ragged
@@ -529,7 +543,7 @@ class Gen:
         if not tail:
             blk += self.qk_mfmas16(nxt) if m16 else self.qk_mfmas(nxt)
             if careful:
-                blk += self.mask_scores16(nxt, 1, (20.0, 36.0, 52.0, 68.0))
+                blk += self.mask_scores16(nxt, 1, tuple(x * c.nq / 4.0 for x in (20.0, 36.0, 52.0, 68.0)))
         if "valu" not in abl:
             blk += (self.softmax_finish16 if m16 else self.softmax_finish)(cur, 0.0, (c.sm_end if not tail else 20.0) * gs)
         blk += self.pv_mfmas16(cur) if m16 else self.pv_mfmas(cur)
@@ -537,7 +551,8 @@ class Gen:
             if "lds" not in abl:
                 blk += (self.k_frag_reads16 if m16 else self.k_frag_reads)((p + 2) % rd, c.k_at * gs, c.k_step * gs)
             if "valu" not in abl and "max" not in abl and not nomax:
-                blk += self.rowmax16(nxt, (20.0, 36.0, 52.0, 68.0), 84.0) if m16 else self.rowmax(nxt, 21.0, 38.0, 52.0)
+                blk += (self.rowmax16(nxt, tuple(x * c.nq / 4.0 for x in (20.0, 36.0, 52.0, 68.0)), 84.0 * c.nq / 4.0) if m16 else
+                        self.rowmax(nxt, 21.0, 38.0, 52.0))
         seq = sched.schedule(blk, cap=c.cap, lookahead=c.lookahead, late_extra=c.late_extra if c.late_extra >= 0 else None)
         seq = sched.insert_lgkm_waits(seq)
         return seq
@@ -565,7 +580,7 @@ class Gen:
     # =============================================================================================
     def rescale_sub16(self) -> List[Instr]:
         out = [isa.label("L_rescale"), isa.nop(15), isa.nop(15)]
-        for qb in range(4):
+        for qb in range(self.cfg.nq):
             mn, d = TMP16[0 + (qb & 1)], TMP16[2 + (qb & 1)]
             out += [isa.vop("v_max_f32", mn, M16[qb], MX16[qb]),
                     isa.vop("v_sub_f32", d, M16[qb], mn),
@@ -577,7 +592,7 @@ class Gen:
                 out.append(isa.vop("v_mul_f32", L16[qb][j], L16[qb][j], ALPHA16[qb]))
         k = 0
         for db in range(8):
-            for qb in range(4):
+            for qb in range(self.cfg.nq):
                 for r in range(4):
                     t = TMP16[4 + (k % 6)]
                     k += 1
@@ -598,7 +613,7 @@ class Gen:
             mx, cp, al, t2 = [TMPL[qb] for qb in range(4)], V(128), [V(129 + qb) for qb in range(4)], V(133)
         else:
             mx, cp, al, t2 = [TMP16[qb] for qb in range(4)], TMP16[4], [TMP16[5 + qb] for qb in range(4)], TMP16[9]
-        for qb in range(4):
+        for qb in range(self.cfg.nq):
             out += [isa.vop("v_mov_b32", cp, mx[qb]), isa.permlane32_swap(mx[qb], cp), isa.vop("v_max_f32", mx[qb], mx[qb], cp),
                     isa.vop("v_mov_b32", cp, mx[qb]), isa.permlane16_swap(mx[qb], cp), isa.vop("v_max_f32", mx[qb], mx[qb], cp),
                     isa.vop("v_max_f32", mx[qb], mx[qb], S_CLAMP)]
@@ -614,9 +629,9 @@ class Gen:
         if self.cfg.opt:
             out.append(isa.sop("s_mov_b32", S_HEAD, I32(0)))
         out += [isa.branch("s_cbranch_scc1", f"L_rescale{nxt}_ret")]
-        for qb in range(4):
+        for qb in range(self.cfg.nq):
             out += [isa.vop("v_exp_f32", al[qb], Neg(mx[qb]))]
-        for qb in range(4):
+        for qb in range(self.cfg.nq):
             if lsum:
                 for j in range(4):
                     out.append(isa.vop("v_mul_f32", LACC[qb].sub(j), LACC[qb].sub(j), al[qb]))
@@ -625,7 +640,7 @@ class Gen:
                     out.append(isa.vop("v_mul_f32", L16F[qb][j], L16F[qb][j], al[qb]))
         k = 0
         for db in range(8):
-            for qb in range(4):
+            for qb in range(self.cfg.nq):
                 for r in range(4):
                     t = [cp, t2][k % 2]
                     k += 1
@@ -675,23 +690,37 @@ class Gen:
                 isa.sop("s_mul_i32", t2, st.sub(1), mult), isa.sop("s_add_u32", t1, t1, t2),
                 isa.sop("s_add_u32", ptr.sub(0), ptr.sub(0), t0), isa.sop("s_addc_u32", ptr.sub(1), ptr.sub(1), t1)]
 
+    def wave_row_base(self) -> List[Instr]:
+        """ST[8] = first query row of the workgroup (rows x query block), ST[7] = first row of this wave inside it (16 nq x wave)."""
+        if self.cfg.nq == 4:
+            return [isa.sop("s_lshl_b32", ST[8], S_QB, I32(8)), isa.sop("s_lshl_b32", ST[7], S_WAVE, I32(6))]
+        return [isa.sop("s_mul_i32", ST[8], S_QB, I32(self.cfg.rows)), isa.sop("s_mul_i32", ST[7], S_WAVE, I32(16 * self.cfg.nq))]
+
     def prologue(self) -> List[Instr]:
         c = self.cfg
+        assert c.nq == 4 or (c.nq == 3 and c.mi == 16 and c.fold and c.lsum), "nq = 3 exists for the fold / lsum 16x16x32 kernels only"
         o: List[Instr] = [isa.label(c.name)]
         o += [isa.s_load(8, S(8, 8), S_KARG, 0), isa.s_load(8, S(16, 8), S_KARG, 32), isa.s_load(8, S(24, 8), S_KARG, 64),
               isa.s_load(2, S_ORS, S_KARG, 96), isa.s_load(8, S(36, 8), S_KARG, 104),
               isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", VT0, I32(6), V(0)),
-              isa.s_load(4, S(84, 4), S_KARG, 136),
+              isa.s_load(4, S(84, 4), S_KARG, 136), isa.s_load(1, S_NITEMS, S_KARG, 152),
               isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, VT0)]
         # ---- 1-D workgroup id -> (query block, head, batch); xcd_mode 1: ids congruent mod 8 (= one XCD) share (batch, head)
         #      pairs, so the 32 CUs of an XCD stream the same K / V^T tiles through their L2 ----
         wid, xcd, j, qd, pair, tt = S(2), ST[0], ST[1], ST[2], ST[3], ST[4]
+        #      xcd_mode 2 (any pair count): item = xcd * items_per_xcd + id / 8 in pair-major order, ids past a run's end exit ----
         o += [isa.sop("s_and_b32", xcd, wid, I32(7)), isa.sop("s_lshr_b32", j, wid, I32(3)),
+              isa.sop("s_cmp_eq_u32", None, S_XMODE, I32(2)), isa.branch("s_cbranch_scc0", "L_id_plain"),
+              isa.sop("s_cmp_lt_u32", None, j, S_IPX), isa.branch("s_cbranch_scc1", "L_id_in_run"),
+              Instr("s_endpgm", cls=isa.BRANCH), isa.label("L_id_in_run"),
+              isa.sop("s_mul_i32", tt, xcd, S_IPX), isa.sop("s_add_u32", j, j, tt),
+              isa.sop("s_cmp_lt_u32", None, j, S_NITEMS), isa.branch("s_cbranch_scc1", "L_id_plain"),
+              Instr("s_endpgm", cls=isa.BRANCH), isa.label("L_id_plain"),
               isa.sop("s_cmp_lg_u32", None, S_XMODE, I32(0)), isa.sop("s_cselect_b32", j, j, wid),
               isa.sop("s_lshl_b32", tt, j, I32(1)), isa.sop("s_mul_hi_u32", qd, tt, S_MAGQ),            # qd = j / nqb
               isa.sop("s_mul_i32", tt, qd, S_NQB), isa.sop("s_sub_u32", S_QB, j, tt),                   # qb = j % nqb
               isa.sop("s_lshl_b32", tt, qd, I32(3)), isa.sop("s_add_u32", tt, tt, xcd),
-              isa.sop("s_cmp_lg_u32", None, S_XMODE, I32(0)), isa.sop("s_cselect_b32", pair, tt, qd),
+              isa.sop("s_cmp_eq_u32", None, S_XMODE, I32(1)), isa.sop("s_cselect_b32", pair, tt, qd),
               isa.sop("s_lshl_b32", tt, pair, I32(1)), isa.sop("s_mul_hi_u32", S_B, tt, S_MAGH),         # b = pair / heads
               isa.sop("s_mul_i32", tt, S_B, S_HEADS), isa.sop("s_sub_u32", S_H, pair, tt)]
         # ---- per (batch, head) base pointers ----
@@ -784,18 +813,17 @@ class Gen:
             # B operand of S^T = K Q^T: lane holds Q[row][32 ks + 8 g .. +7]
             qrsb, orsb, lqm1 = ST[12], ST[13], ST[9]
             o += [isa.sop("s_lshl_b32", qrsb, S_QRS.sub(0), I32(1)), isa.sop("s_lshl_b32", orsb, S_ORS.sub(0), I32(1)),
-                  isa.sop("s_sub_u32", lqm1, S_LQ, I32(1)),
-                  isa.sop("s_lshl_b32", ST[8], S_QB, I32(8)), isa.sop("s_lshl_b32", ST[7], S_WAVE, I32(6)),
+                  isa.sop("s_sub_u32", lqm1, S_LQ, I32(1))] + self.wave_row_base() + [
                   isa.sop("s_add_u32", ST[8], ST[8], ST[7])]
             qa = [TMP16[4 + qb] for qb in range(4)]
-            for qb in range(4):
+            for qb in range(self.cfg.nq):
                 o += [isa.vop("v_add_u32", ROW16[qb], ST[8], ql)]
                 if qb:
                     o += [isa.vop("v_add_u32", ROW16[qb], I32(16 * qb), ROW16[qb])]
                 o += [isa.vop("v_min_u32", t[0], ROW16[qb], lqm1), isa.vop("v_mul_lo_u32", t[0], t[0], qrsb),
                       isa.vop("v_lshl_add_u32", qa[qb], g, I32(4), t[0]),
                       isa.vop("v_mul_lo_u32", t[3], ROW16[qb], orsb), isa.vop("v_lshl_add_u32", OOFF16[qb], g, I32(3), t[3])]
-            for qb in range(4):
+            for qb in range(self.cfg.nq):
                 for ks in range(4):
                     o.append(isa.global_load(4, Qf16(qb, ks), qa[qb], 64 * ks, saddr=S_Q))
             if c.fold:
@@ -804,7 +832,7 @@ class Gen:
                     # callers whose q is in log2 units already pass sl2 == 0 and skip the block (and its wait for the Q loads)
                     o += [isa.sop("s_cmp_eq_u32", None, S_C, I32(0)), isa.branch("s_cbranch_scc1", "L_qdone"), isa.waitcnt(vmcnt=0)]
                     k = 0
-                    for qb in range(4):
+                    for qb in range(self.cfg.nq):
                         for ks in range(4):
                             for i in range(4):
                                 a = Qf16(qb, ks).sub(i)
@@ -845,7 +873,7 @@ class Gen:
                 for i in range(128):
                     o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
                 # running maximum starts at 0; the first tile's subroutine call (unconditional, CLAMP = -inf) sets it to the tile's maximum
-                for qb in range(4):
+                for qb in range(self.cfg.nq):
                     for i in range(4):
                         o.append(isa.vop("v_mov_b32", NEGM[qb].sub(i), I32(0)))
                     if not c.lsum:
@@ -853,13 +881,13 @@ class Gen:
                             o.append(isa.vop("v_mov_b32", L16F[qb][j], I32(0)))
                 o += [isa.sop("s_mov_b32", S_CLAMP, I32(0xFF800000)), isa.sop("s_mov_b32", S_FIRST, I32(1))]
                 if c.lsum:
-                    for qb in range(4):
+                    for qb in range(self.cfg.nq):
                         for i in range(4):
                             o.append(isa.vop("v_mov_b32", LACC[qb].sub(i), I32(0)))
             else:
                 for i in range(128):
                     o.append(isa.vop("v_accvgpr_write_b32", A(i), I32(0)))
-                for qb in range(4):
+                for qb in range(self.cfg.nq):
                     o += [isa.vop("v_mov_b32", M16[qb], F32(-1e30)), isa.vop("v_mul_f32", MC16[qb], M16[qb], S_C)]
                     for j in range(2):
                         o.append(isa.vop("v_mov_b32", L16[qb][j], I32(0)))
@@ -971,10 +999,10 @@ class Gen:
                 # the row / offset registers were given to the row-sum accumulators: rebuild them (row = 256 qb_wg + 64 w + 16 qb + lane % 16)
                 row16, ooff16 = [V(16 + qb) for qb in range(4)], [V(20 + qb) for qb in range(4)]
                 ql, g, t3, orsb = V(24), V(25), V(26), ST[13]
-                e += [isa.sop("s_lshl_b32", orsb, S_ORS.sub(0), I32(1)), isa.sop("s_lshl_b32", ST[8], S_QB, I32(8)),
-                      isa.sop("s_lshl_b32", ST[7], S_WAVE, I32(6)), isa.sop("s_add_u32", ST[8], ST[8], ST[7]),
+                e += [isa.sop("s_lshl_b32", orsb, S_ORS.sub(0), I32(1))] + self.wave_row_base() + [
+                      isa.sop("s_add_u32", ST[8], ST[8], ST[7]),
                       isa.vop("v_and_b32", ql, I32(15), LANE), isa.vop("v_lshrrev_b32", g, I32(4), LANE)]
-                for qb in range(4):
+                for qb in range(self.cfg.nq):
                     e += [isa.vop("v_add_u32", row16[qb], ST[8], ql)]
                     if qb:
                         e += [isa.vop("v_add_u32", row16[qb], I32(16 * qb), row16[qb])]
@@ -983,7 +1011,7 @@ class Gen:
             bad = S(ST[0].idx, 2)
             if opt:
                 e += [Instr("s_mov_b64", [bad], [I32(0)], cls=isa.SALU)]
-            for qb in range(4):
+            for qb in range(self.cfg.nq):
                 a, b = V(4), V(5)
                 lsum = L16F if self.cfg.fold else L16
                 first = ([isa.vop("v_mov_b32", a, LACC[qb].sub(0))] if self.cfg.lsum        # lanes 0-15 hold the sums, the other rows of the block are 0
@@ -1009,7 +1037,7 @@ class Gen:
                       isa.nop(3), isa.sop("s_cmp_eq_u32", None, ST[2], I32(0)), isa.branch("s_cbranch_scc1", "L_store"),
                       isa.sop("s_mov_b32", S_MODE, I32(1)), isa.branch("s_branch", "L_restart"),
                       isa.label("L_store"), isa.nop(7)]
-            for qb in range(4):
+            for qb in range(self.cfg.nq):
                 e += [isa.v_cmp("v_cmp_lt_u32", row16[qb], S_LQ), Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
                 for db in range(8):
                     base = 32 + 6 * (db % 2)
@@ -1148,7 +1176,10 @@ DEFAULT = Cfg(rd=4, cap=5, name="scail_attn4")
 # raw-scale callers --, running maximum folded into the accumulator init, optimistic hot loop).  DEFAULT (32x32x16 MFMAs, scale per
 # score; round 2's raw-scale kernel) lives on in the measurement build and in the emulator tests
 M16F = Cfg(name="scail_attn4_m16f", mi=16, fold=True, lsum=True, ragged=True, cap=1, sm_end=44.0, lookahead=2.0, qscale=True, opt=True, pv_qb=True)
-SHIPPED = [M16F]
+# the same kernel with 3 query blocks per wave = 192-row workgroups: the launch shape of a sequence-parallel rank (Ulysses at 8 ranks: 5 heads x
+# 191 tiles of 256 rows = 3.73 rounds over 256 CUs -> 4; 255 tiles of 192 rows = 4.98 rounds of a shorter tile)
+M16F_Q3 = Cfg(name="scail_attn4_m16f_q3", mi=16, fold=True, lsum=True, ragged=True, cap=1, sm_end=44.0, lookahead=2.0, qscale=True, opt=True, pv_qb=True, nq=3)
+SHIPPED = [M16F, M16F_Q3]
 
 
 def variant_cfgs():

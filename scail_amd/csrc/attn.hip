@@ -818,12 +818,14 @@ struct Attn4Args {
     int64_t q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs;
     int32_t heads, Lq, Lk, Lkp, n_seg;
     float sl2, thr;
-    int32_t nqb;                 // query blocks of 256 rows
+    int32_t nqb;                 // query blocks of 256 rows (192 for the _q3 kernel)
     uint32_t magic_nqb, magic_heads;   // ceil(2^31 / d): x / d == (2 x * magic) >> 32 for the workgroup-id decode
-    int32_t xcd_mode;            // 1: ids congruent mod 8 (one XCD) share (batch, head) pairs -> K / V^T reuse in that XCD's L2
+    int32_t xcd_mode;            // 1: ids congruent mod 8 (one XCD) share (batch, head) pairs -> K / V^T reuse in that XCD's L2;
+                                 // 2 (any pair count): XCD x walks the x-th of 8 equal runs of the pair-major (pair, query block) items
+    int32_t items_per_xcd, n_items;    // xcd_mode 2: ceil(items / 8), items = nqb * heads * batch; the grid is 8 * items_per_xcd
     int32_t pad;
 };
-static_assert(sizeof(Attn4Args) == 152, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
+static_assert(sizeof(Attn4Args) == 160, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
 // Code objects, kernel handles (and the GEMM's tile-order tables, gemm.hip) belong to ONE device: they are cached per HIP device
 // id, so a process that drives several GPUs (a DiT on cuda:0 and another engine on cuda:1, a threaded multi-GPU host) launches the
 // module loaded on the device that is current at the call.
@@ -874,6 +876,30 @@ int scail_attn4_preload() {
 }
 
 static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
+static int g_attn4_rows = 0;               // query rows per workgroup: 0 = chosen per launch by the rounds model below, 256 / 192 = forced
+// Query-tile height of a launch.  One workgroup occupies a CU (512 registers per lane, one wave per SIMD), so a launch of W workgroups
+// takes ceil(W / CUs) rounds of one tile each.  scail_attn4_m16f_q3 (192 rows: 3 of the 4 query blocks per wave, 102 of 136 MFMAs per
+// key tile beside the same K / V^T traffic) costs k_attn4_q3_cost of a 256-row tile; it wins where the 256-row grid wastes most of
+// its last round -- the launches of a sequence-parallel rank (Ulysses, 8 ranks: 5 heads x 191 tiles = 3.73 rounds -> 4, against
+// 4.98 rounds x the shorter tile), never the single-GPU launch (59.7 rounds).
+static const double k_attn4_q3_cost = 0.78;
+static int attn4_cu_count() {
+    static std::map<int, int> cus;
+    std::lock_guard<std::mutex> lk(g_attn4_mutex);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    return cus[dev] = n;
+}
+static int attn4_pick_rows(int64_t n_batch, int64_t heads, int64_t Lq) {
+    if (g_attn4_rows == 256 || g_attn4_rows == 192) return g_attn4_rows;
+    const int64_t cus = attn4_cu_count(), pairs = heads * n_batch;
+    const int64_t w4 = (Lq + 255) / 256 * pairs, w3 = (Lq + 191) / 192 * pairs;
+    const double c4 = (double)((w4 + cus - 1) / cus), c3 = (double)((w3 + cus - 1) / cus) * k_attn4_q3_cost;
+    return c3 < c4 * 0.995 ? 192 : 256;
+}
 // scail_attn4_m16f takes ANY key count >= 512 (ragged last tile: K rows fetched from 64 rows earlier, scores masked) and any scale (q in
 // log2 units as it is, a raw scale through a one-time multiplication of the Q fragments in its prologue); what is left to the 8-wave
 // kernel: short key sets, accumulate, slices beyond 32-bit byte offsets.  (A non-ragged A/B variant of the measurement build needs
@@ -889,8 +915,13 @@ static bool attn4_eligible(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq,
 // The kernel decodes its 1-D workgroup id with reciprocal multiplications that are exact while id * divisor < 2^31
 // (asmgen/attn4.py magic31): query blocks^2 * heads * batch and heads^2 * batch must stay below that; larger grids run the 8-wave kernel.
 static bool attn4_grid_ok(int64_t n_batch, int64_t heads, int64_t Lq) {
-    const int64_t nqb = (Lq + 255) / 256, lim = 1ll << 31;
+    const int64_t nqb = (Lq + 191) / 192, lim = 1ll << 31;       // the finer of the two query tilings
     return heads < (1 << 15) && n_batch < (1 << 15) && nqb * heads * n_batch < lim / nqb && heads * n_batch < lim / heads;
+}
+
+extern "C" int scail_flash_attn_rows_for(int64_t n_batch, int64_t heads, int64_t Lq) {
+    if (n_batch <= 0 || heads <= 0 || Lq <= 0) return 256;
+    return attn4_pick_rows(n_batch, heads, Lq);
 }
 
 extern "C" int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate, int prescaled) {
@@ -906,6 +937,15 @@ int scail_conv4_cont_enable(int v);    // conv.hip
 extern "C" int scail_set_option(const char* name, int value) {
     const std::string k(name ? name : "");
     if (k == "attn4") { g_attn4_mode = value != 0; return 0; }              // 0: 8-wave kernel for every shape
+    if (k == "attn4_rows") {                                                // query rows per workgroup of attn4: 0 = per-launch choice
+        SCAIL_REQUIRE(value == 0 || value == 192 || value == 256, "attn4_rows must be 0 (automatic), 192 or 256");
+        g_attn4_rows = value;
+        return 0;
+    }
+    if (k == "attn4_xcd") {                                                 // 0: plain workgroup-id decode (no XCD-aware K / V^T sharing)
+        g_attn4_xcd = value != 0;
+        return 0;
+    }
     if (k == "gemm4") return scail_gemm4_enable(value);                     // 0: the kernels of csrc/gemm.hip for every shape
     if (k == "conv4") return scail_conv4_enable(value);                     // 0: the kernels of csrc/conv.hip for every convolution
     if (k == "row_wave") return scail_row_wave_enable(value);
@@ -1014,7 +1054,9 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         // measurement build take sl2 per score and the threshold in raw-score units.
         hipFunction_t fn;
         const bool fold = attn4_variant_is("m16f") || attn4_variant_is("m16g");
-        if (int rc = attn4_function(g_attn4_name, &fn)) return rc;
+        // query-tile height: the 192-row form exists for the shipped kernel only
+        const int rows = g_attn4_name == k_attn4_default ? attn4_pick_rows(n_batch, heads, Lq) : 256;
+        if (int rc = attn4_function(rows == 192 ? g_attn4_name + "_q3" : g_attn4_name, &fn)) return rc;
         Attn4Args a;
         a.q = q; a.k = k; a.vt = vt; a.o = o;
         a.q_bs = q_bs; a.q_rs = q_rs; a.k_ss = k_ss; a.k_bs = k_bs; a.k_rs = k_rs; a.vt_ss = vt_ss; a.vt_bs = vt_bs;
@@ -1022,14 +1064,16 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         a.heads = (int32_t)heads; a.Lq = (int32_t)Lq; a.Lk = (int32_t)Lk; a.Lkp = (int32_t)Lkp; a.n_seg = (int32_t)n_seg;
         a.sl2 = fold ? (prescaled ? 0.0f : sl2) : sl2;
         a.thr = fold ? g_attn4_thr_log2 : g_attn4_thr_log2 / sl2;
-        a.nqb = (int32_t)((Lq + 255) / 256);
+        a.nqb = (int32_t)((Lq + rows - 1) / rows);
         a.magic_nqb = (uint32_t)(((1ull << 31) + a.nqb - 1) / a.nqb);
         a.magic_heads = (uint32_t)(((1ull << 31) + heads - 1) / heads);
-        a.xcd_mode = (g_attn4_xcd && (heads * n_batch) % 8 == 0) ? 1 : 0;
+        a.n_items = (int32_t)(a.nqb * heads * n_batch);
+        a.items_per_xcd = (a.n_items + 7) / 8;
+        a.xcd_mode = !g_attn4_xcd ? 0 : ((heads * n_batch) % 8 == 0 ? 1 : 2);
         a.pad = 0;
         size_t sz = sizeof(a);
         void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)(a.nqb * heads * n_batch), 1, 1, 256, 1, 1, 0,
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)(a.xcd_mode == 2 ? 8 * a.items_per_xcd : a.n_items), 1, 1, 256, 1, 1, 0,
                                              (hipStream_t)stream, nullptr, extra);
         if (e != hipSuccess) {
             scail_set_error(std::string("attn4: launch failed: ") + hipGetErrorString(e));

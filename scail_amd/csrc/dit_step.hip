@@ -136,15 +136,22 @@ constexpr float ATTN_LOG2_SCALE = ATTN_SCALE * 1.4426950408889634f;   // queries
 // buffer (hid / att: row stride D; q3: the first column third of a row-stride-3D buffer; xn / ff: scratch of nb * rpb rows):
 // out-projection + gated residual, cross attention (text + CLIP, ungated residual), MLP (dit...:1036-1050, :1107-1203;
 // sat/transformer_defaults.py:163-176).  m = the (6D) modulation row of element b0 (rows of later elements 6D apart).
-static int block_post(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16* att, scail_bf16* q3, scail_bf16* xn, scail_bf16* ff,
-                      const float* m, const scail_dit_cond* cond, int64_t Btot, int64_t b0, int64_t nb, int64_t rpb, void* stream) {
+// block_attn_out: the out-projection + gated residual alone; block_cross_mlp: the rest (the first point of a block at which the two CFG
+// elements of a step differ: scail_dit_step's SCAIL_DIT_CFG_PAIR).
+static int block_attn_out(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16* att, const float* m, int64_t nb, int64_t rpb, void* stream) {
+    const int64_t D = h->cfg.hidden_size;
+    const scail_dit_layer& lw = h->layers[i];
+    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(att, D, lw.o_w, lw.o_b, hid, D, nb * rpb, D, D, SCAIL_EPI_RESID, hid, D, m + 2 * D, 6 * D, rpb, stream));
+    return 0;
+}
+static int block_cross_mlp(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16* att, scail_bf16* q3, scail_bf16* xn, scail_bf16* ff,
+                           const float* m, const scail_dit_cond* cond, int64_t Btot, int64_t b0, int64_t nb, int64_t rpb, void* stream) {
     const scail_dit_config& c = h->cfg;
     const int64_t D = c.hidden_size, FF = c.inner_hidden_size, nh = c.num_heads;
     const float eps = c.layernorm_epsilon;
     const int64_t Ltp = (cond->Lt + 63) / 64 * 64, Lcp = (cond->Lc + 63) / 64 * 64;
     const int64_t M = nb * rpb;
     const scail_dit_layer& lw = h->layers[i];
-    DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(att, D, lw.o_w, lw.o_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, m + 2 * D, 6 * D, rpb, stream));
     // -- cross attention: text + CLIP, ungated residual (dit...:1039-1042, :1107-1203) --
     DIT_TRY(scail_layernorm_affine(hid, D, xn, D, lw.ln_w, lw.ln_b, M, D, eps, stream));
     DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xn, D, lw.cq_w, lw.cq_b, q3, 3 * D, M, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
@@ -164,6 +171,35 @@ static int block_post(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16* att,
     DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(ff, FF, lw.w2, lw.b2, hid, D, M, D, FF, SCAIL_EPI_RESID, hid, D, m + 5 * D, 6 * D, rpb, stream));
     return 0;
 }
+static int block_post(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16* att, scail_bf16* q3, scail_bf16* xn, scail_bf16* ff,
+                      const float* m, const scail_dit_cond* cond, int64_t Btot, int64_t b0, int64_t nb, int64_t rpb, void* stream) {
+    DIT_TRY(block_attn_out(h, i, hid, att, m, nb, rpb, stream));
+    return block_cross_mlp(h, i, hid, att, q3, xn, ff, m, cond, Btot, b0, nb, rpb, stream);
+}
+// Everything after the self-attention of the rows [row0, row0 + rows) of every element (rows == Ltok: the whole block in one set of
+// launches; fewer: per element, the wanted rows only).  pair: hid / att / m of element 1 do not exist yet -- the out-projection runs
+// for element 0 and its result (the hidden states after the self-attention residual) is copied to element 1 before the elements part.
+static int block_tail(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, const scail_dit_cond* cond, int64_t B, int64_t Ltok,
+                      scail_bf16* att, scail_bf16* q, scail_bf16* xn, scail_bf16* ff, int64_t row0, int64_t rows, bool pair, void* stream) {
+    const int64_t D = h->cfg.hidden_size;
+    if (pair) {
+        DIT_TRY(block_attn_out(h, i, hid + row0 * D, att + row0 * D, m, 1, rows, stream));
+        if (hipMemcpyAsync(hid + Ltok * D, hid, (size_t)Ltok * D * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+            scail_set_error("scail_dit (cfg pair): hipMemcpyAsync failed");
+            return 2;
+        }
+    }
+    if (rows == Ltok) {
+        if (!pair) DIT_TRY(block_attn_out(h, i, hid, att, m, B, Ltok, stream));
+        return block_cross_mlp(h, i, hid, att, q, xn, ff, m, cond, B, 0, B, Ltok, stream);
+    }
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t r = b * Ltok + row0;
+        if (!pair) DIT_TRY(block_attn_out(h, i, hid + r * D, att + r * D, m + b * 6 * D, 1, rows, stream));
+        DIT_TRY(block_cross_mlp(h, i, hid + r * D, att + r * D, q + r * 3 * D, xn, ff, m + b * 6 * D, cond, B, b, 1, rows, stream));
+    }
+    return 0;
+}
 
 // One transformer block in place on hid (B, Ltok, D): AdaLNMixin.layer_forward, dit...:1009-1051.
 //   m (B, 6D) fp32 = shift_a | scale_a | gate_a | shift_m | scale_m | gate_m of THIS layer (adaLN emb + table)
@@ -171,31 +207,29 @@ static int block_post(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16* att,
 //   (the LAST layer of a step: only the noise tokens reach the final layer, dit...:771, :825-826): every token still contributes its
 //   key and value, but the queries, the out-projection, the cross attention and the MLP run on the wanted rows only -- the other
 //   rows of hid are left as they were.  Result-preserving: every kernel computes a row of its output from that row alone.
+//   pair (B == 2): element 1 of hid is not filled in yet and equals element 0 up to this block's first cross attention (the CFG pair
+//   of a sampler step): the self-attention part runs for element 0 only.
 static int dit_block(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, const scail_dit_cond* cond,
                      const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok, const BlockBufs& bf,
-                     int64_t row0, int64_t rows, void* stream) {
+                     int64_t row0, int64_t rows, bool pair, void* stream) {
     const scail_dit_config& c = h->cfg;
     const int64_t D = c.hidden_size, nh = c.num_heads;
     const float eps = c.layernorm_epsilon;
     const int64_t Lp = (Ltok + 63) / 64 * 64;
-    const int64_t M = B * Ltok;
+    const int64_t Bs = pair ? 1 : B;          // elements of the self-attention part
+    const int64_t M = Bs * Ltok;
     scail_bf16 *qkv = bf.qkv, *q = qkv, *k = qkv + D, *v = qkv + 2 * D;   // column thirds of the fused projection, row stride 3D
     const scail_dit_layer& lw = h->layers[i];
     // -- self attention (dit...:1031-1036, :1058-1105) --
-    DIT_TRY(scail_ln_modulate(hid, D, bf.xn, D, m, m + D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
+    DIT_TRY(scail_ln_modulate(hid, D, bf.xn, D, m, m + D, 6 * D, Bs, Ltok, Ltok, 0, D, eps, stream));
     DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(bf.xn, D, lw.qkv_w, lw.qkv_b, qkv, 3 * D, M, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
     DIT_TRY(scail_rmsnorm_rope(k, 3 * D, k, 3 * D, lw.kn, rope_cos, rope_sin, M, Ltok, D, 128, eps, stream));
-    DIT_TRY(scail_transpose_v(v, 3 * D, Ltok * 3 * D, bf.vt, B, nh, 128, Ltok, stream));
+    DIT_TRY(scail_transpose_v(v, 3 * D, Ltok * 3 * D, bf.vt, Bs, nh, 128, Ltok, stream));
     // the queries go to the attention in log2 units (q * scale * log2 e, one rounding): its exp2 then needs no scale / shift per score
     DIT_TRY(scail_rmsnorm_rope_scaled(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, M, Ltok, D, 128, eps, ATTN_LOG2_SCALE, stream));
     DIT_PROF(SCAIL_DIT_PROF_SELF_ATTN, scail_flash_attn_bf16(q + row0 * 3 * D, Ltok * 3 * D, 3 * D, k, 0, Ltok * 3 * D, 3 * D, bf.vt, 0, nh * 128 * Lp,
-                                                             bf.att + row0 * D, Ltok * D, D, B, nh, rows, Ltok, 1, SCAIL_ATTN_Q_PRESCALED, 0, stream));
-    if (rows == Ltok) return block_post(h, i, hid, bf.att, q, bf.xn, bf.ff, m, cond, B, 0, B, Ltok, stream);
-    for (int64_t b = 0; b < B; ++b) {
-        const int64_t r = b * Ltok + row0;
-        DIT_TRY(block_post(h, i, hid + r * D, bf.att + r * D, q + r * 3 * D, bf.xn, bf.ff, m + b * 6 * D, cond, B, b, 1, rows, stream));
-    }
-    return 0;
+                                                             bf.att + row0 * D, Ltok * D, D, Bs, nh, rows, Ltok, 1, SCAIL_ATTN_Q_PRESCALED, 0, stream));
+    return block_tail(h, i, hid, m, cond, B, Ltok, bf.att, q, bf.xn, bf.ff, row0, rows, pair, stream);
 }
 
 // ---- the sequence-parallel block (include/scail_dit.h "sequence-parallel execution") ----
@@ -224,13 +258,39 @@ static int sp_check(const scail_dit* h, const scail_dit_sp* sp) {
 
 // hid (B, Ltok, D) = this rank's token slab.  Kernel sequence and results are those of scail_amd.parallel's per-op path (kept as the
 // cross-check: tests/test_dit_gpu.py); only the host side differs: one call per layer instead of ~30 launches through the binding.
+//   [row0, row0 + rows), pair: as for dit_block.  Every token's key and value is exchanged whatever the wanted rows; with fewer rows the
+//   out-projection / cross attention / MLP run on them only, and so do the queries of the all-gather mode (the ulysses attention
+//   keeps all queries: its sequence is rank-major, the wanted rows would be `ranks` separate ranges).
+namespace {
+// Joins the side streams of the ulysses section back into `stream` -- also when the section is left early on an error: kernels and
+// collectives already enqueued on the side streams stay ordered before whatever the caller enqueues on `stream` next (freeing or reusing
+// the workspace and the exchange buffers included).  A status-3 abort (the host's exchange callback failed) leaves collectives unmatched
+// on the peers: the caller must tear down the communicator (include/scail_dit.h).
+struct SideJoin {
+    scail_dit* h;
+    const scail_dit_sp* sp;
+    void* stream;
+    int n = 0;           // side streams forked
+    int join() {
+        int rc = 0;
+        for (int j = 0; j < n; ++j)
+            if (hipEventRecord(h->sp_ev[1 + j], (hipStream_t)sp->side_stream[j]) != hipSuccess ||
+                hipStreamWaitEvent((hipStream_t)stream, h->sp_ev[1 + j], 0) != hipSuccess)
+                rc = 2;
+        n = 0;
+        return rc;
+    }
+    ~SideJoin() { (void)join(); }
+};
+}  // namespace
 static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m, const scail_dit_cond* cond,
-                        const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok, const BlockBufs& bf,
-                        const scail_dit_sp* sp, void* stream) {
+                        const float* rope_cos, const float* rope_sin, int64_t Btot, int64_t Ltok, const BlockBufs& bf,
+                        const scail_dit_sp* sp, int64_t row0, int64_t rows, bool pair, void* stream) {
     const scail_dit_config& c = h->cfg;
     const int64_t D = c.hidden_size, nh = c.num_heads, N = sp->ranks;
     const float eps = c.layernorm_epsilon;
     const int64_t Lf = N * Ltok, Lfp = (Lf + 63) / 64 * 64;
+    const int64_t B = pair ? 1 : Btot;        // elements of the self-attention part
     scail_bf16 *qkv = bf.qkv, *q = qkv;
     const scail_dit_layer& lw = h->layers[i];
     DIT_TRY(scail_ln_modulate(hid, D, bf.xn, D, m, m + D, 6 * D, B, Ltok, Ltok, 0, D, eps, stream));
@@ -241,6 +301,7 @@ static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m
         const int64_t Hn = nh / N, Dn = Hn * 128, slab = Ltok * Dn;
         const bool side = sp->side_stream[0] != nullptr;
         auto st = [&](int64_t b) { return side ? sp->side_stream[b & 1] : stream; };
+        SideJoin sj{h, sp, stream};
         if (side) {
             // one side stream per element (up to 4 ranks: an element's launches leave a partial last round of the chip which the other
             // element's kernels fill).  The collectives are still enqueued in the order fwd(0), fwd(1), back(0), back(1).
@@ -250,8 +311,10 @@ static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m
                     return 2;
                 }
             if (hipEventRecord(h->sp_ev[0], (hipStream_t)stream) != hipSuccess) { scail_set_error("hipEventRecord failed"); return 2; }
-            for (int j = 0; j < (B < 2 ? (int)B : 2); ++j)
+            for (int j = 0; j < (B < 2 ? (int)B : 2); ++j) {
                 if (hipStreamWaitEvent((hipStream_t)sp->side_stream[j], h->sp_ev[0], 0) != hipSuccess) { scail_set_error("hipStreamWaitEvent failed"); return 2; }
+                sj.n = j + 1;
+            }
         }
         for (int64_t b = 0; b < B; ++b) {
             void* s = st(b);
@@ -281,14 +344,10 @@ static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m
             // back[b][g] = my tokens, head group g  ->  att rows (token, all columns)
             DIT_TRY(scail_slabs_to_rows(sp->back + b * N * slab, Dn, slab, bf.att + b * Ltok * D, D, Ltok, D, s));
         }
-        if (side)
-            for (int j = 0; j < (B < 2 ? (int)B : 2); ++j) {
-                if (hipEventRecord(h->sp_ev[1 + j], (hipStream_t)sp->side_stream[j]) != hipSuccess ||
-                    hipStreamWaitEvent((hipStream_t)stream, h->sp_ev[1 + j], 0) != hipSuccess) {
-                    scail_set_error("scail_dit (sequence parallel): joining the side streams failed");
-                    return 2;
-                }
-            }
+        if (sj.join() != 0) {
+            scail_set_error("scail_dit (sequence parallel): joining the side streams failed");
+            return 2;
+        }
     } else {
         // ONE exchange per layer: all-gather of the post-norm, post-RoPE K rows and of the V rows; K / V projection per element first
         // so that element b's gather runs under element b + 1's projection and the Q projection of all elements.
@@ -302,18 +361,26 @@ static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m
             DIT_TRY(scail_rmsnorm_rope(qb + D, 3 * D, send, D, lw.kn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, stream));
             DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_START, i, b, stream));
         }
-        DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(bf.xn, D, lw.qkv_w, lw.qkv_b, q, 3 * D, B * Ltok, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
-        DIT_TRY(scail_rmsnorm_rope_scaled(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, B * Ltok, Ltok, D, 128, eps, ATTN_LOG2_SCALE, stream));
+        if (rows == Ltok) {
+            DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(bf.xn, D, lw.qkv_w, lw.qkv_b, q, 3 * D, B * Ltok, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+            DIT_TRY(scail_rmsnorm_rope_scaled(q, 3 * D, q, 3 * D, lw.qn, rope_cos, rope_sin, B * Ltok, Ltok, D, 128, eps, ATTN_LOG2_SCALE, stream));
+        } else {
+            for (int64_t b = 0; b < B; ++b) {       // the wanted rows' queries only (their RoPE rows start at row0)
+                scail_bf16* qr = q + (b * Ltok + row0) * 3 * D;
+                DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(bf.xn + (b * Ltok + row0) * D, D, lw.qkv_w, lw.qkv_b, qr, 3 * D, rows, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+                DIT_TRY(scail_rmsnorm_rope_scaled(qr, 3 * D, qr, 3 * D, lw.qn, rope_cos + row0 * 64, rope_sin + row0 * 64, rows, rows, D, 128, eps, ATTN_LOG2_SCALE, stream));
+            }
+        }
         for (int64_t b = 0; b < B; ++b) {
             DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_WAIT, i, b, stream));
             const scail_bf16* recv = sp->recv + b * 2 * N * rowsD;      // [2][N * Ltok][D]: gathered k rows | v rows, rank-major
             scail_bf16* vt = bf.vt + b * nh * 128 * Lfp;
             DIT_TRY(scail_transpose_v(recv + N * rowsD, D, 0, vt, 1, nh, 128, Lf, stream));
-            DIT_PROF(SCAIL_DIT_PROF_SELF_ATTN, scail_flash_attn_bf16(q + b * Ltok * 3 * D, 0, 3 * D, recv, 0, 0, D, vt, 0, 0, bf.att + b * rowsD, 0, D, 1, nh, Ltok, Lf, 1,
-                                                                     SCAIL_ATTN_Q_PRESCALED, 0, stream));
+            DIT_PROF(SCAIL_DIT_PROF_SELF_ATTN, scail_flash_attn_bf16(q + (b * Ltok + row0) * 3 * D, 0, 3 * D, recv, 0, 0, D, vt, 0, 0, bf.att + b * rowsD + row0 * D, 0, D,
+                                                                     1, nh, rows, Lf, 1, SCAIL_ATTN_Q_PRESCALED, 0, stream));
         }
     }
-    return block_post(h, i, hid, bf.att, q, bf.xn, bf.ff, m, cond, B, 0, B, Ltok, stream);
+    return block_tail(h, i, hid, m, cond, Btot, Ltok, bf.att, q, bf.xn, bf.ff, row0, rows, pair, stream);
 }
 
 // Seam B2 (SAT hook layer_forward): one block on caller-owned hidden states.  Workspace: scail_dit_block_workspace_bytes.
@@ -348,7 +415,7 @@ extern "C" int scail_dit_block_sp(scail_dit* h, int64_t layer, scail_bf16* hidde
     char* base = static_cast<char*>(workspace);
     auto P = [&](int j) { return reinterpret_cast<scail_bf16*>(base + off[j]); };
     const BlockBufs bf{P(0), P(1), P(2), P(3), P(4)};
-    return dit_block_sp(h, layer, hidden, mod, cond, rope_cos, rope_sin, B, Ltok, bf, sp, stream);
+    return dit_block_sp(h, layer, hidden, mod, cond, rope_cos, rope_sin, B, Ltok, bf, sp, 0, Ltok, false, stream);
 }
 extern "C" int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, const float* mod, const scail_dit_cond* cond,
                                const float* rope_cos, const float* rope_sin, int64_t B, int64_t Ltok,
@@ -362,7 +429,7 @@ extern "C" int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, 
     char* base = static_cast<char*>(workspace);
     auto P = [&](int j) { return reinterpret_cast<scail_bf16*>(base + off[j]); };
     const BlockBufs bf{P(0), P(1), P(2), P(3), P(4)};
-    return dit_block(h, layer, hidden, mod, cond, rope_cos, rope_sin, B, Ltok, bf, 0, Ltok, stream);
+    return dit_block(h, layer, hidden, mod, cond, rope_cos, rope_sin, B, Ltok, bf, 0, Ltok, false, stream);
 }
 
 extern "C" int scail_dit_create(const scail_dit_config* cfg, const scail_dit_weights* w, scail_dit** out) {
@@ -440,34 +507,37 @@ extern "C" int64_t scail_dit_sp_workspace_bytes(const scail_dit* h, int32_t mode
 static int dit_step_impl(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
                          const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
                          const float* rope_cos, const float* rope_sin, float* out,
-                         int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, void* workspace, int64_t workspace_bytes,
+                         int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, uint32_t flags, void* workspace, int64_t workspace_bytes,
                          void* stream);
 
 extern "C" int scail_dit_step(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
                               const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
                               const float* rope_cos, const float* rope_sin, float* out,
-                              int64_t B, int64_t T, int64_t H, int64_t W, void* workspace, int64_t workspace_bytes,
+                              int64_t B, int64_t T, int64_t H, int64_t W, uint32_t flags, void* workspace, int64_t workspace_bytes,
                               void* stream) {
-    return dit_step_impl(h, x, timesteps, cond, ref, n_ref, pose, n_pose, rope_cos, rope_sin, out, B, T, H, W, nullptr, workspace, workspace_bytes, stream);
+    return dit_step_impl(h, x, timesteps, cond, ref, n_ref, pose, n_pose, rope_cos, rope_sin, out, B, T, H, W, nullptr, flags, workspace, workspace_bytes, stream);
 }
 
 extern "C" int scail_dit_step_sp(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
                                  const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
                                  const float* rope_cos, const float* rope_sin, float* out,
-                                 int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, void* workspace, int64_t workspace_bytes,
-                                 void* stream) {
+                                 int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, uint32_t flags, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
     SCAIL_REQUIRE(h != nullptr, "null handle");
     DIT_TRY(sp_check(h, sp));
-    return dit_step_impl(h, x, timesteps, cond, ref, n_ref, pose, n_pose, rope_cos, rope_sin, out, B, T, H, W, sp, workspace, workspace_bytes, stream);
+    return dit_step_impl(h, x, timesteps, cond, ref, n_ref, pose, n_pose, rope_cos, rope_sin, out, B, T, H, W, sp, flags, workspace, workspace_bytes, stream);
 }
 
 // x (B, T, 16, H, W): the whole latent (sp == nullptr) or this rank's H- or W-slab of it (rope tables rank-shifted by the host)
 static int dit_step_impl(scail_dit* h, const float* x, const float* timesteps, const scail_dit_cond* cond,
                          const scail_bf16* ref, int64_t n_ref, const scail_bf16* pose, int64_t n_pose,
                          const float* rope_cos, const float* rope_sin, float* out,
-                         int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, void* workspace, int64_t workspace_bytes,
+                         int64_t B, int64_t T, int64_t H, int64_t W, const scail_dit_sp* sp, uint32_t flags, void* workspace, int64_t workspace_bytes,
                          void* stream) {
     SCAIL_REQUIRE(h != nullptr && cond != nullptr, "null handle / conditioning");
+    SCAIL_REQUIRE((flags & ~(uint32_t)SCAIL_DIT_CFG_PAIR) == 0, "unknown step flag");
+    SCAIL_REQUIRE(!(flags & SCAIL_DIT_CFG_PAIR) || (B == 2 && n_ref == 1 && n_pose == 1),
+                  "SCAIL_DIT_CFG_PAIR needs B == 2 with one shared ref / pose (element 1 = element 0 except for the conditioning)");
     SCAIL_REQUIRE(B > 0 && B <= 8 && T > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "latent batch must be 1..8, H and W multiples of 4");
     SCAIL_REQUIRE((n_ref == 1 || n_ref == B) && (n_pose == 1 || n_pose == B), "ref / pose batch must be 1 or B");
     SCAIL_REQUIRE(cond->Bc == 1 || cond->Bc == B, "clip batch must be 1 or B");
@@ -505,8 +575,12 @@ static int dit_step_impl(scail_dit* h, const float* x, const float* timesteps, c
     DIT_TRY(scail_adaln_table(emb2, w.final_table, fin, 1, B, 2 * D, stream));
 
     // ---- patch embedding straight into the token layout [ref | noise | pose] (dit...:99-130) ----
-    DIT_TRY(scail_patchify(x, ref, pose, tok, B, n_ref, n_pose, T, H, W, KPAD, stream));
-    for (int64_t b = 0; b < B; ++b) {
+    // SCAIL_DIT_CFG_PAIR: the two elements are one latent under two conditionings (VanillaCFG, guiders.py:41-57) and stay equal until the
+    // first cross attention of layer 0 (dit...:1009-1042): patch embedding and layer 0 up to the self-attention residual run once
+    const bool pair = (flags & SCAIL_DIT_CFG_PAIR) != 0 && nl > 1;
+    const int64_t Be = pair ? 1 : B;
+    DIT_TRY(scail_patchify(x, ref, pose, tok, Be, n_ref, n_pose, T, H, W, KPAD, stream));
+    for (int64_t b = 0; b < Be; ++b) {
         DIT_TRY(scail_gemm_bf16(tok + b * Ltok * KPAD, KPAD, w.patch_w, w.patch_b, hid + b * Ltok * D, D, Lrn, D, KPAD,
                                 SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
         DIT_TRY(scail_gemm_bf16(tok + (b * Ltok + Lrn) * KPAD, KPAD, w.pose_w, w.pose_b, hid + (b * Ltok + Lrn) * D, D, Lpose, D,
@@ -515,13 +589,14 @@ static int dit_step_impl(scail_dit* h, const float* x, const float* timesteps, c
 
     const BlockBufs bf{xn, qkv, att, ff, vt};
     for (int64_t i = 0; i < nl; ++i) {
+        // the last layer's output is only read at the noise tokens (final layer below): queries / out-projection / cross attention /
+        // MLP of its ref and pose rows are skipped (23 % of that layer's post-K/V work; same result)
+        const bool last = i == nl - 1;
+        const int64_t row0 = last ? Lref : 0, rows = last ? Lnoise : Ltok;
         if (sp != nullptr) {
-            DIT_TRY(dit_block_sp(h, i, hid, mod + i * B * 6 * D, cond, rope_cos, rope_sin, B, Ltok, bf, sp, stream));
+            DIT_TRY(dit_block_sp(h, i, hid, mod + i * B * 6 * D, cond, rope_cos, rope_sin, B, Ltok, bf, sp, row0, rows, pair && i == 0, stream));
         } else {
-            // the last layer's output is only read at the noise tokens (final layer below): queries / out-projection / cross attention /
-            // MLP of its ref and pose rows are skipped (23 % of that layer's post-K/V work; same result)
-            const bool last = i == nl - 1;
-            DIT_TRY(dit_block(h, i, hid, mod + i * B * 6 * D, cond, rope_cos, rope_sin, B, Ltok, bf, last ? Lref : 0, last ? Lnoise : Ltok, stream));
+            DIT_TRY(dit_block(h, i, hid, mod + i * B * 6 * D, cond, rope_cos, rope_sin, B, Ltok, bf, row0, rows, pair && i == 0, stream));
         }
     }
 
@@ -560,7 +635,7 @@ extern "C" int scail_dit_sample(scail_dit* h, float* x, const float* timesteps, 
             scail_set_error("scail_dit_sample: hipMemcpyAsync failed");
             return 2;
         }
-        DIT_TRY(scail_dit_step(h, xin, timesteps + 2 * i, cond, ref, 1, pose, 1, rope_cos, rope_sin, v, 2, T, H, W, workspace,
+        DIT_TRY(scail_dit_step(h, xin, timesteps + 2 * i, cond, ref, 1, pose, 1, rope_cos, rope_sin, v, 2, T, H, W, SCAIL_DIT_CFG_PAIR, workspace,
                                step_bytes, stream));
         DIT_TRY(scail_cfg_euler(x, v, n, cfg_scale, dsigma[i], stream));
     }

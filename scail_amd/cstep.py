@@ -108,7 +108,11 @@ class CStep:
             raise L.ScailHipError("scail_dit_workspace_bytes: bad shape")
         return n
 
-    def step(self, x32, t32, cond: Dict, ref, pose, cos, sin) -> torch.Tensor:
+    CFG_PAIR = 1                                                  # include/scail_dit.h SCAIL_DIT_CFG_PAIR
+
+    def step(self, x32, t32, cond: Dict, ref, pose, cos, sin, cfg_pair: bool = False) -> torch.Tensor:
+        """``cfg_pair``: the caller states that x32 / t32 hold the same latent and timestep twice (VanillaCFG's batch of 2): layer 0 up to
+        its first cross attention is evaluated once (SCAIL_DIT_CFG_PAIR; bit-identical on such inputs)."""
         B, T, _, H, W = x32.shape
         need = self.workspace_bytes(B, T, H, W)
         if self._ws is None or self._ws.numel() < need or self._ws.device != x32.device:
@@ -119,7 +123,7 @@ class CStep:
         out = torch.empty(B, T, 16, H, W, device=x32.device, dtype=torch.float32)
         L.call("scail_dit_step", self._h, x32.data_ptr(), t32.data_ptr(), C.byref(cc), ref.data_ptr(), ref.shape[0],
                pose.data_ptr(), pose.shape[0], cos.data_ptr(), sin.data_ptr(), out.data_ptr(), B, T, H, W,
-               self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
+               self.CFG_PAIR if cfg_pair else 0, self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream().cuda_stream)
         return out
 
     def sample(self, x32, sigmas, cfg_scale, cond: Dict, ref, pose, cos, sin) -> torch.Tensor:
@@ -182,7 +186,7 @@ class CStep:
             self._ws = torch.empty(need, device=device, dtype=torch.uint8)
         return self._ws
 
-    def step_sp(self, x32, t32, cond: Dict, ref, pose, cos, sin, xch) -> torch.Tensor:
+    def step_sp(self, x32, t32, cond: Dict, ref, pose, cos, sin, xch, cfg_pair: bool = False) -> torch.Tensor:
         """One network evaluation on this rank's latent slab (scail_dit_step_sp); ``xch`` owns the exchange buffers and issues the
         collectives from the executor's callback."""
         B, T, _, H, W = x32.shape
@@ -191,7 +195,7 @@ class CStep:
         out = torch.empty(B, T, 16, H, W, device=x32.device, dtype=torch.float32)
         self._sp_call("scail_dit_step_sp", xch, self._h, x32.data_ptr(), t32.data_ptr(), C.byref(cc), ref.data_ptr(), ref.shape[0],
                       pose.data_ptr(), pose.shape[0], cos.data_ptr(), sin.data_ptr(), out.data_ptr(), B, T, H, W, C.byref(sp),
-                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+                      self.CFG_PAIR if cfg_pair else 0, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
         return out
 
     def block_sp(self, layer: int, hidden: torch.Tensor, mod: torch.Tensor, cond: Dict, cos, sin, xch) -> torch.Tensor:

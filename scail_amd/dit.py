@@ -360,16 +360,20 @@ class DiffusionTransformer(nn.Module):
             self._rope_cache[key] = (cos.to(device), sin.to(device))
         return self._rope_cache[key]
 
-    def _workspace(self, B, Ltok, Lnoise, device):
-        key = (B, Ltok, Lnoise)
+    def _workspace(self, B, Ltok, Lnoise, device, blocks_in_c=False):
+        """Activation scratch of the per-op path.  blocks_in_c (multi-character extension: every block is one executor call with the
+        executor's own block workspace): only the buffers the host-side assembly and the final layer touch."""
+        key = (B, Ltok, Lnoise, blocks_in_c)
         ws = self._ws.get(key)
         if ws is None:
             D, FF, H = self.hidden_size, self.inner_hidden_size, self.num_attention_heads
             e = lambda *s: torch.empty(*s, device=device, dtype=torch.bfloat16)
             Lp = (Ltok + 63) // 64 * 64
-            ws = dict(tok=e(B, Ltok, 128), h=e(B, Ltok, D), xn=e(B, Ltok, D), qkv=e(B, Ltok, 3 * D),
-                      att=e(B, Ltok, D), ff=e(B, Ltok, FF), vt=e(B, H, 128, Lp), xf=e(B, Lnoise, D),
-                      tokout=e(B, Lnoise, 64))
+            ws = dict(tok=e(B, Ltok, 128), h=e(B, Ltok, D), xf=e(B, Lnoise, D), tokout=e(B, Lnoise, 64))
+            if blocks_in_c:
+                ws.update(xn=None, qkv=None, att=None, ff=None, vt=None)
+            else:
+                ws.update(xn=e(B, Ltok, D), qkv=e(B, Ltok, 3 * D), att=e(B, Ltok, D), ff=e(B, Ltok, FF), vt=e(B, H, 128, Lp))
             self._ws = {key: ws}          # keep one shape resident
         return ws
 
@@ -417,7 +421,9 @@ class DiffusionTransformer(nn.Module):
                 W_shift = self.sp.rank * (Wd // 2)
             else:
                 raise NotImplementedError
-        return self._run(x32, t32, ctx, ref, pose, clip, H_shift, W_shift, cond_key)
+        # cfg_pair (set by scail_amd.sampler.VanillaCFG.prepare_inputs): x / timesteps are one latent twice, only the conditioning differs
+        cfg_pair = bool(kwargs.get("cfg_pair", False)) and B == 2 and ref.shape[0] == 1 and pose.shape[0] == 1
+        return self._run(x32, t32, ctx, ref, pose, clip, H_shift, W_shift, cond_key, cfg_pair=cfg_pair)
 
     def sample_c(self, x32, sigmas, cfg_scale, ctx, ref, pose, clip, cond_key=None):
         """The whole RFSampler Euler loop as ONE C call (scail_dit_sample, include/scail_dit.h): x32 (1,T,16,H,W) fp32,
@@ -438,7 +444,7 @@ class DiffusionTransformer(nn.Module):
         x = x32.float().contiguous().clone()
         return self._cstep.sample(x, sigmas, cfg_scale, cond, as_bf16(ref), as_bf16(pose), cos, sin)
 
-    def _run(self, x32, t32, ctx, ref, pose, clip, H_shift=0, W_shift=0, cond_key=None):
+    def _run(self, x32, t32, ctx, ref, pose, clip, H_shift=0, W_shift=0, cond_key=None, cfg_pair=False):
         W = self.prepare()
         dev = x32.device
         B, T, _, H, Wd = x32.shape
@@ -467,9 +473,9 @@ class DiffusionTransformer(nn.Module):
             # the whole evaluation as ONE call into the library (include/scail_dit.h); same kernels, same order.  A sequence-parallel
             # rank runs the same executor: only the collectives of the per-layer exchange come back to the host (xch)
             if sp is None:
-                return self._cstep.step(x32, t32, cond, ref.contiguous(), pose.contiguous(), cos, sin)
-            return self._cstep.step_sp(x32, t32, cond, ref.contiguous(), pose.contiguous(), cos, sin, xch)
-        ws = self._workspace(B, Ltok, Lnoise, dev)
+                return self._cstep.step(x32, t32, cond, ref.contiguous(), pose.contiguous(), cos, sin, cfg_pair=cfg_pair)
+            return self._cstep.step_sp(x32, t32, cond, ref.contiguous(), pose.contiguous(), cos, sin, xch, cfg_pair=cfg_pair)
+        ws = self._workspace(B, Ltok, Lnoise, dev, blocks_in_c=use_c)
 
         # ---- time / AdaLN tables (reference :1521-1555, :1025-1028, :823) ----
         temb = ops.timestep_embedding(t32, self.time_freq_dim)
@@ -499,7 +505,7 @@ class DiffusionTransformer(nn.Module):
             self._tap(-1, h)
 
         xn, qkv, att, ff, vt = ws["xn"], ws["qkv"], ws["att"], ws["ff"], ws["vt"]
-        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        q, k, v = (None, None, None) if use_c else (qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:])
         for i, lw in enumerate(W["layers"]):
             m = mod[i]                                                        # (B, 6D)
             if use_c:

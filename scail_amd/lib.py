@@ -28,6 +28,7 @@ SIGNATURES = {
     "scail_flash_attn_bf16": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
     "scail_flash_attn_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i, _i],
+    "scail_flash_attn_rows_for": [_i64, _i64, _i64],
     "scail_gemm_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i],
     "scail_conv3d_kernel_for": [_p, _i64, _i64, _i],
     "scail_cross_attn2_bf16": [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
@@ -56,13 +57,13 @@ SIGNATURES = {
     "scail_dit_create": [_p, _p, _p],
     "scail_dit_destroy": [_p],
     "scail_dit_workspace_bytes": [_p, _i64, _i64, _i64, _i64],
-    "scail_dit_step": [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i64, _p],
+    "scail_dit_step": [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, C.c_uint32, _p, _i64, _p],
     "scail_dit_profile": [_p, _i],
     "scail_dit_profile_read": [_p, _i, _p, _p],
     "scail_dit_block_workspace_bytes": [_p, _i64, _i64],
     "scail_dit_block": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _i64, _p],
     "scail_dit_sp_workspace_bytes": [_p, C.c_int32, C.c_int32, _i64, _i64, _i64, _i64],
-    "scail_dit_step_sp": [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _p, _i64, _p],
+    "scail_dit_step_sp": [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _p, C.c_uint32, _p, _i64, _p],
     "scail_dit_block_sp_workspace_bytes": [_p, C.c_int32, C.c_int32, _i64, _i64],
     "scail_dit_block_sp": [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _i64, _p],
     "scail_dit_sample_workspace_bytes": [_p, _i64, _i64, _i64],
@@ -88,7 +89,8 @@ ABLATIONS = LIB_PATH.endswith("_abl.so")
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 3          # include/scail_hip.h scail_abi_version: 2 = negative SCAIL_ATTN_Q_PRESCALED sentinel + the SP executor entry points;
+ABI_VERSION = 4          # 4 = `flags` argument of scail_dit_step / scail_dit_step_sp (SCAIL_DIT_CFG_PAIR), options "attn4_rows" / "attn4_xcd";
+                         # include/scail_hip.h scail_abi_version: 2 = negative SCAIL_ATTN_Q_PRESCALED sentinel + the SP executor entry points;
                          # 3 = scail_vae_set_trace, options "row_wave" / "conv_direct", scail_conv3d_kernel_for = 4 for the kt = 1 / narrow / fused-norm shapes
 
 _lib = None

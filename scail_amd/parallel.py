@@ -157,6 +157,31 @@ class ThreadBackend:
         return res
 
 
+class LocalCopyBackend:
+    """MEASUREMENT backend: rank 0 of an N-rank group on ONE GPU, every peer's contribution replaced by a local copy of this rank's own
+    data.  The launch sequence and every kernel shape are those of a real rank (results are meaningless), so a step through it is the
+    compute side of an N-rank step: (T_1 / N) / T_N is the compute-only strong-scaling efficiency; the exchange time comes on top
+    (bench.py ``config.sp_compute_side``, tools/sp_rank_compute.py)."""
+
+    def __init__(self, size):
+        self.rank, self.size = 0, size
+
+    def broadcast(self, t):
+        pass
+
+    def all_gather_into(self, out, inp, async_op=True):
+        for r in range(self.size):
+            out[r].copy_(inp.reshape(out[r].shape))
+        return _Handle(None)
+
+    def all_to_all(self, out, inp, async_op=False):
+        out.copy_(inp)
+        return _Handle(None)
+
+    def gather_cat(self, t, dim):
+        return t
+
+
 class CExchange:
     """Host side of the C executor's exchange callback (include/scail_dit.h "sequence-parallel execution"): owns the send / recv /
     ofull / back buffers of one (B, Ltok) shape and starts / awaits the collectives through the group's backend when the executor

@@ -103,6 +103,9 @@ class VanillaCFG:
                 c_out[k] = torch.cat((uc[k], c[k]), 0)
             else:
                 c_out[k] = c[k]
+        # the batch below is ONE latent and ONE sigma twice: scail_amd's network evaluates layer 0 up to its first cross attention once
+        # (include/scail_dit.h SCAIL_DIT_CFG_PAIR; result-preserving).  A plain bool: other networks ignore the key.
+        c_out["cfg_pair"] = True
         return torch.cat([x] * 2), torch.cat([s] * 2), c_out
 
 
@@ -116,7 +119,8 @@ class OpenAIWrapper(nn.Module):
 
     def forward(self, x, t, c: dict, **kwargs):
         for key in c:
-            c[key] = c[key].to(self.dtype)
+            if torch.is_tensor(c[key]):
+                c[key] = c[key].to(self.dtype)
         kwargs.update(c)
         if "concat" in c:
             x = torch.cat((x, c["concat"]), dim=2 if x.dim() == 5 else 1)

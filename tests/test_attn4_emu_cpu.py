@@ -175,3 +175,70 @@ def test_m16f_raw_scale_callers_scale_q_in_the_prologue(Lk):
     c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
     ref = R.reference(_rt(_rt(q) * c) / c, _rt(k), _rt(v), 2)
     np.testing.assert_allclose(o, ref, rtol=2e-2, atol=6e-3)
+
+
+# ---- round 5: the 192-row form of the shipped kernel (3 query blocks per wave) and the run-per-XCD workgroup-id decode (xcd_mode 2) ----
+Q3 = attn4.M16F_Q3
+
+
+def test_q3_static_hazards_clean():
+    assert R.check_static(Q3) == []
+
+
+@pytest.mark.parametrize("tiles", [1, 2, 3, 4, 5, 6, 7, 9, 11])
+def test_q3_every_remainder_path(tiles):
+    st = _case(Q3, 1, 1, 192, 64 * tiles, lazy=bool(tiles & 1), seed=tiles)
+    assert st["mfma"] == 102 * tiles                     # 96 + 6 (row sums) MFMAs per tile and wave
+
+
+def test_q3_heads_batch_ragged_queries_segments_and_rescale():
+    _case(Q3, 2, 4, 300, 128, seed=1)                    # 8 pairs (round-robin decode), 2 query blocks of 192, the second ragged
+    _case(Q3, 1, 3, 520, 64, seed=2)                     # 3 pairs x 3 query blocks = 9 items in runs of 2 (xcd_mode 2), ids 9..15 exit
+    _case(Q3, 1, 2, 100, 192, nseg=3, spike=True, seed=4)
+    _case(Q3, 1, 1, 192, 640, lazy=False, spike=True, thr=0.0, seed=5)
+    _case(Q3, 1, 1, 192, 640, lazy=True, spike=True, thr=2.0, seed=6)
+
+
+@pytest.mark.parametrize("Lk,nseg", [(513, 1), (64 * 9 + 1, 1), (64 * 12 + 63, 1), (100, 2), (129, 3)])
+def test_q3_ragged_key_counts(Lk, nseg):
+    _case(Q3, 1, 2 if Lk < 200 else 1, 70, Lk, nseg=nseg, spike=(Lk > 200), seed=Lk)
+
+
+def test_q3_is_bit_identical_to_the_256_row_kernel():
+    """a query row sees the same MFMA sequence over the keys whichever workgroup height computes it: the launch-shape choice of
+    scail_flash_attn_bf16 never changes a result bit (incl. an optimistic-pass overflow + restart, which is per workgroup: row 150's
+    spike restarts different sets of rows in the two tilings, both exact)"""
+    rng = np.random.default_rng(50)
+    B, H, Lq, Lk = 1, 2, 400, 64 * 9 + 5
+    q = rng.standard_normal((B, Lq, H * 128)).astype(np.float32)
+    k = rng.standard_normal((B, Lk, H * 128)).astype(np.float32)
+    v = rng.standard_normal((B, Lk, H * 128)).astype(np.float32)
+    o4, _ = R.run(attn4.M16F, q, [k], [v], H)
+    o3, _ = R.run(Q3, q, [k], [v], H)
+    assert np.array_equal(o4, o3)
+
+
+def test_q3_overflow_restarts_the_workgroup_and_raw_scale():
+    rng = np.random.default_rng(51)
+    Lq, Lk = 192, 64 * 11
+    q = rng.standard_normal((1, Lq, 128)).astype(np.float32)
+    k = rng.standard_normal((1, Lk, 128)).astype(np.float32)
+    v = rng.standard_normal((1, Lk, 128)).astype(np.float32)
+    k[0, 64 * 3 + 63] = q[0, 150] * 12.0
+    o, st = R.run(Q3, q, [k], [v], 1)
+    c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
+    np.testing.assert_allclose(o, R.reference(_rt(q * c) / c, _rt(k), _rt(v), 1), rtol=2e-2, atol=6e-3)
+    assert st["mfma"] == 2 * 102 * 11
+    q2 = rng.standard_normal((2, 300, 2 * 128)).astype(np.float32)
+    k2 = rng.standard_normal((2, 513, 2 * 128)).astype(np.float32)
+    v2 = rng.standard_normal((2, 513, 2 * 128)).astype(np.float32)
+    o, _ = R.run(Q3, q2, [k2], [v2], 2, raw_scale=True)
+    np.testing.assert_allclose(o, R.reference(_rt(_rt(q2) * c) / c, _rt(k2), _rt(v2), 2), rtol=2e-2, atol=6e-3)
+
+
+@pytest.mark.parametrize("B,H,Lq", [(1, 5, 700), (1, 3, 256), (3, 3, 300), (1, 1, 2100)])
+def test_xcd_mode2_decode_covers_every_item_once(B, H, Lq):
+    """xcd_mode 2: pair counts that are no multiple of 8 (5 heads = a Ulysses rank of 8) -- every (pair, query block) item is computed
+    by exactly one workgroup (a missing item leaves zero rows, a wrong pair a wrong result), the padded ids exit"""
+    assert attn4.xcd_mode(B, H) == 2
+    _case(attn4.M16F, B, H, Lq, 64, seed=B * 100 + H)

@@ -153,6 +153,16 @@ def _prescaled_attention_case(T_, H_, W_):
             torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2, msg=lambda m: f"batch {b} head {h}: {m}")
             assert _cos(got, ref) >= 0.999
     print(f"scail_attn4_m16f (prescaled q) L={L}: max abs err over sampled rows {worst:.3e}")
+    # round 5: the 192-row form of the kernel (scail_attn4_m16f_q3, option "attn4_rows") on the same launch: a query row sees the same
+    # MFMA sequence whichever tile height computes it -> identical bits, spikes / restarts / ragged tails included
+    o3 = torch.empty_like(o)
+    lib.set_option("attn4_rows", 192)
+    try:
+        ops.flash_attn(q, k, vt, out=o3, q_prescaled=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.set_option("attn4_rows", 0)
+    assert torch.equal(o3, o), f"192-row tiles differ from 256-row tiles: max |d| {float((o3.float() - o.float()).abs().max())}"
 
 
 def test_m16f_prescaled_attention_config2_length():
@@ -163,6 +173,42 @@ def test_m16f_prescaled_attention_config2_length():
 def test_m16f_prescaled_attention_ragged_480x832():
     """(a'') 480x832x81f: L = 42 510 = 664 key tiles + 14 keys (ragged last tile; ragged last query block of 14 rows)"""
     _prescaled_attention_case(21, 60, 104)
+
+
+@pytest.mark.parametrize("heads,Lq,Lk", [(5, 48832, 48832), (5, 42510, 42510), (10, 12208, 48832), (3, 1000, 2100)])
+def test_attention_launch_shapes_of_a_sequence_parallel_rank(heads, Lq, Lk):
+    """The launches of a rank (Ulysses at 8 / 4 ranks: 5 / 10 heads x the full sequence, ONE batch element): pair counts that are no
+    multiple of 8 take the run-per-XCD workgroup-id decode (xcd_mode 2), and the per-launch choice of the query-tile height
+    (asmgen/attn4.py Cfg.nq; csrc/attn.hip attn4_pick_rows).  All four combinations {192, 256 rows} x {XCD-aware, plain decode} must agree
+    bit for bit, and with fp32 softmax on sampled rows (reference sat/mpu/ulysses_attn_layer.py:65-107 -> transformer_defaults.py:67-72)."""
+    from scail_amd import lib, ops
+    lib.load()
+    D = heads * 128
+    g = torch.Generator(device=DEV).manual_seed(heads * 7 + Lq % 13)
+    q = (torch.randn(1, Lq, D, device=DEV, generator=g) * ops.ATTN_LOG2_SCALE).to(torch.bfloat16)
+    k = torch.randn(1, Lk, D, device=DEV, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, Lk, D, device=DEV, generator=g).to(torch.bfloat16)
+    vt = ops.transpose_v(v, heads)
+    outs = {}
+    try:
+        for rows in (256, 192, 0):
+            for xcd in (1, 0):
+                lib.set_option("attn4_rows", rows)
+                lib.set_option("attn4_xcd", xcd)
+                outs[(rows, xcd)] = ops.flash_attn(q, k, vt, q_prescaled=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.set_option("attn4_rows", 0)
+        lib.set_option("attn4_xcd", 1)
+    base = outs[(256, 0)]
+    for key, o in outs.items():
+        assert torch.equal(o, base), f"rows / xcd {key} differs from 256-row plain decode: max |d| {float((o.float() - base.float()).abs().max())}"
+    rows = torch.cat([torch.arange(0, 16), torch.arange(Lq - 20, Lq), torch.randint(0, Lq, (92,), generator=torch.Generator().manual_seed(1))]).to(DEV)
+    for h in sorted({0, heads // 2, heads - 1}):
+        sl = slice(h * 128, (h + 1) * 128)
+        s = (q[0, rows, sl].float() @ k[0, :, sl].float().t()) * math.log(2.0)
+        ref = torch.softmax(s, dim=-1) @ v[0, :, sl].float()
+        torch.testing.assert_close(base[0, rows, sl].float(), ref, rtol=2e-2, atol=2e-2)
 
 
 @pytest.fixture(scope="module")

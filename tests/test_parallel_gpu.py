@@ -33,7 +33,7 @@ def _mk(params, layers, seed=1234):
                                 share_adaln=True, use_i2v_clip=True, device=DEV, init_seed=seed, num_layers=layers, **params)
 
 
-def _run_ranks(world, mode, mk, inputs, chunk_dim, use_c):
+def _run_ranks(world, mode, mk, inputs, chunk_dim, use_c, cfg_pair=False):
     """one network evaluation on `world` virtual ranks; returns the result gathered on rank 0"""
     from scail_amd.parallel import SequenceParallel, ThreadBackend
     x, t, ctx, ref, pose, clip = inputs
@@ -50,7 +50,7 @@ def _run_ranks(world, mode, mk, inputs, chunk_dim, use_c):
             sp.check_latent(x.shape[3], x.shape[4], chunk_dim)
             ch = lambda tt: sp.chunk(tt, chunk_dim)
             o = n.forward_f32(ch(x), t, ctx, None, concat_images=torch.zeros(1, device=DEV), image_clip_features=clip,
-                              ref_concat=ch(ref), concat_smpl_render=ch(pose), chunk_dim=chunk_dim)
+                              ref_concat=ch(ref), concat_smpl_render=ch(pose), chunk_dim=chunk_dim, cfg_pair=cfg_pair)
             if use_c:
                 assert n._cstep is not None, "the C executor must have run"
             outs[rk] = sp.gather_to_rank0(o, chunk_dim)
@@ -97,7 +97,7 @@ def test_sequence_parallel_fullsize_virtual_ranks(world, mode, n_char):
     assert float(d.mean()) <= 6e-3 * max(scale, 1.0) and float(d.max()) <= 0.125
     a, b = got.flatten().double(), single.flatten().double()
     assert float((a @ b) / (a.norm() * b.norm())) >= 0.9999
-    if n_char == 1 and world in (8, 2):
+    if n_char == 1:
         # the executor's sequence-parallel block enqueues the kernels of the per-op host path in the same order: identical bits
         host = _run_ranks(world, mode, mk, inputs, 3, use_c=False)
         assert torch.equal(got, host), f"C executor vs per-op host path: max |d| {float((got - host).abs().max())}"
@@ -116,6 +116,33 @@ def test_sp_c_executor_equals_per_op_path_small(world, mode, chunk_dim):
     x, t, ctx, ref, pose, clip = inputs
     single = mk().forward_f32(x, t, ctx, None, concat_images=torch.zeros(1, device=DEV), image_clip_features=clip, ref_concat=ref, concat_smpl_render=pose)
     torch.testing.assert_close(c, single, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("world,mode", [(1, None), (8, "ulysses"), (4, "ulysses"), (2, "allgather")])
+def test_cfg_pair_is_bit_identical_at_full_size(world, mode):
+    """SCAIL_DIT_CFG_PAIR (include/scail_dit.h; guiders.py:41-57, dit...:1009-1042): the sampler's batch is one latent twice, so layer 0 up to
+    its first cross attention is evaluated once and copied -- same bits as the plain B = 2 evaluation, on one rank and on the
+    sequence-parallel executor (where layer 0 then exchanges element 0 only), at 14B width and L = 48 832 with 3 layers (so that layer 0,
+    a middle layer and the row-pruned last layer all run)."""
+    T, H, W = 21, 64, 112
+    x, t, ctx, ref, pose, clip = _inputs(T, H, W, 1, 4096, 512, 257, seed=5)
+    x = torch.cat([x[:1], x[:1]]).contiguous()
+    inputs = (x, t, ctx, ref, pose, clip)
+    mk = lambda: _mk(P14B, 3)
+    outs = []
+    for pair in (False, True):
+        if world == 1:
+            net = mk()
+            outs.append(net.forward_f32(x, t, ctx, None, concat_images=torch.zeros(1, device=DEV), image_clip_features=clip, ref_concat=ref,
+                                        concat_smpl_render=pose, cfg_pair=pair))
+            assert net._cstep is not None
+            torch.cuda.synchronize()
+            del net
+        else:
+            outs.append(_run_ranks(world, mode, mk, inputs, 3, use_c=True, cfg_pair=pair))
+    assert torch.isfinite(outs[0]).all() and float(outs[0].abs().mean()) > 1e-3
+    assert not torch.equal(outs[0][0], outs[0][1]), "the two elements must differ (different text conditioning)"
+    assert torch.equal(outs[0], outs[1]), f"cfg_pair changed the result: max |d| {float((outs[0] - outs[1]).abs().max())}"
 
 
 def test_exchange_callback_error_reaches_the_caller():
@@ -194,3 +221,82 @@ def test_rccl_single_rank_init_and_self_check():
     print("RCCL single-rank check:", info)
     assert info["backend"] == "nccl" and info["ranks"] == 1 and info["rccl_version"]
     assert info["collectives_verified"] == ["all_to_all", "all_gather", "broadcast"] and info["a2a_ok"] and info["allgather_ok"]
+
+
+_RCCL2_SCRIPT = r"""
+import json, os, sys
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+from scail_amd import lib
+from scail_amd.dit import DiffusionTransformer
+from scail_amd.parallel import SequenceParallel, TorchDistBackend
+lib.load()
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dev = torch.device("cuda", rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+P = dict(hidden_size=5120, num_attention_heads=40, inner_hidden_size=13824, text_dim=4096, time_freq_dim=256, time_embed_dim=5120)
+mk = lambda: DiffusionTransformer(transformer_args=dict(model_parallel_size=1), num_frames=81, latent_width=300, latent_height=300,
+                                  share_adaln=True, use_i2v_clip=True, device=dev, init_seed=1234, num_layers=2, **P)
+T, H, W = 21, 64, 112
+g = torch.Generator().manual_seed(1)
+x = torch.randn(1, T, 16, H, W, generator=g).repeat(2, 1, 1, 1, 1).to(dev)
+ref = torch.randn(1, 1, 16, H, W, generator=g).to(dev).to(torch.bfloat16)
+pose = torch.randn(1, T, 16, H // 2, W // 2, generator=g).to(dev).to(torch.bfloat16)
+ctx = torch.randn(2, 512, 4096, generator=g).to(dev).to(torch.bfloat16)
+clip = torch.randn(1, 257, 1280, generator=g).to(dev).to(torch.bfloat16)
+t = torch.tensor([700.0, 700.0], device=dev)
+res = {}
+for mode in ("ulysses", "allgather"):
+    net = mk()
+    sp = SequenceParallel(TorchDistBackend(None), mode=mode)
+    info = sp.self_check(dev)
+    net.sp = sp
+    ch = lambda tt: sp.chunk(tt, 3)
+    o = net.forward_f32(ch(x), t, ctx, None, concat_images=torch.zeros(1, device=dev), image_clip_features=clip, ref_concat=ch(ref),
+                        concat_smpl_render=ch(pose), chunk_dim=3, cfg_pair=True)
+    assert net._cstep is not None
+    full = sp.gather_to_rank0(o, 3)
+    torch.cuda.synchronize()
+    if rank == 0:
+        net.sp = None
+        single = net.forward_f32(x, t, ctx, None, concat_images=torch.zeros(1, device=dev), image_clip_features=clip, ref_concat=ref,
+                                 concat_smpl_render=pose)
+        d = (full - single).abs()
+        a, b = full.flatten().double(), single.flatten().double()
+        res[mode] = dict(max=float(d.max()), mean=float(d.mean()), scale=float(single.abs().mean()),
+                         cos=float((a @ b) / (a.norm() * b.norm())), rccl=info.get("rccl_version"))
+    del net
+    dist.barrier()
+if rank == 0:
+    print(json.dumps(res))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: two real ranks exchanging over RCCL / xGMI")
+def test_two_real_ranks_over_rccl_fullsize_layers_and_bench_line(tmp_path):
+    """The first multi-GPU box that runs this suite exercises what a 1-GPU box cannot: scail_dit_step_sp on TWO processes whose per-layer
+    exchange is a real RCCL all_to_all_single / all_gather_into_tensor (sat/mpu/ulysses_attn_layer.py:41-110, all_to_all.py:15-108,
+    diffusion_video.py:495-585): 2 full-width layers at L = 48 832, both exchange modes, against the single-rank evaluation; then
+    bench.py --gpus 2 on the tiny config through torch.distributed.run exactly as the driver launches it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    script = tmp_path / "rccl2.py"
+    script.write_text(_RCCL2_SCRIPT % ROOT)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29671", str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print("2 ranks over RCCL:", res)
+    for mode in ("ulysses", "allgather"):
+        m = res[mode]
+        assert m["mean"] <= 6e-3 * max(m["scale"], 1.0) and m["max"] <= 0.125 and m["cos"] >= 0.9999, (mode, m)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29672", "bench.py", "--gpus", "2", "--config", "tiny", "--steps", "2", "--warmup", "1",
+                        "--no-vae", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["path"].startswith("scail_dit_step_sp")

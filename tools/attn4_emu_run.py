@@ -77,12 +77,13 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     if fold and not raw_scale:
         sl2 = 0.0 if getattr(cfg, "qscale", False) else 1.0       # qscale kernels: 0 = q is in log2 units already
     args = attn4.pack_args(pq, pk, pvt, po, Lq * D, D, B * Lk * D, Lk * D, D, B * heads * 128 * Lkp, heads * 128 * Lkp, Lq * D, D,
-                           heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=B, mode=mode)
+                           heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=B, mode=mode, rows=cfg.rows)
     stats = None
-    for wid in range(attn4.grid_blocks(B, heads, Lq)):
+    for wid in range(attn4.grid_blocks(B, heads, Lq, rows=cfg.rows, mode=mode)):
         emu = E.Emu(prog, mem, n_waves=4, lds_bytes=cfg.lds_bytes, lazy=lazy)
         emu.launch(args, block_id=(wid, 0, 0))
-        stats = emu.waves[0].stats
+        if stats is None or emu.waves[0].stats.get("mfma", 0) > 0:       # xcd_mode 2 pads the grid with workgroups that exit at once
+            stats = emu.waves[0].stats
     return from_bf16_bits(mem.read_back("o")), stats
 
 

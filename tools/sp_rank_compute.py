@@ -4,7 +4,7 @@ N-rank run).  Gives the compute part of the strong-scaling efficiency -- (T_1 / 
 exchange time comes on top.
 The timed path is the product's: one scail_dit_step / scail_dit_step_sp call of the C executor per network evaluation, the exchange
 callback served by local copies.  `--host` times the per-op host path (scail_amd.parallel, ~30 binding calls per layer) beside it.
-usage: sp_rank_compute.py [--host] [N ...]      e.g. 1 2 4 8"""
+usage: sp_rank_compute.py [--host] [--no-pair] [--rows=256|192|0] [--xcd=0|1] [N ...]      e.g. 1 2 4 8"""
 import json
 import os
 import sys
@@ -15,29 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scail_amd import ops
 from scail_amd.dit import DiffusionTransformer
-from scail_amd.parallel import SequenceParallel, _Handle
-
-
-class LocalCopyBackend:
-    """Same interface as parallel.TorchDistBackend; every 'peer' contribution is this rank's own data."""
-
-    def __init__(self, size):
-        self.rank, self.size = 0, size
-
-    def broadcast(self, t):
-        pass
-
-    def all_gather_into(self, out, inp, async_op=True):
-        for r in range(self.size):
-            out[r].copy_(inp.reshape(out[r].shape))
-        return _Handle(None)
-
-    def all_to_all(self, out, inp, async_op=False):
-        out.copy_(inp)
-        return _Handle(None)
-
-    def gather_cat(self, t, dim):
-        return t
+from scail_amd.parallel import LocalCopyBackend, SequenceParallel
 
 
 dev = "cuda"
@@ -51,7 +29,14 @@ ctx = torch.randn(2, 512, 4096, generator=g).to(dev).to(torch.bfloat16)
 clip = torch.randn(1, 257, 1280, generator=g).to(dev).to(torch.bfloat16)
 base = None
 HOST = "--host" in sys.argv
-for N in [int(a) for a in ([a for a in sys.argv[1:] if a != "--host"] or ["1", "2", "4", "8"])]:
+PAIR = "--no-pair" not in sys.argv        # SCAIL_DIT_CFG_PAIR, the sampler's default (layer 0 up to the first cross attention evaluated once)
+from scail_amd import lib
+for a in sys.argv[1:]:                    # same-process A/B of the attention launch shape: --rows=256|192|0 (0 = per-launch choice), --xcd=0|1
+    if a.startswith("--rows="):
+        lib.set_option("attn4_rows", int(a[7:]))
+    if a.startswith("--xcd="):
+        lib.set_option("attn4_xcd", int(a[6:]))
+for N in [int(a) for a in ([a for a in sys.argv[1:] if not a.startswith("--")] or ["1", "2", "4", "8"])]:
     sp = SequenceParallel(LocalCopyBackend(N)) if N > 1 else None
     net.sp = sp
     h = H // N
@@ -62,7 +47,7 @@ for N in [int(a) for a in ([a for a in sys.argv[1:] if a != "--host"] or ["1", "
               chunk_dim=3 if N > 1 else None)
 
     def step():
-        v = net.forward_f32(torch.cat([x, x], 0), torch.tensor([700.0, 700.0], device=dev), ctx, None, **kw)
+        v = net.forward_f32(torch.cat([x, x], 0), torch.tensor([700.0, 700.0], device=dev), ctx, None, cfg_pair=PAIR, **kw)
         ops.cfg_euler_(x, v, 4.0, -0.01)
 
     def timed():
@@ -77,7 +62,9 @@ for N in [int(a) for a in ([a for a in sys.argv[1:] if a != "--host"] or ["1", "
     net.use_c_step = True
     dt = timed()
     base = base or dt * N
-    rec = dict(ranks=N, mode=(sp.resolve_mode(40) if sp else "-"), path="C executor", s_per_step_one_rank=dt, compute_only_efficiency=(base / N) / dt)
+    mode = sp.resolve_mode(40) if sp else "-"
+    rows = lib.load().scail_flash_attn_rows_for(1 if sp else 2, 40 // N if mode == "ulysses" else 40, 48832 if mode in ("-", "ulysses") else 48832 // N)
+    rec = dict(ranks=N, mode=mode, path="C executor", s_per_step_one_rank=dt, compute_only_efficiency=(base / N) / dt, attn_query_tile_rows=rows, cfg_pair=PAIR)
     if HOST and N > 1:
         net.use_c_step = False
         rec["s_per_step_one_rank_host_path"] = timed()
