@@ -49,8 +49,8 @@ from .isa import A, S, V, I32, F32, Neg, VCC, EXEC, M0, Instr
 
 KERNARG_SIZE = 160
 # q k vt o | q_bs q_rs k_ss k_bs k_rs vt_ss vt_bs o_bs o_rs | heads Lq Lk Lkp n_seg | sl2 thr | nqb magic_nqb magic_heads xcd_mode |
-# items_per_xcd n_items (xcd_mode 2) pad
-KERNARG_FMT = "<4Q9q5iffiIIiii4x"
+# items_per_xcd (xcd_mode 2) n_items item0 (xcd_modes 0 / 2: this launch covers items [item0, item0 + n_items) of the pair-major list)
+KERNARG_FMT = "<4Q9q5iffiIIiiii"
 
 
 def magic31(d: int) -> int:
@@ -64,6 +64,11 @@ def grid_blocks(n_batch: int, heads: int, Lq: int, rows: int = 256, mode: int = 
     return 8 * ((items + 7) // 8) if mode == 2 else items
 
 
+def grid_for(n_items: int, mode: int) -> int:
+    """workgroups of a launch over n_items consecutive items (a launch may cover a part of the item list: pack_args item0 / n_items)"""
+    return 8 * ((n_items + 7) // 8) if mode == 2 else n_items
+
+
 def xcd_mode(n_batch: int, heads: int) -> int:
     """1: workgroup id -> (XCD = id % 8 works on (batch, head) pairs = XCD mod 8), so the 32 CUs of an XCD stream the SAME K / V^T
     through their L2 (the hardware places consecutive workgroup ids on consecutive XCDs); needs pairs % 8 == 0.
@@ -74,12 +79,15 @@ def xcd_mode(n_batch: int, heads: int) -> int:
 
 
 def pack_args(q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=1,
-              mode=None, rows: int = 256) -> bytes:
+              mode=None, rows: int = 256, item0: int = 0, n_items: int = None) -> bytes:
+    """item0 / n_items (xcd_modes 0 and 2): the launch covers items [item0, item0 + n_items) of the pair-major (pair, query block) list --
+    how scail_flash_attn_bf16 splits one attention into a 256-row launch of whole rounds and a 192-row launch for the rest."""
     nqb = (Lq + rows - 1) // rows
     mode = xcd_mode(n_batch, heads) if mode is None else mode
-    items = nqb * heads * n_batch
+    items = nqb * heads * n_batch - item0 if n_items is None else n_items
+    assert item0 == 0 or mode != 1
     b = struct.pack(KERNARG_FMT, q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr,
-                    nqb, magic31(nqb), magic31(heads), mode, (items + 7) // 8, items)
+                    nqb, magic31(nqb), magic31(heads), mode, (items + 7) // 8, items, item0)
     assert len(b) == KERNARG_SIZE
     return b
 
@@ -207,7 +215,7 @@ S_KRS, S_VTSS, S_VTBS, S_OBS = S(24, 2), S(26, 2), S(28, 2), S(30, 2)
 S_ORS = S(32, 2)
 S_HEADS, S_LQ, S_LK, S_LKP, S_NSEG, S_C, S_THR, S_NQB = S(36), S(37), S(38), S(39), S(40), S(41), S(42), S(43)
 S_MAGQ, S_MAGH, S_XMODE = S(84), S(85), S(86)
-S_IPX, S_NITEMS = S(87), S(88)     # xcd_mode 2: items per XCD run, items in all (live in the id decode only: s87 / s88 are S_CLAMP / S_FIRST later)
+S_IPX, S_NITEMS, S_ITEM0 = S(87), S(88), S(89)     # xcd_mode 2: items per XCD run; items of this launch, its first item (live in the id decode only: s87.. are S_CLAMP / S_FIRST / S_TAILREL later)
 S_KRSRC, S_VRSRC = S(44, 4), S(48, 4)
 S_KOFF, S_VOFF, S_KSTEP, S_VSTEP, S_KMAX, S_VMAX = S(52), S(53), S(54), S(55), S(56), S(57)
 S_T, S_NT, S_SEG, S_WAVE = S(58), S(59), S(60), S(61)
@@ -703,7 +711,7 @@ class Gen:
         o += [isa.s_load(8, S(8, 8), S_KARG, 0), isa.s_load(8, S(16, 8), S_KARG, 32), isa.s_load(8, S(24, 8), S_KARG, 64),
               isa.s_load(2, S_ORS, S_KARG, 96), isa.s_load(8, S(36, 8), S_KARG, 104),
               isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", VT0, I32(6), V(0)),
-              isa.s_load(4, S(84, 4), S_KARG, 136), isa.s_load(1, S_NITEMS, S_KARG, 152),
+              isa.s_load(4, S(84, 4), S_KARG, 136), isa.s_load(2, S(S_NITEMS.idx, 2), S_KARG, 152),
               isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, VT0)]
         # ---- 1-D workgroup id -> (query block, head, batch); xcd_mode 1: ids congruent mod 8 (= one XCD) share (batch, head)
         #      pairs, so the 32 CUs of an XCD stream the same K / V^T tiles through their L2 ----
@@ -717,6 +725,7 @@ class Gen:
               isa.sop("s_cmp_lt_u32", None, j, S_NITEMS), isa.branch("s_cbranch_scc1", "L_id_plain"),
               Instr("s_endpgm", cls=isa.BRANCH), isa.label("L_id_plain"),
               isa.sop("s_cmp_lg_u32", None, S_XMODE, I32(0)), isa.sop("s_cselect_b32", j, j, wid),
+              isa.sop("s_add_u32", j, j, S_ITEM0),                                                     # first item of this launch (0 in xcd_mode 1)
               isa.sop("s_lshl_b32", tt, j, I32(1)), isa.sop("s_mul_hi_u32", qd, tt, S_MAGQ),            # qd = j / nqb
               isa.sop("s_mul_i32", tt, qd, S_NQB), isa.sop("s_sub_u32", S_QB, j, tt),                   # qb = j % nqb
               isa.sop("s_lshl_b32", tt, qd, I32(3)), isa.sop("s_add_u32", tt, tt, xcd),

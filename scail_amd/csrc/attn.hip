@@ -822,8 +822,8 @@ struct Attn4Args {
     uint32_t magic_nqb, magic_heads;   // ceil(2^31 / d): x / d == (2 x * magic) >> 32 for the workgroup-id decode
     int32_t xcd_mode;            // 1: ids congruent mod 8 (one XCD) share (batch, head) pairs -> K / V^T reuse in that XCD's L2;
                                  // 2 (any pair count): XCD x walks the x-th of 8 equal runs of the pair-major (pair, query block) items
-    int32_t items_per_xcd, n_items;    // xcd_mode 2: ceil(items / 8), items = nqb * heads * batch; the grid is 8 * items_per_xcd
-    int32_t pad;
+    int32_t items_per_xcd;       // xcd_mode 2: ceil(n_items / 8); the grid is 8 * items_per_xcd
+    int32_t n_items, item0;      // the launch covers items [item0, item0 + n_items) of the pair-major list (item0 == 0 in xcd_mode 1)
 };
 static_assert(sizeof(Attn4Args) == 160, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
 // Code objects, kernel handles (and the GEMM's tile-order tables, gemm.hip) belong to ONE device: they are cached per HIP device
@@ -876,13 +876,24 @@ int scail_attn4_preload() {
 }
 
 static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
-static int g_attn4_rows = 0;               // query rows per workgroup: 0 = chosen per launch by the rounds model below, 256 / 192 = forced
-// Query-tile height of a launch.  One workgroup occupies a CU (512 registers per lane, one wave per SIMD), so a launch of W workgroups
-// takes ceil(W / CUs) rounds of one tile each.  scail_attn4_m16f_q3 (192 rows: 3 of the 4 query blocks per wave, 102 of 136 MFMAs per
-// key tile beside the same K / V^T traffic) costs k_attn4_q3_cost of a 256-row tile; it wins where the 256-row grid wastes most of
-// its last round -- the launches of a sequence-parallel rank (Ulysses, 8 ranks: 5 heads x 191 tiles = 3.73 rounds -> 4, against
-// 4.98 rounds x the shorter tile), never the single-GPU launch (59.7 rounds).
-static const double k_attn4_q3_cost = 0.78;
+static int g_attn4_rows = 0;               // query rows per workgroup: 0 = planned per launch (below), 256 / 192 = one height for every launch
+static thread_local int g_attn4_rows_hint = 0;   // set by a caller that knows more than one call can (scail_attn4_rows_hint)
+// ---- launch shape of one attention (round 5) ----------------------------------------------------------------------------------
+// One workgroup occupies a CU (512 registers per lane, one wave per SIMD), so W workgroups take ceil(W / CUs) rounds of one tile each, and
+// a launch whose last round is mostly empty wastes it: a sequence-parallel rank's launch (Ulysses, 8 ranks: 5 heads x 191 tiles of 256
+// rows = 3.73 rounds) pays 4.  scail_attn4_m16f_q3 (192 rows: 3 of the 4 query blocks per wave, 102 of 136 MFMAs per key tile beside the
+// same K / V^T traffic) costs 0.79 of a 256-row tile (measured: 0.780-0.791 at 5 / 10 / 40 / 80 pairs, profiles/r05_attn_sp_shape_probe.log).
+// The plan: WHOLE rounds of 256-row tiles first, the remaining rows -- from a 768-row boundary on, so that both tilings agree on it -- as
+// 192-row tiles in a second launch on the same stream (8 ranks: 3 rounds + 250 tiles of 192 rows = 3.79 round-equivalents instead of 4;
+// 4 ranks: 6 + 2 x 0.79 = 7.58 instead of 8); a pure 192-row launch where that is cheaper; the single 256-row launch otherwise (one GPU:
+// 59.7 rounds, nothing to gain).  Results do not depend on the plan except in workgroups that restart after an exp2 overflow of the
+// optimistic pass (a key > 167 log2 units above the first tile's maximum): their rows are recomputed by the lazy-maximum loop, whose
+// rounding differs in the last bit, and which rows share a workgroup depends on the tile height.
+static const double k_attn4_q3_cost = 0.79;
+struct Attn4Launch {
+    int rows;                   // 256 | 192
+    int64_t item0, n_items;     // items [item0, item0 + n_items) of the pair-major (pair, query tile) list of THIS tile height
+};
 static int attn4_cu_count() {
     static std::map<int, int> cus;
     std::lock_guard<std::mutex> lk(g_attn4_mutex);
@@ -893,13 +904,39 @@ static int attn4_cu_count() {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
     return cus[dev] = n;
 }
-static int attn4_pick_rows(int64_t n_batch, int64_t heads, int64_t Lq) {
-    if (g_attn4_rows == 256 || g_attn4_rows == 192) return g_attn4_rows;
-    const int64_t cus = attn4_cu_count(), pairs = heads * n_batch;
-    const int64_t w4 = (Lq + 255) / 256 * pairs, w3 = (Lq + 191) / 192 * pairs;
-    const double c4 = (double)((w4 + cus - 1) / cus), c3 = (double)((w3 + cus - 1) / cus) * k_attn4_q3_cost;
-    return c3 < c4 * 0.995 ? 192 : 256;
+static int attn4_plan(int64_t n_batch, int64_t heads, int64_t Lq, Attn4Launch out[2]) {
+    const int64_t P = heads * n_batch, n4 = (Lq + 255) / 256, n3 = (Lq + 191) / 192, W4 = P * n4, W3 = P * n3;
+    const int forced = g_attn4_rows_hint ? g_attn4_rows_hint : g_attn4_rows;
+    if (forced == 192) { out[0] = {192, 0, W3}; return 1; }
+    if (forced == 256) { out[0] = {256, 0, W4}; return 1; }
+    const int64_t cus = attn4_cu_count();
+    auto rounds = [&](int64_t w) { return (double)((w + cus - 1) / cus); };
+    double best = rounds(W4);
+    out[0] = {256, 0, W4};
+    int n = 1;
+    if (rounds(W3) * k_attn4_q3_cost < best * 0.985) {
+        best = rounds(W3) * k_attn4_q3_cost;
+        out[0] = {192, 0, W3};
+    }
+    const double gap = 0.02;                               // the second launch starts when the first has drained: ~20 us of a ~1 ms round
+    for (int64_t kk = W4 / cus; kk >= 1 && kk >= W4 / cus - 4; --kk) {
+        const int64_t amax = kk * cus, p = amax / n4, c = (amax % n4) / 3;     // split at row 768 c of pair p
+        if (p >= P) continue;
+        const int64_t a = p * n4 + 3 * c, i3 = p * n3 + 4 * c, b = W3 - i3;
+        if (a <= 0 || b <= 0) continue;
+        const double cost = rounds(a) + rounds(b) * k_attn4_q3_cost + gap;
+        if (cost < best * 0.985) {
+            best = cost;
+            out[0] = {256, 0, a};
+            out[1] = {192, i3, b};
+            n = 2;
+        }
+    }
+    return n;
 }
+// A caller that issues several attention launches concurrently (the sequence-parallel executor's two side streams, csrc/dit_step.hip) fills
+// the partial rounds with the other stream's workgroups: it pins the single 256-row launch for its calls on this thread.  0 = no hint.
+void scail_attn4_rows_hint(int rows) { g_attn4_rows_hint = rows; }
 // scail_attn4_m16f takes ANY key count >= 512 (ragged last tile: K rows fetched from 64 rows earlier, scores masked) and any scale (q in
 // log2 units as it is, a raw scale through a one-time multiplication of the Q fragments in its prologue); what is left to the 8-wave
 // kernel: short key sets, accumulate, slices beyond 32-bit byte offsets.  (A non-ragged A/B variant of the measurement build needs
@@ -921,7 +958,8 @@ static bool attn4_grid_ok(int64_t n_batch, int64_t heads, int64_t Lq) {
 
 extern "C" int scail_flash_attn_rows_for(int64_t n_batch, int64_t heads, int64_t Lq) {
     if (n_batch <= 0 || heads <= 0 || Lq <= 0) return 256;
-    return attn4_pick_rows(n_batch, heads, Lq);
+    Attn4Launch pl[2];
+    return attn4_plan(n_batch, heads, Lq, pl) == 2 ? 448 : pl[0].rows;
 }
 
 extern "C" int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate, int prescaled) {
@@ -1021,8 +1059,8 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     SCAIL_REQUIRE(vt_bs == 0 || vt_bs == heads * HD * Lkp, "vt batch stride must be 0 or heads*128*ceil64(Lk)");
     SCAIL_REQUIRE(Lq < (1ll << 31) && Lkp * n_seg < (1ll << 31), "sequence too long");
     if (Lq == 0 || n_batch == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ScailDeviceOnce attr_set;
+    if (attr_set.need()) {
         const void* fns[] = {reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4, 0, 1>),
 #ifdef SCAIL_ABLATIONS
                              reinterpret_cast<const void*>(&flash_attn_swp_kernel<5, 5>), reinterpret_cast<const void*>(&flash_attn_swp_kernel<4, 4>),
@@ -1045,7 +1083,7 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
                               reinterpret_cast<const void*>(&flash_attn_kernel<50, 8>)};
         for (const void* f : lock) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES);
 #endif
-        attr_set = true;
+        attr_set.done();
     }
     if (g_attn4_mode && attn4_eligible(q_rs, k_rs, o_rs, Lq, Lk, accumulate, prescaled) && attn4_grid_ok(n_batch, heads, Lq)) {
         // scail_attn4_m16f (or the variant chosen with the measurement build's "attn4_kernel" knob).  The 16x16x32 "fold" kernels
@@ -1054,30 +1092,43 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         // measurement build take sl2 per score and the threshold in raw-score units.
         hipFunction_t fn;
         const bool fold = attn4_variant_is("m16f") || attn4_variant_is("m16g");
-        // query-tile height: the 192-row form exists for the shipped kernel only
-        const int rows = g_attn4_name == k_attn4_default ? attn4_pick_rows(n_batch, heads, Lq) : 256;
-        if (int rc = attn4_function(rows == 192 ? g_attn4_name + "_q3" : g_attn4_name, &fn)) return rc;
-        Attn4Args a;
-        a.q = q; a.k = k; a.vt = vt; a.o = o;
-        a.q_bs = q_bs; a.q_rs = q_rs; a.k_ss = k_ss; a.k_bs = k_bs; a.k_rs = k_rs; a.vt_ss = vt_ss; a.vt_bs = vt_bs;
-        a.o_bs = o_bs; a.o_rs = o_rs;
-        a.heads = (int32_t)heads; a.Lq = (int32_t)Lq; a.Lk = (int32_t)Lk; a.Lkp = (int32_t)Lkp; a.n_seg = (int32_t)n_seg;
-        a.sl2 = fold ? (prescaled ? 0.0f : sl2) : sl2;
-        a.thr = fold ? g_attn4_thr_log2 : g_attn4_thr_log2 / sl2;
-        a.nqb = (int32_t)((Lq + rows - 1) / rows);
-        a.magic_nqb = (uint32_t)(((1ull << 31) + a.nqb - 1) / a.nqb);
-        a.magic_heads = (uint32_t)(((1ull << 31) + heads - 1) / heads);
-        a.n_items = (int32_t)(a.nqb * heads * n_batch);
-        a.items_per_xcd = (a.n_items + 7) / 8;
-        a.xcd_mode = !g_attn4_xcd ? 0 : ((heads * n_batch) % 8 == 0 ? 1 : 2);
-        a.pad = 0;
-        size_t sz = sizeof(a);
-        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)(a.xcd_mode == 2 ? 8 * a.items_per_xcd : a.n_items), 1, 1, 256, 1, 1, 0,
-                                             (hipStream_t)stream, nullptr, extra);
-        if (e != hipSuccess) {
-            scail_set_error(std::string("attn4: launch failed: ") + hipGetErrorString(e));
-            return 2;
+        // launch plan (tile heights): the 192-row form exists for the shipped kernel only
+        Attn4Launch plan[2];
+        int n_launch = 1;
+        if (g_attn4_name == k_attn4_default) {
+            n_launch = attn4_plan(n_batch, heads, Lq, plan);
+        } else {
+            plan[0] = {256, 0, (Lq + 255) / 256 * heads * n_batch};
+        }
+        const int64_t pairs = heads * n_batch;
+        for (int li = 0; li < n_launch; ++li) {
+            const Attn4Launch& pl = plan[li];
+            if (int rc = attn4_function(pl.rows == 192 ? g_attn4_name + "_q3" : g_attn4_name, &fn)) return rc;
+            Attn4Args a;
+            a.q = q; a.k = k; a.vt = vt; a.o = o;
+            a.q_bs = q_bs; a.q_rs = q_rs; a.k_ss = k_ss; a.k_bs = k_bs; a.k_rs = k_rs; a.vt_ss = vt_ss; a.vt_bs = vt_bs;
+            a.o_bs = o_bs; a.o_rs = o_rs;
+            a.heads = (int32_t)heads; a.Lq = (int32_t)Lq; a.Lk = (int32_t)Lk; a.Lkp = (int32_t)Lkp; a.n_seg = (int32_t)n_seg;
+            a.sl2 = fold ? (prescaled ? 0.0f : sl2) : sl2;
+            a.thr = fold ? g_attn4_thr_log2 : g_attn4_thr_log2 / sl2;
+            a.nqb = (int32_t)((Lq + pl.rows - 1) / pl.rows);
+            a.magic_nqb = (uint32_t)(((1ull << 31) + a.nqb - 1) / a.nqb);
+            a.magic_heads = (uint32_t)(((1ull << 31) + heads - 1) / heads);
+            a.n_items = (int32_t)pl.n_items;
+            a.item0 = (int32_t)pl.item0;
+            a.items_per_xcd = (a.n_items + 7) / 8;
+            // XCD-aware ids (measured, profiles/r05_attn_sp_shape_probe.log): fewer than 8 pairs -> plain decode (all XCDs stream the one
+            // pair in step; 5 pairs: 4 % faster than a run per XCD); whole launches of 8 k pairs -> pairs dealt round-robin (mode 1);
+            // anything else -> 8 equal runs of the item list (mode 2)
+            a.xcd_mode = (!g_attn4_xcd || pairs < 8) ? 0 : ((pairs % 8 == 0 && n_launch == 1) ? 1 : 2);
+            size_t sz = sizeof(a);
+            void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+            hipError_t e = hipModuleLaunchKernel(fn, (unsigned)(a.xcd_mode == 2 ? 8 * a.items_per_xcd : a.n_items), 1, 1, 256, 1, 1, 0,
+                                                 (hipStream_t)stream, nullptr, extra);
+            if (e != hipSuccess) {
+                scail_set_error(std::string("attn4: launch failed: ") + hipGetErrorString(e));
+                return 2;
+            }
         }
         return 0;
     }
@@ -1162,14 +1213,14 @@ extern "C" int scail_cross_attn2_bf16(const scail_bf16* q, int64_t q_bs, int64_t
                       (reinterpret_cast<uintptr_t>(vt1) & 15) == 0 && (reinterpret_cast<uintptr_t>(vt2) & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 7) == 0,
                   "cross_attn2: pointer alignment");
     if (n_batch == 0 || Lq == 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ScailDeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X2_LDS_BYTES);
         if (e != hipSuccess) {
             scail_set_error(std::string("cross_attn2: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
             return 2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     Cross2Params p;
     p.q = q; p.q_bs = q_bs; p.q_rs = q_rs;

@@ -29,6 +29,21 @@ int scail_check_launch(const char* what);
         }                                                                          \
     } while (0)
 
+// One-time per-DEVICE setup at a call site (hipFuncSetAttribute opt-ins of dynamic LDS are per device: a process that drives several
+// GPUs must repeat them on each): `static ScailDeviceOnce once_;  if (once_.need()) { ...setup...; once_.done(); }`.  Lock-free; two
+// threads racing on the same device both run the (idempotent) setup.
+#include <atomic>
+struct ScailDeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    static uint64_t device_bit() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        return 1ull << (dev & 63);
+    }
+    bool need() const { return (mask.load(std::memory_order_acquire) & device_bit()) == 0; }
+    void done() { mask.fetch_or(device_bit(), std::memory_order_release); }
+};
+
 // ---- bf16 <-> f32 -----------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }

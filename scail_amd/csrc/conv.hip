@@ -919,7 +919,7 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
     // measured equal (283 / 490 ms vs 281 / 487 ms encode / decode): the barrier is not what bounds the kernel
     const bool fuse = gamma != nullptr;       // conv + RMS_norm + SiLU: always the halo kernel, whatever the knob says
     const bool k1 = g_conv4 && !fuse && resid == nullptr && conv4u_eligible(p, ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-    const bool nar = g_conv4 && !fuse && resid == nullptr && conv4n_eligible(p, ldc);
+    const bool nar = g_conv4 && !fuse && resid == nullptr && conv4n_eligible(p, ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0;   // (8-byte stores)
     // conv -> RMS_norm -> SiLU (scail_conv3d_cl_norm) on the generated kernel: one n tile of 96 channels; gamma travels in the residual argument
     const bool fnorm = g_conv4 && fuse && resid == nullptr && p.N == 96 && conv4_eligible(p, ldc, ldc) && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(gamma) & 15) == 0;
@@ -965,14 +965,14 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
 #define HALO_LAUNCH(EPI_, CS_, NWB_, SWZ_, BN_, ...)                                                                        \
     {                                                                                                              \
         constexpr int lds_ = HaloCfg<CS_, NWB_, SWZ_, BN_, ##__VA_ARGS__>::LDS;                                             \
-        static bool attr_ = false;                                                                                 \
-        if (!attr_) {                                                                                              \
+        static ScailDeviceOnce attr_;                                                                                 \
+        if (attr_.need()) {                                                                                              \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_, ##__VA_ARGS__>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) {             \
                 scail_set_error("conv3d: hipFuncSetAttribute failed");                                             \
                 return 2;                                                                                          \
             }                                                                                                      \
-            attr_ = true;                                                                                          \
+            attr_.done();                                                                                          \
         }                                                                                                          \
         hipLaunchKernelGGL((conv_halo_kernel<EPI_, CS_, NWB_, SWZ_, BN_, ##__VA_ARGS__>), dim3((unsigned)tiles), dim3(256), lds_, (hipStream_t)stream, p); \
     }
@@ -1034,13 +1034,13 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
             const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((p.M + 255) / 256, conv4_cu_count()));
 #define CD_LAUNCH(KS_, NB_)                                                                                                          \
     {                                                                                                                                \
-        static bool attr_ = false;                                                                                                   \
-        if (!attr_) {                                                                                                                \
+        static ScailDeviceOnce attr_;                                                                                                   \
+        if (attr_.need()) {                                                                                                                \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_kernel<KS_, NB_>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) { \
                 scail_set_error("conv3d: hipFuncSetAttribute failed");                                                               \
                 return 2;                                                                                                            \
             }                                                                                                                        \
-            attr_ = true;                                                                                                            \
+            attr_.done();                                                                                                            \
         }                                                                                                                            \
         hipLaunchKernelGGL((conv_direct_kernel<KS_, NB_>), dim3(grid), dim3(CD_THREADS), lds, (hipStream_t)stream, q, wld);          \
     }
@@ -1071,14 +1071,14 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
 #define CONV_LAUNCH(EPI_, BN_, WM_, WN_)                                                                           \
     {                                                                                                              \
         constexpr int lds_ = 2 * (CBM + BN_) * CLDT * 2;                                                           \
-        static bool attr_ = false;                                                                                 \
-        if (!attr_) {                                                                                              \
+        static ScailDeviceOnce attr_;                                                                                 \
+        if (attr_.need()) {                                                                                              \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<EPI_, BN_, WM_, WN_>),        \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) {             \
                 scail_set_error("conv3d: hipFuncSetAttribute failed");                                             \
                 return 2;                                                                                          \
             }                                                                                                      \
-            attr_ = true;                                                                                          \
+            attr_.done();                                                                                          \
         }                                                                                                          \
         const int64_t tiles = ((p.M + CBM - 1) / CBM) * ((p.N + BN_ - 1) / BN_);                                   \
         SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");                                                      \

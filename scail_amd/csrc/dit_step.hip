@@ -8,6 +8,7 @@
 
 #include "common.h"
 int scail_attn4_preload();   // attn.hip
+void scail_attn4_rows_hint(int rows);   // attn.hip: pins the query-tile height of this thread's attention launches (0 = planned per launch)
 int scail_gemm4_preload();   // gemm.hip
 #include "../../include/scail_dit.h"
 
@@ -334,6 +335,9 @@ static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m
             scail_bf16* vt = bf.vt + b * Hn * 128 * Lfp;
             scail_bf16* of = sp->ofull + b * N * slab;
             DIT_TRY(scail_transpose_v(recv + 2 * N * slab, Dn, 0, vt, 1, Hn, 128, Lf, s));
+            // two elements' launches run side by side on the two streams and fill each other's partial rounds: one 256-row launch each
+            // (a lone launch gets the planned shape: whole 256-row rounds + 192-row tiles for the rest, csrc/attn.hip attn4_plan)
+            struct Hint { Hint(int r) { scail_attn4_rows_hint(r); } ~Hint() { scail_attn4_rows_hint(0); } } hint(side && B > 1 ? 256 : 0);
             DIT_PROF_S(SCAIL_DIT_PROF_SELF_ATTN, s, scail_flash_attn_bf16(recv, 0, Dn, recv + N * slab, 0, 0, Dn, vt, 0, 0, of, 0, Dn, 1, Hn, Lf, Lf, 1,
                                                                           SCAIL_ATTN_Q_PRESCALED, 0, s));
             DIT_TRY(sp_exchange(sp, SCAIL_SP_BACK_START, i, b, s));

@@ -488,15 +488,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_q8_kernel(GemmParams p) {
 template <int BM, int BN, int WM, int WN, int EPI, bool DMA, int ABL = 0>
 static int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * (DMA ? BK : LDT) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ScailDeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, WM, WN, EPI, DMA, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             scail_set_error(std::string("gemm: hipFuncSetAttribute failed: ") + hipGetErrorString(e));
             return 2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, EPI, DMA, ABL>), dim3((unsigned)tiles), dim3(64 * WM * WN), lds, stream, p);
@@ -506,15 +506,15 @@ static int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
 template <int EPI, int ABL = 0>
 static int launch_gemm_q8(const GemmParams& p, hipStream_t stream) {
     constexpr int lds = 2 * (256 + 256) * BK * 2;   // 128 KB
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ScailDeviceOnce attr_set;
+    if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_q8_kernel<EPI, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             scail_set_error(std::string("scail_gemm_bf16: hipFuncSetAttribute: ") + hipGetErrorString(e));
             return 2;
         }
-        attr_set = true;
+        attr_set.done();
     }
     const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
     hipLaunchKernelGGL((gemm_bf16_q8_kernel<EPI, ABL>), dim3((unsigned)tiles), dim3(512), lds, stream, p);

@@ -512,13 +512,13 @@ static int ln_wave_launch(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64
 #define LN_WAVE(CPL_)                                                                                                                  \
     case CPL_: {                                                                                                                       \
         constexpr int lds_ = 2 * 512 * CPL_ * 4;                                                                                       \
-        static bool attr_ = false;                                                                                                     \
-        if (!attr_) {                                                                                                                  \
+        static ScailDeviceOnce attr_;                                                                                                     \
+        if (attr_.need()) {                                                                                                                  \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_wave_kernel<MODE, CPL_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_) != hipSuccess) { \
                 scail_set_error("ln_wave: hipFuncSetAttribute failed");                                                                \
                 return 2;                                                                                                              \
             }                                                                                                                          \
-            attr_ = true;                                                                                                              \
+            attr_.done();                                                                                                              \
         }                                                                                                                              \
         hipLaunchKernelGGL((ln_wave_kernel<MODE, CPL_>), dim3((unsigned)(n_batch * wpb)), dim3(256), lds_, (hipStream_t)stream, x, ldx, y, ldy, \
                            p0, p1, mod_stride, rows_out, src_rows_per_batch, src_row_offset, (int)wpb, eps);                           \

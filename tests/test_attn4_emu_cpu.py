@@ -242,3 +242,23 @@ def test_xcd_mode2_decode_covers_every_item_once(B, H, Lq):
     by exactly one workgroup (a missing item leaves zero rows, a wrong pair a wrong result), the padded ids exit"""
     assert attn4.xcd_mode(B, H) == 2
     _case(attn4.M16F, B, H, Lq, 64, seed=B * 100 + H)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_split_attention_256_row_launch_then_192_row_launch(mode):
+    """scail_flash_attn_bf16's mixed launch (csrc/attn.hip attn4_plan): items [0, a) of the 256-row tiling, then the remaining rows -- from a
+    768-row boundary inside a pair on -- as 192-row tiles starting at item0 of THEIR tiling.  3 pairs x 1000 queries: the split falls
+    inside pair 1 at row 768 (a = 4 + 3 tiles of 256; the 192-row launch starts at item 6 + 4 = 10 of 18).  Every row is computed exactly
+    once (the output buffer starts as zeros) and equals the single-launch result bit for bit."""
+    rng = np.random.default_rng(77)
+    B, H, Lq, Lk = 1, 3, 1000, 64 * 3 + 9
+    q = rng.standard_normal((B, Lq, H * 128)).astype(np.float32)
+    k = rng.standard_normal((B, Lk, H * 128)).astype(np.float32)
+    v = rng.standard_normal((B, Lk, H * 128)).astype(np.float32)
+    whole, _ = R.run(attn4.M16F, q, [k], [v], H, mode=mode)
+    nq4, nq3 = 4, 6                                   # ceil(1000 / 256), ceil(1000 / 192)
+    a, item0 = 1 * nq4 + 3, 1 * nq3 + 4
+    split, _ = R.run(attn4.M16F, q, [k], [v], H, launches=[(attn4.M16F, 0, a, mode), (Q3, item0, H * nq3 - item0, mode)])
+    assert np.array_equal(split, whole)
+    c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
+    np.testing.assert_allclose(split, R.reference(_rt(q * c) / c, _rt(k), _rt(v), H), rtol=2e-2, atol=6e-3)

@@ -154,7 +154,9 @@ def _prescaled_attention_case(T_, H_, W_):
             assert _cos(got, ref) >= 0.999
     print(f"scail_attn4_m16f (prescaled q) L={L}: max abs err over sampled rows {worst:.3e}")
     # round 5: the 192-row form of the kernel (scail_attn4_m16f_q3, option "attn4_rows") on the same launch: a query row sees the same
-    # MFMA sequence whichever tile height computes it -> identical bits, spikes / restarts / ragged tails included
+    # MFMA sequence whichever tile height computes it -> identical bits (ragged tails included) -- except in workgroups that RESTART after
+    # an exp2 overflow of the optimistic pass (the alpha = 102 spikes): their rows are recomputed by the lazy-maximum loop, whose last-bit
+    # rounding differs, and which rows share a workgroup with a spiked row depends on the tile height
     o3 = torch.empty_like(o)
     lib.set_option("attn4_rows", 192)
     try:
@@ -162,7 +164,14 @@ def _prescaled_attention_case(T_, H_, W_):
         torch.cuda.synchronize()
     finally:
         lib.set_option("attn4_rows", 0)
-    assert torch.equal(o3, o), f"192-row tiles differ from 256-row tiles: max |d| {float((o3.float() - o.float()).abs().max())}"
+    same = torch.ones(2, L, dtype=torch.bool, device=DEV)
+    for b, row, key, alpha in spikes:
+        if alpha > 80:
+            for rows_ in (256, 192):
+                same[b, row // rows_ * rows_: row // rows_ * rows_ + rows_] = False
+    assert torch.equal(o3[same], o[same]), f"192-row tiles differ from 256-row tiles outside restarted workgroups: max |d| {float((o3[same].float() - o[same].float()).abs().max())}"
+    torch.testing.assert_close(o3.float(), o.float(), rtol=2e-2, atol=2e-2)
+    assert int((~same).sum()) <= 3 * (256 + 192)
 
 
 def test_m16f_prescaled_attention_config2_length():
@@ -180,7 +189,8 @@ def test_attention_launch_shapes_of_a_sequence_parallel_rank(heads, Lq, Lk):
     """The launches of a rank (Ulysses at 8 / 4 ranks: 5 / 10 heads x the full sequence, ONE batch element): pair counts that are no
     multiple of 8 take the run-per-XCD workgroup-id decode (xcd_mode 2), and the per-launch choice of the query-tile height
     (asmgen/attn4.py Cfg.nq; csrc/attn.hip attn4_pick_rows).  All four combinations {192, 256 rows} x {XCD-aware, plain decode} must agree
-    bit for bit, and with fp32 softmax on sampled rows (reference sat/mpu/ulysses_attn_layer.py:65-107 -> transformer_defaults.py:67-72)."""
+    bit for bit -- and so must the planned shape (rows = 0: whole rounds of 256-row workgroups + 192-row workgroups for the remaining rows,
+    two launches) --, and with fp32 softmax on sampled rows (reference sat/mpu/ulysses_attn_layer.py:65-107 -> transformer_defaults.py:67-72)."""
     from scail_amd import lib, ops
     lib.load()
     D = heads * 128
@@ -201,6 +211,10 @@ def test_attention_launch_shapes_of_a_sequence_parallel_rank(heads, Lq, Lk):
         lib.set_option("attn4_rows", 0)
         lib.set_option("attn4_xcd", 1)
     base = outs[(256, 0)]
+    plan = lib.load().scail_flash_attn_rows_for(1, heads, Lq)
+    print(f"launch plan for 1 x {heads} pairs x {Lq} queries: {plan}")
+    if heads in (5, 10) and Lq > 40000:
+        assert plan == 448, "a rank-sized launch must get the mixed plan (whole 256-row rounds + 192-row tiles)"
     for key, o in outs.items():
         assert torch.equal(o, base), f"rows / xcd {key} differs from 256-row plain decode: max |d| {float((o.float() - base.float()).abs().max())}"
     rows = torch.cat([torch.arange(0, 16), torch.arange(Lq - 20, Lq), torch.randint(0, Lq, (92,), generator=torch.Generator().manual_seed(1))]).to(DEV)

@@ -52,7 +52,7 @@ def reference(q, k, v, heads):
 
 
 def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = True, thr_log2: float = 8.0, program=None, mode=None,
-        raw_scale: bool = False):
+        raw_scale: bool = False, launches=None):
     """q (B, Lq, H*128) fp32; ksegs / vsegs: lists (one per segment) of (B, Lk, H*128) fp32.  Returns O (B, Lq, H*128) fp32
     and the emulator statistics of the last workgroup.  raw_scale (qscale kernels): q goes in UNSCALED with sl2 = scale * log2(e)
     as the kernel argument (the prologue multiplies the fragments), instead of pre-multiplied with sl2 = 0."""
@@ -72,18 +72,25 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     pk = mem.alloc("k", kb)
     pvt = mem.alloc("vt", vt)
     po = mem.alloc("o", np.zeros((B, Lq, D), dtype=np.uint16))
-    prog = program if program is not None else attn4.Gen(cfg).program()
     thr = thr_log2 if fold else thr_log2 / sl2           # fold kernels see scores in log2 units
     if fold and not raw_scale:
         sl2 = 0.0 if getattr(cfg, "qscale", False) else 1.0       # qscale kernels: 0 = q is in log2 units already
-    args = attn4.pack_args(pq, pk, pvt, po, Lq * D, D, B * Lk * D, Lk * D, D, B * heads * 128 * Lkp, heads * 128 * Lkp, Lq * D, D,
-                           heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=B, mode=mode, rows=cfg.rows)
+    # one launch over all items, or the launches of a split attention: [(cfg, item0, n_items, mode), ...] (scail_flash_attn_bf16's mixed
+    # launch: whole rounds of 256-row tiles, then 192-row tiles for the remaining rows)
+    plan = launches if launches is not None else [(cfg, 0, None, mode)]
     stats = None
-    for wid in range(attn4.grid_blocks(B, heads, Lq, rows=cfg.rows, mode=mode)):
-        emu = E.Emu(prog, mem, n_waves=4, lds_bytes=cfg.lds_bytes, lazy=lazy)
-        emu.launch(args, block_id=(wid, 0, 0))
-        if stats is None or emu.waves[0].stats.get("mfma", 0) > 0:       # xcd_mode 2 pads the grid with workgroups that exit at once
-            stats = emu.waves[0].stats
+    for lcfg, item0, n_items, lmode in plan:
+        prog = program if (program is not None and lcfg is cfg) else attn4.Gen(lcfg).program()
+        m = attn4.xcd_mode(B, heads) if lmode is None else lmode
+        total = ((Lq + lcfg.rows - 1) // lcfg.rows) * heads * B
+        n = total - item0 if n_items is None else n_items
+        args = attn4.pack_args(pq, pk, pvt, po, Lq * D, D, B * Lk * D, Lk * D, D, B * heads * 128 * Lkp, heads * 128 * Lkp, Lq * D, D,
+                               heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=B, mode=m, rows=lcfg.rows, item0=item0, n_items=n)
+        for wid in range(attn4.grid_for(n, m)):
+            emu = E.Emu(prog, mem, n_waves=4, lds_bytes=lcfg.lds_bytes, lazy=lazy)
+            emu.launch(args, block_id=(wid, 0, 0))
+            if stats is None or emu.waves[0].stats.get("mfma", 0) > 0:       # xcd_mode 2 pads the grid with workgroups that exit at once
+                stats = emu.waves[0].stats
     return from_bf16_bits(mem.read_back("o")), stats
 
 
