@@ -597,11 +597,28 @@ template <int CPL, int VPT>
 __global__ __launch_bounds__(256) void rms_silu_kernel(const u16* __restrict__ x, u16* __restrict__ y,
                                                        const float* __restrict__ gamma, int64_t nvox, int C,
                                                        int lpv_log2, int silu) {
+    // persistent blocks (round 5): a lane keeps its gamma chunks in registers and walks over voxel groups -- the one-shot form issued 8 scalar
+    // gamma loads per 16-byte data load and ran at 2.5 TB/s (read + write) where the row passes of the DiT reach 5.2
     const int lpv = 1 << lpv_log2;
-    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t vox0 = (gtid >> lpv_log2) * VPT;
-    const int sub = (int)(gtid & (lpv - 1));
+    const int sub = (int)(threadIdx.x & (lpv - 1));
     const int nch = C >> 3;
+    float gm[CPL][8];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = min(sub + c * lpv, nch - 1);
+        if ((reinterpret_cast<uintptr_t>(gamma) & 15) == 0) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
+            gm[c][0] = g0.x; gm[c][1] = g0.y; gm[c][2] = g0.z; gm[c][3] = g0.w;
+            gm[c][4] = g1.x; gm[c][5] = g1.y; gm[c][6] = g1.z; gm[c][7] = g1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gm[c][e] = gamma[ch * 8 + e];
+        }
+    }
+    const float sC = sqrtf((float)C);
+    const int64_t gpb = blockDim.x >> lpv_log2;                 // voxel groups (of VPT voxels) per block and iteration
+    for (int64_t grp = (int64_t)blockIdx.x * gpb + (threadIdx.x >> lpv_log2); grp * VPT < nvox; grp += (int64_t)gridDim.x * gpb) {
+    const int64_t vox0 = grp * VPT;
     uint4 raw[VPT][CPL];
 #pragma unroll
     for (int j = 0; j < VPT; ++j)
@@ -610,14 +627,6 @@ __global__ __launch_bounds__(256) void rms_silu_kernel(const u16* __restrict__ x
             const int ch = sub + c * lpv;
             raw[j][c] = (vox0 + j < nvox && ch < nch) ? *reinterpret_cast<const uint4*>(x + (vox0 + j) * C + ch * 8) : make_uint4(0, 0, 0, 0);
         }
-    float gm[CPL][8];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int ch = min(sub + c * lpv, nch - 1);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) gm[c][e] = gamma[ch * 8 + e];
-    }
-    const float sC = sqrtf((float)C);
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         float v[CPL][8];
@@ -629,7 +638,9 @@ __global__ __launch_bounds__(256) void rms_silu_kernel(const u16* __restrict__ x
             for (int e = 0; e < 8; ++e) q += v[c][e] * v[c][e];
         }
         for (int o = 1; o < lpv; o <<= 1) q += __shfl_xor(q, o, 64);
-        const float inv = sC / fmaxf(sqrtf(q), 1e-12f);
+        // v_sqrt / v_rcp / v_exp forms (1 ulp), the arithmetic of the generated kernels' fused norm epilogue (asmgen/conv4.py norm_silu): the
+        // IEEE division sequences of `sC / x` and `t / (1 + exp(-t))` were 2/3 of this kernel's VALU work (19 -> 8 instructions per element)
+        const float inv = sC * __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(q), 1e-12f));
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
             const int ch = sub + c * lpv;
@@ -638,11 +649,12 @@ __global__ __launch_bounds__(256) void rms_silu_kernel(const u16* __restrict__ x
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float t = v[c][e] * inv * gm[c][e];
-                    o8[e] = silu ? silu_f(t) : t;
+                    o8[e] = silu ? t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t)) : t;
                 }
                 *reinterpret_cast<uint4*>(y + (vox0 + j) * C + ch * 8) = pack8(o8);
             }
         }
+    }
     }
 }
 
@@ -1116,7 +1128,8 @@ extern "C" int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* g
     while ((1 << lg) < lanes) ++lg;
     constexpr int VPT = 2;
     const int64_t threads = ((nvox + VPT - 1) / VPT) << lg;
-    const dim3 grid((unsigned)((threads + 255) / 256));
+    // persistent blocks: 8 per CU (40 registers per lane), each walking over its share of the voxel groups
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((threads + 255) / 256, (int64_t)conv4_cu_count() * 8)));
     if (three)
         hipLaunchKernelGGL((rms_silu_kernel<3, VPT>), grid, dim3(256), 0, (hipStream_t)stream, x, y, gamma, nvox, (int)C, lg, silu);
     else

@@ -19,6 +19,7 @@ elements are independent sequences, so the exchange of one runs under the attent
 from __future__ import annotations
 
 import contextlib
+import os
 import threading
 from typing import List, Optional
 
@@ -182,6 +183,9 @@ class LocalCopyBackend:
         return t
 
 
+SIDE_STREAM_MAX_RANKS = 4       # ulysses exchange: one side stream per CFG element up to this many ranks (CExchange)
+
+
 class CExchange:
     """Host side of the C executor's exchange callback (include/scail_dit.h "sequence-parallel execution"): owns the send / recv /
     ofull / back buffers of one (B, Ltok) shape and starts / awaits the collectives through the group's backend when the executor
@@ -205,7 +209,10 @@ class CExchange:
             self.ofull = self.back = None
         # two side streams for the two CFG elements up to 4 ranks (4 ranks 91.4 -> 93.9 % compute-side
         # efficiency, 8 ranks 90.7 -> 89.4 %), none beyond
-        self.side = [torch.cuda.Stream(device=device) for _ in range(2)] if (self.mode == "ulysses" and N <= 4 and torch.device(device).type == "cuda") else None
+        # (SCAIL_SP_SIDE_STREAMS = 0 / 1 overrides the rule: same-process A/B against the planned single-stream launch shape)
+        want = os.environ.get("SCAIL_SP_SIDE_STREAMS")
+        use_side = (N <= SIDE_STREAM_MAX_RANKS) if want is None else want == "1"
+        self.side = [torch.cuda.Stream(device=device) for _ in range(2)] if (self.mode == "ulysses" and use_side and torch.device(device).type == "cuda") else None
         self.device = torch.device(device)
         self.handles = {}
         self.error = None
