@@ -53,6 +53,19 @@ KERNARG_SIZE = 160
 KERNARG_FMT = "<4Q9q5iffiIIiiii"
 
 
+# x2 kernels: appended to the base block -- k2 vt2 | k2_bs vt2_bs | Lk2 Lkp2 | n_wgs pad
+X2_EXTRA_FMT = "<2Q2q3i4x"
+X2_KERNARG_SIZE = KERNARG_SIZE + struct.calcsize(X2_EXTRA_FMT)
+
+
+def pack_args_x2(q, k1, vt1, k2, vt2, o, q_bs, q_rs, k1_bs, k_rs, vt1_bs, k2_bs, vt2_bs, o_bs, o_rs, heads, Lq, Lk1, Lkp1, Lk2, Lkp2, sl2, thr,
+                 n_batch, n_wgs, rows=256) -> bytes:
+    base = pack_args(q, k1, vt1, o, q_bs, q_rs, 0, k1_bs, k_rs, 0, vt1_bs, o_bs, o_rs, heads, Lq, Lk1, Lkp1, 1, sl2, thr, n_batch=n_batch, mode=0, rows=rows)
+    b = base + struct.pack(X2_EXTRA_FMT, k2, vt2, k2_bs, vt2_bs, Lk2, Lkp2, n_wgs)
+    assert len(b) == X2_KERNARG_SIZE
+    return b
+
+
 def magic31(d: int) -> int:
     """x // d == (2 x * magic31(d)) >> 32 for the small x the kernel divides (x * d < 2^31)."""
     return -(-(1 << 31) // d)
@@ -134,6 +147,12 @@ class Cfg:
     nq: int = 4            # (mi = 16, fold, lsum) 16-row query blocks per wave: 4 = 256-row workgroups; 3 = 192-row workgroups (102 MFMAs
                            # per tile instead of 136 beside the same K / V^T traffic): the launch shape of a sequence-parallel rank, where
                            # ceil(workgroups / CUs) x tile cost is lower for the shorter tile (scail_flash_attn_bf16 picks per launch)
+    x2: bool = False       # (M16F family) CROSS ATTENTION OVER TWO KEY SETS, persistent workgroups: o = bf16(bf16(softmax(q K1^T) V1) + softmax(q K2^T) V2)
+                           # (dit_video_crossattn_sc_xc.py:1107-1203: text + CLIP image tokens).  One workgroup per CU walks over the (pair, query
+                           # block) items id, id + n_wgs, ...; per item the Q fragments are loaded once and the key pipeline runs twice (set 0, set 1:
+                           # own key count, own softmax state, own optimistic pass / restart); set 0's normalised output is stored as bf16 at its
+                           # final place and read back (same lane, same address) by set 1's epilogue, which adds and stores.  Kernel arguments:
+                           # the base block (set 0 in the k / vt fields, xcd_mode 0, n_items = all items) + X2_EXTRA
     align: int = 0         # .p2align of the hot-loop entry labels (0 = none): code placement A/B (guide: hand-asm streams are
                            # sensitive to a uniform shift of the instruction stream)
 
@@ -215,6 +234,7 @@ S_KRS, S_VTSS, S_VTBS, S_OBS = S(24, 2), S(26, 2), S(28, 2), S(30, 2)
 S_ORS = S(32, 2)
 S_HEADS, S_LQ, S_LK, S_LKP, S_NSEG, S_C, S_THR, S_NQB = S(36), S(37), S(38), S(39), S(40), S(41), S(42), S(43)
 S_MAGQ, S_MAGH, S_XMODE = S(84), S(85), S(86)
+S_ITEM, S_SET, S_NWG, S_NIT = S(5), S(6), S(7), S(34)     # x2: current item, key set (0 / 1), workgroups of the launch, items of the launch
 S_IPX, S_NITEMS, S_ITEM0 = S(87), S(88), S(89)     # xcd_mode 2: items per XCD run; items of this launch, its first item (live in the id decode only: s87.. are S_CLAMP / S_FIRST / S_TAILREL later)
 S_KRSRC, S_VRSRC = S(44, 4), S(48, 4)
 S_KOFF, S_VOFF, S_KSTEP, S_VSTEP, S_KMAX, S_VMAX = S(52), S(53), S(54), S(55), S(56), S(57)
@@ -704,15 +724,60 @@ class Gen:
             return [isa.sop("s_lshl_b32", ST[8], S_QB, I32(8)), isa.sop("s_lshl_b32", ST[7], S_WAVE, I32(6))]
         return [isa.sop("s_mul_i32", ST[8], S_QB, I32(self.cfg.rows)), isa.sop("s_mul_i32", ST[7], S_WAVE, I32(16 * self.cfg.nq))]
 
+    def x2_set_block(self, krsb) -> List[Instr]:
+        """x2: entry of a key set's pass (S_SET = 0 right after the item's Q loads, 1 after set 0's epilogue).  Set 1 takes its K / V^T
+        pointers, batch strides and key counts from the appended kernel arguments; both sets (re)derive what depends on the key
+        count: V^T row stride -> the V^T DMA lane offsets, tile count, clamps of the DMA offsets, the ragged tail.  Temporaries: score
+        registers (dead between passes; TMP16 overlaps the ONES fragment, which is live from the first item on)."""
+        t = [V(i) for i in range(8)]
+        o: List[Instr] = [isa.sop("s_mov_b32", S_SET, I32(0)), isa.label("L_set"), isa.nop(15),
+                          isa.sop("s_cmp_eq_u32", None, S_SET, I32(0)), isa.branch("s_cbranch_scc1", "L_set_args")]
+        X = KERNARG_SIZE
+        o += [isa.s_load(2, S_K, S_KARG, X), isa.s_load(2, S_VT, S_KARG, X + 8), isa.s_load(2, S_KBS, S_KARG, X + 16),
+              isa.s_load(2, S_VTBS, S_KARG, X + 24), isa.s_load(2, S(S_LK.idx, 2), S_KARG, X + 32), isa.waitcnt(lgkmcnt=0)]
+        o += self.addr64_madd(S_K, S_KBS, S_B, 1) + self.addr64_madd(S_VT, S_VTBS, S_B, 1)
+        o += [isa.sop("s_lshl_b32", ST[6], S_H, I32(8)),
+              isa.sop("s_add_u32", S_K.sub(0), S_K.sub(0), ST[6]), isa.sop("s_addc_u32", S_K.sub(1), S_K.sub(1), I32(0)),
+              isa.sop("s_lshl_b32", ST[7], S_LKP, I32(8)), isa.sop("s_mul_i32", ST[8], ST[7], S_H), isa.sop("s_mul_hi_u32", ST[9], ST[7], S_H),
+              isa.sop("s_add_u32", S_VT.sub(0), S_VT.sub(0), ST[8]), isa.sop("s_addc_u32", S_VT.sub(1), S_VT.sub(1), ST[9])]
+        o += [isa.label("L_set_args"), isa.nop(3)]
+        lkpb = ST[11]
+        o += [isa.sop("s_lshl_b32", lkpb, S_LKP, I32(1)),
+              isa.sop("s_lshr_b32", S_NT, S_LKP, I32(6)), isa.sop("s_sub_u32", ST[12], S_NT, I32(1)),
+              isa.sop("s_mul_i32", S_KMAX, ST[12], S_KSTEP), isa.sop("s_lshl_b32", S_VMAX, ST[12], I32(7))]
+        # V^T piece i: rows 32 w + 8 i + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7)   (as in the prologue)
+        o += [isa.vop("v_lshrrev_b32", t[0], I32(3), LANE), isa.vop("v_and_b32", t[1], I32(7), LANE),
+              isa.vop("v_lshlrev_b32", t[3], I32(5), S_WAVE)]
+        for i in range(4):
+            o += [isa.vop("v_add_u32", t[4], I32(8 * i), t[0]), isa.vop("v_add_u32", t[6], t[4], t[3]),
+                  isa.vop("v_lshrrev_b32", t[5], I32(1), t[6]), isa.vop("v_and_b32", t[5], I32(7), t[5]),
+                  isa.vop("v_xor_b32", t[5], t[1], t[5]),
+                  isa.vop("v_mul_lo_u32", t[6], t[6], lkpb), isa.vop("v_lshl_add_u32", t[6], t[5], I32(4), t[6]),
+                  isa.vop("v_subrev_u32", VDMA[i], I32(1024 * i), t[6])]
+        o += [isa.sop("s_lshl_b32", ST[0], ST[12], I32(6)),
+              isa.sop("s_sub_u32", S_TAIL, S_LK, ST[0]), isa.sop("s_lshl_b32", ST[1], S_WAVE, I32(4)), isa.sop("s_sub_u32", ST[1], S_TAIL, ST[1])]
+        for i in range(4):
+            o.append(isa.sop("s_sub_u32", S_TAILREL[i], ST[1], I32(4 * i)))
+        return o
+
     def prologue(self) -> List[Instr]:
         c = self.cfg
         assert c.nq == 4 or (c.nq == 3 and c.mi == 16 and c.fold and c.lsum), "nq = 3 exists for the fold / lsum 16x16x32 kernels only"
         o: List[Instr] = [isa.label(c.name)]
+        if c.x2:
+            # one-time part (V0 = workitem id is overwritten by the score tiles later), then the item loop: every item reloads the kernel
+            # arguments (the per-item pointer arithmetic and the set switch overwrite them) -- scalar-cache hits after the first item
+            assert c.fold and c.lsum and c.opt and c.ragged and c.nq == 4
+            o += [isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", VT0, I32(6), V(0)),
+                  isa.s_load(1, S_NWG, S_KARG, KERNARG_SIZE + 40), isa.s_load(1, S_NIT, S_KARG, 152),
+                  isa.sop("s_mov_b32", S_ITEM, S(2)), isa.nop(3), isa.vop("v_readfirstlane_b32", S_WAVE, VT0), isa.waitcnt(lgkmcnt=0),
+                  isa.label("L_item"), isa.nop(15)]
         o += [isa.s_load(8, S(8, 8), S_KARG, 0), isa.s_load(8, S(16, 8), S_KARG, 32), isa.s_load(8, S(24, 8), S_KARG, 64),
-              isa.s_load(2, S_ORS, S_KARG, 96), isa.s_load(8, S(36, 8), S_KARG, 104),
-              isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", VT0, I32(6), V(0)),
-              isa.s_load(4, S(84, 4), S_KARG, 136), isa.s_load(2, S(S_NITEMS.idx, 2), S_KARG, 152),
-              isa.waitcnt(lgkmcnt=0), isa.vop("v_readfirstlane_b32", S_WAVE, VT0)]
+              isa.s_load(2, S_ORS, S_KARG, 96), isa.s_load(8, S(36, 8), S_KARG, 104)]
+        if not c.x2:
+            o += [isa.vop("v_and_b32", LANE, I32(63), V(0)), isa.vop("v_lshrrev_b32", VT0, I32(6), V(0))]
+        o += [isa.s_load(4, S(84, 4), S_KARG, 136), isa.s_load(2, S(S_NITEMS.idx, 2), S_KARG, 152), isa.waitcnt(lgkmcnt=0)]
+        o += [isa.sop("s_mov_b32", S(2), S_ITEM)] if c.x2 else [isa.vop("v_readfirstlane_b32", S_WAVE, VT0)]
         # ---- 1-D workgroup id -> (query block, head, batch); xcd_mode 1: ids congruent mod 8 (= one XCD) share (batch, head)
         #      pairs, so the 32 CUs of an XCD stream the same K / V^T tiles through their L2 ----
         wid, xcd, j, qd, pair, tt = S(2), ST[0], ST[1], ST[2], ST[3], ST[4]
@@ -869,6 +934,8 @@ class Gen:
                 if c.ragged:
                     assert c.lsum, "ragged reuses VT0 / VT1, which only the lsum epilogue leaves free"
                     o.append(isa.vop("v_mov_b32", VT1, F32(-3.0e38)))             # the masked score (ql is not needed past this point)
+                if c.x2:
+                    o += self.x2_set_block(krsb)
                 if c.opt:
                     assert c.lsum, "the optimistic pass is verified on the matrix-pipe row sums"
                     o += [isa.sop("s_mov_b32", S_MODE, I32(0)), isa.sop("s_mov_b32", S_HEAD, F32(c.head))]
@@ -1018,6 +1085,18 @@ class Gen:
                     e += [isa.vop("v_mul_lo_u32", t3, row16[qb], orsb), isa.vop("v_lshl_add_u32", ooff16[qb], g, I32(3), t3)]
             opt = self.cfg.opt
             bad = S(ST[0].idx, 2)
+            x2 = self.cfg.x2
+            stash = [[V(64 + (qb * 8 + db) * 2, 2) for db in range(8)] for qb in range(4)]      # x2, set 1: bf16(O of set 0) as stored (score tile 1 is dead)
+            if x2:
+                # set 1: request set 0's stored output now (same lane, same addresses; sc0 sc1 = from L2, where the store went), the row-sum
+                # reduction and the restart check below run under the latency.  A restarted pass requests it again (harmless).
+                e += [isa.sop("s_cmp_eq_u32", None, S_SET, I32(0)), isa.branch("s_cbranch_scc1", "L_x2_noload"), isa.nop(3)]
+                for qb in range(self.cfg.nq):
+                    e += [isa.v_cmp("v_cmp_lt_u32", row16[qb], S_LQ), Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+                    for db in range(8):
+                        e.append(isa.global_load(2, stash[qb][db], ooff16[qb], 32 * db, saddr=S_O, sc=True, extra_reads=[EXEC]))
+                    e += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+                e += [isa.label("L_x2_noload"), isa.nop(3)]
             if opt:
                 e += [Instr("s_mov_b64", [bad], [I32(0)], cls=isa.SALU)]
             for qb in range(self.cfg.nq):
@@ -1046,19 +1125,42 @@ class Gen:
                       isa.nop(3), isa.sop("s_cmp_eq_u32", None, ST[2], I32(0)), isa.branch("s_cbranch_scc1", "L_store"),
                       isa.sop("s_mov_b32", S_MODE, I32(1)), isa.branch("s_branch", "L_restart"),
                       isa.label("L_store"), isa.nop(7)]
-            for qb in range(self.cfg.nq):
-                e += [isa.v_cmp("v_cmp_lt_u32", row16[qb], S_LQ), Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
-                for db in range(8):
-                    base = 32 + 6 * (db % 2)
-                    f = [V(base + i) for i in range(4)]
-                    w = V(base + 4, 2)
-                    for i in range(4):
-                        e += [isa.vop("v_accvgpr_read_b32", f[i], O16(db, qb).sub(i)), isa.vop("v_mul_f32", f[i], f[i], inv[qb])]
-                    e += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
-                          isa.global_store(2, ooff16[qb], w, 32 * db, saddr=S_O, extra_reads=[EXEC])]
-                e += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
-            e += [isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
-            return o + sched.pad_hazards(e)
+
+            def store_pass(add_stash: bool) -> List[Instr]:
+                r: List[Instr] = []
+                for qb in range(self.cfg.nq):
+                    r += [isa.v_cmp("v_cmp_lt_u32", row16[qb], S_LQ), Instr("s_and_saveexec_b64", [S_SAVE], [VCC], extra_reads=[EXEC], extra_writes=[EXEC, isa.SCC], cls=isa.SALU)]
+                    for db in range(8):
+                        base = 32 + 6 * (db % 2)
+                        f = [V(base + i) for i in range(4)]
+                        w = V(base + 4, 2)
+                        for i in range(4):
+                            r += [isa.vop("v_accvgpr_read_b32", f[i], O16(db, qb).sub(i)), isa.vop("v_mul_f32", f[i], f[i], inv[qb])]
+                        if add_stash:       # + bf16(O of set 0): element 2 j of the pair is the low half
+                            st = stash[qb][db]
+                            lo, hi = V(44), V(45)
+                            for j in range(2):
+                                r += [isa.vop("v_lshlrev_b32", lo, I32(16), st.sub(j)), isa.vop("v_and_b32", hi, I32(0xFFFF0000), st.sub(j)),
+                                      isa.vop("v_add_f32", f[2 * j], f[2 * j], lo), isa.vop("v_add_f32", f[2 * j + 1], f[2 * j + 1], hi)]
+                        r += [isa.vop("v_cvt_pk_bf16_f32", w.sub(0), f[0], f[1]), isa.vop("v_cvt_pk_bf16_f32", w.sub(1), f[2], f[3]),
+                              isa.global_store(2, ooff16[qb], w, 32 * db, saddr=S_O, extra_reads=[EXEC])]
+                    r += [Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU)]
+                return r
+
+            if not x2:
+                e += store_pass(False)
+                e += [isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
+                return o + sched.pad_hazards(e)
+            # x2.  Set 0: store bf16(O / l) at its final place and run the pass of set 1.  Set 1: add what set 0 stored, store, next item.
+            e += [isa.sop("s_cmp_eq_u32", None, S_SET, I32(0)), isa.branch("s_cbranch_scc0", "L_x2_final")]
+            e += store_pass(False)
+            e += [isa.sop("s_mov_b32", S_SET, I32(1)), isa.branch("s_branch", "L_set")]
+            e += [isa.label("L_x2_final"), isa.nop(7), isa.waitcnt(vmcnt=0)]
+            e += store_pass(True)
+            e += [isa.sop("s_add_u32", S_ITEM, S_ITEM, S_NWG), isa.sop("s_cmp_lt_u32", None, S_ITEM, S_NIT),
+                  isa.branch("s_cbranch_scc1", "L_item"), isa.waitcnt(vmcnt=0), Instr("s_endpgm", cls=isa.BRANCH)]
+            i0 = next(k for k, x in enumerate(e) if x.label == "L_x2_final")
+            return o + sched.pad_hazards(e[:i0]) + sched.pad_hazards(e[i0:])
         # ---- epilogue: O / l -> bf16, rows of this lane: d = 32 db + 8 rr + 4 g + e ----
         e: List[Instr] = [isa.label("L_epilogue")]
         inv = [TMP[0], TMP[1]]
@@ -1120,7 +1222,7 @@ def kernel_text(c: Cfg) -> str:
 \t.amdhsa_kernel {c.name}
 \t\t.amdhsa_group_segment_fixed_size {c.lds_bytes}
 \t\t.amdhsa_private_segment_fixed_size 0
-\t\t.amdhsa_kernarg_size {KERNARG_SIZE}
+\t\t.amdhsa_kernarg_size {X2_KERNARG_SIZE if c.x2 else KERNARG_SIZE}
 \t\t.amdhsa_user_sgpr_count 2
 \t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
 \t\t.amdhsa_system_sgpr_workgroup_id_x 1
@@ -1145,11 +1247,11 @@ def metadata(cfgs) -> str:
     ks = "".join(f"""  - .agpr_count:     256
     .args:
       - .offset:         0
-        .size:           {KERNARG_SIZE}
+        .size:           {X2_KERNARG_SIZE if c.x2 else KERNARG_SIZE}
         .value_kind:     by_value
     .group_segment_fixed_size: {c.lds_bytes}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: {KERNARG_SIZE}
+    .kernarg_segment_size: {X2_KERNARG_SIZE if c.x2 else KERNARG_SIZE}
     .max_flat_workgroup_size: 256
     .name:           {c.name}
     .private_segment_fixed_size: 0
@@ -1188,7 +1290,9 @@ M16F = Cfg(name="scail_attn4_m16f", mi=16, fold=True, lsum=True, ragged=True, ca
 # the same kernel with 3 query blocks per wave = 192-row workgroups: the launch shape of a sequence-parallel rank (Ulysses at 8 ranks: 5 heads x
 # 191 tiles of 256 rows = 3.73 rounds over 256 CUs -> 4; 255 tiles of 192 rows = 4.98 rounds of a shorter tile)
 M16F_Q3 = Cfg(name="scail_attn4_m16f_q3", mi=16, fold=True, lsum=True, ragged=True, cap=1, sm_end=44.0, lookahead=2.0, qscale=True, opt=True, pv_qb=True, nq=3)
-SHIPPED = [M16F, M16F_Q3]
+# cross attention over the text and the CLIP key set (Cfg.x2): the M16F pipeline with persistent workgroups
+X2 = Cfg(name="scail_attn4_x2", mi=16, fold=True, lsum=True, ragged=True, cap=1, sm_end=44.0, lookahead=2.0, qscale=True, opt=True, pv_qb=True, x2=True)
+SHIPPED = [M16F, M16F_Q3, X2]
 
 
 def variant_cfgs():

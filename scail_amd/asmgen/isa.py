@@ -277,13 +277,14 @@ def buffer_load(ndw: int, dst: Reg, voff: Reg, rsrc: Reg, soff, offset: int = 0,
     return i
 
 
-def global_load(ndw: int, dst: Reg, vaddr: Reg, offset: int = 0, saddr: Optional[Reg] = None, **kw) -> Instr:
-    """vaddr(2) + offset, or -- with ``saddr`` -- saddr(2 SGPRs) + zero-extended vaddr(1) + offset."""
+def global_load(ndw: int, dst: Reg, vaddr: Reg, offset: int = 0, saddr: Optional[Reg] = None, sc: bool = False, **kw) -> Instr:
+    """vaddr(2) + offset, or -- with ``saddr`` -- saddr(2 SGPRs) + zero-extended vaddr(1) + offset.  sc: system-coherent read (sc0 sc1:
+    served by L2, not by a possibly stale line of the CU's vector L1) -- for data this wave stored earlier in the kernel."""
     op = {1: "global_load_dword", 2: "global_load_dwordx2", 4: "global_load_dwordx4"}[ndw]
     assert dst.n == ndw and -4096 <= offset <= 4095 and vaddr.n == (1 if saddr is not None else 2)
     base = str(saddr) if saddr is not None else "off"
     i = Instr(op, [dst], [vaddr] + ([saddr] if saddr is not None else []), offset=offset, **kw)
-    i.text = f"{op} {dst}, {vaddr}, {base}" + (f" offset:{offset}" if offset else "")
+    i.text = f"{op} {dst}, {vaddr}, {base}" + (f" offset:{offset}" if offset else "") + (" sc0 sc1" if sc else "")
     return i
 
 

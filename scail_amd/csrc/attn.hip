@@ -876,6 +876,7 @@ int scail_attn4_preload() {
 }
 
 static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
+static int g_cross4 = 1;                   // option "cross4": scail_attn4_x2 for the two-set cross attention where eligible
 static int g_attn4_rows = 0;               // query rows per workgroup: 0 = planned per launch (below), 256 / 192 = one height for every launch
 static thread_local int g_attn4_rows_hint = 0;   // set by a caller that knows more than one call can (scail_attn4_rows_hint)
 // ---- launch shape of one attention (round 5) ----------------------------------------------------------------------------------
@@ -975,6 +976,7 @@ int scail_conv4_cont_enable(int v);    // conv.hip
 extern "C" int scail_set_option(const char* name, int value) {
     const std::string k(name ? name : "");
     if (k == "attn4") { g_attn4_mode = value != 0; return 0; }              // 0: 8-wave kernel for every shape
+    if (k == "cross4") { g_cross4 = value != 0; return 0; }                // 0: cross_attn2_kernel of csrc/attn.hip for every shape
     if (k == "attn4_rows") {                                                // query rows per workgroup of attn4: 0 = per-launch choice
         SCAIL_REQUIRE(value == 0 || value == 192 || value == 256, "attn4_rows must be 0 (automatic), 192 or 256");
         g_attn4_rows = value;
@@ -1199,6 +1201,26 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
     return scail_check_launch("flash_attn");
 }
 
+// ---- cross attention over two key sets on the generated 4-wave pipeline (scail_attn4_x2) ----
+struct Attn4X2Args {
+    Attn4Args base;              // set 0 in the k / vt / k_bs / vt_bs / Lk / Lkp fields, n_seg = 1, xcd_mode 0, n_items = all items
+    const void* k2; const void* vt2;
+    int64_t k2_bs, vt2_bs;
+    int32_t Lk2, Lkp2, n_wgs, pad;
+};
+static_assert(sizeof(Attn4X2Args) == 208, "Attn4X2Args must match asmgen/attn4.py X2_KERNARG_SIZE");
+// one K row stride for both sets (the set switch keeps the K DMA lane offsets), at least one whole key tile per set (a ragged tile's
+// missing rows are fetched from 64 rows earlier), 32-bit byte offsets inside a (batch, head) slice, exact reciprocal id decode
+static bool cross4_eligible(int64_t q_rs, int64_t k1_rs, int64_t k2_rs, int64_t o_rs, int64_t Lq, int64_t Lk1, int64_t Lk2, int64_t n_batch, int64_t heads) {
+    const int64_t lim = (1ll << 30);
+    return g_cross4 && g_attn4_mode && k1_rs == k2_rs && Lk1 >= 64 && Lk2 >= 64 && Lq * q_rs < lim && Lq * o_rs < lim && Lk1 * k1_rs < lim &&
+           Lk2 * k2_rs < lim && 128 * (Lk1 + 63) < lim && 128 * (Lk2 + 63) < lim && attn4_grid_ok(n_batch, heads, Lq);
+}
+extern "C" int scail_cross_attn2_kernel_for(int64_t q_rs, int64_t k1_rs, int64_t k2_rs, int64_t o_rs, int64_t Lq, int64_t Lk1, int64_t Lk2,
+                                            int64_t n_batch, int64_t heads) {
+    return cross4_eligible(q_rs, k1_rs, k2_rs, o_rs, Lq, Lk1, Lk2, n_batch, heads) ? 4 : 2;
+}
+
 extern "C" int scail_cross_attn2_bf16(const scail_bf16* q, int64_t q_bs, int64_t q_rs,
                                       const scail_bf16* k1, int64_t k1_bs, int64_t k1_rs, const scail_bf16* vt1, int64_t vt1_bs, int64_t Lk1,
                                       const scail_bf16* k2, int64_t k2_bs, int64_t k2_rs, const scail_bf16* vt2, int64_t vt2_bs, int64_t Lk2,
@@ -1213,6 +1235,40 @@ extern "C" int scail_cross_attn2_bf16(const scail_bf16* q, int64_t q_bs, int64_t
                       (reinterpret_cast<uintptr_t>(vt1) & 15) == 0 && (reinterpret_cast<uintptr_t>(vt2) & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 7) == 0,
                   "cross_attn2: pointer alignment");
     if (n_batch == 0 || Lq == 0) return 0;
+    const bool prescaled = scale == SCAIL_ATTN_Q_PRESCALED;        // q already carries scale * log2(e)
+    SCAIL_REQUIRE(prescaled || (scale > 0.0f && scale < 3.0e38f), "cross_attn2: scale must be a positive finite number or SCAIL_ATTN_Q_PRESCALED");
+    if (cross4_eligible(q_rs, k1_rs, k2_rs, o_rs, Lq, Lk1, Lk2, n_batch, heads)) {
+        // scail_attn4_x2 (csrc/attn4.s, asmgen/attn4.py Cfg.x2): the 4-wave pipeline of the self-attention kernel, persistent workgroups (one
+        // per CU) walking over the (pair, 256-row query block) items, the key pipeline run once per key set and item
+        hipFunction_t fn;
+        if (int rc = attn4_function("scail_attn4_x2", &fn)) return rc;
+        Attn4X2Args a;
+        Attn4Args& b = a.base;
+        const int64_t Lkp1 = (Lk1 + 63) / 64 * 64, Lkp2 = (Lk2 + 63) / 64 * 64;
+        b.q = q; b.k = k1; b.vt = vt1; b.o = o;
+        b.q_bs = q_bs; b.q_rs = q_rs; b.k_ss = 0; b.k_bs = k1_bs; b.k_rs = k1_rs; b.vt_ss = 0; b.vt_bs = vt1_bs; b.o_bs = o_bs; b.o_rs = o_rs;
+        b.heads = (int32_t)heads; b.Lq = (int32_t)Lq; b.Lk = (int32_t)Lk1; b.Lkp = (int32_t)Lkp1; b.n_seg = 1;
+        b.sl2 = prescaled ? 0.0f : scale * 1.4426950408889634f;
+        b.thr = g_attn4_thr_log2;
+        b.nqb = (int32_t)((Lq + 255) / 256);
+        b.magic_nqb = (uint32_t)(((1ull << 31) + b.nqb - 1) / b.nqb);
+        b.magic_heads = (uint32_t)(((1ull << 31) + heads - 1) / heads);
+        b.xcd_mode = 0;
+        b.n_items = (int32_t)(b.nqb * heads * n_batch);
+        b.items_per_xcd = (b.n_items + 7) / 8;
+        b.item0 = 0;
+        a.k2 = k2; a.vt2 = vt2; a.k2_bs = k2_bs; a.vt2_bs = vt2_bs; a.Lk2 = (int32_t)Lk2; a.Lkp2 = (int32_t)Lkp2;
+        a.n_wgs = (int32_t)std::min<int64_t>(b.n_items, attn4_cu_count());
+        a.pad = 0;
+        size_t sz = sizeof(a);
+        void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        hipError_t e = hipModuleLaunchKernel(fn, (unsigned)a.n_wgs, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, extra);
+        if (e != hipSuccess) {
+            scail_set_error(std::string("cross_attn2 (attn4_x2): launch failed: ") + hipGetErrorString(e));
+            return 2;
+        }
+        return 0;
+    }
     static ScailDeviceOnce attr_set;
     if (attr_set.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cross_attn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X2_LDS_BYTES);
@@ -1228,7 +1284,7 @@ extern "C" int scail_cross_attn2_bf16(const scail_bf16* q, int64_t q_bs, int64_t
     p.k1 = k2; p.k1_bs = k2_bs; p.k1_rs = k2_rs; p.vt1 = vt2; p.vt1_bs = vt2_bs; p.Lk1 = (int)Lk2; p.Lkp1 = (int)((Lk2 + KVBLK - 1) / KVBLK * KVBLK);
     p.o = o; p.o_bs = o_bs; p.o_rs = o_rs;
     p.heads = (int)heads; p.Lq = (int)Lq;
-    p.sl2 = scale * 1.44269504088896340736f;
+    p.sl2 = prescaled ? 1.0f : scale * 1.44269504088896340736f;
     dim3 grid((unsigned)((Lq + 127) / 128), (unsigned)heads, (unsigned)n_batch);
     hipLaunchKernelGGL(cross_attn2_kernel, grid, dim3(X2_THREADS), X2_LDS_BYTES, (hipStream_t)stream, p);
     return scail_check_launch("cross_attn2");

@@ -156,7 +156,8 @@ static int block_cross_mlp(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16*
     // -- cross attention: text + CLIP, ungated residual (dit...:1039-1042, :1107-1203) --
     DIT_TRY(scail_layernorm_affine(hid, D, xn, D, lw.ln_w, lw.ln_b, M, D, eps, stream));
     DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xn, D, lw.cq_w, lw.cq_b, q3, 3 * D, M, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
-    DIT_TRY(scail_rmsnorm_rope(q3, 3 * D, q3, 3 * D, lw.cqn, nullptr, nullptr, M, M, D, 128, eps, stream));
+    // (the queries go to the attention in log2 units, like the self-attention's: no scale / shift per score in the kernel)
+    DIT_TRY(scail_rmsnorm_rope_scaled(q3, 3 * D, q3, 3 * D, lw.cqn, nullptr, nullptr, M, M, D, 128, eps, ATTN_LOG2_SCALE, stream));
     const bool shared_clip = cond->Bc == 1;
     const scail_bf16* kt = cond->k_text + (i * Btot + b0) * cond->Lt * D;
     const scail_bf16* vtt = cond->vt_text + (i * Btot + b0) * nh * 128 * Ltp;
@@ -164,7 +165,7 @@ static int block_cross_mlp(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16*
     const scail_bf16* vtc = cond->vt_clip + (i * cond->Bc + (shared_clip ? 0 : b0)) * nh * 128 * Lcp;
     DIT_PROF(SCAIL_DIT_PROF_CROSS_ATTN, scail_cross_attn2_bf16(q3, rpb * 3 * D, 3 * D, kt, cond->Lt * D, D, vtt, nh * 128 * Ltp, cond->Lt,
                                                                kc, shared_clip ? 0 : cond->Lc * D, D, vtc, shared_clip ? 0 : nh * 128 * Lcp, cond->Lc,
-                                                               att, rpb * D, D, nb, nh, rpb, ATTN_SCALE, stream));
+                                                               att, rpb * D, D, nb, nh, rpb, SCAIL_ATTN_Q_PRESCALED, stream));
     DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(att, D, lw.co_w, lw.co_b, hid, D, M, D, D, SCAIL_EPI_RESID, hid, D, nullptr, 0, 0, stream));
     // -- MLP (dit...:1045-1050; sat/transformer_defaults.py:163-176) --
     DIT_TRY(scail_ln_modulate(hid, D, xn, D, m + 3 * D, m + 4 * D, 6 * D, nb, rpb, rpb, 0, D, eps, stream));

@@ -532,8 +532,8 @@ class DiffusionTransformer(nn.Module):
             ops.layernorm_affine(h, lw["ln_w"], lw["ln_b"], out=xn, eps=eps)
             cq = qkv[..., :D]
             ops.gemm(xn, lw["cq_w"], lw["cq_b"], out=cq)
-            ops.rmsnorm_rope(cq, lw["cqn"], eps=eps)
-            ops.cross_attn2(cq, cond["k_text"][i], cond["vt_text"][i], cond["k_clip"][i], cond["vt_clip"][i], out=att)
+            ops.rmsnorm_rope(cq, lw["cqn"], eps=eps, out_scale=ops.ATTN_LOG2_SCALE)                # q in log2 units (as the executor does)
+            ops.cross_attn2(cq, cond["k_text"][i], cond["vt_text"][i], cond["k_clip"][i], cond["vt_clip"][i], out=att, q_prescaled=True)
             ops.gemm(att, lw["co_w"], lw["co_b"], out=h, epilogue=L.EPI_RESID, resid=h)
             # -- MLP (:1045-1050; sat/transformer_defaults.py:163-176) --
             ops.ln_modulate(h, sh_m, sc_m, out=xn, eps=eps)

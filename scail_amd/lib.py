@@ -29,6 +29,7 @@ SIGNATURES = {
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
     "scail_flash_attn_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i, _i],
     "scail_flash_attn_rows_for": [_i64, _i64, _i64],
+    "scail_cross_attn2_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64],
     "scail_gemm_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i],
     "scail_conv3d_kernel_for": [_p, _i64, _i64, _i],
     "scail_cross_attn2_bf16": [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,

@@ -195,9 +195,10 @@ def flash_attn(q, k, vt, out=None, scale=None, accumulate=False, n_seg=1, k_seg_
     return out
 
 
-def cross_attn2(q, k1, vt1, k2, vt2, out=None, scale=None):
+def cross_attn2(q, k1, vt1, k2, vt2, out=None, scale=None, q_prescaled=False):
     """softmax(q k1^T) v1 + softmax(q k2^T) v2 in one launch (text + CLIP cross attention, dit_video_crossattn_sc_xc.py:1107-1203).
-    q (B, Lq, H*128) view; k1 / k2 (B|1, Lk, H*128) views; vt1 / vt2 (B|1, H, 128, ceil64(Lk)) transpose_v images."""
+    q (B, Lq, H*128) view; k1 / k2 (B|1, Lk, H*128) views; vt1 / vt2 (B|1, H, 128, ceil64(Lk)) transpose_v images.
+    ``q_prescaled``: q already carries scale * log2(e) (rmsnorm_rope(..., out_scale=ATTN_LOG2_SCALE))."""
     _chk(q, bf16, "cross_attn2.q")
     B, Lq, D = q.shape
     H = D // 128
@@ -215,6 +216,8 @@ def cross_attn2(q, k1, vt1, k2, vt2, out=None, scale=None):
         sets += [k.data_ptr(), 0 if k.shape[0] == 1 else k.stride(0), k.stride(1), vt.data_ptr(), 0 if vt.shape[0] == 1 else vt.stride(0), Lk]
     if scale is None:
         scale = 1.0 / math.sqrt(128)
+    if q_prescaled:
+        scale = ATTN_Q_PRESCALED
     L.call("scail_cross_attn2_bf16", q.data_ptr(), q.stride(0), q.stride(1), *sets, out.data_ptr(), out.stride(0), out.stride(1),
            B, H, Lq, scale, _stream())
     return out

@@ -262,3 +262,64 @@ def test_split_attention_256_row_launch_then_192_row_launch(mode):
     assert np.array_equal(split, whole)
     c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
     np.testing.assert_allclose(split, R.reference(_rt(q * c) / c, _rt(k), _rt(v), H), rtol=2e-2, atol=6e-3)
+
+
+# ---- round 5: cross attention over two key sets, persistent workgroups (Cfg.x2, scail_attn4_x2) ----
+X2 = attn4.X2
+
+
+def _x2_case(B, H, Lq, Lk1, Lk2, n_wgs, shared2=True, seed=0, lazy=True, spikes=(), raw_scale=False):
+    """spikes: (set, batch, key, query row, factor) -- key <- factor x that query (a score ~16.3 x factor log2 units above the rest)"""
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((B, Lq, H * 128)).astype(np.float32)
+    k1 = rng.standard_normal((B, Lk1, H * 128)).astype(np.float32)
+    v1 = rng.standard_normal((B, Lk1, H * 128)).astype(np.float32)
+    B2 = 1 if shared2 else B
+    k2 = rng.standard_normal((B2, Lk2, H * 128)).astype(np.float32)
+    v2 = rng.standard_normal((B2, Lk2, H * 128)).astype(np.float32)
+    for st, b, key, row, f in spikes:
+        (k1 if st == 0 else k2)[b, key] = q[b, row] * f
+    o, stats = R.run_x2(X2, q, k1, v1, k2, v2, H, n_wgs=n_wgs, lazy=lazy, raw_scale=raw_scale)
+    c = np.float32((1.0 / np.sqrt(128.0)) * 1.4426950408889634)
+    qq = _rt(_rt(q) * c) / c if raw_scale else _rt(q * c) / c
+    ref = R.reference_x2(qq, _rt(k1), _rt(v1), _rt(k2), _rt(v2), H)
+    assert np.isfinite(o).all()
+    np.testing.assert_allclose(o, ref, rtol=2e-2, atol=8e-3)
+    return stats
+
+
+def test_x2_static_hazards_clean():
+    assert R.check_static(X2) == []
+
+
+def test_x2_generated_kernel_matches_two_softmaxes_summed():
+    """dit_video_crossattn_sc_xc.py:1107-1203: bf16(bf16(softmax(q K_text^T) V_text) + softmax(q K_clip^T) V_clip); the shipped shape in
+    small: 8 + 5 key tiles with the CLIP set's last tile holding ONE key (512 + 257 keys)"""
+    st = _x2_case(1, 1, 256, 512, 257, n_wgs=1, seed=1)
+    assert st[0]["mfma"] == 136 * 13
+
+
+@pytest.mark.parametrize("n_wgs", [1, 2, 3])
+def test_x2_persistent_workgroups_walk_over_the_items(n_wgs):
+    """2 batch elements x 2 heads x 3 query blocks (ragged last: 600 rows) = 12 items over 1 / 2 / 3 workgroups: every item exactly
+    once whatever the workgroup count (the output starts as zeros), per-item reload of the kernel arguments, the CLIP set shared by
+    the batch (stride 0) like the engine passes it"""
+    st = _x2_case(2, 2, 600, 128, 65, n_wgs=n_wgs, seed=2 + n_wgs, lazy=bool(n_wgs & 1))
+    assert sum(x["mfma"] for x in st) == 12 * 136 * (2 + 2)
+
+
+def test_x2_per_batch_second_set_and_ragged_first_set():
+    _x2_case(2, 1, 100, 64 * 3 + 9, 64 * 2, n_wgs=2, shared2=False, seed=9)
+    _x2_case(1, 3, 256, 64, 64 * 6 + 63, n_wgs=2, seed=10)            # one-tile first set, long ragged second set
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_x2_optimistic_overflow_restarts_only_that_set(which):
+    """a key ~196 log2 units above its row's first-tile maximum in set `which` (far from tile 0): that set's pass runs again with the
+    lazy-maximum loop, the other set's pass runs once; set 0's stored output is read back unchanged either way"""
+    st = _x2_case(1, 1, 256, 64 * 11, 64 * 12, n_wgs=1, seed=20 + which, spikes=[(which, 0, 64 * 3 + 7, 150, 12.0)])
+    assert st[0]["mfma"] == 136 * (11 + 12) + 136 * (11 if which == 0 else 12)       # (the optimistic hot loop needs >= 10 tiles: shorter sets track the maximum)
+
+
+def test_x2_raw_scale_callers():
+    _x2_case(1, 2, 300, 128, 70, n_wgs=2, seed=30, raw_scale=True)

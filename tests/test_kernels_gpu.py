@@ -549,9 +549,22 @@ def test_patchify_embed_and_unpatchify(ops):
 
 # ------------------------------------------------------------------------------------------------
 # fused two-key-set cross attention (text + CLIP, dit_video_crossattn_sc_xc.py:1107-1203)
+@pytest.mark.parametrize("cross4", [1, 0])
 @pytest.mark.parametrize("B,H,Lq,Lk1,Lk2,shared2", [(2, 2, 300, 512, 257, True), (1, 3, 128, 77, 1, False), (2, 1, 515, 64, 320, False),
-                                                     (1, 2, 40, 130, 257, True), (2, 2, 1000, 512, 257, False)])
-def test_cross_attn2_vs_oracle(ops, B, H, Lq, Lk1, Lk2, shared2):
+                                                     (1, 2, 40, 130, 257, True), (2, 2, 1000, 512, 257, False), (2, 5, 1500, 512, 257, True),
+                                                     (1, 1, 256 * 300 + 17, 64, 65, True)])
+def test_cross_attn2_vs_oracle(ops, B, H, Lq, Lk1, Lk2, shared2, cross4):
+    from scail_amd import lib as L_
+    L_.set_option("cross4", cross4)       # 1: scail_attn4_x2 (generated, persistent workgroups) where eligible; 0: cross_attn2_kernel for every shape
+    try:
+        which = L_.load().scail_cross_attn2_kernel_for(3 * H * 128, H * 128, H * 128, H * 128, Lq, Lk1, Lk2, B, H)
+        assert which == (4 if (cross4 and Lk1 >= 64 and Lk2 >= 64) else 2)
+        _cross_attn2_case(ops, B, H, Lq, Lk1, Lk2, shared2)
+    finally:
+        L_.set_option("cross4", 1)
+
+
+def _cross_attn2_case(ops, B, H, Lq, Lk1, Lk2, shared2):
     """one launch over two key sets = the oracle's two attentions, each rounded to bf16, added (the reference adds the bf16
     outputs of two attention_fn calls); ragged last tiles in both sets, one-key set, query rows not a multiple of 128, the
     second set shared by the batch (CLIP of an unbatched reference image) or per batch element, strided q view."""
@@ -574,6 +587,10 @@ def test_cross_attn2_vs_oracle(ops, B, H, Lq, Lk1, Lk2, shared2):
     o2 = ops.flash_attn(g[..., :D], gpu_bf16(k1), vt1)
     ops.flash_attn(g[..., :D], gpu_bf16(k2), vt2, out=o2, accumulate=True)
     close(o[:, :Lq], o2.float(), rtol=1e-2, atol=4e-3, msg="cross_attn2 vs flash_attn + accumulate")
+    # queries handed over in log2 units (what the DiT executor does: scail_rmsnorm_rope_scaled + SCAIL_ATTN_Q_PRESCALED)
+    qs = gpu_bf16(q * ops.ATTN_LOG2_SCALE)
+    o3 = ops.cross_attn2(qs, gpu_bf16(k1), vt1, gpu_bf16(k2), vt2, q_prescaled=True)
+    close(o3, ref, rtol=2e-2, atol=1.5e-2, msg="cross_attn2, prescaled q")
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,which", [(1, 1, 256, 512, 4), (2, 2, 300, 576, 4), (1, 2, 700, 1024, 4), (1, 3, 130, 832, 4), (1, 2, 520, 1088, 4),

@@ -94,6 +94,45 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     return from_bf16_bits(mem.read_back("o")), stats
 
 
+def run_x2(cfg: attn4.Cfg, q: np.ndarray, k1, v1, k2, v2, heads: int, n_wgs: int = 2, lazy: bool = True, thr_log2: float = 8.0, raw_scale: bool = False,
+           program=None):
+    """The two-key-set cross attention kernel (Cfg.x2): q (B, Lq, H*128) fp32; k1 / v1 (B, Lk1, H*128), k2 / v2 (B2, Lk2, H*128) with B2 in
+    {1, B} (a shared CLIP set has batch stride 0).  ``n_wgs`` persistent workgroups walk over the items.  Returns O and the statistics."""
+    B, Lq, D = q.shape
+    Lk1, Lk2 = k1.shape[1], k2.shape[1]
+    Lkp1, Lkp2 = (Lk1 + 63) // 64 * 64, (Lk2 + 63) // 64 * 64
+    mem = E.Memory(size=1 << 26)
+    sl2 = (1.0 / math.sqrt(128.0)) * 1.4426950408889634
+    qb = to_bf16_bits(q) if raw_scale else to_bf16_bits(q * np.float32(sl2))
+    pq = mem.alloc("q", qb)
+    pk1 = mem.alloc("k1", to_bf16_bits(k1))
+    pv1 = mem.alloc("vt1", transpose_v(to_bf16_bits(v1), heads))
+    pk2 = mem.alloc("k2", to_bf16_bits(k2))
+    pv2 = mem.alloc("vt2", transpose_v(to_bf16_bits(v2), heads))
+    po = mem.alloc("o", np.zeros((B, Lq, D), dtype=np.uint16))
+    prog = program if program is not None else attn4.Gen(cfg).program()
+    bs = lambda x, n: 0 if x.shape[0] == 1 and B > 1 else n
+    args = attn4.pack_args_x2(pq, pk1, pv1, pk2, pv2, po, Lq * D, D, bs(k1, Lk1 * D), D, bs(k1, heads * 128 * Lkp1), bs(k2, Lk2 * D),
+                              bs(k2, heads * 128 * Lkp2), Lq * D, D, heads, Lq, Lk1, Lkp1, Lk2, Lkp2, sl2 if raw_scale else 0.0, thr_log2,
+                              n_batch=B, n_wgs=n_wgs)
+    stats = []
+    for wid in range(n_wgs):
+        emu = E.Emu(prog, mem, n_waves=4, lds_bytes=cfg.lds_bytes, lazy=lazy)
+        emu.launch(args, block_id=(wid, 0, 0))
+        stats.append(emu.waves[0].stats)
+    return from_bf16_bits(mem.read_back("o")), stats
+
+
+def reference_x2(q, k1, v1, k2, v2, heads):
+    """bf16(bf16(softmax(q k1^T / sqrt d) v1) + softmax(q k2^T / sqrt d) v2) in fp64 on the given (already rounded) operands."""
+    rt = lambda x: from_bf16_bits(to_bf16_bits(x.astype(np.float32))).astype(np.float64)
+    B = q.shape[0]
+    bc = lambda x: np.broadcast_to(x, (B,) + x.shape[1:])
+    o1 = reference(q, bc(k1), bc(v1), heads)
+    o2 = reference(q, bc(k2), bc(v2), heads)
+    return rt(o1) + o2
+
+
 def check_static(cfg: attn4.Cfg):
     """hazard re-check of every scheduled block (loop bodies circularly)."""
     g = attn4.Gen(cfg)

@@ -40,9 +40,21 @@ def two():
     ops.flash_attn(q, k2, vt2, out=o2, accumulate=True)
 
 
-ms1 = timeit(lambda: ops.cross_attn2(q, k1, vt1, k2, vt2, out=o))
-ms2 = timeit(two)
+from scail_amd import lib  # noqa: E402
 fl = 4.0 * B * H * Lq * (Lt + Lc) * 128
-print(json.dumps({"shape": {"B": B, "heads": H, "Lq": Lq, "Lt": Lt, "Lc": Lc}, "fused_ms": ms1, "two_launch_ms": ms2,
-                  "fused_TFLOPs": fl / ms1 / 1e9, "two_launch_TFLOPs": fl / ms2 / 1e9,
-                  "max_abs_diff": float((o.float() - o2.float()).abs().max())}))
+qs = (q.float() * ops.ATTN_LOG2_SCALE).to(torch.bfloat16)
+res = {"shape": {"B": B, "heads": H, "Lq": Lq, "Lt": Lt, "Lc": Lc}}
+outs = {}
+for name, c4 in (("attn4_x2", 1), ("cross_attn2_kernel", 0)):        # same process: the generated persistent kernel, the round-2 hipcc kernel
+    lib.set_option("cross4", c4)
+    ms = timeit(lambda: ops.cross_attn2(qs, k1, vt1, k2, vt2, out=o, q_prescaled=True))
+    outs[name] = o.clone()
+    res[name] = {"ms": ms, "TFLOPs": fl / ms / 1e9, "frac_of_2500": fl / ms / 1e9 / 2500.0}
+    if c4:
+        ms = timeit(lambda: ops.cross_attn2(q, k1, vt1, k2, vt2, out=o))
+        res[name]["ms_raw_scale_q"] = ms
+lib.set_option("cross4", 1)
+ms2 = timeit(two)
+res["two_launch_ms"] = ms2
+res["max_abs_diff_x2_vs_hipcc"] = float((outs["attn4_x2"].float() - outs["cross_attn2_kernel"].float()).abs().max())
+print(json.dumps(res))
