@@ -876,7 +876,11 @@ int scail_attn4_preload() {
 }
 
 static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
-static int g_cross4 = 1;                   // option "cross4": scail_attn4_x2 for the two-set cross attention where eligible
+// option "cross4": scail_attn4_x2 for the two-set cross attention where eligible.  OFF by default: measured SLOWER than cross_attn2_kernel at
+// the shipped shape (2.57 vs 2.20 ms at B = 2, 40 heads, 48 832 queries, 512 + 257 keys; profiles/r05_cross_attn_probe.log): with 8 + 5
+// key tiles per item every tile runs in the remainder chain of the pipeline and each set pays the fill / drain of the software pipeline
+// (~8 us per set beside ~17 us of tiles per item); DESIGN.md section 4.3 has the phase budget and what a continuous pipeline would need.
+static int g_cross4 = 0;
 static int g_attn4_rows = 0;               // query rows per workgroup: 0 = planned per launch (below), 256 / 192 = one height for every launch
 static thread_local int g_attn4_rows_hint = 0;   // set by a caller that knows more than one call can (scail_attn4_rows_hint)
 // ---- launch shape of one attention (round 5) ----------------------------------------------------------------------------------

@@ -183,7 +183,11 @@ class LocalCopyBackend:
         return t
 
 
-SIDE_STREAM_MAX_RANKS = 4       # ulysses exchange: one side stream per CFG element up to this many ranks (CExchange)
+# ulysses exchange: one side stream per CFG element up to this many ranks (CExchange).  0 since round 5: with the planned attention launch
+# shape (whole 256-row rounds + 192-row tiles, csrc/attn.hip attn4_plan) one stream is faster at 4 ranks -- compute-side efficiency 95.3 %
+# against 94.2 % with the two side streams, same box, same process order (profiles/r05_sp4_side_streams_ab.log); rounds 3-4, before the
+# plan: 93.9 % with, 91.4 % without.  SCAIL_SP_SIDE_STREAMS=1 brings them back.
+SIDE_STREAM_MAX_RANKS = 0
 
 
 class CExchange:
@@ -207,8 +211,7 @@ class CExchange:
         else:
             self.send, self.recv = e(B, 2, Ltok, D), e(B, 2, N, Ltok, D)
             self.ofull = self.back = None
-        # two side streams for the two CFG elements up to 4 ranks (4 ranks 91.4 -> 93.9 % compute-side
-        # efficiency, 8 ranks 90.7 -> 89.4 %), none beyond
+        # optional: two side streams for the two CFG elements (see SIDE_STREAM_MAX_RANKS)
         # (SCAIL_SP_SIDE_STREAMS = 0 / 1 overrides the rule: same-process A/B against the planned single-stream launch shape)
         want = os.environ.get("SCAIL_SP_SIDE_STREAMS")
         use_side = (N <= SIDE_STREAM_MAX_RANKS) if want is None else want == "1"

@@ -103,9 +103,13 @@ def test_sequence_parallel_fullsize_virtual_ranks(world, mode, n_char):
         assert torch.equal(got, host), f"C executor vs per-op host path: max |d| {float((got - host).abs().max())}"
 
 
-@pytest.mark.parametrize("world,mode,chunk_dim", [(2, "allgather", 3), (2, "ulysses", 3), (4, "ulysses", 4), (4, "allgather", 3)])
-def test_sp_c_executor_equals_per_op_path_small(world, mode, chunk_dim):
-    """toy width (4 heads), both exchange modes, H- and W-split, with and without the two side streams (ulysses <= 4 ranks uses them)"""
+@pytest.mark.parametrize("world,mode,chunk_dim,side", [(2, "allgather", 3, None), (2, "ulysses", 3, None), (4, "ulysses", 4, None), (4, "allgather", 3, None),
+                                                       (2, "ulysses", 3, "1"), (4, "ulysses", 4, "1")])
+def test_sp_c_executor_equals_per_op_path_small(world, mode, chunk_dim, side, monkeypatch):
+    """toy width (4 heads), both exchange modes, H- and W-split, without and with the two side streams of the ulysses exchange
+    (SCAIL_SP_SIDE_STREAMS=1: fork / join inside scail_dit_block_sp; off by default since round 5)"""
+    if side is not None:
+        monkeypatch.setenv("SCAIL_SP_SIDE_STREAMS", side)
     cfgd = dict(hidden_size=512, num_attention_heads=4, inner_hidden_size=1024, text_dim=64, time_freq_dim=256, time_embed_dim=512)
     T, H, W = (2, 16, 32) if chunk_dim == 3 else (2, 32, 16)
     inputs = _inputs(T, H, W, 1, 64, 12, 5, seed=11)
