@@ -10,7 +10,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from scail_amd.dit import DiffusionTransformer  # noqa: E402
 
 dev = "cuda"
