@@ -238,12 +238,20 @@ from scail_amd.dit import DiffusionTransformer
 from scail_amd.parallel import SequenceParallel, TorchDistBackend
 lib.load()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(rank)
-dev = torch.device("cuda", rank)
-dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+backend = os.environ.get("SCAIL_TEST_BACKEND", "nccl")
+# nccl: one GPU per rank, the exchange is RCCL over xGMI.  gloo: the TEST vehicle of scail_amd.parallel.TorchDistBackend -- both ranks on GPU 0,
+# the exchange staged through the host -- so that everything but the transport runs on a 1-GPU box
+local = rank if backend == "nccl" else 0
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group(backend, rank=rank, world_size=world)
+LAYERS = int(os.environ.get("SCAIL_TEST_LAYERS", "2"))
 P = dict(hidden_size=5120, num_attention_heads=40, inner_hidden_size=13824, text_dim=4096, time_freq_dim=256, time_embed_dim=5120)
 mk = lambda: DiffusionTransformer(transformer_args=dict(model_parallel_size=1), num_frames=81, latent_width=300, latent_height=300,
-                                  share_adaln=True, use_i2v_clip=True, device=dev, init_seed=1234, num_layers=2, **P)
+                                  share_adaln=True, use_i2v_clip=True, device=dev, init_seed=1234, num_layers=LAYERS, **P)
 T, H, W = 21, 64, 112
 g = torch.Generator().manual_seed(1)
 x = torch.randn(1, T, 16, H, W, generator=g).repeat(2, 1, 1, 1, 1).to(dev)
@@ -271,7 +279,7 @@ for mode in ("ulysses", "allgather"):
         d = (full - single).abs()
         a, b = full.flatten().double(), single.flatten().double()
         res[mode] = dict(max=float(d.max()), mean=float(d.mean()), scale=float(single.abs().mean()),
-                         cos=float((a @ b) / (a.norm() * b.norm())), rccl=info.get("rccl_version"))
+                         cos=float((a @ b) / (a.norm() * b.norm())), rccl=info.get("rccl_version"), backend=info.get("backend"))
     del net
     dist.barrier()
 if rank == 0:
@@ -280,24 +288,40 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: two real ranks exchanging over RCCL / xGMI")
-def test_two_real_ranks_over_rccl_fullsize_layers_and_bench_line(tmp_path):
-    """The first multi-GPU box that runs this suite exercises what a 1-GPU box cannot: scail_dit_step_sp on TWO processes whose per-layer
-    exchange is a real RCCL all_to_all_single / all_gather_into_tensor (sat/mpu/ulysses_attn_layer.py:41-110, all_to_all.py:15-108,
-    diffusion_video.py:495-585): 2 full-width layers at L = 48 832, both exchange modes, against the single-rank evaluation; then
-    bench.py --gpus 2 on the tiny config through torch.distributed.run exactly as the driver launches it."""
+def _two_process_ranks(tmp_path, backend, port):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    script = tmp_path / "rccl2.py"
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", SCAIL_TEST_BACKEND=backend)
+    script = tmp_path / "ranks2.py"
     script.write_text(_RCCL2_SCRIPT % ROOT)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29671", str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+                        "--master-port", str(port), str(script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    print("2 ranks over RCCL:", res)
+    print(f"2 ranks ({backend}):", res)
     for mode in ("ulysses", "allgather"):
         m = res[mode]
+        assert m["backend"] == backend
         assert m["mean"] <= 6e-3 * max(m["scale"], 1.0) and m["max"] <= 0.125 and m["cos"] >= 0.9999, (mode, m)
+    return res
+
+
+def test_two_process_ranks_fullsize_layers_host_staged_exchange(tmp_path):
+    """TWO PROCESSES (torch.distributed.run, as the driver launches a scaling job) run scail_dit_step_sp with SCAIL_DIT_CFG_PAIR on 2 full-width
+    layers at L = 48 832, both exchange modes, against the single-rank evaluation -- with the gloo vehicle (both ranks on GPU 0, exchange
+    staged through the host), so that every line of the script below except the transport is exercised on a 1-GPU box."""
+    _two_process_ranks(tmp_path, "gloo", 29673)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: two real ranks exchanging over RCCL / xGMI")
+def test_two_real_ranks_over_rccl_fullsize_layers_and_bench_line(tmp_path):
+    """The first multi-GPU box that runs this suite exercises what a 1-GPU box cannot: the SAME script with backend nccl -- scail_dit_step_sp
+    on two GPUs whose per-layer exchange is a real RCCL all_to_all_single / all_gather_into_tensor (sat/mpu/ulysses_attn_layer.py:41-110,
+    all_to_all.py:15-108, diffusion_video.py:495-585); then bench.py --gpus 2 on the tiny config through torch.distributed.run exactly as
+    the driver launches it."""
+    res = _two_process_ranks(tmp_path, "nccl", 29671)
+    assert res["ulysses"]["rccl"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29672", "bench.py", "--gpus", "2", "--config", "tiny", "--steps", "2", "--warmup", "1",
                         "--no-vae", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)

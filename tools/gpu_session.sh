@@ -13,7 +13,7 @@
 #   vae-prof         kernel stats of the VAE leg (tools/vae_leg_probe.py)
 #   pmc-attn | pmc-gemm | pmc-conv    PMC passes (FETCH_SIZE, WRITE_SIZE, busy counters; each its own rocprofv3 run) -> pmc_summary.txt
 #   traffic          tools/update_traffic.py from pmc_summary.txt (run after the pmc legs)
-#   sp               tools/sp_rank_compute.py 1 2 4 8
+#   sp               tools/sp_rank_compute.py 1 2 4 8                   sp8-prof | sp4-prof   kernel stats of one rank's launches of an 8- / 4-rank step
 #   py:<script> [..] python tools/<script> (arguments up to the next leg name are NOT supported: wrap them in quotes: "py:gemm_probe.py 4")
 TAG=$1; shift
 cd "${GRAFT_REPO_ROOT:-.}"
@@ -59,6 +59,8 @@ for LEG in "$@"; do
                    rm -rf "$O/pmcc_${CC}_$C"; done; done
                  for C in "$BUSY" "$LDS"; do pmc_pass "conv_$(echo $C | cut -d' ' -f1)" conv4 "$C" -- python tools/conv_pmc_probe.py 96 2; done ;;
     traffic)     python tools/update_traffic.py "$O/pmc_summary.txt" "$TAG (tools/gpu_session.sh)" > "$O/traffic_update.log" 2>&1; cp profiles/traffic.json "$O/traffic.json"; tail -30 "$O/traffic_update.log" ;;
+    sp8-prof)    kstats sp8 python tools/sp_rank_compute.py 8 ;;
+    sp4-prof)    kstats sp4 python tools/sp_rank_compute.py 4 ;;
     sp)          timeout 900 python tools/sp_rank_compute.py 1 2 4 8 > "$O/sp_rank_compute.log" 2>&1; cut -c1-220 "$O/sp_rank_compute.log" ;;
     py:*)        S=${LEG#py:}; N=$(echo "$S" | cut -d' ' -f1 | sed 's/\.py$//'); timeout 900 python tools/$S > "$O/$N.log" 2>&1; tail -40 "$O/$N.log" | cut -c1-300 ;;
     abl:*)       S=${LEG#abl:}; N=$(echo "$S" | cut -d' ' -f1 | sed 's/\.py$//'); SCAIL_ABLATIONS=1 timeout 900 python tools/$S > "$O/${N}_abl.log" 2>&1; tail -40 "$O/${N}_abl.log" | cut -c1-300 ;;
