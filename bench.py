@@ -636,7 +636,7 @@ def main():
                     "fit_standard_error": Lnoise / t_cpu * cb["sigma_block"] / cb["t_block"]},
             # spread of this figure over the GPU boxes of the pool (same code, rounds 3-5: host load and NUMA placement differ from box to box);
             # much wider than the fit's standard error above -- quote the baseline as "about 2-2.5 tokens/s"
-            "box_to_box_range": [1.95, 2.5],
+            "box_to_box_range": [1.9, 2.5],
             "sample": f"oracle block (fp32, torch CPU, {cb['threads']} threads = fastest of "
                       + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in sorted(cb["probe"].items())) + " on the 2016x5120x15360 projection) at full "
                       f"width D={p['hidden_size']}, B=2, after one warm-up call: whole block at L = "
