@@ -876,11 +876,13 @@ int scail_attn4_preload() {
 }
 
 static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
-// option "cross4": scail_attn4_x2 for the two-set cross attention where eligible.  OFF by default: measured SLOWER than cross_attn2_kernel at
-// the shipped shape (2.57 vs 2.20 ms at B = 2, 40 heads, 48 832 queries, 512 + 257 keys; profiles/r05_cross_attn_probe.log): with 8 + 5
-// key tiles per item every tile runs in the remainder chain of the pipeline and each set pays the fill / drain of the software pipeline
-// (~8 us per set beside ~17 us of tiles per item); DESIGN.md section 4.3 has the phase budget and what a continuous pipeline would need.
-static int g_cross4 = 0;
+// option "cross4": scail_attn4_x2 for the two-set cross attention.  2 (default) = by key count: measured per 256-row item at the config-2
+// query shape (profiles/r05_cross_x2_phase_probe.log): scail_attn4_x2 22.6 us + 1.5 us per key tile (1.2-1.3 in the hot loop, which a set
+// reaches from 10 tiles on), cross_attn2_kernel 8.5 us + 2.17 us per tile -> the generated kernel wins from 21 tiles of both sets together
+// (1024 + 64 keys: 2.67 vs 2.74 ms; 4096 + 64: 6.39 vs 9.04), the hipcc kernel below -- the SHIPPED shape (512 + 257 keys = 13 tiles:
+// 2.55 vs 2.19 ms) stays on the hipcc kernel.  1 = wherever eligible, 0 = never.  DESIGN.md section 4.3 has the phase budget.
+static int g_cross4 = 2;
+constexpr int64_t k_cross4_min_tiles = 21;
 static int g_attn4_rows = 0;               // query rows per workgroup: 0 = planned per launch (below), 256 / 192 = one height for every launch
 static thread_local int g_attn4_rows_hint = 0;   // set by a caller that knows more than one call can (scail_attn4_rows_hint)
 // ---- launch shape of one attention (round 5) ----------------------------------------------------------------------------------
@@ -980,7 +982,11 @@ int scail_conv4_cont_enable(int v);    // conv.hip
 extern "C" int scail_set_option(const char* name, int value) {
     const std::string k(name ? name : "");
     if (k == "attn4") { g_attn4_mode = value != 0; return 0; }              // 0: 8-wave kernel for every shape
-    if (k == "cross4") { g_cross4 = value != 0; return 0; }                // 0: cross_attn2_kernel of csrc/attn.hip for every shape
+    if (k == "cross4") {                                                    // 2: scail_attn4_x2 from 21 key tiles on; 1: wherever eligible; 0: never
+        SCAIL_REQUIRE(value >= 0 && value <= 2, "cross4 must be 0, 1 or 2");
+        g_cross4 = value;
+        return 0;
+    }
     if (k == "attn4_rows") {                                                // query rows per workgroup of attn4: 0 = per-launch choice
         SCAIL_REQUIRE(value == 0 || value == 192 || value == 256, "attn4_rows must be 0 (automatic), 192 or 256");
         g_attn4_rows = value;
@@ -1217,7 +1223,8 @@ static_assert(sizeof(Attn4X2Args) == 208, "Attn4X2Args must match asmgen/attn4.p
 // missing rows are fetched from 64 rows earlier), 32-bit byte offsets inside a (batch, head) slice, exact reciprocal id decode
 static bool cross4_eligible(int64_t q_rs, int64_t k1_rs, int64_t k2_rs, int64_t o_rs, int64_t Lq, int64_t Lk1, int64_t Lk2, int64_t n_batch, int64_t heads) {
     const int64_t lim = (1ll << 30);
-    return g_cross4 && g_attn4_mode && k1_rs == k2_rs && Lk1 >= 64 && Lk2 >= 64 && Lq * q_rs < lim && Lq * o_rs < lim && Lk1 * k1_rs < lim &&
+    const bool want = g_cross4 == 1 || (g_cross4 == 2 && (Lk1 + 63) / 64 + (Lk2 + 63) / 64 >= k_cross4_min_tiles);
+    return want && g_attn4_mode && k1_rs == k2_rs && Lk1 >= 64 && Lk2 >= 64 && Lq * q_rs < lim && Lq * o_rs < lim && Lk1 * k1_rs < lim &&
            Lk2 * k2_rs < lim && 128 * (Lk1 + 63) < lim && 128 * (Lk2 + 63) < lim && attn4_grid_ok(n_batch, heads, Lq);
 }
 extern "C" int scail_cross_attn2_kernel_for(int64_t q_rs, int64_t k1_rs, int64_t k2_rs, int64_t o_rs, int64_t Lq, int64_t Lk1, int64_t Lk2,

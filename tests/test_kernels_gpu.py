@@ -549,19 +549,20 @@ def test_patchify_embed_and_unpatchify(ops):
 
 # ------------------------------------------------------------------------------------------------
 # fused two-key-set cross attention (text + CLIP, dit_video_crossattn_sc_xc.py:1107-1203)
-@pytest.mark.parametrize("cross4", [1, 0])
+@pytest.mark.parametrize("cross4", [1, 0, 2])
 @pytest.mark.parametrize("B,H,Lq,Lk1,Lk2,shared2", [(2, 2, 300, 512, 257, True), (1, 3, 128, 77, 1, False), (2, 1, 515, 64, 320, False),
                                                      (1, 2, 40, 130, 257, True), (2, 2, 1000, 512, 257, False), (2, 5, 1500, 512, 257, True),
-                                                     (1, 1, 256 * 300 + 17, 64, 65, True)])
+                                                     (1, 1, 256 * 300 + 17, 64, 65, True), (1, 2, 700, 1100, 300, True)])
 def test_cross_attn2_vs_oracle(ops, B, H, Lq, Lk1, Lk2, shared2, cross4):
     from scail_amd import lib as L_
     L_.set_option("cross4", cross4)       # 1: scail_attn4_x2 (generated, persistent workgroups) where eligible; 0: cross_attn2_kernel for every shape
     try:
         which = L_.load().scail_cross_attn2_kernel_for(3 * H * 128, H * 128, H * 128, H * 128, Lq, Lk1, Lk2, B, H)
-        assert which == (4 if (cross4 and Lk1 >= 64 and Lk2 >= 64) else 2)
+        tiles = (Lk1 + 63) // 64 + (Lk2 + 63) // 64
+        assert which == (4 if (Lk1 >= 64 and Lk2 >= 64 and (cross4 == 1 or (cross4 == 2 and tiles >= 21))) else 2)
         _cross_attn2_case(ops, B, H, Lq, Lk1, Lk2, shared2, generated=which == 4)
     finally:
-        L_.set_option("cross4", 0)
+        L_.set_option("cross4", 2)
 
 
 def _cross_attn2_case(ops, B, H, Lq, Lk1, Lk2, shared2, generated=False):
