@@ -52,6 +52,25 @@ def test_bench_two_ranks_one_gpu(mode):
     assert abs(two["config"]["x_abs_mean"] - one["config"]["x_abs_mean"]) < 2e-3 * one["config"]["x_abs_mean"]
 
 
+def test_bench_eight_process_ranks_full_width_two_layers():
+    """The driver's 8-rank launch line, `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`, at FULL WIDTH AND LENGTH (14B
+    layer shapes, 512x896x81f: 8 ulysses ranks of 5 heads x 6 104 token rows) with 2 of the 40 layers, on the gloo vehicle (all ranks on GPU 0, the
+    exchange staged through the host): eight PROCESSES drive scail_dit_step_sp with SCAIL_DIT_CFG_PAIR, the last-layer pruning and the planned
+    attention launch shape through a real process group, and the gathered result must reproduce the single-rank run of the same 2 layers."""
+    common = ["--config", "14b", "--layers", "2", "--steps", "1", "--warmup", "1", "--no-vae", "--no-cpu-baseline", "--no-extra-legs"]
+    one = _run([sys.executable, "bench.py"] + common, timeout=900)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29643",
+           "bench.py", "--gpus", "8"]
+    eight = _run(cmd + common, {"SCAIL_DIST_BACKEND": "gloo"}, base_env=env, timeout=1500)
+    cfg = eight["config"]
+    assert eight["n_gpus"] == 8 and cfg["finite"] and cfg["parallelism"] == "sp8-ulysses" and cfg["path"].startswith("scail_dit_step_sp")
+    assert cfg["sp_check"]["ranks"] == 8 and cfg["attn_query_tile_rows"] == 448
+    assert cfg["result_preserving_prunings"] == {"last_layer_noise_rows_only": True, "cfg_pair_layer0_once": True}
+    assert eight["roofline"]["launches_timed"] == 2 * 2 - 1                       # per CFG element and layer, layer 0 once (cfg pair)
+    assert abs(cfg["x_abs_mean"] - one["config"]["x_abs_mean"]) < 2e-3 * one["config"]["x_abs_mean"]
+
+
 def test_bench_config5_line_reduced_layers():
     """BASELINE config 5 (2 reference frames + 2 pose streams in one token sequence, L = 60 032: the long-sequence self-attention stress) through
     `bench.py --config 14b-2char` at full width and full length with 2 of the 40 layers, so that GPUTEST exercises the code path behind the
