@@ -735,7 +735,10 @@ int scail_gemm4_release_tables() {
 static bool gemm4_eligible(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int64_t N, int64_t K, int epilogue) {
     const int64_t lim = 1ll << 31;
     const int64_t tail = M % 256;
-    return M >= 2048 && (tail == 0 || tail >= 8) && N % 256 == 0 && K % 64 == 0 && K >= 128 &&
+    // M >= 2048: always; 512 <= M < 2048 (round 5: the text K / V projections of the conditioning, 1024 x 10240 x 5120): where the 256 x 256 tiling
+    // still yields at least half a round of tiles (the 128 x 128 hipcc kernel keeps the shapes with few tiles)
+    const bool rows = M >= 2048 || (M >= 512 && (M + 255) / 256 * (N / 256) >= 128);
+    return rows && (tail == 0 || tail >= 8) && N % 256 == 0 && K % 64 == 0 && K >= 128 &&
            (epilogue == SCAIL_EPI_BIAS || epilogue == SCAIL_EPI_GELU_TANH || epilogue == SCAIL_EPI_RESID) &&
            M * ldc < lim && M * std::max<int64_t>(ldr, 1) < lim && 256 * lda < lim;
 }
