@@ -147,6 +147,8 @@ class Cfg:
     nq: int = 4            # (mi = 16, fold, lsum) 16-row query blocks per wave: 4 = 256-row workgroups; 3 = 192-row workgroups (102 MFMAs
                            # per tile instead of 136 beside the same K / V^T traffic): the launch shape of a sequence-parallel rank, where
                            # ceil(workgroups / CUs) x tile cost is lower for the shorter tile (scail_flash_attn_bf16 picks per launch)
+    pksum: bool = False    # (fold, not lsum) row sums on the VALU with v_pk_add_f32 (two fp32 adds per instruction): 32 instructions per tile where lsum
+                           # spends 8 of the tile's 136 MFMAs -- EXPERIMENT of round 5 (measurement build)
     x2: bool = False       # (M16F family) CROSS ATTENTION OVER TWO KEY SETS, persistent workgroups: o = bf16(bf16(softmax(q K1^T) V1) + softmax(q K2^T) V2)
                            # (dit_video_crossattn_sc_xc.py:1107-1203: text + CLIP image tokens).  One workgroup per CU walks over the (pair, query
                            # block) items id, id + n_wgs, ...; per item the Q fragments are loaded once and the key pipeline runs twice (set 0, set 1:
@@ -408,8 +410,12 @@ class Gen:
                     if not nofma and not self.cfg.fold:
                         out.append(isa.vop("v_fma_f32", r, r, S_C, Neg(MC16[qb])))
                     out.append(isa.vop("v_exp_f32", r, r))
-                    if not self.cfg.lsum:
+                    if not self.cfg.lsum and not self.cfg.pksum:
                         out.append(isa.vop("v_add_f32", lsum[qb][j & 1], lsum[qb][j & 1], r))
+                    if self.cfg.pksum and (j & 1):
+                        # row sums on the VALU, two per instruction: l[0:1] += p[j-1 : j]  (32 v_pk_add_f32 per tile instead of the 8 ones-row MFMAs)
+                        lp = V(lsum[qb][0].idx, 2)
+                        out.append(isa.vop("v_pk_add_f32", lp, lp, V(base + j - 1, 2)))
                 for i in range(4):
                     out.append(isa.vop("v_cvt_pk_bf16_f32", regs[i], regs[2 * i], regs[2 * i + 1]))
         n = len(out)
@@ -932,12 +938,12 @@ class Gen:
                     for i in range(1, 4):
                         o.append(isa.vop("v_mov_b32", ONES.sub(i), ONES.sub(0)))
                 if c.ragged:
-                    assert c.lsum, "ragged reuses VT0 / VT1, which only the lsum epilogue leaves free"
+                    assert c.lsum or c.pksum, "ragged reuses VT0 / VT1, which only the lsum epilogue leaves free"
                     o.append(isa.vop("v_mov_b32", VT1, F32(-3.0e38)))             # the masked score (ql is not needed past this point)
                 if c.x2:
                     o += self.x2_set_block(krsb)
                 if c.opt:
-                    assert c.lsum, "the optimistic pass is verified on the matrix-pipe row sums"
+                    assert c.lsum or c.pksum, "the optimistic pass is verified on the row sums"
                     o += [isa.sop("s_mov_b32", S_MODE, I32(0)), isa.sop("s_mov_b32", S_HEAD, F32(c.head))]
                     # ---- (re)start of a pass over the keys: the epilogue jumps back here with S_MODE = 1 when the optimistic pass
                     #      overflowed; the K / V^T descriptors may have walked over the key segments ----
@@ -1389,6 +1395,13 @@ def variant_cfgs():
     out.append(Cfg(name="scail_attn4_m16f_q_la1", **{**Q, "lookahead": 1.0}))
     out.append(Cfg(name="scail_attn4_m16f_q_la4", **{**Q, "lookahead": 4.0}))
     out.append(Cfg(name="scail_attn4_m16f_q_u_le4", late_extra=4.0, v_step=3.0, k_at=20.0, k_step=3.0, dma_k_at=1.0, dma_v_at=33.0, dma_step=8.0, **Q))
+    # round 5: row sums by v_pk_add_f32 instead of the ones-row MFMAs (128 MFMAs per tile), the shipped kernel's other knobs
+    PK = {**P, "opt": True, "pv_qb": True, "lsum": False, "pksum": True}
+    out.append(Cfg(name="scail_attn4_m16f_pk", **PK))
+    out.append(Cfg(name="scail_attn4_m16f_pk_c2", **{**PK, "cap": 2}))
+    out.append(Cfg(name="scail_attn4_m16f_pk_sm52", **{**PK, "sm_end": 52.0}))
+    out.append(Cfg(name="scail_attn4_m16f_pk_c2sm52", **{**PK, "cap": 2, "sm_end": 52.0}))
+    out.append(Cfg(name="scail_attn4_m16f_pk_le2", late_extra=2.0, **PK))
     out.append(Cfg(name="scail_attn4_m16_abl_fma", abl="fma", mi=16, cap=2, lookahead=2.0))
     out.append(Cfg(name="scail_attn4_m16_abl_fma_c3", abl="fma", mi=16, cap=3))
     out.append(Cfg(name="scail_attn4_m16_abl_fma_sm44", abl="fma", mi=16, cap=2, sm_end=44.0, lookahead=2.0))

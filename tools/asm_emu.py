@@ -554,6 +554,9 @@ class Emu:
                 self._wrv(w, d, R(0))
             elif op == "v_add_f32":
                 self._wrv(w, d, _u(F(0) + F(1)))
+            elif op == "v_pk_add_f32":                             # two fp32 adds: register pairs
+                for h in range(2):
+                    self._wrv(w, d.sub(h), _u(_f(self._rd(w, s[0].sub(h))) + _f(self._rd(w, s[1].sub(h)))))
             elif op == "v_sub_f32":
                 self._wrv(w, d, _u(F(0) - F(1)))
             elif op == "v_mul_f32":
