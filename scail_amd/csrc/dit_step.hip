@@ -173,11 +173,6 @@ static int block_cross_mlp(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16*
     DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(ff, FF, lw.w2, lw.b2, hid, D, M, D, FF, SCAIL_EPI_RESID, hid, D, m + 5 * D, 6 * D, rpb, stream));
     return 0;
 }
-static int block_post(scail_dit* h, int64_t i, scail_bf16* hid, scail_bf16* att, scail_bf16* q3, scail_bf16* xn, scail_bf16* ff,
-                      const float* m, const scail_dit_cond* cond, int64_t Btot, int64_t b0, int64_t nb, int64_t rpb, void* stream) {
-    DIT_TRY(block_attn_out(h, i, hid, att, m, nb, rpb, stream));
-    return block_cross_mlp(h, i, hid, att, q3, xn, ff, m, cond, Btot, b0, nb, rpb, stream);
-}
 // Everything after the self-attention of the rows [row0, row0 + rows) of every element (rows == Ltok: the whole block in one set of
 // launches; fewer: per element, the wanted rows only).  pair: hid / att / m of element 1 do not exist yet -- the out-projection runs
 // for element 0 and its result (the hidden states after the self-attention residual) is copied to element 1 before the elements part.
