@@ -615,11 +615,19 @@ def main():
         out["config"]["INVALID_debug_layers"] = args.layers
     if args.latent_hw is not None:
         out["config"]["INVALID_other_resolution"] = list(args.latent_hw)
+    def leg(fn, *a):
+        """a leg after the timed region must never cost the headline line: a failure is reported in its place"""
+        try:
+            return fn(*a)
+        except Exception as e:          # noqa: BLE001
+            torch.cuda.synchronize()
+            return {"error": f"{type(e).__name__}: {e}"[:500]}
+
     if rank == 0 and world == 1 and use_c and args.config == "14b" and args.latent_hw is None and not args.no_extra_legs:
-        out["config"]["sp_compute_side"] = sp_compute_side_leg(net, p, (T, H, W), ctx, clip, dev, t_step, args)
-        out["config"]["multichar"] = multichar_leg(net, p, (T, H, W), ctx, clip, dev, Lt, Lc, args)
+        out["config"]["sp_compute_side"] = leg(sp_compute_side_leg, net, p, (T, H, W), ctx, clip, dev, t_step, args)
+        out["config"]["multichar"] = leg(multichar_leg, net, p, (T, H, W), ctx, clip, dev, Lt, Lc, args)
     if rank == 0 and world == 1 and not args.no_vae:
-        out["config"]["vae"] = vae_leg(dev)
+        out["config"]["vae"] = leg(vae_leg, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(p, L)
         t_cpu = p["num_layers"] * cb["t_block"]
