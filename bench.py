@@ -620,7 +620,10 @@ def main():
         try:
             return fn(*a)
         except Exception as e:          # noqa: BLE001
-            torch.cuda.synchronize()
+            try:
+                torch.cuda.synchronize()
+            except Exception:           # noqa: BLE001
+                pass
             return {"error": f"{type(e).__name__}: {e}"[:500]}
 
     if rank == 0 and world == 1 and use_c and args.config == "14b" and args.latent_hw is None and not args.no_extra_legs:
