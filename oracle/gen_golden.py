@@ -13,6 +13,9 @@ parity tests use are outputs of the reference's own classes on seeded inputs:
   rope_tiny.npz     Rotary3DPositionEmbeddingMixin.rotary/_ref/_pose on a random tensor
   sampler_tiny.npz  RFSampler + Denoiser(RFScaling) + VanillaCFG + OpenAIWrapper, 2 steps
   sigmas50.npz      50-step schedule (sampling.py:888-903)
+  sampler_tiny_50.npz  the SHIPPED step count (yaml :113-131: 50 steps, shift 5, CFG 4) on BASELINE config 1's network
+                    (2-layer / 128-dim, 4x8x8 latent): final latent + the latents after steps 2 / 10 / 25 (the drift curve
+                    of a bf16 network is measured against these)
   sampler_long_tiny.npz  RFSamplerLong (sampling.py:986-1085): 6-frame latent, three overlapping 4-frame tiles, 2 steps
 """
 from __future__ import annotations
@@ -157,6 +160,58 @@ def gen_sampler(cfg, sd, net, inp):
     print("sampler_tiny: xT abs-mean", float(xT.abs().mean()), "sigmas", sig.tolist())
 
 
+def gen_sampler50():
+    """The step count config 2 actually runs (configs/video_model/Wan2.1-i2v-14Bsc-pose-xc-latent.yaml:113-131:
+    num_steps 50, shift_scale 5, VanillaCFG scale 4) through the real RFSampler.__call__ (sampling.py:965-982) +
+    Denoiser + OpenAIWrapper + the config-1 DiT, fp32 on CPU.  The latent after k steps is what the denoiser
+    receives at call k (sampler_step :960-963 is the only writer), recorded for k = 2, 10, 25."""
+    ref = ref_shims.load_reference()
+    sampling, denoiser_mod, wrappers = ref["sampling"], ref["denoiser"], ref["wrappers"]
+    from sgm.modules.diffusionmodules.denoiser_scaling import RFScaling
+    from sgm.modules.diffusionmodules.denoiser_weighting import EpsWeighting
+    cfg = O.DiTConfig(**O.CONFIG1)
+    sd = O.make_state_dict(cfg, seed=1234)
+    net = ref_shims.build_reference_dit(cfg, sd)
+    inp = tiny_inputs()
+
+    class _Den(denoiser_mod.Denoiser):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.weighting = EpsWeighting()
+            self.scaling = RFScaling()
+
+    den = _Den()
+    wrapped = wrappers.OpenAIWrapper(net, compile_model=False, dtype=torch.float32)
+    sampler = sampling.RFSampler(
+        schedule_shift=False, hunyuan_schedule=True, shift_scale=5, mode="normal", num_steps=50, verbose=False,
+        device="cpu",
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.RFDiscretization",
+                               "params": {"reverse": False}},
+        guider_config={"target": "sgm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 4}})
+    g = torch.Generator().manual_seed(50)
+    x0 = torch.randn(1, *inp["x"].shape[1:], generator=g)
+    uc_ctx = torch.zeros_like(inp["ctx"][:1])
+    uc_ctx[:, :1] = bf16r(torch.randn(1, 1, inp["ctx"].shape[-1], generator=g))
+    c_ctx = inp["ctx"][1:2]
+    shared = dict(concat_images=torch.zeros(1, *inp["x"].shape[1:]), ref_concat=inp["ref"],
+                  concat_smpl_render=inp["pose"], image_clip_features=inp["clip"])
+    c = dict(crossattn=c_ctx.clone(), **{k: v.clone() for k, v in shared.items()})
+    uc = dict(crossattn=uc_ctx.clone(), **{k: v.clone() for k, v in shared.items()})
+    seen = []
+
+    def fn(inp_, sigma, cc, **kw):          # diffusion_video.py:555-563
+        seen.append(inp_[:1].detach().clone())          # CFG batch = [x; x] (guiders.py:47-57)
+        return den(wrapped, inp_, sigma, cc, concat_images=None, chunk_dim=None, **kw)
+
+    with torch.no_grad():
+        xT = sampler(fn, x0.clone(), c, uc=uc)
+    assert len(seen) == 50 and torch.equal(seen[0], x0)
+    np.savez_compressed(os.path.join(OUT, "sampler_tiny_50.npz"), seed=1234, x0=x0.numpy(), uc_ctx=uc_ctx.numpy(),
+                        c_ctx=c_ctx.numpy(), ref=inp["ref"].numpy(), pose=inp["pose"].numpy(), clip=inp["clip"].numpy(),
+                        x2=seen[2].numpy(), x10=seen[10].numpy(), x25=seen[25].numpy(), xT=xT.numpy())
+    print("sampler_tiny_50: xT abs-mean", float(xT.abs().mean()), "x0 abs-mean", float(x0.abs().mean()))
+
+
 def gen_sampler_long(cfg, sd, net, inp):
     """RFSamplerLong (sampling.py:986-1085) on a 6-frame latent, two overlapping 4-frame tiles, 2 steps."""
     ref = ref_shims.load_reference()
@@ -238,6 +293,7 @@ def main():
     gen_rope(cfg, net)
     gen_sampler(cfg, sd, net, inp)
     gen_sampler_long(cfg, sd, net, inp)
+    gen_sampler50()
 
 
 if __name__ == "__main__":

@@ -73,6 +73,20 @@ def test_sampler_matches_reference(golden_dir):
     torch.testing.assert_close(xT, g["xT"], rtol=5e-5, atol=5e-5)
 
 
+def test_sampler_50_steps_matches_reference(golden_dir):
+    """The shipped step count (50, shift 5, CFG 4) on BASELINE config 1's network: the restatement follows the real
+    reference's trajectory (latents after 2 / 10 / 25 / 50 steps), i.e. the oracle is pinned over the whole schedule and
+    not just its first two steps."""
+    g = _load(golden_dir, "sampler_tiny_50.npz")
+    cfg = O.DiTConfig(**O.CONFIG1)
+    sd = O.make_state_dict(cfg, seed=int(g["seed"]))
+    xT, traj = O.sample(cfg, sd, g["x0"], g["c_ctx"], g["uc_ctx"], g["ref"], g["pose"], g["clip"], num_steps=50)
+    assert len(traj) == 50
+    for k in (2, 10, 25):
+        torch.testing.assert_close(traj[k - 1], g[f"x{k}"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(xT, g["xT"], rtol=2e-4, atol=2e-4)
+
+
 def test_sampler_long_matches_reference(golden_dir):
     """RFSamplerLong (temporal tiling, sampling.py:986-1085) on the real reference vs the restatement."""
     g = _load(golden_dir, "sampler_long_tiny.npz")
