@@ -180,10 +180,10 @@ def run(cfg, inputs=None, steps=None, load=None, seed=1234, device="cuda", frame
     if callable(inputs):                                      # file-based request: needs the network's text width
         inputs = inputs(net.text_dim)
     req = inputs or synthetic_request(H, W, frames, net.text_dim, 512 if net.text_dim == 4096 else 12, device, seed)
-    vae = engine.first_stage_model
     t0 = time.perf_counter()
-    ref_lat = vae.encode([req["ref"]])
-    pose_lat = vae.encode([req["pose"]])                                    # already half resolution (sample_video.py:350-351)
+    # model.encode_first_stage(..., force_encode=True): VAE mean x scale_factor (sample_video.py:366, :381; diffusion_video.py:311-331)
+    ref_lat = engine.encode_first_stage(req["ref"].unsqueeze(0), None, force_encode=True)
+    pose_lat = engine.encode_first_stage(req["pose"].unsqueeze(0), None, force_encode=True)   # already half resolution (:350-351)
     ref_concat = ref_lat.permute(0, 2, 1, 3, 4).contiguous().to(torch.bfloat16)      # B C T H W -> B T C H W
     pose_latent = pose_lat.permute(0, 2, 1, 3, 4).contiguous().to(torch.bfloat16)
     T, C, h, w = pose_latent.shape[1], ref_concat.shape[2], ref_concat.shape[3], ref_concat.shape[4]

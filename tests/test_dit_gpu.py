@@ -408,6 +408,61 @@ def test_cli_tiny_end_to_end():
     assert torch.isfinite(video).all() and 0.0 <= float(video.min()) and float(video.max()) <= 1.0
 
 
+def test_request_pipeline_composition_vs_reference_golden(golden_dir, tmp_path, capsys):
+    """The encode -> sample -> decode COMPOSITION against the reference's own (e2e_tiny.npz, oracle/gen_golden_e2e.py: the real
+    SATVideoDiffusionEngine.encode_first_stage / sample / decode_first_stage with the script lines of sample_video.py:338-391,
+    :455-494 between them): reference frame (examples/001/ref.jpg at the tiny size) and a driving clip as FILES through
+    cli.request_from_files (loaders, [-1, 1] mapping, half-resolution pose), cli.run (VAE mean x scale factor 0.8, layout
+    permutes, 3 CFG steps on the global RNG stream's noise, 1 / scale factor, decode, clamp((x + 1) / 2)).  Values, not shapes."""
+    import copy
+    from PIL import Image
+    from oracle import wan_vae_oracle as V
+    from scail_amd import cli
+    g = _load(golden_dir, "e2e_tiny.npz")
+    H, W = (int(v) for v in g["size"])
+    Image.fromarray(g["ref_u8"][0].permute(1, 2, 0).numpy()).save(tmp_path / "ref.png")               # lossless
+    np.save(tmp_path / "rendered.npy", g["pose_u8"].numpy())
+    torch.save({"context": g["ctx"], "uncond_context": g["uc_ctx"], "clip": g["clip"]}, tmp_path / "cond.pt")
+    cfg = copy.deepcopy(cli.TINY)
+    cfg["model"]["scale_factor"] = float(g["scale_factor"])
+    cfg["model"]["sampler_config"]["params"]["num_steps"] = int(g["steps"])
+    cfg["args"]["sampling_image_size"] = [H, W]
+    engine = cli.build_engine(cfg)
+    dcfg = O.DiTConfig(**O.CONFIG1)
+    missing, unexpected = engine.network.load_state_dict(O.make_state_dict(dcfg, seed=int(g["dit_seed"])), strict=True)
+    assert not missing and not unexpected
+    missing, unexpected = engine.first_stage_model.model.load_state_dict(
+        V.make_state_dict(V.VAEConfig(dim=32, z_dim=16), seed=int(g["vae_seed"])), strict=True)
+    assert not missing and not unexpected
+    req, size = cli.request_from_files(str(tmp_path / "ref.png"), str(tmp_path / "rendered.npy"), cfg, str(tmp_path / "cond.pt"),
+                                       text_dim=engine.network.text_dim)
+    assert size == (H, W) and req["ref"].shape == (3, 1, H, W) and req["pose"].shape == (3, 13, H // 2, W // 2)
+    # stage 1: the two conditioning latents (b c t h w -> b t c h w, scale factor applied)
+    ref_concat = engine.encode_first_stage(req["ref"].unsqueeze(0), None, force_encode=True).permute(0, 2, 1, 3, 4)
+    smpl = engine.encode_first_stage(req["pose"].unsqueeze(0), None, force_encode=True).permute(0, 2, 1, 3, 4)
+    torch.testing.assert_close(ref_concat.float().cpu(), g["ref_concat"], rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(smpl.float().cpu(), g["smpl_render_latent"], rtol=3e-2, atol=3e-2)
+    # stage 2 + 3: the driver
+    video, z, _ = cli.run(cfg, req, engine=engine, seed=int(g["noise_seed"]))
+    assert z.shape == g["samples_z"].shape and video.shape == (1, 3, 13, H, W)
+    samples = video.permute(0, 2, 1, 3, 4).float().cpu()                                               # sample_video.py:493
+    want_z, want = g["samples_z"], g["samples"].float()
+    dz, dv = (z.float().cpu() - want_z).abs(), (samples - want).abs()
+    with capsys.disabled():
+        print("\npipeline vs reference: latent max %.4f mean %.5f cos %.6f | video max %.4f mean %.5f cos %.6f"
+              % (float(dz.max()), float(dz.mean()), _cos(z.float().cpu(), want_z), float(dv.max()), float(dv.mean()), _cos(samples, want)))
+    # latents: the sampler tests' bound (CFG carries 7 x the bf16 forward error) on top of conditioning latents that are
+    # themselves bf16 VAE outputs
+    assert _cos(z.float().cpu(), want_z) >= 0.999
+    assert float(dz.mean()) < 2e-2
+    torch.testing.assert_close(z.float().cpu(), want_z, rtol=3e-2, atol=0.14)
+    # video in [0, 1]: the VAE tests' 3e-2 on [-1, 1] is 1.5e-2 here, plus the latent error through the decoder
+    assert _cos(samples, want) >= 0.999
+    assert float(dv.mean()) < 1e-2
+    # a missing scale factor on either side would not pass: 0.8 vs 1.0 on the conditioning latents is a 25 % error
+    assert float((ref_concat.float().cpu() / float(g["scale_factor"]) - g["ref_concat"]).abs().mean()) > 0.05
+
+
 def test_cli_from_files_to_saved_video(tmp_path):
     """The request as files (reference image + driving video) through preprocessing, VAE, sampler, VAE, and the saved result
     read back (sample_video.py:300-351 / :484-507; containers: scail_amd/video_io.py)."""

@@ -87,6 +87,36 @@ def test_sampler_50_steps_matches_reference(golden_dir):
     torch.testing.assert_close(xT, g["xT"], rtol=2e-4, atol=2e-4)
 
 
+def test_request_pipeline_composition_matches_reference(golden_dir):
+    """e2e_tiny.npz (oracle/gen_golden_e2e.py): the reference's own encode_first_stage -> sample -> decode_first_stage chain with the
+    script lines of sample_video.py between them.  The restatements composed the same way (pixels -> half-resolution pose ->
+    VAE mean x scale factor -> b c t h w <-> b t c h w -> 3 CFG / Euler steps on the global RNG stream's noise -> 1 / scale
+    factor -> decode -> clamp((x + 1) / 2)) reproduce every stage -- the checker of tests/test_dit_gpu.py's pipeline test."""
+    import torch.nn.functional as F
+    from oracle import wan_vae_oracle as V
+    g = _load(golden_dir, "e2e_tiny.npz")
+    bf = lambda t: t.to(torch.bfloat16).float()
+    sf = float(g["scale_factor"])
+    vcfg = V.VAEConfig(dim=32, z_dim=16)
+    vsd = V.make_state_dict(vcfg, seed=int(g["vae_seed"]))
+    cfg = O.DiTConfig(**O.CONFIG1)
+    sd = O.make_state_dict(cfg, seed=int(g["dit_seed"]))
+    ref_px = bf((g["ref_u8"].float() / 255.0) * 2 - 1)                                        # (1, 3, H, W)
+    pose_px = (g["pose_u8"].permute(0, 3, 1, 2).float() - 127.5) / 127.5
+    smpl_px = bf(F.interpolate(pose_px, scale_factor=0.5, mode="bilinear", align_corners=False))
+    ref_concat = (sf * V.encode(vcfg, vsd, ref_px.unsqueeze(2))).permute(0, 2, 1, 3, 4)      # B C 1 H W -> B 1 C H W
+    smpl_lat = (sf * V.encode(vcfg, vsd, smpl_px.permute(1, 0, 2, 3).unsqueeze(0))).permute(0, 2, 1, 3, 4)
+    torch.testing.assert_close(ref_concat, g["ref_concat"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(smpl_lat, g["smpl_render_latent"], rtol=1e-4, atol=1e-4)
+    torch.manual_seed(int(g["noise_seed"]))
+    x0 = torch.randn(1, smpl_lat.shape[1], 16, ref_concat.shape[3], ref_concat.shape[4])
+    z, _ = O.sample(cfg, sd, x0, g["ctx"], g["uc_ctx"], ref_concat, smpl_lat, g["clip"], num_steps=int(g["steps"]))
+    z = z.permute(0, 2, 1, 3, 4)
+    torch.testing.assert_close(z, g["samples_z"], rtol=2e-4, atol=2e-4)
+    video = torch.clamp((V.decode(vcfg, vsd, z / sf).permute(0, 2, 1, 3, 4) + 1.0) / 2.0, 0.0, 1.0)
+    torch.testing.assert_close(video, g["samples"].float(), rtol=0, atol=1e-3)             # the fixture stores the video as fp16
+
+
 def test_sampler_long_matches_reference(golden_dir):
     """RFSamplerLong (temporal tiling, sampling.py:986-1085) on the real reference vs the restatement."""
     g = _load(golden_dir, "sampler_long_tiny.npz")
