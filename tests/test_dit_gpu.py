@@ -227,10 +227,12 @@ def test_sampler_fifty_steps_drift_vs_reference_golden(golden_dir, capsys):
         for row in curve:
             print("   step %2d  max %.4f  mean %.5f  cos %.6f" % row)
     assert min(r[3] for r in curve) >= 0.999
-    # element bound: the 2-step tests' 0.14 is 7 x 2e-2 x sum |dsigma| (CFG carries (2 * 4 - 1) x the forward error); over the
-    # whole schedule sum |dsigma| is again 1, and the per-step errors are not all of one sign -> the same bound holds at step 50
-    torch.testing.assert_close(xT.cpu(), g["xT"], rtol=3e-2, atol=0.14)
-    assert curve[-1][2] < 1.5e-2
+    # element bound: the 2-step tests' 0.14 is 7 x 2e-2 x sum |dsigma| (CFG carries (2 * 4 - 1) x the forward error) -- a worst
+    # case; over the whole schedule sum |dsigma| is again 1 and the per-step errors are not of one sign.  Measured (round 6, MI355X):
+    # step 2 max 0.0005 / mean 0.00009, step 10 0.0020 / 0.00032, step 25 0.0052 / 0.00080, step 50 0.0199 / 0.00359, cosine
+    # 0.999995 -- the error grows with 1 / sigma-like steepness near the end of the schedule but stays 7x inside the bound.
+    torch.testing.assert_close(xT.cpu(), g["xT"], rtol=3e-2, atol=0.05)
+    assert curve[-1][2] < 8e-3 and curve[0][1] < 5e-3
     # the reference's protocol path (Denoiser + OpenAIWrapper + VanillaCFG objects) over the same 50 steps
     den = S.Denoiser()
     wrapped = S.OpenAIWrapper(net, dtype=torch.bfloat16)
@@ -458,7 +460,7 @@ def test_request_pipeline_composition_vs_reference_golden(golden_dir, tmp_path, 
     torch.testing.assert_close(z.float().cpu(), want_z, rtol=3e-2, atol=0.14)
     # video in [0, 1]: the VAE tests' 3e-2 on [-1, 1] is 1.5e-2 here, plus the latent error through the decoder
     assert _cos(samples, want) >= 0.999
-    assert float(dv.mean()) < 1e-2
+    assert float(dv.mean()) < 1e-2 and float(dv.max()) < 6e-2          # measured (round 6): mean 0.0028, max 0.023; latents mean 0.011
     # a missing scale factor on either side would not pass: 0.8 vs 1.0 on the conditioning latents is a 25 % error
     assert float((ref_concat.float().cpu() / float(g["scale_factor"]) - g["ref_concat"]).abs().mean()) > 0.05
 
