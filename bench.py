@@ -504,10 +504,21 @@ def main():
         ms, n_att = cs.profile_read(cs.PROF_SELF_ATTN)
         attn_ms = ms / n_att if n_att else None
         gemm_ms, gemm_n = cs.profile_read(cs.PROF_GEMM)
+        # workgroups of the timed self-attention launches that restarted after an overflow of the optimistic pass (0 on this synthetic data;
+        # on trained weights it says whether the measured rate holds: profiles/r06_attn_restart_sensitivity.log)
+        attn_restarts = cs.profile_read(cs.PROF_ATTN_RESTARTS)[1]
+        xch = None
+        if sp is not None:
+            # the EXPOSED part of the layer exchange on this rank: event pairs around nothing but the launch stream's waits for the collectives
+            fw, n_fw = cs.profile_read(cs.PROF_XCH_FWD_WAIT)
+            bw, n_bw = cs.profile_read(cs.PROF_XCH_BACK_WAIT)
+            xch = {"fwd_wait_ms_per_step": fw / args.steps, "back_wait_ms_per_step": bw / args.steps, "waits_per_step": (n_fw + n_bw) / args.steps,
+                   "rank": rank, "timed_by": "scail_dit_profile categories 3 / 4 (event pairs around the stream waits inside the C executor)"}
         cs.profile(False)
     else:
         attn_ms = timer.mean_ms("self_attn")
         n_att = len(timer.events.get("self_attn", []))
+        attn_restarts = None
     # one launch = local queries x all keys; in ulysses mode a launch covers heads/world heads of ONE source rank's queries
     sp_mode = sp.resolve_mode(nh) if sp is not None else "none"
     attn_heads = nh // world if sp_mode == "ulysses" else nh
@@ -545,10 +556,10 @@ def main():
     # or the launch shape differs, so the field cannot go stale silently
     traffic = None
     Dm = p["hidden_size"]
-    if sp_mode == "ulysses":                 # (L, Dn) matrices of this rank's head group (parallel.py)
-        strides = (Dm // world, Dm // world, Dm // world)
-    elif sp_mode == "allgather":             # local q rows of the fused qkv buffer, gathered K rows
-        strides = (3 * Dm, Dm, Dm)
+    if sp_mode == "ulysses":                 # column thirds of the received (L, 3 Dn) q | k | v matrix of this rank's head group (parallel.py)
+        strides = (3 * Dm // world, 3 * Dm // world, Dm // world)
+    elif sp_mode == "allgather":             # local q rows of the fused qkv buffer, gathered k | v rows
+        strides = (3 * Dm, 2 * Dm, Dm)
     else:
         strides = (3 * Dm, 3 * Dm, Dm)
     which = lib.load().scail_flash_attn_kernel_for(*strides, attn_Lq, L, 0, 1)
@@ -579,8 +590,14 @@ def main():
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": (ach / PEAK_BF16_TFLOPS) if ach else None,
                      "traffic": traffic, "flop_per_launch": attn_flops, "ms_per_launch": attn_ms,
                      "launches_timed": n_att,
+                     "attn_restarts_per_launch": (attn_restarts / n_att) if (attn_restarts is not None and n_att) else None,
                      "timed_by": "scail_dit_profile (event pairs inside the C executor)" if use_c else "HIP events around the tagged host launches"},
     }
+    if use_c and sp is not None and xch is not None:
+        # what the exchange adds to this rank's step (the rest of it runs under the other CFG element's kernels); with the per-rank compute
+        # known from config.sp_compute_side of the 1-GPU line, a scaling run explains itself: t_step(N) ~ compute side + these waits
+        out["config"]["exchange_exposed"] = xch
+        out["config"]["exchange_collectives_per_layer"] = 4 if sp_mode == "ulysses" else 2
     if not use_c:
         out["config"]["path"] = "per-op host path (scail_amd.dit._run)"
     elif n_char > 1:

@@ -110,16 +110,19 @@ int scail_dit_block(scail_dit* h, int64_t layer, scail_bf16* hidden, const float
  * with the latent split and rank-shifted RoPE of diffusion_video.py:495-585 and dit...:1578-1585) ----------------------------------------
  * Each rank holds an aligned token slab (B, Ltok, D) of [ref | noise | pose] tokens.  A block is per-token except for the self-attention,
  * whose exchange comes in two modes:
- *   SCAIL_SP_ULYSSES    q, k, v head <-> sequence all-to-alls after norm + RoPE, attention over the FULL sequence for heads / ranks heads,
- *                       one all-to-all back (heads % ranks == 0).  Buffers (bf16, caller-owned, contiguous):
- *                         send, recv  [B][3][ranks][Ltok][D / ranks]   (q | k | v; send: one slab per destination rank; recv: per source rank,
- *                                                                       i.e. one (ranks * Ltok, D / ranks) matrix in rank-major token order)
+ *   SCAIL_SP_ULYSSES    q, k, v head <-> sequence all-to-all after norm + RoPE -- ONE collective for the three (the reference: three,
+ *                       ulysses_attn_layer.py:65-80) --, attention over the FULL sequence for heads / ranks heads, one all-to-all back
+ *                       (heads % ranks == 0).  Buffers (bf16, caller-owned, contiguous):
+ *                         send, recv  [B][ranks][Ltok][3 * D / ranks] (send: one message per destination rank, q | k | v of that rank's heads side
+ *                                                                       by side in a row; recv: per source rank, i.e. one (ranks * Ltok, 3 D / ranks)
+ *                                                                       matrix in rank-major token order whose column thirds are q, k, v)
  *                         ofull, back [B][ranks][Ltok][D / ranks]      (attention output of all tokens for my heads; my tokens for all head groups)
- *   SCAIL_SP_ALLGATHER  ONE exchange: all-gather of the post-RoPE K rows and of the V rows.  Buffers:
- *                         send [B][2][Ltok][D] (k rows | v rows),  recv [B][2][ranks][Ltok][D];  ofull / back unused (NULL).
+ *   SCAIL_SP_ALLGATHER  ONE exchange: all-gather of the post-RoPE K rows and of the V rows as ONE collective.  Buffers:
+ *                         send [B][Ltok][2 D] (k | v side by side),  recv [B][ranks][Ltok][2 D];  ofull / back unused (NULL).
  * The executor enqueues every kernel and calls `exchange` where a collective has to be started or awaited:
  *   SCAIL_SP_FWD_START   element b's send buffers are complete on `stream` (stream order): start its forward collectives
- *                        (ulysses: send[b][j] -> recv[b][j] for j = 0..2, all-to-all with equal splits; allgather: send[b][j] -> recv[b][j], j = 0, 1)
+ *                        (ulysses: all-to-all send[b] -> recv[b] with equal splits; allgather: all-gather send[b] -> recv[b]): 2 collectives per
+ *                        element and layer in ulysses mode (this one + the way back), 1 in all-gather mode
  *   SCAIL_SP_FWD_WAIT    make `stream` wait for them (the kernels enqueued next read recv[b])
  *   SCAIL_SP_BACK_START  ulysses: ofull[b] is complete on `stream`: start the all-to-all ofull[b] -> back[b]
  *   SCAIL_SP_BACK_WAIT   make `stream` wait for it
@@ -182,6 +185,15 @@ int scail_dit_block_sp(scail_dit* h, int64_t layer, scail_bf16* hidden, const fl
 #define SCAIL_DIT_PROF_SELF_ATTN 0   /* scail_flash_attn_bf16 of the self-attention (dit...:1058-1105) */
 #define SCAIL_DIT_PROF_GEMM 1        /* the six per-token GEMMs of a block: qkv, attention out, cross q, cross out, MLP up, MLP down */
 #define SCAIL_DIT_PROF_CROSS_ATTN 2  /* scail_cross_attn2_bf16 (dit...:1107-1203) */
+/* sequence-parallel steps: the EXPOSED part of the layer exchange -- the event pair brackets nothing but the launch stream's wait for
+ * the collective (SCAIL_SP_FWD_WAIT / SCAIL_SP_BACK_WAIT), so its time is what the exchange adds to the step (0 when the collective
+ * finished under the other CFG element's kernels); launches = waits.  An N-rank bench line carries both (bench.py `exchange_exposed`). */
+#define SCAIL_DIT_PROF_XCH_FWD_WAIT 3
+#define SCAIL_DIT_PROF_XCH_BACK_WAIT 4
+/* not a time: `launches` = workgroups of the profiled self-attention launches that RESTARTED (the optimistic pass of scail_attn4_m16f
+ * overflowed, scail_hip.h scail_flash_attn_count_restarts; a restarted workgroup costs about twice), ms_total = 0.  0 on random data;
+ * on real weights it says whether the kernel's measured rate holds (bench.py `roofline.attn_restarts_per_launch`). */
+#define SCAIL_DIT_PROF_ATTN_RESTARTS 5
 int scail_dit_profile(scail_dit* h, int enable);
 int scail_dit_profile_read(scail_dit* h, int category, double* ms_total, int64_t* launches);
 

@@ -47,10 +47,13 @@ from typing import List
 from . import isa, sched
 from .isa import A, S, V, I32, F32, Neg, VCC, EXEC, M0, Instr
 
-KERNARG_SIZE = 160
+KERNARG_SIZE = 168
 # q k vt o | q_bs q_rs k_ss k_bs k_rs vt_ss vt_bs o_bs o_rs | heads Lq Lk Lkp n_seg | sl2 thr | nqb magic_nqb magic_heads xcd_mode |
-# items_per_xcd (xcd_mode 2) n_items item0 (xcd_modes 0 / 2: this launch covers items [item0, item0 + n_items) of the pair-major list)
-KERNARG_FMT = "<4Q9q5iffiIIiiii"
+# items_per_xcd (xcd_mode 2) n_items item0 (xcd_modes 0 / 2: this launch covers items [item0, item0 + n_items) of the pair-major list) |
+# restarts: optional device pointer to a u32 counter (0 = none), incremented once per WORKGROUP that leaves the optimistic pass and runs
+# again with the lazy-maximum loop (read in the restart path only: nothing in the hot loop)
+KERNARG_FMT = "<4Q9q5iffiIIiiiiQ"
+KARG_RESTARTS = 160
 
 
 # x2 kernels: appended to the base block -- k2 vt2 | k2_bs vt2_bs | Lk2 Lkp2 | n_wgs pad
@@ -92,7 +95,7 @@ def xcd_mode(n_batch: int, heads: int) -> int:
 
 
 def pack_args(q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=1,
-              mode=None, rows: int = 256, item0: int = 0, n_items: int = None) -> bytes:
+              mode=None, rows: int = 256, item0: int = 0, n_items: int = None, restarts: int = 0) -> bytes:
     """item0 / n_items (xcd_modes 0 and 2): the launch covers items [item0, item0 + n_items) of the pair-major (pair, query block) list --
     how scail_flash_attn_bf16 splits one attention into a 256-row launch of whole rounds and a 192-row launch for the rest."""
     nqb = (Lq + rows - 1) // rows
@@ -100,7 +103,7 @@ def pack_args(q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_r
     items = nqb * heads * n_batch - item0 if n_items is None else n_items
     assert item0 == 0 or mode != 1
     b = struct.pack(KERNARG_FMT, q, k, vt, o, q_bs, q_rs, k_ss, k_bs, k_rs, vt_ss, vt_bs, o_bs, o_rs, heads, Lq, Lk, Lkp, n_seg, sl2, thr,
-                    nqb, magic31(nqb), magic31(heads), mode, (items + 7) // 8, items, item0)
+                    nqb, magic31(nqb), magic31(heads), mode, (items + 7) // 8, items, item0, restarts)
     assert len(b) == KERNARG_SIZE
     return b
 
@@ -1129,6 +1132,16 @@ class Gen:
                       isa.vop("v_readfirstlane_b32", ST[2], flag),
                       isa.barrier(),                     # every wave has read the flags before a restarting workgroup's DMA reuses the ring
                       isa.nop(3), isa.sop("s_cmp_eq_u32", None, ST[2], I32(0)), isa.branch("s_cbranch_scc1", "L_store"),
+                      # restart counter (optional kernel argument): wave 0, one lane, one atomic per restarting workgroup; drained
+                      # before the pass starts again (the ring's counted vmcnt waits must not see it)
+                      isa.sop("s_cmp_lg_u32", None, S_WAVE, I32(0)), isa.branch("s_cbranch_scc1", "L_nocount"),
+                      isa.s_load(2, S(ST[4].idx, 2), S_KARG, KARG_RESTARTS), isa.waitcnt(lgkmcnt=0),
+                      isa.sop("s_cmp_eq_u64", None, S(ST[4].idx, 2), I32(0)), isa.branch("s_cbranch_scc1", "L_nocount"),
+                      isa.vop("v_mov_b32", addr, I32(0)), isa.vop("v_mov_b32", flag, I32(1)),
+                      Instr("s_mov_b64", [S_SAVE], [EXEC], cls=isa.SALU), Instr("s_mov_b64", [EXEC], [I32(1)], cls=isa.SALU),
+                      isa.global_atomic_add(addr, flag, S(ST[4].idx, 2), extra_reads=[EXEC]), isa.waitcnt(vmcnt=0),
+                      Instr("s_mov_b64", [EXEC], [S_SAVE], cls=isa.SALU),
+                      isa.label("L_nocount"), isa.nop(3),
                       isa.sop("s_mov_b32", S_MODE, I32(1)), isa.branch("s_branch", "L_restart"),
                       isa.label("L_store"), isa.nop(7)]
 

@@ -104,7 +104,7 @@ def classify(op: str) -> str:
         return DS_WRITE
     if op.startswith("buffer_load") or op.startswith("global_load"):
         return VMEM_LOAD
-    if op.startswith("buffer_store") or op.startswith("global_store"):
+    if op.startswith("buffer_store") or op.startswith("global_store") or op.startswith("global_atomic"):
         return VMEM_STORE
     if op in _TRANS_OPS:
         return TRANS
@@ -294,6 +294,14 @@ def global_store(ndw: int, vaddr: Reg, data: Reg, offset: int = 0, saddr: Option
     base = str(saddr) if saddr is not None else "off"
     i = Instr(op, [], [vaddr, data] + ([saddr] if saddr is not None else []), offset=offset, **kw)
     i.text = f"{op} {vaddr}, {data}, {base}" + (f" offset:{offset}" if offset else "")
+    return i
+
+
+def global_atomic_add(vaddr: Reg, data: Reg, saddr: Reg, offset: int = 0, **kw) -> Instr:
+    """global_atomic_add (u32, no return value): mem[saddr + vaddr + offset] += data, per active lane."""
+    assert data.n == 1 and vaddr.n == 1 and saddr.n == 2
+    i = Instr("global_atomic_add", [], [vaddr, data, saddr], offset=offset, **kw)
+    i.text = f"global_atomic_add {vaddr}, {data}, {saddr}" + (f" offset:{offset}" if offset else "")
     return i
 
 

@@ -21,6 +21,7 @@
 // in); a row's two lanes (g = 0, 1) keep the same m and separate partial l that are added once at
 // the end.  LDS rows are padded (K: 272 B, V^T: 144 B) so every ds_read_b128 service group touches
 // 16 distinct 16-byte slots.
+#include <atomic>
 #include <map>
 #include <mutex>
 #include "common.h"
@@ -824,8 +825,9 @@ struct Attn4Args {
                                  // 2 (any pair count): XCD x walks the x-th of 8 equal runs of the pair-major (pair, query block) items
     int32_t items_per_xcd;       // xcd_mode 2: ceil(n_items / 8); the grid is 8 * items_per_xcd
     int32_t n_items, item0;      // the launch covers items [item0, item0 + n_items) of the pair-major list (item0 == 0 in xcd_mode 1)
+    uint32_t* restarts;          // optional device counter: + 1 per workgroup that restarts after an overflow of the optimistic pass (NULL: none)
 };
-static_assert(sizeof(Attn4Args) == 160, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
+static_assert(sizeof(Attn4Args) == 168, "Attn4Args must match asmgen/attn4.py KERNARG_SIZE");
 // Code objects, kernel handles (and the GEMM's tile-order tables, gemm.hip) belong to ONE device: they are cached per HIP device
 // id, so a process that drives several GPUs (a DiT on cuda:0 and another engine on cuda:1, a threaded multi-GPU host) launches the
 // module loaded on the device that is current at the call.
@@ -834,8 +836,8 @@ static const char* const k_attn4_default = "scail_attn4_m16f";   // the shipped 
 static std::string g_attn4_name = k_attn4_default;               // A/B variants of the measurement build replace it ("attn4_kernel:<suffix>")
 static std::map<std::pair<int, std::string>, hipFunction_t> g_attn4_fns;
 static std::mutex g_attn4_mutex;
-static float g_attn4_thr_log2 = 8.0f;      // lazy-rescale threshold: P <= 2^thr
-static int g_attn4_xcd = 1;                // XCD-aware workgroup-id decode (A/B knob "attn4_xcd")
+static std::atomic<float> g_attn4_thr_log2{8.0f};   // lazy-rescale threshold: P <= 2^thr
+static std::atomic<int> g_attn4_xcd{1};      // XCD-aware workgroup-id decode (A/B knob "attn4_xcd")
 
 static int attn4_function(const std::string& name, hipFunction_t* fn) {
     std::lock_guard<std::mutex> lk(g_attn4_mutex);
@@ -870,21 +872,34 @@ static int attn4_function(const std::string& name, hipFunction_t* fn) {
 
 // load the embedded code object and resolve the shipped kernel now (scail_dit_create calls this: a first launch inside
 // hipStreamBeginCapture must not have to load a module)
+static int attn4_cu_count();
 int scail_attn4_preload() {
     hipFunction_t fn;
-    return attn4_function(k_attn4_default, &fn);
+    // every shipped kernel the launch plan / the cross-attention dispatch can pick, and the per-device CU count the plan reads
+    for (const char* name : {"scail_attn4_m16f", "scail_attn4_m16f_q3", "scail_attn4_x2"})
+        if (int rc = attn4_function(name, &fn)) return rc;
+    return attn4_cu_count() > 0 ? 0 : 2;
 }
 
-static int g_attn4_mode = 1;               // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
+static std::atomic<int> g_attn4_mode{1};     // 1 = use attn4 where eligible (default), 0 = never (8-wave kernels only)
 // option "cross4": scail_attn4_x2 for the two-set cross attention.  2 (default) = by key count: measured per 256-row item at the config-2
 // query shape (profiles/r05_cross_x2_phase_probe.log): scail_attn4_x2 22.6 us + 1.5 us per key tile (1.2-1.3 in the hot loop, which a set
 // reaches from 10 tiles on), cross_attn2_kernel 8.5 us + 2.17 us per tile -> the generated kernel wins from 21 tiles of both sets together
 // (1024 + 64 keys: 2.67 vs 2.74 ms; 4096 + 64: 6.39 vs 9.04), the hipcc kernel below -- the SHIPPED shape (512 + 257 keys = 13 tiles:
 // 2.55 vs 2.19 ms) stays on the hipcc kernel.  1 = wherever eligible, 0 = never.  DESIGN.md section 4.3 has the phase budget.
-static int g_cross4 = 2;
+static std::atomic<int> g_cross4{2};
 constexpr int64_t k_cross4_min_tiles = 21;
-static int g_attn4_rows = 0;               // query rows per workgroup: 0 = planned per launch (below), 256 / 192 = one height for every launch
+// Option state is read by every launching thread and may be set by another one: plain loads / stores of std::atomic<int> (relaxed is
+// enough: an option is a hint about FUTURE launches, a launch reads each option once).  include/scail_hip.h scail_set_option.
+static std::atomic<int> g_attn4_rows{0};       // query rows per workgroup: 0 = planned per launch (below), 256 / 192 = one height for every launch
+static std::atomic<int> g_attn4_cus{0};        // option "attn4_cus": CUs the launch plan may count on (0 = all CUs of the device)
 static thread_local int g_attn4_rows_hint = 0;   // set by a caller that knows more than one call can (scail_attn4_rows_hint)
+static thread_local uint32_t* g_attn4_restart_ctr = nullptr;   // scail_flash_attn_count_restarts (include/scail_hip.h)
+extern "C" int scail_flash_attn_count_restarts(uint32_t* device_counter) {
+    SCAIL_REQUIRE((reinterpret_cast<uintptr_t>(device_counter) & 3) == 0, "the restart counter must be 4-byte aligned");
+    g_attn4_restart_ctr = device_counter;
+    return 0;
+}
 // ---- launch shape of one attention (round 5) ----------------------------------------------------------------------------------
 // One workgroup occupies a CU (512 registers per lane, one wave per SIMD), so W workgroups take ceil(W / CUs) rounds of one tile each, and
 // a launch whose last round is mostly empty wastes it: a sequence-parallel rank's launch (Ulysses, 8 ranks: 5 heads x 191 tiles of 256
@@ -901,22 +916,38 @@ struct Attn4Launch {
     int rows;                   // 256 | 192
     int64_t item0, n_items;     // items [item0, item0 + n_items) of the pair-major (pair, query tile) list of THIS tile height
 };
+// CUs of the current device (cached per device); 0 + scail_last_error when the runtime cannot say -- the plan does not guess
 static int attn4_cu_count() {
     static std::map<int, int> cus;
     std::lock_guard<std::mutex> lk(g_attn4_mutex);
     int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        scail_set_error("attn4: hipGetDevice failed");
+        return 0;
+    }
     auto it = cus.find(dev);
     if (it != cus.end()) return it->second;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) {
+        scail_set_error("attn4: the device's compute-unit count is not available (hipDeviceAttributeMultiprocessorCount)");
+        return 0;
+    }
     return cus[dev] = n;
 }
+// Returns the number of launches (1 or 2), or 0 + scail_last_error when the device's CU count is unavailable.
+// Constants of the plan (measured, profiles/r05_attn_sp_shape_probe.log): k_attn4_q3_cost = 0.79 (a 192-row tile against a 256-row one),
+// a 1.5 % minimum gain before anything but the single 256-row launch is chosen, 0.02 round-equivalents for the gap between two launches.
+// CUs: the device's count, or option "attn4_cus" when a concurrent kernel (RCCL's channels on a sequence-parallel rank) holds some.
 static int attn4_plan(int64_t n_batch, int64_t heads, int64_t Lq, Attn4Launch out[2]) {
     const int64_t P = heads * n_batch, n4 = (Lq + 255) / 256, n3 = (Lq + 191) / 192, W4 = P * n4, W3 = P * n3;
-    const int forced = g_attn4_rows_hint ? g_attn4_rows_hint : g_attn4_rows;
+    // an explicit option wins; the caller's hint (thread-local: two attentions side by side) applies to the automatic choice only
+    const int opt = g_attn4_rows.load(std::memory_order_relaxed);
+    const int forced = opt ? opt : g_attn4_rows_hint;
     if (forced == 192) { out[0] = {192, 0, W3}; return 1; }
     if (forced == 256) { out[0] = {256, 0, W4}; return 1; }
-    const int64_t cus = attn4_cu_count();
+    int64_t cus = attn4_cu_count();
+    if (cus <= 0) return 0;
+    const int avail = g_attn4_cus.load(std::memory_order_relaxed);
+    if (avail > 0 && avail < cus) cus = avail;
     auto rounds = [&](int64_t w) { return (double)((w + cus - 1) / cus); };
     double best = rounds(W4);
     out[0] = {256, 0, W4};
@@ -966,7 +997,8 @@ static bool attn4_grid_ok(int64_t n_batch, int64_t heads, int64_t Lq) {
 extern "C" int scail_flash_attn_rows_for(int64_t n_batch, int64_t heads, int64_t Lq) {
     if (n_batch <= 0 || heads <= 0 || Lq <= 0) return 256;
     Attn4Launch pl[2];
-    return attn4_plan(n_batch, heads, Lq, pl) == 2 ? 448 : pl[0].rows;
+    const int n = attn4_plan(n_batch, heads, Lq, pl);
+    return n == 0 ? -1 : (n == 2 ? 448 : pl[0].rows);
 }
 
 extern "C" int scail_flash_attn_kernel_for(int64_t q_rs, int64_t k_rs, int64_t o_rs, int64_t Lq, int64_t Lk, int accumulate, int prescaled) {
@@ -994,6 +1026,11 @@ extern "C" int scail_set_option(const char* name, int value) {
     }
     if (k == "attn4_xcd") {                                                 // 0: plain workgroup-id decode (no XCD-aware K / V^T sharing)
         g_attn4_xcd = value != 0;
+        return 0;
+    }
+    if (k == "attn4_cus") {                                                 // CUs the launch plan may count on; 0 = all CUs of the device
+        SCAIL_REQUIRE(value >= 0 && value <= 4096, "attn4_cus must be in [0, 4096]");
+        g_attn4_cus = value;
         return 0;
     }
     if (k == "gemm4") return scail_gemm4_enable(value);                     // 0: the kernels of csrc/gemm.hip for every shape
@@ -1109,6 +1146,7 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
         int n_launch = 1;
         if (g_attn4_name == k_attn4_default) {
             n_launch = attn4_plan(n_batch, heads, Lq, plan);
+            if (n_launch == 0) return 2;
         } else {
             plan[0] = {256, 0, (Lq + 255) / 256 * heads * n_batch};
         }
@@ -1122,12 +1160,14 @@ extern "C" int scail_flash_attn_bf16(const scail_bf16* q, int64_t q_bs, int64_t 
             a.o_bs = o_bs; a.o_rs = o_rs;
             a.heads = (int32_t)heads; a.Lq = (int32_t)Lq; a.Lk = (int32_t)Lk; a.Lkp = (int32_t)Lkp; a.n_seg = (int32_t)n_seg;
             a.sl2 = fold ? (prescaled ? 0.0f : sl2) : sl2;
-            a.thr = fold ? g_attn4_thr_log2 : g_attn4_thr_log2 / sl2;
+            const float thr_log2 = g_attn4_thr_log2;
+            a.thr = fold ? thr_log2 : thr_log2 / sl2;
             a.nqb = (int32_t)((Lq + pl.rows - 1) / pl.rows);
             a.magic_nqb = (uint32_t)(((1ull << 31) + a.nqb - 1) / a.nqb);
             a.magic_heads = (uint32_t)(((1ull << 31) + heads - 1) / heads);
             a.n_items = (int32_t)pl.n_items;
             a.item0 = (int32_t)pl.item0;
+            a.restarts = g_attn4_restart_ctr;
             a.items_per_xcd = (a.n_items + 7) / 8;
             // XCD-aware ids (measured, profiles/r05_attn_sp_shape_probe.log): fewer than 8 pairs -> plain decode (all XCDs stream the one
             // pair in step; 5 pairs: 4 % faster than a run per XCD); whole launches of 8 k pairs -> pairs dealt round-robin (mode 1);
@@ -1218,7 +1258,7 @@ struct Attn4X2Args {
     int64_t k2_bs, vt2_bs;
     int32_t Lk2, Lkp2, n_wgs, pad;
 };
-static_assert(sizeof(Attn4X2Args) == 208, "Attn4X2Args must match asmgen/attn4.py X2_KERNARG_SIZE");
+static_assert(sizeof(Attn4X2Args) == 216, "Attn4X2Args must match asmgen/attn4.py X2_KERNARG_SIZE");
 // one K row stride for both sets (the set switch keeps the K DMA lane offsets), at least one whole key tile per set (a ragged tile's
 // missing rows are fetched from 64 rows earlier), 32-bit byte offsets inside a (batch, head) slice, exact reciprocal id decode
 static bool cross4_eligible(int64_t q_rs, int64_t k1_rs, int64_t k2_rs, int64_t o_rs, int64_t Lq, int64_t Lk1, int64_t Lk2, int64_t n_batch, int64_t heads) {
@@ -1268,6 +1308,7 @@ extern "C" int scail_cross_attn2_bf16(const scail_bf16* q, int64_t q_bs, int64_t
         b.n_items = (int32_t)(b.nqb * heads * n_batch);
         b.items_per_xcd = (b.n_items + 7) / 8;
         b.item0 = 0;
+        b.restarts = nullptr;            // the cross attention is not counted (scail_flash_attn_count_restarts is about the self-attention)
         a.k2 = k2; a.vt2 = vt2; a.k2_bs = k2_bs; a.vt2_bs = vt2_bs; a.Lk2 = (int32_t)Lk2; a.Lkp2 = (int32_t)Lkp2;
         a.n_wgs = (int32_t)std::min<int64_t>(b.n_items, attn4_cu_count());
         a.pad = 0;

@@ -11,6 +11,7 @@
 // reference's 1/4/4-frame chunking and its per-conv feature caches are unnecessary (the equivalence is
 // pinned by oracle/wan_vae_oracle.py against the chunked reference).
 #include "common.h"
+#include <atomic>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -837,11 +838,11 @@ static int conv4_cu_count() {
     return it->second;
 }
 
-static int g_conv4_cont = 1;                                   // option "conv4_cont": the tile-continuation variants (scail_conv4c_e0 / e3 / e4) for the one-n-tile shapes
+static std::atomic<int> g_conv4_cont{1};                                   // option "conv4_cont": the tile-continuation variants (scail_conv4c_e0 / e3 / e4) for the one-n-tile shapes
 int scail_conv4_cont_enable(int v) { g_conv4_cont = v != 0; return 0; }
-static int g_conv_direct = 1;                                  // option "conv_direct": the direct-gather kernel for the HBM-bound convolutions
+static std::atomic<int> g_conv_direct{1};                                  // option "conv_direct": the direct-gather kernel for the HBM-bound convolutions
 int scail_conv_direct_enable(int v) { g_conv_direct = v != 0; return 0; }
-static int g_conv4 = 1;                                        // option "conv4": the generated kernels where scail_conv3d_kernel_for says 4
+static std::atomic<int> g_conv4{1};                                        // option "conv4": the generated kernels where scail_conv3d_kernel_for says 4
 int scail_conv4_enable(int v) { g_conv4 = v != 0; return 0; }
 #ifdef SCAIL_ABLATIONS
 static int g_conv_halo = 4;                                    // measurement build: A/B of the halo-kernel layouts (comment below)

@@ -14,7 +14,7 @@ int scail_gemm4_preload();   // gemm.hip
 
 // Optional HIP-event timing of the executor's own launches (scail_dit_profile, include/scail_dit.h): event pairs recorded on the
 // launch stream around every launch of a category; the events are pooled in the handle and reused by the next enable.
-constexpr int PROF_CATS = 3;     // SCAIL_DIT_PROF_SELF_ATTN / _GEMM / _CROSS_ATTN
+constexpr int PROF_CATS = 5;     // SCAIL_DIT_PROF_SELF_ATTN / _GEMM / _CROSS_ATTN / _XCH_FWD_WAIT / _XCH_BACK_WAIT
 struct ProfPool {
     std::vector<hipEvent_t> ev;  // start / stop alternating
     size_t used = 0;
@@ -27,6 +27,7 @@ struct scail_dit {
     bool prof = false;
     ProfPool pool[PROF_CATS];
     hipEvent_t sp_ev[3] = {nullptr, nullptr, nullptr};   // fork / join events of the sequence-parallel block's side streams (created on first use)
+    uint32_t* restart_ctr = nullptr;                     // device counter of restarted self-attention workgroups (allocated by the first scail_dit_profile(h, 1))
 };
 
 namespace {
@@ -110,10 +111,19 @@ static int prof_mark(scail_dit* h, int cat, void* stream) {
     }
     return 0;
 }
+// while profiling, the self-attention launches of this thread count their restarted workgroups into the handle's device counter
+struct RestartCount {
+    bool on;
+    explicit RestartCount(scail_dit* h, int cat) : on(h->prof && cat == SCAIL_DIT_PROF_SELF_ATTN && h->restart_ctr != nullptr) {
+        if (on) (void)scail_flash_attn_count_restarts(h->restart_ctr);
+    }
+    ~RestartCount() { if (on) (void)scail_flash_attn_count_restarts(nullptr); }
+};
 // one launch of category cat_, bracketed by an event pair when profiling is on
 #define DIT_PROF(cat_, call_)                                   \
     {                                                           \
         if (h->prof) DIT_TRY(prof_mark(h, cat_, stream));       \
+        RestartCount rc_guard_(h, cat_);                        \
         DIT_TRY(call_);                                         \
         if (h->prof) DIT_TRY(prof_mark(h, cat_, stream));       \
     }
@@ -122,6 +132,7 @@ static int prof_mark(scail_dit* h, int cat, void* stream) {
 #define DIT_PROF_S(cat_, st_, call_)                            \
     {                                                           \
         if (h->prof) DIT_TRY(prof_mark(h, cat_, st_));          \
+        RestartCount rc_guard_(h, cat_);                        \
         DIT_TRY(call_);                                         \
         if (h->prof) DIT_TRY(prof_mark(h, cat_, st_));          \
     }
@@ -316,31 +327,32 @@ static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m
         for (int64_t b = 0; b < B; ++b) {
             void* s = st(b);
             scail_bf16* qb = qkv + b * Ltok * 3 * D;
-            scail_bf16* send = sp->send + b * 3 * N * slab;             // [3][N][Ltok][Dn]: q | k | v, one slab per destination rank
+            scail_bf16* send = sp->send + b * 3 * N * slab;             // [N][Ltok][3 Dn]: ONE message per destination rank, q | k | v side by side
             DIT_PROF_S(SCAIL_DIT_PROF_GEMM, s, scail_gemm_bf16(bf.xn + b * Ltok * D, D, lw.qkv_w, lw.qkv_b, qb, 3 * D, Ltok, 3 * D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, s));
             // the norm + RoPE kernels write the send layout themselves; v is a plain copy into it
-            DIT_TRY(scail_rmsnorm_rope_slabs(qb + D, 3 * D, send + N * slab, Dn, slab, lw.kn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, 1.0f, s));
-            DIT_TRY(scail_rmsnorm_rope_slabs(qb, 3 * D, send, Dn, slab, lw.qn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, ATTN_LOG2_SCALE, s));
-            DIT_TRY(scail_rmsnorm_rope_slabs(qb + 2 * D, 3 * D, send + 2 * N * slab, Dn, slab, nullptr, nullptr, nullptr, Ltok, Ltok, D, 128, eps, 1.0f, s));
+            DIT_TRY(scail_rmsnorm_rope_slabs(qb + D, 3 * D, send + Dn, Dn, 3 * Dn, 3 * slab, lw.kn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, 1.0f, s));
+            DIT_TRY(scail_rmsnorm_rope_slabs(qb, 3 * D, send, Dn, 3 * Dn, 3 * slab, lw.qn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, ATTN_LOG2_SCALE, s));
+            DIT_TRY(scail_rmsnorm_rope_slabs(qb + 2 * D, 3 * D, send + 2 * Dn, Dn, 3 * Dn, 3 * slab, nullptr, nullptr, nullptr, Ltok, Ltok, D, 128, eps, 1.0f, s));
             DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_START, i, b, s));
         }
         for (int64_t b = 0; b < B; ++b) {
             void* s = st(b);
-            DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_WAIT, i, b, s));
-            const scail_bf16* recv = sp->recv + b * 3 * N * slab;       // [3][N * Ltok][Dn]: all ranks' tokens (rank-major), my heads
+            // exposed wait: the event pair brackets nothing but the stream's wait for the collective (0 when it finished under other work)
+            DIT_PROF_S(SCAIL_DIT_PROF_XCH_FWD_WAIT, s, sp_exchange(sp, SCAIL_SP_FWD_WAIT, i, b, s));
+            const scail_bf16* recv = sp->recv + b * 3 * N * slab;       // [N * Ltok][3 Dn]: all ranks' tokens (rank-major), q | k | v of my heads
             scail_bf16* vt = bf.vt + b * Hn * 128 * Lfp;
             scail_bf16* of = sp->ofull + b * N * slab;
-            DIT_TRY(scail_transpose_v(recv + 2 * N * slab, Dn, 0, vt, 1, Hn, 128, Lf, s));
+            DIT_TRY(scail_transpose_v(recv + 2 * Dn, 3 * Dn, 0, vt, 1, Hn, 128, Lf, s));
             // two elements' launches run side by side on the two streams and fill each other's partial rounds: one 256-row launch each
             // (a lone launch gets the planned shape: whole 256-row rounds + 192-row tiles for the rest, csrc/attn.hip attn4_plan)
             struct Hint { Hint(int r) { scail_attn4_rows_hint(r); } ~Hint() { scail_attn4_rows_hint(0); } } hint(side && B > 1 ? 256 : 0);
-            DIT_PROF_S(SCAIL_DIT_PROF_SELF_ATTN, s, scail_flash_attn_bf16(recv, 0, Dn, recv + N * slab, 0, 0, Dn, vt, 0, 0, of, 0, Dn, 1, Hn, Lf, Lf, 1,
+            DIT_PROF_S(SCAIL_DIT_PROF_SELF_ATTN, s, scail_flash_attn_bf16(recv, 0, 3 * Dn, recv + Dn, 0, 0, 3 * Dn, vt, 0, 0, of, 0, Dn, 1, Hn, Lf, Lf, 1,
                                                                           SCAIL_ATTN_Q_PRESCALED, 0, s));
             DIT_TRY(sp_exchange(sp, SCAIL_SP_BACK_START, i, b, s));
         }
         for (int64_t b = 0; b < B; ++b) {
             void* s = st(b);
-            DIT_TRY(sp_exchange(sp, SCAIL_SP_BACK_WAIT, i, b, s));
+            DIT_PROF_S(SCAIL_DIT_PROF_XCH_BACK_WAIT, s, sp_exchange(sp, SCAIL_SP_BACK_WAIT, i, b, s));
             // back[b][g] = my tokens, head group g  ->  att rows (token, all columns)
             DIT_TRY(scail_slabs_to_rows(sp->back + b * N * slab, Dn, slab, bf.att + b * Ltok * D, D, Ltok, D, s));
         }
@@ -354,11 +366,11 @@ static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m
         const int64_t rowsD = Ltok * D;
         for (int64_t b = 0; b < B; ++b) {
             scail_bf16* qb = qkv + b * Ltok * 3 * D;
-            scail_bf16* send = sp->send + b * 2 * rowsD;                // [2][Ltok][D]: k rows | v rows
+            scail_bf16* send = sp->send + b * 2 * rowsD;                // [Ltok][2 D]: ONE message, k | v side by side
             const scail_bf16* xb = bf.xn + b * rowsD;
             DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xb, D, lw.qkv_w + D * D, lw.qkv_b + D, qb + D, 3 * D, Ltok, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
-            DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xb, D, lw.qkv_w + 2 * D * D, lw.qkv_b + 2 * D, send + rowsD, D, Ltok, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
-            DIT_TRY(scail_rmsnorm_rope(qb + D, 3 * D, send, D, lw.kn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, stream));
+            DIT_PROF(SCAIL_DIT_PROF_GEMM, scail_gemm_bf16(xb, D, lw.qkv_w + 2 * D * D, lw.qkv_b + 2 * D, send + D, 2 * D, Ltok, D, D, SCAIL_EPI_BIAS, nullptr, 0, nullptr, 0, 0, stream));
+            DIT_TRY(scail_rmsnorm_rope(qb + D, 3 * D, send, 2 * D, lw.kn, rope_cos, rope_sin, Ltok, Ltok, D, 128, eps, stream));
             DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_START, i, b, stream));
         }
         if (rows == Ltok) {
@@ -372,11 +384,11 @@ static int dit_block_sp(scail_dit* h, int64_t i, scail_bf16* hid, const float* m
             }
         }
         for (int64_t b = 0; b < B; ++b) {
-            DIT_TRY(sp_exchange(sp, SCAIL_SP_FWD_WAIT, i, b, stream));
-            const scail_bf16* recv = sp->recv + b * 2 * N * rowsD;      // [2][N * Ltok][D]: gathered k rows | v rows, rank-major
+            DIT_PROF(SCAIL_DIT_PROF_XCH_FWD_WAIT, sp_exchange(sp, SCAIL_SP_FWD_WAIT, i, b, stream));
+            const scail_bf16* recv = sp->recv + b * 2 * N * rowsD;      // [N * Ltok][2 D]: gathered rows (rank-major), k | v
             scail_bf16* vt = bf.vt + b * nh * 128 * Lfp;
-            DIT_TRY(scail_transpose_v(recv + N * rowsD, D, 0, vt, 1, nh, 128, Lf, stream));
-            DIT_PROF(SCAIL_DIT_PROF_SELF_ATTN, scail_flash_attn_bf16(q + (b * Ltok + row0) * 3 * D, 0, 3 * D, recv, 0, 0, D, vt, 0, 0, bf.att + b * rowsD + row0 * D, 0, D,
+            DIT_TRY(scail_transpose_v(recv + D, 2 * D, 0, vt, 1, nh, 128, Lf, stream));
+            DIT_PROF(SCAIL_DIT_PROF_SELF_ATTN, scail_flash_attn_bf16(q + (b * Ltok + row0) * 3 * D, 0, 3 * D, recv, 0, 0, 2 * D, vt, 0, 0, bf.att + b * rowsD + row0 * D, 0, D,
                                                                      1, nh, rows, Lf, 1, SCAIL_ATTN_Q_PRESCALED, 0, stream));
         }
     }
@@ -458,6 +470,7 @@ extern "C" void scail_dit_destroy(scail_dit* h) {
             for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->sp_ev)
             if (e != nullptr) (void)hipEventDestroy(e);
+        if (h->restart_ctr != nullptr) (void)hipFree(h->restart_ctr);
     }
     delete h;
 }
@@ -465,13 +478,39 @@ extern "C" void scail_dit_destroy(scail_dit* h) {
 extern "C" int scail_dit_profile(scail_dit* h, int enable) {
     SCAIL_REQUIRE(h != nullptr, "null handle");
     h->prof = enable != 0;
-    if (h->prof)
+    if (h->prof) {
         for (ProfPool& p : h->pool) p.used = 0;       // a new measurement: reuse the pooled events
+        // restart counter of the self-attention (SCAIL_DIT_PROF_ATTN_RESTARTS): allocated once, zeroed per measurement (blocking calls:
+        // profiling is enabled outside of stream captures)
+        if (h->restart_ctr == nullptr && hipMalloc(reinterpret_cast<void**>(&h->restart_ctr), sizeof(uint32_t)) != hipSuccess) {
+            h->restart_ctr = nullptr;
+            scail_set_error("scail_dit_profile: hipMalloc of the restart counter failed");
+            return 2;
+        }
+        if (hipMemset(h->restart_ctr, 0, sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            scail_set_error("scail_dit_profile: clearing the restart counter failed");
+            return 2;
+        }
+    }
     return 0;
 }
 
 extern "C" int scail_dit_profile_read(scail_dit* h, int category, double* ms_total, int64_t* launches) {
     SCAIL_REQUIRE(h != nullptr && ms_total != nullptr && launches != nullptr, "null argument");
+    if (category == SCAIL_DIT_PROF_ATTN_RESTARTS) {
+        // workgroups of the timed self-attention launches that left the optimistic pass and ran again (scail_hip.h
+        // scail_flash_attn_count_restarts); read after the launches have finished
+        ProfPool& pa = h->pool[SCAIL_DIT_PROF_SELF_ATTN];
+        uint32_t n = 0;
+        if ((pa.used >= 2 && hipEventSynchronize(pa.ev[pa.used - 1]) != hipSuccess) || h->restart_ctr == nullptr ||
+            hipDeviceSynchronize() != hipSuccess || hipMemcpy(&n, h->restart_ctr, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) {
+            scail_set_error("scail_dit_profile_read: reading the restart counter failed (was profiling enabled?)");
+            return 2;
+        }
+        *ms_total = 0.0;
+        *launches = (int64_t)n;
+        return 0;
+    }
     SCAIL_REQUIRE(category >= 0 && category < PROF_CATS, "unknown category");
     ProfPool& p = h->pool[category];
     SCAIL_REQUIRE(p.used % 2 == 0, "unbalanced event pairs (a step failed between the marks)");

@@ -15,7 +15,7 @@ int scail_check_launch(const char* what) {
 }
 
 extern "C" const char* scail_last_error(void) { return g_last_error.c_str(); }
-extern "C" int scail_abi_version(void) { return 4; }
+extern "C" int scail_abi_version(void) { return 5; }
 
 // Device-side caches of the library that outlive a call: the GEMM's tile-order tables (one small hipMalloc per tile grid and device).
 int scail_gemm4_release_tables();   // gemm.hip

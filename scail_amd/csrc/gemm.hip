@@ -15,6 +15,7 @@
 // of tiles so neighbours share operand panels in that XCD's L2), then grouped ordering (g_group_m = 4 m-tiles
 // per group, m fastest) so the co-resident tiles of an XCD share a few operand panels.
 #include "common.h"
+#include <atomic>
 #include <algorithm>
 #include <map>
 #include <tuple>
@@ -593,7 +594,7 @@ static std::map<std::pair<int, int>, hipModule_t> g_gemm4_modules;          // (
 static std::map<std::pair<int, std::string>, hipFunction_t> g_gemm4_fn;     // (device, kernel name)
 static std::map<std::tuple<int, int, int, int, int>, std::pair<uint32_t*, int>> g_gemm4_tables;   // (device, m tiles, n tiles, group height, table mode) -> device order table, entries
 static std::mutex g_gemm4_mutex;
-static int g_gemm4_mode = 4;               // generated kernels where eligible: 4 = gemm4 (default), 0 = never (csrc/gemm.hip only), 8 = gemm8 (measurement build)
+static std::atomic<int> g_gemm4_mode{4};               // generated kernels where eligible: 4 = gemm4 (default), 0 = never (csrc/gemm.hip only), 8 = gemm8 (measurement build)
 static std::string g_gemm4_suffix;         // A/B variants of the measurement build ("gemm4_kernel:<suffix>")
 static int g_gemm4_table_mode = 1;         // tile -> XCD assignment of the order table (0, 2: measurement build A/B, knob "gemm4_table")
 
@@ -744,7 +745,8 @@ static bool gemm4_eligible(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int
 }
 
 extern "C" int scail_gemm_kernel_for(int64_t lda, int64_t ldc, int64_t ldr, int64_t M, int64_t N, int64_t K, int epilogue) {
-    return (g_gemm4_mode && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) ? g_gemm4_mode : 0;
+    const int mode = g_gemm4_mode;
+    return (mode && gemm4_eligible(lda, ldc, ldr, M, N, K, epilogue)) ? mode : 0;
 }
 
 // load the embedded code object and resolve the four shipped kernels now (see scail_attn4_preload)

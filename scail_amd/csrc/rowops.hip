@@ -3,6 +3,7 @@
 // timestep embedding, tiny linears, AdaLN tables, patchify / unpatchify, CFG+Euler.
 // One 256-thread workgroup per row for the norm kernels; every bf16 access is a 16-byte vector.
 #include "common.h"
+#include <atomic>
 
 #define ROW_THREADS 256
 #define ROW_MAXV 3  // D <= 256 * 8 * 3 = 6144 kept in registers
@@ -76,8 +77,9 @@ __global__ __launch_bounds__(ROW_THREADS) void ln_kernel(
 // RMSNorm over D (+ optional interleaved RoPE with per-token pair tables)
 // ------------------------------------------------------------------------------------------------
 // Output layout: row-major (row stride ldy, slab_w == 0), or COLUMN SLABS (slab_w > 0): the D columns are cut into D / slab_w
-// slabs, slab g holds a dense (rows, slab_w) matrix at y + g * slab_stride -- the send layout of the Ulysses head <-> sequence
-// all-to-all (scail_amd/parallel.py: one slab per destination rank), written by the norm itself instead of a pack pass.
+// slabs, slab g holds a (rows, slab_w) matrix with row stride ldy (>= slab_w) at y + g * slab_stride -- the send layout of the Ulysses
+// head <-> sequence all-to-all (scail_amd/parallel.py: one slab per destination rank; ldy = 3 * slab_w puts q | k | v side by side in
+// ONE message per destination), written by the norm itself instead of a pack pass.
 // w == nullptr: no normalisation / RoPE / scale, a plain copy into the chosen layout (the V third of the exchange).
 __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
     const u16* __restrict__ x, int64_t ldx, u16* __restrict__ y, int64_t ldy,
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(ROW_THREADS) void rmsnorm_rope_kernel(
     auto dst = [&](int c) -> u16* {                      // 16-byte chunk c of this row in the output layout
         if (slab_w == 0) return yr + (int64_t)c * 8;
         const int col = c * 8, gsl = col / slab_w;
-        return y + (int64_t)gsl * slab_stride + r * slab_w + (col - gsl * slab_w);
+        return y + (int64_t)gsl * slab_stride + r * ldy + (col - gsl * slab_w);
     };
     if (w == nullptr) {
         for (int c = threadIdx.x; c < nvec; c += ROW_THREADS)
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_wave_kernel(
                 dst = yr + c * 8;
             } else {
                 const int col = c * 8, gsl = col / slab_w;
-                dst = y + (int64_t)gsl * slab_stride + r * slab_w + (col - gsl * slab_w);
+                dst = y + (int64_t)gsl * slab_stride + r * ldy + (col - gsl * slab_w);
             }
             *reinterpret_cast<uint4*>(dst) = pack8(o);
         }
@@ -491,7 +493,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 // option "row_wave" (scail_set_option): 1 (default) = the one-wave-per-row norm kernels where D is 1536 / 2048 / 4096 / 5120 / 6144,
 // 0 = the block-per-row kernels for every D (same-process A/B; the results agree up to the order of the fp32 sums)
-static int g_row_wave = 1;
+static std::atomic<int> g_row_wave{1};   // option state: atomic (set by one thread, read by every launching thread)
 int scail_row_wave_enable(int on) { g_row_wave = on != 0; return 0; }
 static int row_cu_count() {
     static int cus[64] = {0};
@@ -581,8 +583,8 @@ static int rmsnorm_rope_launch(const scail_bf16* x, int64_t ldx, scail_bf16* y, 
     SCAIL_REQUIRE(aligned16(x) && aligned16(y) && aligned16(w) && aligned16(cos_tab) && aligned16(sin_tab),
                   "pointers must be 16-byte aligned");
     SCAIL_REQUIRE(rows_per_batch > 0, "rows_per_batch must be positive");
-    SCAIL_REQUIRE(slab_w == 0 || (slab_w % 8 == 0 && D % slab_w == 0 && slab_stride % 8 == 0 && slab_stride >= rows * slab_w),
-                  "slab width must be a multiple of 8 dividing D, slab stride a multiple of 8 and >= rows * slab_w");
+    SCAIL_REQUIRE(slab_w == 0 || (slab_w % 8 == 0 && D % slab_w == 0 && ldy >= slab_w && slab_stride % 8 == 0 && slab_stride >= (rows - 1) * ldy + slab_w),
+                  "slab width must be a multiple of 8 dividing D, slab row stride >= slab width, slab stride a multiple of 8 that holds rows of that stride");
     if (rows == 0) return 0;
     // with RoPE the wave form wins (0.455 -> 0.41 ms at config 2: the (cos, sin) pairs once per row instead of per chunk); without, the block
     // kernel is already at the pass's plateau (0.367 against 0.383 ms; profiles/r04_row_pass_probe.log)
@@ -618,13 +620,13 @@ extern "C" int scail_rmsnorm_rope_scaled(const scail_bf16* x, int64_t ldx, scail
     return rmsnorm_rope_launch(x, ldx, y, ldy, w, cos_tab, sin_tab, rows, rows_per_batch, D, head_dim, eps, out_scale, 0, 0, stream);
 }
 
-extern "C" int scail_rmsnorm_rope_slabs(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t slab_w, int64_t slab_stride,
+extern "C" int scail_rmsnorm_rope_slabs(const scail_bf16* x, int64_t ldx, scail_bf16* y, int64_t slab_w, int64_t slab_ld, int64_t slab_stride,
                                         const float* w, const float* cos_tab, const float* sin_tab,
                                         int64_t rows, int64_t rows_per_batch, int64_t D, int64_t head_dim,
                                         float eps, float out_scale, void* stream) {
     SCAIL_REQUIRE(slab_w > 0, "slab width must be positive");
     SCAIL_REQUIRE(w != nullptr || (cos_tab == nullptr && sin_tab == nullptr), "a plain slab copy (w == NULL) takes no RoPE tables");
-    return rmsnorm_rope_launch(x, ldx, y, 0, w, cos_tab, sin_tab, rows, rows_per_batch, D, head_dim, eps, out_scale, slab_w, slab_stride, stream);
+    return rmsnorm_rope_launch(x, ldx, y, slab_ld, w, cos_tab, sin_tab, rows, rows_per_batch, D, head_dim, eps, out_scale, slab_w, slab_stride, stream);
 }
 
 // slabs -> rows: the way back of the Ulysses exchange (the inverse layout of scail_rmsnorm_rope_slabs): slab g is a dense [rows, slab_w]
@@ -873,4 +875,20 @@ extern "C" int scail_row_affine(const scail_bf16* x, scail_bf16* y, const float*
     hipLaunchKernelGGL(row_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, rowscale,
                        addrow, add_rows > 0 ? add_rows : 1, rows, (int)(D / 8));
     return scail_check_launch("row_affine");
+}
+
+// ------------------------------------------------------------------------------------------------
+// MEASUREMENT helper: a collective's CU occupancy on one GPU (include/scail_hip.h scail_comm_standin)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void comm_standin_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16, int64_t min_ticks) {
+    const int64_t t0 = (int64_t)wall_clock64();                    // 100 MHz constant clock
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+    while ((int64_t)wall_clock64() - t0 < min_ticks) __builtin_amdgcn_s_sleep(64);
+}
+extern "C" int scail_comm_standin(const void* src, void* dst, int64_t bytes, int32_t workgroups, int64_t min_ns, void* stream) {
+    SCAIL_REQUIRE(bytes >= 0 && bytes % 16 == 0 && aligned16(src) && aligned16(dst), "bytes must be a multiple of 16, pointers 16-byte aligned");
+    SCAIL_REQUIRE(workgroups >= 1 && workgroups <= 4096 && min_ns >= 0 && min_ns <= 1000000000ll, "workgroups in [1, 4096], min_ns in [0, 1e9]");
+    hipLaunchKernelGGL(comm_standin_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), bytes / 16, min_ns / 10);
+    return scail_check_launch("comm_standin");
 }

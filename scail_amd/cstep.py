@@ -91,6 +91,8 @@ class CStep:
             pass
 
     PROF_SELF_ATTN, PROF_GEMM, PROF_CROSS_ATTN = 0, 1, 2          # include/scail_dit.h SCAIL_DIT_PROF_*
+    PROF_XCH_FWD_WAIT, PROF_XCH_BACK_WAIT = 3, 4                  # exposed part of the sequence-parallel exchange (stream waits)
+    PROF_ATTN_RESTARTS = 5                                        # not a time: restarted self-attention workgroups (second value of profile_read)
 
     def profile(self, enable: bool) -> None:
         """HIP-event timing of the executor's own launches (scail_dit_profile): on = restart the counters."""

@@ -423,6 +423,14 @@ class DiffusionTransformer(nn.Module):
                 raise NotImplementedError
         # cfg_pair (set by scail_amd.sampler.VanillaCFG.prepare_inputs): x / timesteps are one latent twice, only the conditioning differs
         cfg_pair = bool(kwargs.get("cfg_pair", False)) and B == 2 and ref.shape[0] == 1 and pose.shape[0] == 1
+        if cfg_pair and (not getattr(self, "_cfg_pair_checked", False) or os.environ.get("SCAIL_CHECK_CFG_PAIR") == "1"):
+            # the flag is a statement about the inputs (include/scail_dit.h): element 1 receives element 0's layer-0 self-attention.  It is
+            # verified the FIRST time a network object sees it (a guider / denoiser that sets the key without duplicating x and sigma does so
+            # on every call) and on every call under SCAIL_CHECK_CFG_PAIR=1 -- one host synchronisation each.
+            if not (torch.equal(x32[0], x32[1]) and bool(t32[0] == t32[1])):
+                raise ValueError("cfg_pair was passed, but x[0] != x[1] or timesteps[0] != timesteps[1]: the flag states that the batch is ONE latent and "
+                                 "ONE sigma twice (scail_amd.sampler.VanillaCFG.prepare_inputs); drop the key for any other batch")
+            self._cfg_pair_checked = True
         return self._run(x32, t32, ctx, ref, pose, clip, H_shift, W_shift, cond_key, cfg_pair=cfg_pair)
 
     def sample_c(self, x32, sigmas, cfg_scale, ctx, ref, pose, clip, cond_key=None):

@@ -22,13 +22,15 @@ SIGNATURES = {
     "scail_layernorm_affine": [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _f, _p],
     "scail_rmsnorm_rope": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _p],
     "scail_rmsnorm_rope_scaled": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
-    "scail_rmsnorm_rope_slabs": [_p, _i64, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
+    "scail_rmsnorm_rope_slabs": [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _f, _f, _p],
     "scail_slabs_to_rows": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p],
     "scail_transpose_v": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "scail_flash_attn_bf16": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
                               _i64, _i64, _i64, _i64, _i64, _f, _i, _p],
     "scail_flash_attn_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i, _i],
     "scail_flash_attn_rows_for": [_i64, _i64, _i64],
+    "scail_flash_attn_count_restarts": [_p],
+    "scail_comm_standin": [_p, _p, _i64, C.c_int32, _i64, _p],
     "scail_cross_attn2_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64],
     "scail_gemm_kernel_for": [_i64, _i64, _i64, _i64, _i64, _i64, _i],
     "scail_conv3d_kernel_for": [_p, _i64, _i64, _i],
@@ -90,7 +92,9 @@ ABLATIONS = LIB_PATH.endswith("_abl.so")
 
 EPI_BIAS, EPI_GELU_TANH, EPI_GELU_ERF, EPI_RESID = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2
-ABI_VERSION = 4          # 4 = `flags` argument of scail_dit_step / scail_dit_step_sp (SCAIL_DIT_CFG_PAIR), options "attn4_rows" / "attn4_xcd";
+ABI_VERSION = 5          # 5 = scail_rmsnorm_rope_slabs takes a slab row stride; the sequence-parallel exchange is ONE collective per direction
+                         # (send / recv layouts of scail_dit.h), exchange-wait / restart categories of scail_dit_profile_read;
+                         # 4 = `flags` argument of scail_dit_step / scail_dit_step_sp (SCAIL_DIT_CFG_PAIR), options "attn4_rows" / "attn4_xcd";
                          # include/scail_hip.h scail_abi_version: 2 = negative SCAIL_ATTN_Q_PRESCALED sentinel + the SP executor entry points;
                          # 3 = scail_vae_set_trace, options "row_wave" / "conv_direct", scail_conv3d_kernel_for = 4 for the kt = 1 / narrow / fused-norm shapes
 

@@ -132,13 +132,14 @@ def rmsnorm_rope(x, w, cos=None, sin=None, out=None, rows_per_batch=None, head_d
 
 
 def rmsnorm_rope_slabs(x, w, out, cos=None, sin=None, rows_per_batch=None, head_dim=128, eps=1e-6, out_scale=1.0):
-    """RMSNorm (+RoPE, x out_scale) of x (rows, D) (row-strided view ok) written as COLUMN SLABS: out (n_slabs, rows, D / n_slabs)
-    contiguous -- the (destination rank, token, head-group columns) send layout of the Ulysses all-to-all.  ``w`` None: plain copy of
-    x into that layout (include/scail_hip.h scail_rmsnorm_rope_slabs)."""
+    """RMSNorm (+RoPE, x out_scale) of x (rows, D) (row-strided view ok) written as COLUMN SLABS: out (n_slabs, rows, D / n_slabs),
+    last dim contiguous, any row / slab stride -- the (destination rank, token, head-group columns) send layout of the Ulysses
+    all-to-all; a view ``msg[:, :, j * Dn:(j + 1) * Dn]`` of a (n_slabs, rows, 3 * Dn) message puts q | k | v side by side.  ``w`` None:
+    plain copy of x into that layout (include/scail_hip.h scail_rmsnorm_rope_slabs)."""
     _chk(x, bf16, "rmsnorm_rope_slabs.x"); _chk(out, bf16, "rmsnorm_rope_slabs.out")
     rows, D, ldx = _rowmajor2d(x, "rmsnorm_rope_slabs.x")
-    if out.dim() != 3 or not out.is_contiguous() or out.shape[1] != rows or out.shape[0] * out.shape[2] != D:
-        raise L.ScailHipError(f"rmsnorm_rope_slabs.out must be a contiguous (n_slabs, {rows}, {D} / n_slabs) tensor, got {tuple(out.shape)}")
+    if out.dim() != 3 or out.stride(2) != 1 or out.shape[1] != rows or out.shape[0] * out.shape[2] != D:
+        raise L.ScailHipError(f"rmsnorm_rope_slabs.out must be a (n_slabs, {rows}, {D} / n_slabs) tensor with a contiguous last dim, got {tuple(out.shape)}")
     if w is not None:
         _chk(w, f32, "w")
     if cos is not None:
@@ -147,8 +148,8 @@ def rmsnorm_rope_slabs(x, w, out, cos=None, sin=None, rows_per_batch=None, head_
         rows_per_batch = cos.shape[0] if rows_per_batch is None else rows_per_batch
     else:
         rows_per_batch = rows if rows_per_batch is None else rows_per_batch
-    L.call("scail_rmsnorm_rope_slabs", x.data_ptr(), ldx, out.data_ptr(), out.shape[2], out.stride(0), _ptr(w), _ptr(cos), _ptr(sin),
-           rows, rows_per_batch, D, head_dim, eps, float(out_scale), _stream())
+    L.call("scail_rmsnorm_rope_slabs", x.data_ptr(), ldx, out.data_ptr(), out.shape[2], out.stride(1), out.stride(0), _ptr(w), _ptr(cos),
+           _ptr(sin), rows, rows_per_batch, D, head_dim, eps, float(out_scale), _stream())
     return out
 
 

@@ -183,6 +183,47 @@ class LocalCopyBackend:
         return t
 
 
+class ConcurrentCopyBackend(LocalCopyBackend):
+    """MEASUREMENT backend: LocalCopyBackend whose "collectives" behave like RCCL's on the chip -- they run on their OWN stream as a kernel of
+    ``workgroups`` resident workgroups (one CU each, like RCCL's channels) that moves the real message and stays resident for the time the
+    xGMI links would need for the bytes that leave the GPU (``link_gbps`` per direction and peer link, N - 1 links in parallel), while the
+    compute stream carries on until the executor's WAIT callback.  What it shows on one GPU: how much of a rank's step the CU occupancy of
+    its collectives costs (the attention launches one workgroup per CU; a CU held by a channel is missing from its round), for a channel
+    count K -- the measurement behind NCCL_MAX_NCHANNELS in bench.py / cli.py (tools/sp_rank_compute.py --comm-wgs K)."""
+
+    def __init__(self, size, workgroups=16, link_gbps=48.0, device="cuda"):
+        super().__init__(size)
+        self.workgroups, self.link_gbps = int(workgroups), float(link_gbps)
+        self.stream = torch.cuda.Stream(device=device)
+
+    def _launch(self, out, inp, link_bytes):
+        """link_bytes: what the busiest peer link carries in one direction; the kernel stays resident for link_bytes / link_gbps"""
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)                     # the message is complete on the compute stream (stream order)
+        min_ns = int(link_bytes / self.link_gbps)        # bytes / (GB/s) = ns
+        nb = inp.numel() * inp.element_size()
+        L.call("scail_comm_standin", inp.data_ptr(), out.data_ptr(), nb, self.workgroups, min_ns, self.stream.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+
+        class _H:
+            def wait(self_inner):
+                torch.cuda.current_stream().wait_event(ev)
+        return _H()
+
+    def all_to_all(self, out, inp, async_op=False):
+        nb = inp.numel() * inp.element_size()
+        h = self._launch(out, inp, nb / self.size)       # one of the N equal chunks to every peer, each over its own link
+        if not async_op:
+            h.wait()
+        return h
+
+    def all_gather_into(self, out, inp, async_op=True):
+        nb = inp.numel() * inp.element_size()
+        hs = [self._launch(out[r], inp, nb if r == self.size - 1 else 0) for r in range(self.size)]     # the whole message to (from) every peer
+        return hs[-1]
+
+
 # ulysses exchange: one side stream per CFG element up to this many ranks (CExchange).  0 since round 5: with the planned attention launch
 # shape (whole 256-row rounds + 192-row tiles, csrc/attn.hip attn4_plan) one stream is faster at 4 ranks -- compute-side efficiency 95.3 %
 # against 94.2 % with the two side streams, same box, same process order (profiles/r05_sp4_side_streams_ab.log); rounds 3-4, before the
@@ -194,7 +235,7 @@ class CExchange:
     """Host side of the C executor's exchange callback (include/scail_dit.h "sequence-parallel execution"): owns the send / recv /
     ofull / back buffers of one (B, Ltok) shape and starts / awaits the collectives through the group's backend when the executor
     asks for them.  The executor enqueues every kernel of a block itself; per layer this object only sees 4 (all-gather) or 8
-    (ulysses) callbacks."""
+    (ulysses) callbacks, which start 2 / 4 collectives (one all-gather, or one all-to-all each way, per CFG element)."""
 
     def __init__(self, sp: "SequenceParallel", heads: int, D: int, B: int, Ltok: int, device):
         from . import cstep
@@ -206,10 +247,10 @@ class CExchange:
         e = lambda *sh: torch.empty(*sh, device=device, dtype=torch.bfloat16)
         if self.mode == "ulysses":
             Dn = D // N
-            self.send, self.recv = e(B, 3, N, Ltok, Dn), e(B, 3, N, Ltok, Dn)
+            self.send, self.recv = e(B, N, Ltok, 3 * Dn), e(B, N, Ltok, 3 * Dn)      # one message per peer: q | k | v side by side
             self.ofull, self.back = e(B, N, Ltok, Dn), e(B, N, Ltok, Dn)
         else:
-            self.send, self.recv = e(B, 2, Ltok, D), e(B, 2, N, Ltok, D)
+            self.send, self.recv = e(B, Ltok, 2 * D), e(B, N, Ltok, 2 * D)             # k | v side by side
             self.ofull = self.back = None
         # optional: two side streams for the two CFG elements (see SIDE_STREAM_MAX_RANKS)
         # (SCAIL_SP_SIDE_STREAMS = 0 / 1 overrides the rule: same-process A/B against the planned single-stream launch shape)
@@ -244,9 +285,9 @@ class CExchange:
             with self._on(stream):
                 if op == cs.SP_FWD_START:
                     if self.mode == "ulysses":
-                        self.handles["f", b] = [self.backend.all_to_all(self.recv[b, j], self.send[b, j], async_op=True) for j in range(3)]
+                        self.handles["f", b] = [self.backend.all_to_all(self.recv[b], self.send[b], async_op=True)]
                     else:
-                        self.handles["f", b] = [self.backend.all_gather_into(self.recv[b, j], self.send[b, j]) for j in range(2)]
+                        self.handles["f", b] = [self.backend.all_gather_into(self.recv[b], self.send[b])]
                 elif op == cs.SP_FWD_WAIT:
                     for h in self.handles.pop(("f", b)):
                         h.wait()
@@ -363,8 +404,9 @@ class SequenceParallel:
         """The reference's exchange (sat/mpu/ulysses_attn_layer.py:65-107): scatter heads / gather sequence for q, k, v,
         attention over the full sequence for heads/size heads, all-to-all back.  Norm + RoPE are applied before the
         exchange (the q/k RMSNorm spans all heads of a token).
-        Layout: q, k and v travel in THREE all-to-alls of (dst rank, Ltok, Dn) slabs, so what a rank receives for each is
-        (src rank, Ltok, Dn) = one CONTIGUOUS (size * Ltok, Dn) matrix in rank-major token order.  The attention is then the
+        Layout: q, k and v travel in ONE all-to-all of (dst rank, Ltok, 3 Dn) messages (q | k | v of the destination's heads side
+        by side in a row; the reference issues three collectives), so what a rank receives is (src rank, Ltok, 3 Dn) = one
+        (size * Ltok, 3 Dn) matrix in rank-major token order whose column thirds are q, k, v.  The attention is then the
         ordinary single-segment full-length launch on heads/size heads -- size * Ltok is a multiple of 64 whenever the
         unsharded length is, so the 4-wave kernel (scail_flash_attn_kernel_for == 4) serves it although the per-rank slabs
         are ragged (6 104 tokens at 8 ranks).  Key order is rank-major, not raster order: softmax is permutation invariant
@@ -380,7 +422,7 @@ class SequenceParallel:
         if key not in self._buf:
             dev = xn.device
             e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.bfloat16)
-            self._buf = {key: dict(send=e(B, 3, N, Ltok, Dn), recv=e(B, 3, N, Ltok, Dn), vt=e(B, 1, Hn, 128, (Lf + 63) // 64 * 64),
+            self._buf = {key: dict(send=e(B, N, Ltok, 3 * Dn), recv=e(B, N, Ltok, 3 * Dn), vt=e(B, 1, Hn, 128, (Lf + 63) // 64 * 64),
                                    ofull=e(B, N, Ltok, Dn), back=e(B, N, Ltok, Dn))}
         bf = self._buf[key]
         send, recv, vt, ofull, back = bf["send"], bf["recv"], bf["vt"], bf["ofull"], bf["back"]
@@ -404,16 +446,16 @@ class SequenceParallel:
                 # the norm + RoPE kernels write the SEND layout (dst rank, Ltok, Dn) themselves -- one column slab per destination
                 # rank -- instead of normalising in place and packing afterwards (the reference's `.permute().contiguous()` before
                 # all_to_all_single, sat/mpu/ulysses_attn_layer.py:65-80); v is a plain copy into the same layout
-                self.pack_rows(qkv[b, :, D:2 * D], send[b, 1], lw["kn"], cos, sin, Ltok, eps, 1.0)
-                self.pack_rows(qkv[b, :, :D], send[b, 0], lw["qn"], cos, sin, Ltok, eps, ops.ATTN_LOG2_SCALE)     # q in log2 units
-                self.pack_rows(qkv[b, :, 2 * D:], send[b, 2], None, None, None, Ltok, eps, 1.0)
-                fwd.append([self.backend.all_to_all(recv[b, j], send[b, j], async_op=True) for j in range(3)])
+                self.pack_rows(qkv[b, :, D:2 * D], send[b, :, :, Dn:2 * Dn], lw["kn"], cos, sin, Ltok, eps, 1.0)
+                self.pack_rows(qkv[b, :, :D], send[b, :, :, :Dn], lw["qn"], cos, sin, Ltok, eps, ops.ATTN_LOG2_SCALE)     # q in log2 units
+                self.pack_rows(qkv[b, :, 2 * D:], send[b, :, :, 2 * Dn:], None, None, None, Ltok, eps, 1.0)
+                fwd.append([self.backend.all_to_all(recv[b], send[b], async_op=True)])
         bwd = []
         for b in range(B):
             with ctx(b):
                 for h in fwd[b]:
                     h.wait()
-                qf, kf, vf = (recv[b, j].view(1, Lf, Dn) for j in range(3))              # all ranks' tokens, my heads
+                qf, kf, vf = recv[b].view(1, Lf, 3 * Dn).split(Dn, dim=2)                # all ranks' tokens, my heads
                 ops.transpose_v(vf, Hn, out=vt[b])
                 net._timed("self_attn", ops.flash_attn, qf, kf, vt[b], out=ofull[b].view(1, Lf, Dn), q_prescaled=True)
                 bwd.append(self.backend.all_to_all(back[b], ofull[b], async_op=True))    # back[b][g] = my tokens, head group g
@@ -428,7 +470,7 @@ class SequenceParallel:
 
     @staticmethod
     def pack_rows(x, out, w, cos, sin, Ltok, eps, out_scale):
-        """x (Ltok, D) view -> out (N, Ltok, D / N): RMSNorm + RoPE (w given) or plain copy (w None) straight into the send layout
+        """x (Ltok, D) view -> out (N, Ltok, D / N) (a column third of the (N, Ltok, 3 D / N) message): RMSNorm + RoPE (w given) or plain copy (w None) straight into the send layout
         of the head <-> sequence all-to-all: one kernel (scail_rmsnorm_rope_slabs).  GPU tensors only -- there is no CPU path; the layout
         is pinned by tests/test_kernels_gpu.py::test_rmsnorm_rope_slabs: out == rows.view(Ltok, N, D / N).permute(1, 0, 2) of the
         row-major kernel's result, bit for bit."""
@@ -440,8 +482,8 @@ class SequenceParallel:
         """xn (B, Lloc, D) -> att (B, Lloc, D): per CFG batch element K / V projection, K norm + RoPE and the all-gather of
         both (so the gather of element b runs under the projection of element b+1), Q projection + norm + RoPE under the
         last gather, then attention of the local queries over all ranks' keys element by element.
-        Layout: K and V ROWS are gathered (not per-rank V^T images), so each arrives as one contiguous (size * Ltok, D)
-        matrix in rank-major token order and the attention is the ordinary single-segment launch (4-wave kernel whenever
+        Layout: K and V ROWS are gathered (not per-rank V^T images) side by side in ONE collective, so they arrive as one
+        (size * Ltok, 2 D) matrix in rank-major token order (column halves k, v) and the attention is the ordinary single-segment launch (4-wave kernel whenever
         the unsharded length is a multiple of 64, however ragged the per-rank slabs are); V^T is staged from the gathered
         rows (one pass over 2 L D bytes per element: 0.1 % of the attention it feeds)."""
         D, nh, N = net.hidden_size, net.num_attention_heads, self.size
@@ -452,23 +494,22 @@ class SequenceParallel:
         if key not in self._buf:
             dev = xn.device
             e = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.bfloat16)
-            self._buf = {key: dict(kloc=e(B, Ltok, D), vloc=e(B, Ltok, D), kg=e(B, N, Ltok, D), vg=e(B, N, Ltok, D),
-                                   vt=e(B, 1, nh, 128, (Lf + 63) // 64 * 64))}
+            self._buf = {key: dict(kvloc=e(B, Ltok, 2 * D), kvg=e(B, N, Ltok, 2 * D), vt=e(B, 1, nh, 128, (Lf + 63) // 64 * 64))}
         bufs = self._buf[key]
-        kloc, vloc, kg, vg, vt = bufs["kloc"], bufs["vloc"], bufs["kg"], bufs["vg"], bufs["vt"]
+        kvloc, kvg, vt = bufs["kvloc"], bufs["kvg"], bufs["vt"]          # k | v side by side in a row: ONE all-gather per element
         hs = []
         for b in range(B):      # K / V projection per element: the gather of element b runs under the projection of element b+1
             ops.gemm(xn[b], lw["qkv_w"][D:2 * D], lw["qkv_b"][D:2 * D], out=qkv[b, :, D:2 * D])
-            ops.gemm(xn[b], lw["qkv_w"][2 * D:], lw["qkv_b"][2 * D:], out=vloc[b])
-            ops.rmsnorm_rope(qkv[b:b + 1, :, D:2 * D], lw["kn"], cos, sin, out=kloc[b:b + 1], rows_per_batch=Ltok, eps=eps)
-            hs.append((self.backend.all_gather_into(kg[b], kloc[b]), self.backend.all_gather_into(vg[b], vloc[b])))
+            ops.gemm(xn[b], lw["qkv_w"][2 * D:], lw["qkv_b"][2 * D:], out=kvloc[b, :, D:])
+            ops.rmsnorm_rope(qkv[b:b + 1, :, D:2 * D], lw["kn"], cos, sin, out=kvloc[b:b + 1, :, :D], rows_per_batch=Ltok, eps=eps)
+            hs.append(self.backend.all_gather_into(kvg[b], kvloc[b]))
         ops.gemm(xn, lw["qkv_w"][:D], lw["qkv_b"][:D], out=q)                       # overlaps the exchange
         ops.rmsnorm_rope(q, lw["qn"], cos, sin, rows_per_batch=Ltok, eps=eps, out_scale=ops.ATTN_LOG2_SCALE)        # q in log2 units
         for b in range(B):
-            hs[b][0].wait()
-            hs[b][1].wait()
-            ops.transpose_v(vg[b].view(1, Lf, D), nh, out=vt[b])
-            net._timed("self_attn", ops.flash_attn, q[b:b + 1], kg[b].view(1, Lf, D), vt[b], out=att[b:b + 1], q_prescaled=True)
+            hs[b].wait()
+            kg, vg = kvg[b].view(1, Lf, 2 * D).split(D, dim=2)
+            ops.transpose_v(vg, nh, out=vt[b])
+            net._timed("self_attn", ops.flash_attn, q[b:b + 1], kg, vt[b], out=att[b:b + 1], q_prescaled=True)
         return att
 
 

@@ -40,3 +40,33 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def attention_plan_rows(cus: int, pairs: int, Lq: int) -> int:
+    """Independent statement of the launch plan of csrc/attn.hip attn4_plan (include/scail_hip.h scail_flash_attn_rows_for) for a device
+    with ``cus`` compute units: 256 / 192 = one launch of that tile height, 448 = whole rounds of 256-row workgroups + 192-row workgroups
+    for the remaining rows.  Tests derive their expectation from the device's CU count with this instead of a constant that only holds
+    at 256 CUs."""
+    import math
+    n4, n3 = -(-Lq // 256), -(-Lq // 192)
+    W4, W3 = pairs * n4, pairs * n3
+    rounds = lambda w: float(-(-w // cus))
+    best, rows = rounds(W4), 256
+    if rounds(W3) * 0.79 < best * 0.985:
+        best, rows = rounds(W3) * 0.79, 192
+    kk = W4 // cus
+    for k in range(kk, max(0, kk - 5), -1):
+        if k < 1:
+            break
+        amax = k * cus
+        p, c = amax // n4, (amax % n4) // 3
+        if p >= pairs:
+            continue
+        a, i3 = p * n4 + 3 * c, p * n3 + 4 * c
+        b = W3 - i3
+        if a <= 0 or b <= 0:
+            continue
+        cost = rounds(a) + rounds(b) * 0.79 + 0.02
+        if cost < best * 0.985:
+            best, rows = cost, 448
+    return rows

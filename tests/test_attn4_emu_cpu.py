@@ -137,6 +137,7 @@ def test_m16f_optimistic_pass_needs_no_restart_inside_the_headroom():
     """a key 80 log2 units above the first tile's maximum (P up to 2^40 with 40 units of headroom): one pass, exact"""
     st, tiles = _m16f_spiked(5.0, row=7, key=64 * 2 + 5)
     assert st["mfma"] == 136 * tiles                     # 128 + 8 (row sums) MFMAs per tile and wave, nothing recomputed
+    assert st["restarts"] == 0                           # the restart counter of the kernel arguments stays untouched
 
 
 @pytest.mark.parametrize("row,key", [(7, 64 * 2 + 5), (150, 64 * 3 + 63), (255, 64 * 1)])
@@ -146,6 +147,20 @@ def test_m16f_optimistic_pass_overflow_restarts_the_workgroup(row, key):
     runs again with the lazy-maximum loop -- twice the MFMAs, the right result, nothing stored from the first pass"""
     st, tiles = _m16f_spiked(12.0, row=row, key=key, lazy=bool(row & 1))
     assert st["mfma"] == 2 * 136 * tiles
+    assert st["restarts"] == 1                           # ONE count per restarting workgroup (wave 0, one lane), whichever wave saw the overflow
+
+
+def test_m16f_restart_counter_is_optional():
+    """a null counter pointer (every caller but the profiler): the restart path skips the atomic"""
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((1, 256, 128)).astype(np.float32)
+    k = rng.standard_normal((1, 64 * 11, 128)).astype(np.float32)
+    v = rng.standard_normal((1, 64 * 11, 128)).astype(np.float32)
+    k[0, 64 * 4 + 1] = q[0, 9] * 12.0
+    o, st = R.run(attn4.M16F, q, [k], [v], 1, count_restarts=False)
+    o2, st2 = R.run(attn4.M16F, q, [k], [v], 1, count_restarts=True)
+    assert st["restarts"] == 0 and st2["restarts"] == 1 and st["mfma"] == st2["mfma"] == 2 * 136 * 11
+    assert np.array_equal(o, o2)
 
 
 def test_m16f_restart_with_key_segments_and_ragged_tail():

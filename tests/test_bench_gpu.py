@@ -65,7 +65,11 @@ def test_bench_eight_process_ranks_full_width_two_layers():
     eight = _run(cmd + common, {"SCAIL_DIST_BACKEND": "gloo"}, base_env=env, timeout=1500)
     cfg = eight["config"]
     assert eight["n_gpus"] == 8 and cfg["finite"] and cfg["parallelism"] == "sp8-ulysses" and cfg["path"].startswith("scail_dit_step_sp")
-    assert cfg["sp_check"]["ranks"] == 8 and cfg["attn_query_tile_rows"] == 448
+    import torch
+    from conftest import attention_plan_rows
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert cfg["sp_check"]["ranks"] == 8 and cfg["attn_query_tile_rows"] == attention_plan_rows(cus, 5, 48832)      # 448 on the 256-CU part
+    assert cfg["exchange_collectives_per_layer"] == 4 and cfg["exchange_exposed"]["waits_per_step"] == 2 * (2 * 2 - 1)   # fwd + back waits per element-layer
     assert cfg["result_preserving_prunings"] == {"last_layer_noise_rows_only": True, "cfg_pair_layer0_once": True}
     assert eight["roofline"]["launches_timed"] == 2 * 2 - 1                       # per CFG element and layer, layer 0 once (cfg pair)
     assert abs(cfg["x_abs_mean"] - one["config"]["x_abs_mean"]) < 2e-3 * one["config"]["x_abs_mean"]

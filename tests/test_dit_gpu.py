@@ -166,6 +166,26 @@ def test_dit_conditioning_cache_and_batch_of_one(golden_dir):
     assert not torch.equal(o1, o3)
 
 
+def test_cfg_pair_flag_is_checked_against_the_inputs(golden_dir):
+    """SCAIL_DIT_CFG_PAIR is a statement about the inputs (x[1] == x[0], t[1] == t[0]: element 1 receives element 0's layer-0
+    self-attention).  The binding verifies it the first time a network sees the key, so a guider / denoiser that sets it on a batch
+    that is NOT one latent twice fails loudly instead of silently computing something else."""
+    g = _load(golden_dir, "dit_tiny.npz")
+    cfg, sd, net = _net(O.TINY, int(g["seed"]))
+    kw = dict(concat_images=torch.zeros(1, device=DEV), ref_concat=g["ref"].to(DEV), concat_smpl_render=g["pose"].to(DEV),
+              image_clip_features=g["clip"].to(DEV))
+    x, t = g["x"].to(DEV), g["t"].to(DEV)
+    assert not torch.equal(x[0], x[1])                                    # the golden's batch holds two different latents
+    with pytest.raises(ValueError, match="cfg_pair"):
+        net(x, timesteps=t, context=g["ctx"].to(DEV), cfg_pair=True, **kw)
+    xx = torch.cat([x[:1], x[:1]])
+    with pytest.raises(ValueError, match="cfg_pair"):
+        net(xx, timesteps=torch.tensor([700.0, 701.0], device=DEV), context=g["ctx"].to(DEV), cfg_pair=True, **kw)
+    a = net(xx, timesteps=t, context=g["ctx"].to(DEV), cfg_pair=True, **kw)          # a true pair: accepted, and bit-identical to the plain evaluation
+    b = net(xx, timesteps=t, context=g["ctx"].to(DEV), **kw)
+    assert torch.equal(a, b)
+
+
 def test_sampler_two_steps_vs_reference_golden(golden_dir):
     """RFSampler + Denoiser + VanillaCFG + OpenAIWrapper protocol (generic path) and the fused HIP
     path against the reference's 2-step run (sampler_tiny.npz)."""

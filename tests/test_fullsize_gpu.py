@@ -188,7 +188,7 @@ def test_m16f_prescaled_attention_ragged_480x832():
 def test_attention_launch_shapes_of_a_sequence_parallel_rank(heads, Lq, Lk):
     """The launches of a rank (Ulysses at 8 / 4 ranks: 5 / 10 heads x the full sequence, ONE batch element): pair counts that are no
     multiple of 8 take the run-per-XCD workgroup-id decode (xcd_mode 2), and the per-launch choice of the query-tile height
-    (asmgen/attn4.py Cfg.nq; csrc/attn.hip attn4_pick_rows).  All four combinations {192, 256 rows} x {XCD-aware, plain decode} must agree
+    (asmgen/attn4.py Cfg.nq; csrc/attn.hip attn4_plan).  All four combinations {192, 256 rows} x {XCD-aware, plain decode} must agree
     bit for bit -- and so must the planned shape (rows = 0: whole rounds of 256-row workgroups + 192-row workgroups for the remaining rows,
     two launches) --, and with fp32 softmax on sampled rows (reference sat/mpu/ulysses_attn_layer.py:65-107 -> transformer_defaults.py:67-72)."""
     from scail_amd import lib, ops
@@ -213,8 +213,17 @@ def test_attention_launch_shapes_of_a_sequence_parallel_rank(heads, Lq, Lk):
     base = outs[(256, 0)]
     plan = lib.load().scail_flash_attn_rows_for(1, heads, Lq)
     print(f"launch plan for 1 x {heads} pairs x {Lq} queries: {plan}")
-    if heads in (5, 10) and Lq > 40000:
-        assert plan == 448, "a rank-sized launch must get the mixed plan (whole 256-row rounds + 192-row tiles)"
+    from conftest import attention_plan_rows
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert plan == attention_plan_rows(cus, heads, Lq), "scail_flash_attn_rows_for vs the plan stated in tests/conftest.py for this device's CU count"
+    if heads in (5, 10) and Lq > 40000 and cus == 256:
+        assert plan == 448, "on the 256-CU part a rank-sized launch gets the mixed plan (whole 256-row rounds + 192-row tiles)"
+    # option "attn4_cus": CUs the plan may count on (a rank whose collectives hold some) -- same statement with fewer CUs
+    try:
+        lib.set_option("attn4_cus", cus - 16)
+        assert lib.load().scail_flash_attn_rows_for(1, heads, Lq) == attention_plan_rows(cus - 16, heads, Lq)
+    finally:
+        lib.set_option("attn4_cus", 0)
     for key, o in outs.items():
         assert torch.equal(o, base), f"rows / xcd {key} differs from 256-row plain decode: max |d| {float((o.float() - base.float()).abs().max())}"
     rows = torch.cat([torch.arange(0, 16), torch.arange(Lq - 20, Lq), torch.randint(0, Lq, (92,), generator=torch.Generator().manual_seed(1))]).to(DEV)

@@ -261,9 +261,116 @@ def test_rmsnorm_rope_slabs(ops, heads, n_slabs):
             rows = torch.empty(Ltok, D, device=DEV, dtype=torch.bfloat16)
             ops.rmsnorm_rope(src, wt, tabs[0], tabs[1], out=rows, out_scale=scale)
         assert torch.equal(slabs, rows.view(Ltok, n_slabs, Dn).permute(1, 0, 2)), (col, scale)
+        # the ONE-message layout of the fused exchange (include/scail_dit.h): (dst rank, token, q | k | v) -- this third's columns of
+        # every message row hold the same values, the other two thirds are left alone
+        msg = torch.full((n_slabs, Ltok, 3 * Dn), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.rmsnorm_rope_slabs(src, wt, msg[:, :, col * Dn:(col + 1) * Dn], tabs[0], tabs[1], out_scale=scale)
+        assert torch.equal(msg[:, :, col * Dn:(col + 1) * Dn], slabs), (col, scale)
+        keep = [j for j in range(3) if j != col]
+        assert all(bool((msg[:, :, j * Dn:(j + 1) * Dn] == 7.0).all()) for j in keep)
     from scail_amd import lib as L
-    with pytest.raises(L.ScailHipError, match="contiguous"):
+    with pytest.raises(L.ScailHipError, match="contiguous last dim"):
         ops.rmsnorm_rope_slabs(xg[:, :D], w, torch.empty(n_slabs, Ltok + 1, Dn, device=DEV, dtype=torch.bfloat16))
+
+
+def test_options_flipped_by_another_thread_while_launching(ops):
+    """scail_set_option state is std::atomic (include/scail_hip.h): a thread that flips "attn4_rows" / "attn4_xcd" / "attn4_cus" while
+    another thread launches attentions is defined behaviour -- every launch reads each option once, and all tile heights give the
+    same bits (no exp2 overflow on this data), so every result of the launching thread is identical."""
+    import threading
+    from scail_amd import lib as L
+    heads, Lq, Lk = 3, 1000, 2100
+    D = heads * 128
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q = (torch.randn(1, Lq, D, device=DEV, generator=g) * ops.ATTN_LOG2_SCALE).to(torch.bfloat16)
+    k = torch.randn(1, Lk, D, device=DEV, generator=g).to(torch.bfloat16)
+    vt = ops.transpose_v(torch.randn(1, Lk, D, device=DEV, generator=g).to(torch.bfloat16), heads)
+    base = ops.flash_attn(q, k, vt, q_prescaled=True)
+    stop, errs = threading.Event(), []
+
+    def flipper():
+        i = 0
+        while not stop.is_set():
+            L.set_option("attn4_rows", (0, 192, 256)[i % 3])
+            L.set_option("attn4_xcd", i & 1)
+            L.set_option("attn4_cus", (0, 200, 17)[i % 3])
+            i += 1
+
+    def launcher():
+        try:
+            torch.cuda.set_device(0)
+            for _ in range(300):
+                o = ops.flash_attn(q, k, vt, q_prescaled=True)
+                if not torch.equal(o, base):
+                    errs.append("result changed under a concurrent option flip")
+                    break
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    t1, t2 = threading.Thread(target=flipper), threading.Thread(target=launcher)
+    try:
+        t1.start(); t2.start()
+        t2.join()
+    finally:
+        stop.set()
+        t1.join()
+        for name, v in (("attn4_rows", 0), ("attn4_xcd", 1), ("attn4_cus", 0)):
+            L.set_option(name, v)
+    assert not errs, errs
+
+
+def test_explicit_attn4_rows_wins_over_the_executor_hint(ops):
+    """the executor's thread-local hint (two attentions side by side -> one 256-row launch each) applies to the automatic
+    choice only; an operator's explicit option "attn4_rows" wins.  scail_flash_attn_rows_for reports the shape a launch would take."""
+    from scail_amd import lib as L
+    lib = L.load()
+    try:
+        L.set_option("attn4_rows", 192)
+        assert lib.scail_flash_attn_rows_for(1, 5, 48832) == 192
+        L.set_option("attn4_rows", 256)
+        assert lib.scail_flash_attn_rows_for(1, 5, 48832) == 256
+    finally:
+        L.set_option("attn4_rows", 0)
+
+
+def test_restart_counter_counts_workgroups(ops):
+    """scail_flash_attn_count_restarts (include/scail_hip.h): a device counter gets + 1 per workgroup of scail_attn4_m16f that leaves the
+    optimistic pass (a score > ~167 log2 units above the first key tile's row maximum) and runs again; random data never restarts.  Two
+    spiked query rows in different 256-row tiles of one head -> exactly 2; results equal fp32 softmax either way."""
+    from scail_amd import lib as L
+    heads, Lq, Lk = 2, 1024, 1536
+    D = heads * 128
+    g = torch.Generator(device=DEV).manual_seed(9)
+    q = torch.randn(1, Lq, D, device=DEV, generator=g)
+    k = torch.randn(1, Lk, D, device=DEV, generator=g)
+    v = torch.randn(1, Lk, D, device=DEV, generator=g).to(torch.bfloat16)
+    vt = ops.transpose_v(v, heads)
+    ctr = torch.zeros(1, device=DEV, dtype=torch.int32)
+
+    def run(qq, kk):
+        ctr.zero_()
+        L.call("scail_flash_attn_count_restarts", ctr.data_ptr())
+        try:
+            o = ops.flash_attn((qq * ops.ATTN_LOG2_SCALE).to(torch.bfloat16), kk.to(torch.bfloat16), vt, q_prescaled=True)
+        finally:
+            L.call("scail_flash_attn_count_restarts", None)
+        torch.cuda.synchronize()
+        return o, int(ctr.item())
+
+    o0, n0 = run(q, k)
+    assert n0 == 0
+    k2 = k.clone()
+    k2[0, 64 * 5 + 3, :128] = q[0, 10, :128] * 12.0          # head 0: query row 10 (tile 0) against key 323: ~196 log2 units above tile 0's maximum
+    k2[0, 64 * 9 + 1, :128] = q[0, 700, :128] * 12.0         # head 0: query row 700 (tile 2)
+    o2, n2 = run(q, k2)
+    assert n2 == 2, n2
+    qb, kb = (q * ops.ATTN_LOG2_SCALE).to(torch.bfloat16).float(), k2.to(torch.bfloat16).float()
+    for h in range(heads):
+        sl = slice(h * 128, (h + 1) * 128)
+        ref = torch.softmax(qb[0, :, sl] @ kb[0, :, sl].t() * math.log(2.0), dim=-1) @ v[0, :, sl].float()
+        torch.testing.assert_close(o2[0, :, sl].float(), ref, rtol=2e-2, atol=2e-2)
+    o3, n3 = run(q, k2)                                       # the count is per registration (the caller zeroes its counter)
+    assert n3 == 2 and torch.equal(o3, o2)
 
 
 def test_rope_tables_match_oracle():

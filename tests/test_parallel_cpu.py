@@ -35,11 +35,11 @@ def _worker(rank, world, port, golden, q):
     sp.check_latent(x.shape[3], x.shape[4], cd)
 
     def kv_gather(k, v):                                   # the per-layer exchange (parallel.py)
-        kg = torch.empty(world, *k.shape)
-        vg = torch.empty(world, *v.shape)
-        sp.backend.all_gather_into(kg, k.contiguous(), async_op=False)
-        sp.backend.all_gather_into(vg, v.contiguous(), async_op=False)
-        return torch.cat(list(kg), dim=2), torch.cat(list(vg), dim=2)
+        kv = torch.cat([k, v], dim=-1).contiguous()        # ONE collective: k | v side by side, like the product's message layout
+        g2 = torch.empty(world, *kv.shape)
+        sp.backend.all_gather_into(g2, kv, async_op=False)
+        kg, vg = torch.cat(list(g2), dim=2).split(k.shape[-1], dim=-1)
+        return kg, vg
 
     shift = rank * (x.shape[cd] // world // 2)            # rank-shifted RoPE window along the split axis (dit...:1578-1585)
     out = O.dit_forward(cfg, sd, sp.chunk(x, cd), g["t"], g["ctx"], sp.chunk(g["ref"], cd), sp.chunk(g["pose"], cd),

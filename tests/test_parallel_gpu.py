@@ -122,6 +122,33 @@ def test_sp_c_executor_equals_per_op_path_small(world, mode, chunk_dim, side, mo
     torch.testing.assert_close(c, single, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("world,mode,use_c", [(4, "ulysses", True), (4, "ulysses", False), (2, "allgather", True), (2, "allgather", False)])
+def test_exchange_is_one_collective_each_way(world, mode, use_c, monkeypatch):
+    """The layer exchange is ONE collective per direction and CFG element: q | k | v travel side by side in one all-to-all (the
+    reference issues three, sat/mpu/ulysses_attn_layer.py:65-80) + one back = 4 per layer at B = 2 (round 5: 8); all-gather mode:
+    one gather of k | v per element = 2 per layer (round 5: 4).  Counted on every virtual rank, C executor and per-op path."""
+    from scail_amd.parallel import ThreadBackend
+    counts, lock = {}, threading.Lock()
+
+    def counted(name):
+        orig = getattr(ThreadBackend, name)
+
+        def f(self, *a, **k):
+            with lock:
+                counts[name, self.rank] = counts.get((name, self.rank), 0) + 1
+            return orig(self, *a, **k)
+        return f
+
+    monkeypatch.setattr(ThreadBackend, "all_to_all", counted("all_to_all"))
+    monkeypatch.setattr(ThreadBackend, "all_gather_into", counted("all_gather_into"))
+    cfgd = dict(hidden_size=512, num_attention_heads=4, inner_hidden_size=1024, text_dim=64, time_freq_dim=256, time_embed_dim=512)
+    layers = 3
+    _run_ranks(world, mode, lambda: _mk(cfgd, layers, seed=77), _inputs(2, 16, 32, 1, 64, 12, 5, seed=11), 3, use_c=use_c)
+    for rk in range(world):
+        a2a, ag = counts.get(("all_to_all", rk), 0), counts.get(("all_gather_into", rk), 0)
+        assert (a2a, ag) == ((layers * 2 * 2, 0) if mode == "ulysses" else (0, layers * 2)), (rk, a2a, ag)
+
+
 @pytest.mark.parametrize("world,mode", [(1, None), (8, "ulysses"), (4, "ulysses"), (2, "allgather")])
 def test_cfg_pair_is_bit_identical_at_full_size(world, mode):
     """SCAIL_DIT_CFG_PAIR (include/scail_dit.h; guiders.py:41-57, dit...:1009-1042): the sampler's batch is one latent twice, so layer 0 up to

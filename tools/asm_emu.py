@@ -439,6 +439,15 @@ class Emu:
                             bank[d.idx + i][l] = data[i]
             self._queue(w, "vm", commit)
             return
+        if op == "global_atomic_add":
+            addr = self._gaddr(w, s[0], s[2]) + ins.offset
+            data = w.v[s[1].idx]
+            for l in range(64):
+                if w.exec[l]:
+                    cur = self.mem.load(int(addr[l]), 4).view(np.uint32)[0]
+                    self.mem.store(int(addr[l]), np.array([(int(cur) + int(data[l])) & 0xFFFFFFFF], np.uint32).view(np.uint8))
+            self._queue(w, "vm", lambda: None)
+            return
         if op.startswith("global_store"):
             nb = s[1].n * 4
             addr = self._gaddr(w, s[0], s[2] if len(s) > 2 else None) + ins.offset

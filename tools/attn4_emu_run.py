@@ -52,7 +52,7 @@ def reference(q, k, v, heads):
 
 
 def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = True, thr_log2: float = 8.0, program=None, mode=None,
-        raw_scale: bool = False, launches=None):
+        raw_scale: bool = False, launches=None, count_restarts: bool = True):
     """q (B, Lq, H*128) fp32; ksegs / vsegs: lists (one per segment) of (B, Lk, H*128) fp32.  Returns O (B, Lq, H*128) fp32
     and the emulator statistics of the last workgroup.  raw_scale (qscale kernels): q goes in UNSCALED with sl2 = scale * log2(e)
     as the kernel argument (the prologue multiplies the fragments), instead of pre-multiplied with sl2 = 0."""
@@ -72,6 +72,7 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
     pk = mem.alloc("k", kb)
     pvt = mem.alloc("vt", vt)
     po = mem.alloc("o", np.zeros((B, Lq, D), dtype=np.uint16))
+    pctr = mem.alloc("restarts", np.zeros(4, dtype=np.uint32))          # the optional restart counter of the kernel arguments
     thr = thr_log2 if fold else thr_log2 / sl2           # fold kernels see scores in log2 units
     if fold and not raw_scale:
         sl2 = 0.0 if getattr(cfg, "qscale", False) else 1.0       # qscale kernels: 0 = q is in log2 units already
@@ -85,12 +86,15 @@ def run(cfg: attn4.Cfg, q: np.ndarray, ksegs, vsegs, heads: int, lazy: bool = Tr
         total = ((Lq + lcfg.rows - 1) // lcfg.rows) * heads * B
         n = total - item0 if n_items is None else n_items
         args = attn4.pack_args(pq, pk, pvt, po, Lq * D, D, B * Lk * D, Lk * D, D, B * heads * 128 * Lkp, heads * 128 * Lkp, Lq * D, D,
-                               heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=B, mode=m, rows=lcfg.rows, item0=item0, n_items=n)
+                               heads, Lq, Lk, Lkp, n_seg, sl2, thr, n_batch=B, mode=m, rows=lcfg.rows, item0=item0, n_items=n,
+                               restarts=pctr if count_restarts else 0)
         for wid in range(attn4.grid_for(n, m)):
             emu = E.Emu(prog, mem, n_waves=4, lds_bytes=lcfg.lds_bytes, lazy=lazy)
             emu.launch(args, block_id=(wid, 0, 0))
             if stats is None or emu.waves[0].stats.get("mfma", 0) > 0:       # xcd_mode 2 pads the grid with workgroups that exit at once
                 stats = emu.waves[0].stats
+    stats = dict(stats or {})
+    stats["restarts"] = int(mem.read_back("restarts")[0])              # workgroups that ran again (0 without count_restarts)
     return from_bf16_bits(mem.read_back("o")), stats
 
 
