@@ -665,6 +665,12 @@ def main():
             # spread of this figure over the GPU boxes of the pool (same code, rounds 3-5: host load and NUMA placement differ from box to box);
             # much wider than the fit's standard error above -- quote the baseline as "about 2-2.5 tokens/s"
             "box_to_box_range": [1.9, 2.5],
+            # Does the port cost what the reference costs?  Both timed side by side in the BUILD container (the reference cannot travel):
+            # the reference's own AdaLNMixin.layer_forward inside DiffusionTransformer.forward vs O.block inside O.dit_forward, same
+            # weights / inputs / 8 threads, D = 5120, B = 2: 2.35 vs 2.83 s at L = 1008, 6.52 vs 9.04 s at L = 2128 (outputs equal to 3e-6).
+            # The port is the SLOWER of the two: the reference's block on this host would give about value x this ratio.
+            # tools/cpu_port_vs_reference.py, profiles/r06_cpu_port_vs_reference.log; a constant, not measured in this run.
+            "port_vs_reference_time_ratio": 1.34,
             "sample": f"oracle block (fp32, torch CPU, {cb['threads']} threads = fastest of "
                       + ", ".join(f"{k}: {v * 1e3:.0f} ms" for k, v in sorted(cb["probe"].items())) + " on the 2016x5120x15360 projection) at full "
                       f"width D={p['hidden_size']}, B=2, after one warm-up call: whole block at L = "

@@ -20,6 +20,12 @@ MFMA_RESULT_DIST = 16      # slots between an MFMA and a non-accumulate reader /
 VALU_TO_MFMA_DIST = 3      # VALU (incl. v_accvgpr_write, v_cvt_pk) result -> MFMA operand: 2 wait states
 TRANS_DIST = 2             # v_exp / v_rcp result -> non-transcendental VALU: 1 wait state
 PERMLANE_DIST = 3          # VALU result -> v_permlane32_swap operand: 2 wait states
+READLANE_DIST = 2          # VALU result -> v_readfirstlane / v_readlane source VGPR: 1 wait state, NOT interlocked (measured on MI355X in
+                           # round 6: the lane read returned the register's PREVIOUS value -- the attention restart flag of wave 3 was
+                           # lost this way, profiles/r06_attn_restart_readlane_hazard.log)
+VALU_SGPR_TO_VALU_DIST = 3   # VALU-written SGPR / VCC (v_cmp, v_readfirstlane) -> VALU reading it as an operand (v_cndmask, v_mov ...): 2 wait states
+                           # (the gfx940-family rule the vendor compiler pads with s_nop 1; same source as READLANE_DIST)
+WIDE_STORE_WAR_DIST = 2    # VMEM store of more than 64 bits -> VALU overwriting its data registers: 1 wait state
 M0_DIST = 2                # s_mov / s_add m0 -> LDS-DMA
 VCC_BRANCH_DIST = 2        # v_cmp -> s_cbranch_vcc*
 SGPR_VALU_TO_VMEM_DIST = 6   # VALU-written SGPR (readfirstlane) -> VMEM / SMEM use: 5 wait states
@@ -50,16 +56,22 @@ def min_distance(p: Instr, c: Instr, kind: str, unit: Tuple[str, int]) -> int:
                 return TRANS_DIST
             if c.op in ("v_permlane32_swap_b32", "v_permlane16_swap_b32") and p.cls in (isa.VALU, isa.TRANS):
                 return PERMLANE_DIST
+            if c.op in ("v_readfirstlane_b32", "v_readlane_b32") and unit[0] == "v" and p.cls in (isa.VALU, isa.TRANS):
+                return max(READLANE_DIST, TRANS_DIST if p.cls == isa.TRANS else 0)
             if unit[0] == "m0" and c.cls == isa.LDS_DMA:
                 return M0_DIST
             if unit[0] == "vcc" and c.cls == isa.BRANCH and p.cls in (isa.VALU, isa.TRANS):
                 return VCC_BRANCH_DIST
             if unit[0] == "s" and p.cls in (isa.VALU,) and c.cls in (isa.VMEM_LOAD, isa.VMEM_STORE, isa.LDS_DMA, isa.SALU):
                 return SGPR_VALU_TO_VMEM_DIST
+            if unit[0] in ("s", "vcc") and p.cls in (isa.VALU, isa.TRANS) and c.cls in (isa.VALU, isa.TRANS, isa.MFMA):
+                return VALU_SGPR_TO_VALU_DIST
         return 1
     # war
     if p.cls == isa.MFMA:
         return MFMA_SRC_WAR_DIST
+    if p.cls == isa.VMEM_STORE and c.cls in (isa.VALU, isa.TRANS) and unit[0] == "v" and ("dwordx4" in p.op or "dwordx3" in p.op):
+        return WIDE_STORE_WAR_DIST
     return 1
 
 

@@ -44,6 +44,29 @@ def test_generated_file_is_current():
     assert open(os.path.join(ROOT, "scail_amd", "csrc", "attn4.s")).read() == text, "run `python -m scail_amd.asmgen.attn4`"
 
 
+def test_hazard_table_lane_read_valu_sgpr_and_wide_store_rules():
+    """Rules the hardware does not interlock and the emulator (in-order, every result visible at once) cannot see.  Round 6, MI355X:
+    v_or_b32 v6, v6, v11 ; v_readfirstlane_b32 s68, v6  returned v6's previous value -- the attention restart flag of wave 3 was lost
+    (profiles/r06_attn_restart_readlane_hazard.log).  The static table pads and re-checks: VALU result -> lane read 1 wait state,
+    VALU-written SGPR / VCC -> VALU operand 2, VMEM store > 64 bits -> VALU overwrite of its data 1."""
+    from scail_amd.asmgen import isa, sched
+    from scail_amd.asmgen.isa import V, S, I32
+    seq = [isa.vop("v_or_b32", V(6), V(6), V(11)), isa.vop("v_readfirstlane_b32", S(68), V(6))]
+    assert any("RAW" in e and "v_readfirstlane_b32" in e for e in sched.check_hazards(seq))
+    padded = sched.pad_hazards(seq)
+    assert [i.op for i in padded] == ["v_or_b32", "s_nop", "v_readfirstlane_b32"] and sched.check_hazards(padded) == []
+    seq = [isa.v_cmp("v_cmp_eq_u32", V(1), I32(0)), isa.v_cndmask(V(2), V(3), V(4))]
+    assert sched.check_hazards(seq)
+    padded = sched.pad_hazards(seq)
+    assert sched.check_hazards(padded) == [] and sum(getattr(i, "count", 1) for i in padded if i.op == "s_nop") == 2
+    seq = [isa.vop("v_readfirstlane_b32", S(68), V(6)), isa.vop("v_mov_b32", V(7), S(68))]
+    assert sched.check_hazards(seq) and sched.check_hazards(sched.pad_hazards(seq)) == []
+    seq = [isa.global_store(4, V(20, 2), V(8, 4)), isa.vop("v_mov_b32", V(9), I32(0))]
+    assert any("WAR" in e for e in sched.check_hazards(seq)) and sched.check_hazards(sched.pad_hazards(seq)) == []
+    seq = [isa.global_store(2, V(20, 2), V(8, 2)), isa.vop("v_mov_b32", V(9), I32(0))]
+    assert sched.check_hazards(seq) == []
+
+
 @pytest.mark.parametrize("rd", [4, 2])
 def test_static_hazards_clean(rd):
     assert R.check_static(attn4.Cfg(rd=rd)) == []

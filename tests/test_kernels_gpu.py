@@ -333,6 +333,47 @@ def test_explicit_attn4_rows_wins_over_the_executor_hint(ops):
         L.set_option("attn4_rows", 0)
 
 
+@pytest.mark.parametrize("rows", [256, 192])
+def test_restart_decision_reaches_every_wave(ops, rows):
+    """The decision to run a workgroup again is taken from four per-wave flags exchanged through LDS; each wave ORs the four words and reads
+    the result with v_readfirstlane.  Round 6 found on MI355X that a VALU result read by v_readfirstlane in the NEXT issue slot returns the
+    register's previous value (not interlocked; asmgen/sched.py READLANE_DIST): the flag of wave 3 -- the last OR -- was lost, waves
+    disagreed and stored inf / inf rows (profiles/r06_attn_restart_readlane_hazard.log).  Here: the overflowing query row sits in each of
+    the four waves in turn, for both tile heights, several launches each (the failure was intermittent); every launch must count exactly
+    one restart and match fp32 softmax on ALL rows."""
+    from scail_amd import lib as L
+    Lq, Lk = rows, 64 * 40
+    g = torch.Generator(device=DEV).manual_seed(3)
+    q = torch.randn(1, Lq, 128, device=DEV, generator=g)
+    k0 = torch.randn(1, Lk, 128, device=DEV, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, Lk, 128, device=DEV, generator=g).to(torch.bfloat16)
+    vt = ops.transpose_v(v, 1)
+    qb = (q * ops.ATTN_LOG2_SCALE).to(torch.bfloat16)
+    ctr = torch.zeros(1, device=DEV, dtype=torch.int32)
+    per_wave = rows // 4
+    L.set_option("attn4_rows", rows)
+    try:
+        for wave in range(4):
+            for r, key in ((wave * per_wave, 64 * 10), (wave * per_wave + per_wave // 2 + 1, 64 * 3 + 17), ((wave + 1) * per_wave - 1, 64 * 20 + 33)):      # keys of hot-loop tiles (the remainder tiles track the maximum)
+                k = k0.clone()
+                k[0, key] = (q[0, r] * 14.0).to(torch.bfloat16)          # ~230 log2 units above the first tile's maximum: exp2 overflows
+                s = qb[0].float() @ k[0].float().t()
+                ref = torch.softmax(s * math.log(2.0), dim=-1) @ v[0].float()
+                for rep in range(3):
+                    ctr.zero_()
+                    L.call("scail_flash_attn_count_restarts", ctr.data_ptr())
+                    try:
+                        o = ops.flash_attn(qb, k, vt, q_prescaled=True)
+                        torch.cuda.synchronize()
+                    finally:
+                        L.call("scail_flash_attn_count_restarts", None)
+                    assert int(ctr.item()) == 1, (wave, r, key, rep, int(ctr.item()))
+                    assert torch.isfinite(o.float()).all(), (wave, r, key, rep)
+                    torch.testing.assert_close(o[0].float(), ref, rtol=2e-2, atol=2e-2, msg=lambda m: f"wave {wave} row {r} key {key} rep {rep}: {m}")
+    finally:
+        L.set_option("attn4_rows", 0)
+
+
 def test_restart_counter_counts_workgroups(ops):
     """scail_flash_attn_count_restarts (include/scail_hip.h): a device counter gets + 1 per workgroup of scail_attn4_m16f that leaves the
     optimistic pass (a score > ~167 log2 units above the first key tile's row maximum) and runs again; random data never restarts.  Two
@@ -668,6 +709,38 @@ def test_cross_attn2_vs_oracle(ops, B, H, Lq, Lk1, Lk2, shared2, cross4):
         tiles = (Lk1 + 63) // 64 + (Lk2 + 63) // 64
         assert which == (4 if (Lk1 >= 64 and Lk2 >= 64 and (cross4 == 1 or (cross4 == 2 and tiles >= 21))) else 2)
         _cross_attn2_case(ops, B, H, Lq, Lk1, Lk2, shared2, generated=which == 4)
+    finally:
+        L_.set_option("cross4", 2)
+
+
+@pytest.mark.parametrize("which_set", [0, 1])
+def test_cross_attn2_generated_restart_in_every_wave(ops, which_set):
+    """scail_attn4_x2 carries the same four-flag restart decision as scail_attn4_m16f, once per key set (see
+    test_restart_decision_reaches_every_wave): an overflowing query row in each wave, in either set, must give fp32 softmax on all rows."""
+    from scail_amd import lib as L_
+    H, Lq, Lk1, Lk2 = 1, 512, 64 * 8, 64 * 5 + 1
+    g = torch.Generator(device=DEV).manual_seed(11)
+    q = torch.randn(1, Lq, 128, device=DEV, generator=g)
+    ks = [torch.randn(1, n, 128, device=DEV, generator=g).to(torch.bfloat16) for n in (Lk1, Lk2)]
+    vs = [torch.randn(1, n, 128, device=DEV, generator=g).to(torch.bfloat16) for n in (Lk1, Lk2)]
+    vts = [ops.transpose_v(v, H) for v in vs]
+    qb = (q * ops.ATTN_LOG2_SCALE).to(torch.bfloat16)
+    L_.set_option("cross4", 1)
+    try:
+        assert L_.load().scail_cross_attn2_kernel_for(128, 128, 128, 128, Lq, Lk1, Lk2, 1, H) == 4
+        for wave in range(4):
+            for r in (256 + wave * 64, 256 + wave * 64 + 37, wave * 64 + 63):
+                kk = [k.clone() for k in ks]
+                kk[which_set][0, 64 * 2 + 9] = (q[0, r] * 14.0).to(torch.bfloat16)
+                ref = torch.zeros(Lq, 128, device=DEV)
+                for i, (k, v) in enumerate(zip(kk, vs)):
+                    part = torch.softmax(qb[0].float() @ k[0].float().t() * math.log(2.0), dim=-1) @ v[0].float()
+                    ref = part.to(torch.bfloat16).float() if i == 0 else ref + part      # set 0 is stored as bf16 and added to set 1
+                for rep in range(3):
+                    o = ops.cross_attn2(qb, kk[0], vts[0], kk[1], vts[1], q_prescaled=True)
+                    torch.cuda.synchronize()
+                    assert torch.isfinite(o.float()).all(), (wave, r, rep)
+                    torch.testing.assert_close(o[0].float(), ref, rtol=2e-2, atol=2e-2, msg=lambda m: f"set {which_set} wave {wave} row {r} rep {rep}: {m}")
     finally:
         L_.set_option("cross4", 2)
 

@@ -151,6 +151,8 @@ def check_static(cfg: attn4.Cfg):
             errs += sched.check_hazards(fast + g.iter_block((p + 1) % cfg.unroll, tail=False, nomax=True))
             errs += sched.check_hazards(fast + g.iter_block((p + 1) % cfg.unroll, tail=False, careful=True))
     errs += sched.check_hazards(g.prologue() + g.segment_start() + g.iter_block(0, tail=False))
+    if hasattr(g, "segment_end_and_epilogue") and cfg.mi == 16:      # the restart decision lives here (round 6: lane read of a fresh VALU result)
+        errs += sched.check_hazards(g.segment_end_and_epilogue())
     return errs
 
 
