@@ -1185,6 +1185,9 @@ def variant_cfgs():
     out.append(Cfg(epi=3, name="scail_gemm4p_e3", wpacked=True, **SHIPPED))
     for abl in ("wpack", "xpack", "wpack,xpack"):
         out.append(Cfg(epi=0, abl=abl, name="scail_gemm4_e0_abl_" + abl.replace(",", "_"), **SHIPPED))
+    # round 6: timing ablations of the SHIPPED schedule (wrong results on purpose): what each instruction class of the k-loop costs beside the MFMAs
+    for abl in ("dma", "lds", "bar", "dma,lds", "dma,lds,bar"):
+        out.append(Cfg(epi=0, abl=abl, name="scail_gemm4_e0_s_abl_" + abl.replace(",", "_"), **SHIPPED))
     out.append(Cfg(**M16, rd2_step=0.25, b1_at=5.5, dma_step=1.75, name="scail_gemm4_e0_mi16_early175"))
     out.append(Cfg(**M16, rd2_step=0.25, b1_at=5.5, dma_step=1.9, name="scail_gemm4_e0_mi16_early19"))
     out.append(Cfg(**M16, rd2_step=0.25, b1_at=4.5, dma_step=1.85, name="scail_gemm4_e0_mi16_early185"))

@@ -52,7 +52,7 @@ for LEG in "$@"; do
     vae-prof)    timeout 900 rocprofv3 --kernel-trace --stats -d "$O/prof_vae" -o vae -- python tools/vae_leg_probe.py > "$O/vae_prof.log" 2>&1
                  DB=$(find "$O/prof_vae" -name "*.db" | head -1); python tools/rocpd_summary.py "$DB" --by-grid > "$O/vae_kernel_stats.md" 2>&1; head -24 "$O/vae_kernel_stats.md" | cut -c1-150; rm -rf "$O/prof_vae" ;;
     pmc-attn)    for C in FETCH_SIZE WRITE_SIZE "$BUSY"; do pmc_pass "attn_$(echo $C | cut -d' ' -f1)" attn4 "$C" -- python tools/attn_pmc_probe.py prescaled 3; done; grep -h "FETCH\|WRITE" "$O/pmc_summary.txt" | cut -c1-200 ;;
-    pmc-gemm)    for C in FETCH_SIZE WRITE_SIZE "$BUSY"; do pmc_pass "gemm_$(echo $C | cut -d' ' -f1)" gemm4 "$C" -- python tools/gemm_layer_pmc_probe.py 2; done ;;
+    pmc-gemm)    for C in FETCH_SIZE WRITE_SIZE "$BUSY" "$LDS"; do pmc_pass "gemm_$(echo $C | cut -d' ' -f1)" gemm4 "$C" -- python tools/gemm_layer_pmc_probe.py 2; done ;;
     pmc-conv)    for CC in 96 192 384; do for C in FETCH_SIZE WRITE_SIZE; do
                    timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$O/pmcc_${CC}_$C" -o pmc -- python tools/conv_pmc_probe.py $CC 2 > "$O/pmcc_${CC}_$C.log" 2>&1
                    DB=$(find "$O/pmcc_${CC}_$C" -name "*.db" | head -1); python tools/rocpd_counters.py "$DB" conv4 | awk -v C=$CC '{print "conv4 C=" C, $(NF-4), $(NF-2)}' >> "$O/pmc_summary.txt" 2>&1
