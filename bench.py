@@ -38,6 +38,12 @@ import time
 
 # the host driver supports only dmabuf IPC: RCCL between the ranks of one node fails without this (set before HIP starts)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# RCCL channel count: deliberately NOT capped (no NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS here).  Round 6 measured on one GPU what a
+# collective's CU occupancy costs a rank of 8 (a K-workgroup resident kernel on a side stream moving the real exchange volume, 48 GB/s
+# per link and direction; profiles/r06_sp_comm_standin.log): K = 8 / 16 / 32 / 64 channels -> 71 / 81 / 88 / 90 % of T1 / 8 against 94.6 %
+# with free communication -- the exchange's DURATION (fewer channels = a longer exposed way back) costs more than the CUs the channels
+# hold, so a cap would hurt; telling the attention launch plan about the held CUs (option "attn4_cus") moved the four points by
+# +2.1 / +3.6 / -3.4 / +0.5 and stays off.  An operator's NCCL_* settings are reported in the N > 1 line (config.rccl_env).
 
 import torch  # noqa: E402
 
@@ -505,7 +511,7 @@ def main():
         attn_ms = ms / n_att if n_att else None
         gemm_ms, gemm_n = cs.profile_read(cs.PROF_GEMM)
         # workgroups of the timed self-attention launches that restarted after an overflow of the optimistic pass (0 on this synthetic data;
-        # on trained weights it says whether the measured rate holds: profiles/r06_attn_restart_sensitivity.log)
+        # on trained weights it says whether the measured rate holds: profiles/r06_attn_restart_probe.log)
         attn_restarts = cs.profile_read(cs.PROF_ATTN_RESTARTS)[1]
         xch = None
         if sp is not None:
@@ -598,6 +604,7 @@ def main():
         # known from config.sp_compute_side of the 1-GPU line, a scaling run explains itself: t_step(N) ~ compute side + these waits
         out["config"]["exchange_exposed"] = xch
         out["config"]["exchange_collectives_per_layer"] = 4 if sp_mode == "ulysses" else 2
+        out["config"]["rccl_env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}
     if not use_c:
         out["config"]["path"] = "per-op host path (scail_amd.dit._run)"
     elif n_char > 1:

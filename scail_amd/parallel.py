@@ -189,7 +189,8 @@ class ConcurrentCopyBackend(LocalCopyBackend):
     xGMI links would need for the bytes that leave the GPU (``link_gbps`` per direction and peer link, N - 1 links in parallel), while the
     compute stream carries on until the executor's WAIT callback.  What it shows on one GPU: how much of a rank's step the CU occupancy of
     its collectives costs (the attention launches one workgroup per CU; a CU held by a channel is missing from its round), for a channel
-    count K -- the measurement behind NCCL_MAX_NCHANNELS in bench.py / cli.py (tools/sp_rank_compute.py --comm-wgs K)."""
+    count K -- the measurement behind the decision NOT to cap RCCL's channels (bench.py header; tools/sp_rank_compute.py --comm-wgs K,
+    profiles/r06_sp_comm_standin.log)."""
 
     def __init__(self, size, workgroups=16, link_gbps=48.0, device="cuda"):
         super().__init__(size)
