@@ -46,9 +46,11 @@ from typing import List
 from . import isa, sched
 from .isa import A, S, V, I32, F32, VCC, EXEC, M0, Instr
 
-KERNARG_SIZE = 136
+KERNARG_SIZE = 152
 # x w bias y resid | Ti To H W | Cin N Kpad pt | tiles_t tiles_w tiles_n magic_n | magic_w magic_t n_slices ot_mul | ot_off tiles_per_wg | ldc ldr | wgs_per_xcd tiles
-KERNARG_FMT = "<5Q4i4i3iI2I2iii2q2i"
+# | gamma (epi 5 / 6: fp32 [96]) | y2 - y in bytes (epi 5: where the normalised copy goes, same row stride and frame mapping as y)
+KERNARG_FMT = "<5Q4i4i3iI2I2iii2q2iQq"
+KARG_GAMMA, KARG_Y2D = 136, 144
 
 TH, TW, NF = 16, 16, 2
 PR, PC = TH + 2, TW + 2                 # patch rows / columns
@@ -69,12 +71,13 @@ def magic31(d: int) -> int:
     return -(-(1 << 31) // d)
 
 
-def pack_args(x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt=2, ot_mul=1, ot_off=0, ldc=0, ldr=0, cus=256) -> bytes:
-    """ldc / ldr: output / residual row strides in elements (0 = N); cus: compute units (one persistent workgroup each)."""
+def pack_args(x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt=2, ot_mul=1, ot_off=0, ldc=0, ldr=0, cus=256, gamma=0, y2=0) -> bytes:
+    """ldc / ldr: output / residual row strides in elements (0 = N); cus: compute units (one persistent workgroup each); gamma / y2: the norm
+    weights and the second output of the residual + norm epilogues (epi 5 / 6)."""
     tp, tw, tn = (To + NF - 1) // NF, (W + TW - 1) // TW, (N + 95) // 96
     tiles, grid = grid_tiles(To, H, W, N), grid_blocks(To, H, W, N, cus)
     b = struct.pack(KERNARG_FMT, x, w, bias, y, resid, Ti, To, H, W, Cin, N, Kpad, pt, tp, tw, tn, magic31(tn), magic31(tw), magic31(tp),
-                    Cin // 32, ot_mul, ot_off, tiles // grid if tn == 1 else 0, ldc or N, ldr or N, grid // 8, tiles)
+                    Cin // 32, ot_mul, ot_off, tiles // grid if tn == 1 else 0, ldc or N, ldr or N, grid // 8, tiles, gamma, (y2 - y) if y2 else 0)
     assert len(b) == KERNARG_SIZE, len(b)
     return b
 
@@ -100,6 +103,11 @@ class Cfg:
     epi: int = 0            # 0: y = conv + bias;  3: y = resid + conv + bias;  4: y = SiLU(RMS_norm(bf16(conv + bias)) * gamma) -- the first
                             # convolution of a ResidualBlock with its RMS_norm and SiLU (wan_vae.py:190-196); one n tile (N = 96), gamma (fp32 [96])
                             # arrives in the `resid` argument
+                            # 6: y = SiLU(RMS_norm(bf16(resid + conv + bias)) * gamma) -- the LAST convolution of a ResidualBlock with its shortcut add and
+                            # the norm + SiLU of whatever reads the block's output next, when nothing else reads it (the decoder head, wan_vae.py:417);
+                            # 5: y = bf16(resid + conv + bias) AND y2 = SiLU(RMS_norm(y) * gamma) -- the same when the raw sum is still needed (the next
+                            # ResidualBlock's shortcut): the block-input rms_silu pass disappears (round 6).  One n tile; gamma: kernel argument 136,
+                            # y2 - y: argument 144
     kt: int = 3             # temporal taps: 3 = CausalConv3d 3x3x3;  1 = the 1x3x3 convolution of Resample (behind the nearest 2x upsample when the
                             # kernel argument `pt` -- no padding frames exist for kt = 1 -- is 1: patch voxel (h, w) reads input (h >> 1, w >> 1))
     cont: bool = False      # TILE CONTINUATION (one n tile, kt = 3): when the next tile of a workgroup's run is the next frame pair of the same spatial tile,
@@ -143,7 +151,8 @@ WDMA = [V(138 + i) for i in range(2)]                       # per-lane source of
 LANE = V(141)
 T_ = [V(144 + i) for i in range(40)]                        # v144..v183 temporaries
 EPI_BQ, EPI_RP, EPI_F = 184, 208, 220                       # epilogue: bias quads v184..207, residual pairs v208..219, staging v220..235
-EPI_GQ = 228                                                # (epi 4) gamma quads v228..251 of this lane's channels 16 nb + 4 (l / 16) + e, loaded once at entry
+EPI_GQ = 228                                                # (epi 4 / 5 / 6) gamma quads v228..251 of this lane's channels 16 nb + 4 (l / 16) + e, loaded once at entry
+EPI_Y2D = 225                                               # (epi 5) v225, v226: y2 - y in bytes (64 bit), kept in a VGPR pair: the SGPR file is full and the kernarg pointer is gone after entry
 
 S_KARG = S(0, 2)
 S_WG = S(2)
@@ -198,7 +207,8 @@ class Gen:
         self.TAPS = 9 * cfg.kt                  # taps of a 32-channel slice
         self.NGRP = self.TAPS // 3              # tap groups (dt, dw) of a slice: the 10 patch rows of a group serve its 3 taps dh
         self.NFR = NF + cfg.kt - 1              # patch frames of a slice
-        assert cfg.nb in (1, 6) and not (cfg.nb == 1 and (cfg.epi != 0 or cfg.kt != 3)) and cfg.epi in (0, 3, 4)
+        assert cfg.nb in (1, 6) and not (cfg.nb == 1 and (cfg.epi != 0 or cfg.kt != 3)) and cfg.epi in (0, 3, 4, 5, 6)
+        assert not (cfg.epi in (5, 6) and (cfg.kt != 3 or cfg.prof))
         self.NB = cfg.nb
         self.gs = cfg.nb / 6.0                  # the fillers' target gaps scale with the MFMAs of a tap (48 -> 8)
         assert not (cfg.cont and (cfg.kt != 3 or cfg.prof))
@@ -449,6 +459,11 @@ class Gen:
         if c.epi == 4:      # gamma quads (one n tile: the same 96 channels for every tile of the launch); landed long before the first epilogue
             assert not c.prof
             o += [isa.vop("v_lshlrev_b32", t[1], I32(4), g)] + [isa.global_load(4, V(EPI_GQ + 4 * nb, 4), t[1], 64 * nb, saddr=S_RES) for nb in range(6)]
+        if c.epi in (5, 6):  # the same through the kernel argument of their own (the residual pointer is in use); (5) the distance of the second output
+            gp, yd = S(ST[6].idx, 2), S(ST[4].idx, 2)
+            o += [isa.s_load(2, gp, S_KARG, KARG_GAMMA), isa.s_load(2, yd, S_KARG, KARG_Y2D), isa.waitcnt(lgkmcnt=0),
+                  isa.vop("v_mov_b32", V(EPI_Y2D), yd.sub(0)), isa.vop("v_mov_b32", V(EPI_Y2D + 1), yd.sub(1)),
+                  isa.vop("v_lshlrev_b32", t[1], I32(4), g)] + [isa.global_load(4, V(EPI_GQ + 4 * nb, 4), t[1], 64 * nb, saddr=gp) for nb in range(6)]
         # patch: row 8 rh of the slot of frame f (+ dt slots, + the ring position: tile_setup); the lane's place in a row per column shift
         o += [isa.sop("s_mul_i32", ST[0], S_RH, I32(8 * ROWB)), isa.sop("s_mul_i32", ST[1], S_F, I32(FSLOT)), isa.sop("s_add_u32", ST[1], ST[1], ST[0]),
               isa.sop("s_add_u32", ST[1], ST[1], I32(PBASE0)), isa.vop("v_mov_b32", PBL, ST[1])]
@@ -743,6 +758,8 @@ class Gen:
         RQ = lambda k, i: V(96 + 12 * k + 4 * i, 4)         # output row block in memory layout, two in flight
         F = lambda k: [V(120 + 4 * k + i) for i in range(4)]
 
+        with_resid = c.epi in (3, 5, 6)
+
         def to_packed(mb, k):
             """accumulators of row block mb (+ residual pairs RB[k]) -> packed bf16 OUT(mb, .)."""
             r = []
@@ -751,7 +768,7 @@ class Gen:
                 acc = ACC(nb, mb)
                 for i in range(4):
                     r.append(isa.vop("v_accvgpr_read_b32", f[i], acc.sub(i)))
-                if c.epi == 3:
+                if with_resid:
                     r_ = t[16 + (nb % 2)]
                     for i in range(4):
                         src = RB(k, nb).sub(i >> 1)
@@ -794,7 +811,7 @@ class Gen:
                           isa.vop("v_cvt_pk_bf16_f32", src, f0, f1)]
             return r
 
-        if c.epi == 3:
+        if with_resid:
             # residual rows: whole lines from memory (3 x 16 bytes per lane and row block, everything requested first), through LDS into the
             # accumulator layout
             for mb in range(8):
@@ -809,6 +826,8 @@ class Gen:
                     e += [isa.ds_read(8, RB(mb % 2, nb), EW, 32 * nb) for nb in range(6)]
                 if mb >= 1:
                     e += to_packed(mb - 1, (mb - 1) % 2)
+                    if c.epi == 6:
+                        e += norm_silu(mb - 1)
         else:
             for mb in range(8):
                 e += to_packed(mb, 0)
@@ -820,18 +839,31 @@ class Gen:
         e.append(isa.waitcnt(vmcnt=0))
         e += self.stamp(3)                                        # phase 3: wait for the next tile's first loads
         # row blocks through LDS into the memory layout: 3 stores of 64 x 16 contiguous bytes instead of 6 of 64 x 8 scattered ones
-        for mb in range(9):
-            if mb < 8:
-                e += [isa.ds_write(8, EW, OUT(mb, nb), 32 * nb) for nb in range(6)]
-                e += [isa.ds_read_b128(RQ(mb % 2, i), ER[i]) for i in range(3)]
-            if mb >= 1:
-                pm = mb - 1
-                e += row_sgprs(pm, ST[11], ST[7], ldc2)
-                for i in range(3):
-                    st = isa.global_store(4, voff, RQ(pm % 2, i), 0, saddr=S_YF, extra_reads=[EXEC])
-                    if c.nt:
-                        st.text += " nt"
-                    e += masked(ST[11], i, [isa.vop("v_add_u32", voff, ST[7], E_Y[i]), st])
+        def store_pass(base):
+            r = []
+            for mb in range(9):
+                if mb < 8:
+                    r += [isa.ds_write(8, EW, OUT(mb, nb), 32 * nb) for nb in range(6)]
+                    r += [isa.ds_read_b128(RQ(mb % 2, i), ER[i]) for i in range(3)]
+                if mb >= 1:
+                    pm = mb - 1
+                    r += row_sgprs(pm, ST[11], ST[7], ldc2)
+                    for i in range(3):
+                        st = isa.global_store(4, voff, RQ(pm % 2, i), 0, saddr=base, extra_reads=[EXEC])
+                        if c.nt:
+                            st.text += " nt"
+                        r += masked(ST[11], i, [isa.vop("v_add_u32", voff, ST[7], E_Y[i]), st])
+            return r
+
+        e += store_pass(S_YF)
+        if c.epi == 5:
+            # second output: the packed sums are still in OUT(., .): normalise them in place and store the row blocks again, y2 - y bytes further
+            # (the residual frame base is free since the residual rows arrived)
+            e += [isa.vop("v_readfirstlane_b32", ST[0], V(EPI_Y2D)), isa.vop("v_readfirstlane_b32", ST[1], V(EPI_Y2D + 1)),
+                  isa.sop("s_add_u32", S_RF.sub(0), S_YF.sub(0), ST[0]), isa.sop("s_addc_u32", S_RF.sub(1), S_YF.sub(1), ST[1])]
+            for mb in range(8):
+                e += norm_silu(mb)
+            e += store_pass(S_RF)
         e += self.stamp(4)                                        # phase 4: stores
         e += [isa.sop("s_bitcmp1_b32", None, self.HAVE_PREV, I32(1)), isa.branch("s_cbranch_scc1", "L_done" if c.prof else "L_exit"), isa.branch("s_branch", "L_start")]
         return sched.pad_hazards(sched.insert_lgkm_waits(e))
@@ -942,6 +974,8 @@ FUSED = [Cfg(epi=4, name="scail_conv4f_e4")]
 # tile continuation (Cfg.cont) of the three 96-channel kernels: A/B candidates beside the shipped ones, in csrc/conv4u.s
 CONT = [Cfg(epi=0, cont=True, name="scail_conv4c_e0"), Cfg(epi=3, cont=True, name="scail_conv4c_e3"), Cfg(epi=4, cont=True, name="scail_conv4c_e4"),
         Cfg(epi=0, nb=1, cont=True, name="scail_conv4cn_e0")]      # the narrow kernel: no staging strip, the rings simply continue
+# round 6: the last convolution of a 96-channel ResidualBlock with the NEXT consumer's RMS_norm + SiLU (Cfg.epi 5: raw sum + normalised copy; 6: normalised only)
+RESNORM = [Cfg(epi=5, cont=True, name="scail_conv4c_e5"), Cfg(epi=6, cont=True, name="scail_conv4c_e6")]
 
 
 def variant_cfgs():

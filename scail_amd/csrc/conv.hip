@@ -782,8 +782,10 @@ struct Conv4Args {
     int32_t ot_off, tiles_per_wg;
     int64_t ldc, ldr;
     int32_t wgs_per_xcd, tiles;      // persistent workgroups per XCD (the tile stride of a workgroup), tiles in all
+    const void* gamma;               // (scail_conv4c_e5 / e6) RMS_norm weights of the consumer behind the residual sum, fp32 [96]
+    int64_t y2_delta;                // (scail_conv4c_e5) bytes from y (the raw sum) to the normalised copy: same row stride and frame mapping
 };
-static_assert(sizeof(Conv4Args) == 136, "Conv4Args must match asmgen/conv4.py KERNARG_SIZE");
+static_assert(sizeof(Conv4Args) == 152, "Conv4Args must match asmgen/conv4.py KERNARG_SIZE");
 static std::map<std::pair<int, int>, hipModule_t> g_conv4_modules;          // (device, code object: 0 conv4.s, 1 conv4u.s) -> loaded module
 static std::map<std::pair<int, std::string>, hipFunction_t> g_conv4_fn;     // (device, kernel name)
 static std::mutex g_conv4_mutex;
@@ -840,6 +842,8 @@ static int conv4_cu_count() {
 
 static std::atomic<int> g_conv4_cont{1};                                   // option "conv4_cont": the tile-continuation variants (scail_conv4c_e0 / e3 / e4) for the one-n-tile shapes
 int scail_conv4_cont_enable(int v) { g_conv4_cont = v != 0; return 0; }
+static std::atomic<int> g_conv4_resnorm{1};                                // option "conv4_resnorm": scail_conv3d_cl_resid_norm on the generated dual-output / norm-only epilogues (scail_conv4c_e5 / e6)
+int scail_conv4_resnorm_enable(int v) { g_conv4_resnorm = v != 0; return 0; }
 static std::atomic<int> g_conv_direct{1};                                  // option "conv_direct": the direct-gather kernel for the HBM-bound convolutions
 int scail_conv_direct_enable(int v) { g_conv_direct = v != 0; return 0; }
 static std::atomic<int> g_conv4{1};                                        // option "conv4": the generated kernels where scail_conv3d_kernel_for says 4
@@ -906,13 +910,19 @@ extern "C" int scail_conv3d_kernel_for(const int32_t* geom, int64_t ldc, int64_t
     if (geom == nullptr) return 0;
     ConvParams p;
     conv_params(p, geom);
+    if (fused_norm == 2) // residual sum + the NEXT consumer's RMS_norm + SiLU (scail_conv3d_cl_resid_norm): one n tile of 96 channels, tile continuation on
+        return (g_conv4 && g_conv4_cont && g_conv4_resnorm && g_conv4_suffix.empty() && ldr > 0 && p.N == 96 && ldc == 96 && p.ot_mul == 1 && p.ot_off == 0 &&
+                conv4_eligible(p, ldc, ldr)) ? 4 : 0;
     if (fused_norm)      // conv + RMS_norm + SiLU: the generated kernel where one n tile holds a voxel's 96 channels, no residual
         return (g_conv4 && ldr == 0 && p.N == 96 && conv4_eligible(p, ldc, ldc)) ? 4 : 0;
     return (g_conv4 && (conv4_eligible(p, ldc, ldr > 0 ? ldr : ldc) || (ldr == 0 && (conv4u_eligible(p, ldc) || conv4n_eligible(p, ldc))))) ? 4 : 0;
 }
 
+// next_gamma / y_norm (scail_conv3d_cl_resid_norm, generated kernels only -- the caller checked scail_conv3d_kernel_for(.., 2)): the residual sum
+// goes to y (nullptr: nowhere) and SiLU(RMS_norm(bf16(sum)) * next_gamma) to y_norm
 static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, int64_t ldc,
-                       const scail_bf16* resid, int64_t ldr, const float* gamma, const int32_t* geom, void* stream) {
+                       const scail_bf16* resid, int64_t ldr, const float* gamma, const int32_t* geom, void* stream,
+                       const float* next_gamma = nullptr, scail_bf16* y_norm = nullptr) {
     // geom: Ti Hi Wi Cin | To Ho Wo | kt kh kw | st sh sw | pt ph pw | ups | ot_mul ot_off | N Kpad
     ConvParams p;
     p.x = x; p.w = w; p.bias = bias; p.y = y; p.ldc = ldc; p.resid = resid; p.ldr = ldr; p.gamma = gamma;
@@ -920,6 +930,8 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
     SCAIL_REQUIRE(p.Cin % 8 == 0, "Cin must be a multiple of 8 (pad the channels)");
     SCAIL_REQUIRE(p.N % 8 == 0 && p.Kpad % CBK == 0 && p.Kpad >= p.Ktrue, "N % 8 == 0, Kpad % 64 == 0, Kpad >= taps*Cin");
     SCAIL_REQUIRE(ldc % 4 == 0 && (resid == nullptr || ldr % 4 == 0), "output / residual row strides must be multiples of 4");
+    const bool rn = next_gamma != nullptr;
+    if (rn && y == nullptr) { y = y_norm; p.y = y_norm; }      // norm-only form: the one output IS the normalised tensor
     SCAIL_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0,
                   "pointer alignment");
@@ -955,11 +967,14 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         a.wgs_per_xcd = (int32_t)std::min<int64_t>((tiles + 7) / 8, cus / 8);
         a.tiles_per_wg = a.tiles_n == 1 ? (int32_t)(tiles / (8 * a.wgs_per_xcd)) : 0;
         a.tiles = (int32_t)tiles;
+        a.gamma = next_gamma;
+        a.y2_delta = (rn && y != y_norm) ? (int64_t)(reinterpret_cast<const char*>(y_norm) - reinterpret_cast<const char*>(y)) : 0;
         hipFunction_t fn;
         // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)
         const bool prof = g_conv4_suffix.find("prof") != std::string::npos;
         const bool cont = g_conv4_cont && !k1 && !nar && a.tiles_n == 1 && g_conv4_suffix.empty();      // one n tile: runs of frame pairs per workgroup (a measurement-build kernel variant takes precedence)
-        if (int rc = k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function(g_conv4_cont && g_conv4_suffix.empty() ? "scail_conv4cn_e0" : "scail_conv4n_e0", &fn)
+        if (int rc = rn ? conv4_function(y != y_norm ? "scail_conv4c_e5" : "scail_conv4c_e6", &fn)
+                        : k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function(g_conv4_cont && g_conv4_suffix.empty() ? "scail_conv4cn_e0" : "scail_conv4n_e0", &fn)
                         : fnorm ? conv4_function(cont ? "scail_conv4c_e4" : "scail_conv4f_e4", &fn)
                         : cont ? conv4_function(resid ? "scail_conv4c_e3" : "scail_conv4c_e0", &fn)
                         : conv4_function(std::string(resid && !prof ? "scail_conv4_e3" : "scail_conv4_e0") + g_conv4_suffix, &fn)) return rc;
@@ -1115,6 +1130,25 @@ extern "C" int scail_conv3d_cl_norm(const scail_bf16* x, const scail_bf16* w, co
                                     const float* gamma, const int32_t* geom, void* stream) {
     SCAIL_REQUIRE(gamma != nullptr, "null argument");
     return conv3d_impl(x, w, bias, y, ldc, nullptr, 0, gamma, geom, stream);
+}
+
+extern "C" int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* gamma, int64_t nvox, int64_t C, int silu, void* stream);
+
+extern "C" int scail_conv3d_cl_resid_norm(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, scail_bf16* y_norm, int64_t ldc,
+                                          const scail_bf16* resid, int64_t ldr, const float* gamma, const int32_t* geom, void* stream) {
+    SCAIL_REQUIRE(x != nullptr && w != nullptr && y_norm != nullptr && resid != nullptr && gamma != nullptr && geom != nullptr, "null argument");
+    SCAIL_REQUIRE(y != y_norm, "y and y_norm must be different tensors (pass y = NULL when the raw sum is not needed)");
+    ConvParams p;
+    conv_params(p, geom);
+    SCAIL_REQUIRE(ldc == p.N && p.ot_mul == 1 && p.ot_off == 0, "scail_conv3d_cl_resid_norm needs dense outputs: ldc == N, ot_mul = 1, ot_off = 0");
+    const bool aligned = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y_norm) | reinterpret_cast<uintptr_t>(resid) |
+                           reinterpret_cast<uintptr_t>(gamma)) & 15) == 0;
+    if (aligned && scail_conv3d_kernel_for(geom, ldc, ldr, 2) == 4)
+        return conv3d_impl(x, w, bias, y, ldc, resid, ldr, nullptr, geom, stream, gamma, y_norm);
+    // everything else: the two separate calls this entry point stands for
+    scail_bf16* raw = y != nullptr ? y : y_norm;
+    if (int rc = conv3d_impl(x, w, bias, raw, ldc, resid, ldr, nullptr, geom, stream)) return rc;
+    return scail_rms_silu(raw, y_norm, gamma, p.M, p.N, 1, stream);
 }
 
 extern "C" int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* gamma, int64_t nvox, int64_t C, int silu,

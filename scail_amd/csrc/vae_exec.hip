@@ -74,14 +74,24 @@ int conv(Arena& a, const Tens& x, const scail_conv_w& cw, Tens& out, int64_t To,
     return 0;
 }
 
-// ResidualBlock (wan_vae.py:180-218); consumes x
-int res_block(Arena& a, const scail_vae_res& r, Tens& x) {
+// ResidualBlock (wan_vae.py:180-218); consumes x.
+// xn (optional), on entry: SiLU(RMS_norm(x) * r.gamma0) if x's producer already wrote it (xn->p != nullptr; consumed), else empty.
+// next_gamma: the RMS_norm weights of whatever reads this block's output next (the next ResidualBlock's residual.0, the decoder head's norm) or nullptr.
+// Where ONE generated kernel covers "last convolution + shortcut sum + that consumer's norm" (scail_conv3d_kernel_for(.., 2): 96 channels at full
+// resolution) the block's last call is scail_conv3d_cl_resid_norm: *xn returns the consumer's normalised input, and with need_raw = false (nobody reads
+// the raw sum) x comes back EMPTY.  Everywhere else the sequence is what it was and *xn comes back empty.  scail_amd/wan_vae.py _res follows the same rule.
+int res_block(Arena& a, const scail_vae_res& r, Tens& x, Tens* xn = nullptr, const float* next_gamma = nullptr, bool need_raw = true) {
     Tens h = x, y, y2, out;
     const bool sc = r.shortcut.w != nullptr;
     if (sc) VAE_TRY(conv(a, x, r.shortcut, h, x.T, x.H, x.W));
-    y = a.get(x.T, x.H, x.W, x.C); VAE_CHK(a)
-    VAE_TRY(scail_rms_silu(x.p, y.p, r.gamma0, x.vox(), x.C, 1, a.stream));
-    a.emit("rms_silu", y);
+    if (xn != nullptr && xn->p != nullptr) {
+        y = *xn;
+        *xn = Tens();
+    } else {
+        y = a.get(x.T, x.H, x.W, x.C); VAE_CHK(a)
+        VAE_TRY(scail_rms_silu(x.p, y.p, r.gamma0, x.vox(), x.C, 1, a.stream));
+        a.emit("rms_silu", y);
+    }
     int32_t geom[21] = {(int32_t)y.T, (int32_t)y.H, (int32_t)y.W, (int32_t)y.C, (int32_t)x.T, (int32_t)x.H, (int32_t)x.W,
                         3, 3, 3, 1, 1, 1, 2, 1, 1, 0, 1, 0, r.conv2.N, r.conv2.Kpad};
     if (r.conv2.kt == 3 && r.conv2.kh == 3 && r.conv2.kw == 3 && y.C % 32 == 0 && r.conv2.N <= 96 &&
@@ -100,12 +110,28 @@ int res_block(Arena& a, const scail_vae_res& r, Tens& x) {
         VAE_TRY(scail_rms_silu(y2.p, y2.p, r.gamma3, y2.vox(), y2.C, 1, a.stream));
         a.emit("rms_silu", y2);
     }
-    VAE_TRY(conv(a, y2, r.conv6, out, x.T, x.H, x.W, 1, 1, 1, -1, -1, -1, 0, 1, 0, &h));
+    int32_t geom6[21] = {(int32_t)y2.T, (int32_t)y2.H, (int32_t)y2.W, (int32_t)y2.C, (int32_t)x.T, (int32_t)x.H, (int32_t)x.W,
+                         r.conv6.kt, r.conv6.kh, r.conv6.kw, 1, 1, 1, r.conv6.kt - 1, r.conv6.kh / 2, r.conv6.kw / 2, 0, 1, 0, r.conv6.N, r.conv6.Kpad};
+    if (xn != nullptr && next_gamma != nullptr && y2.C == r.conv6.Cin && scail_conv3d_kernel_for(geom6, r.conv6.N, h.C, 2) == 4) {
+        Tens nrm = a.get(x.T, x.H, x.W, r.conv6.N); VAE_CHK(a)
+        if (need_raw) { out = a.get(x.T, x.H, x.W, r.conv6.N); VAE_CHK(a) }
+        VAE_TRY(scail_conv3d_cl_resid_norm(y2.p, r.conv6.w, r.conv6.b, need_raw ? out.p : nullptr, nrm.p, r.conv6.N, h.p, h.C, next_gamma, geom6, a.stream));
+        if (need_raw) a.emit("conv", out);
+        a.emit("conv_resid_norm", nrm);
+        *xn = nrm;
+    } else {
+        VAE_TRY(conv(a, y2, r.conv6, out, x.T, x.H, x.W, 1, 1, 1, -1, -1, -1, 0, 1, 0, &h));
+    }
     a.put(y2);
     if (sc) a.put(h);
     a.put(x);
     x = out;
     return 0;
+}
+
+// the norm weights the consumer of stage i's output applies first, when that consumer is a ResidualBlock of the table (else nullptr)
+const float* next_res_gamma(const std::vector<scail_vae_stage>& st, size_t i) {
+    return (i + 1 < st.size() && st[i + 1].kind == 0) ? st[i + 1].res.gamma0 : nullptr;
 }
 
 // AttentionBlock (wan_vae.py:221-262): per frame, single head over the H*W tokens; consumes x
@@ -254,8 +280,10 @@ extern "C" int scail_vae_encode(scail_vae* h, const float* video, float* latent,
     VAE_TRY(conv(a, x, w.enc_conv1, y, T, H, W));
     a.put(x);
     x = y;
-    for (const scail_vae_stage& s : h->enc) {
-        if (s.kind == 0) { VAE_TRY(res_block(a, s.res, x)); }
+    Tens xn;       // the next ResidualBlock's normalised input, when its producer wrote it (res_block)
+    for (size_t i = 0; i < h->enc.size(); ++i) {
+        const scail_vae_stage& s = h->enc[i];
+        if (s.kind == 0) { VAE_TRY(res_block(a, s.res, x, &xn, next_res_gamma(h->enc, i))); }
         else if (s.kind == 1) { VAE_TRY(down_stage(a, s, x)); }
         else { scail_set_error("scail_vae_encode: upsampling stage in the encoder table"); return 1; }
     }
@@ -299,13 +327,21 @@ extern "C" int scail_vae_decode(scail_vae* h, const float* latent, float* video,
     VAE_TRY(res_block(a, w.dec_mid0, x));
     VAE_TRY(attn_block(a, w.dec_attn, x));
     VAE_TRY(res_block(a, w.dec_mid2, x));
-    for (const scail_vae_stage& s : h->dec) {
-        if (s.kind == 0) { VAE_TRY(res_block(a, s.res, x)); }
+    Tens xn;       // the next consumer's normalised input, when its producer wrote it (res_block)
+    for (size_t i = 0; i < h->dec.size(); ++i) {
+        const scail_vae_stage& s = h->dec[i];
+        const bool last = i + 1 == h->dec.size();      // the last block feeds the head's norm and nothing else
+        if (s.kind == 0) { VAE_TRY(res_block(a, s.res, x, &xn, last ? w.dec_head_gamma : next_res_gamma(h->dec, i), !last)); }
         else if (s.kind == 2) { VAE_TRY(up_stage(a, s, x)); }
         else { scail_set_error("scail_vae_decode: downsampling stage in the decoder table"); return 1; }
     }
-    VAE_TRY(scail_rms_silu(x.p, x.p, w.dec_head_gamma, x.vox(), x.C, 1, stream));
-    a.emit("rms_silu", x);
+    if (xn.p != nullptr) {             // the head's RMS_norm + SiLU came out of the last block's epilogue
+        if (x.p != nullptr) a.put(x);
+        x = xn;
+    } else {
+        VAE_TRY(scail_rms_silu(x.p, x.p, w.dec_head_gamma, x.vox(), x.C, 1, stream));
+        a.emit("rms_silu", x);
+    }
     VAE_TRY(conv(a, x, w.dec_head, y, x.T, x.H, x.W));
     a.put(x);
     x = y;

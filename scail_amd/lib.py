@@ -44,6 +44,7 @@ SIGNATURES = {
     "scail_cfg_euler": [_p, _p, _i64, _f, _f, _p],
     "scail_conv3d_cl": [_p, _p, _p, _p, _i64, _p, _i64, _p, _p],
     "scail_conv3d_cl_norm": [_p, _p, _p, _p, _i64, _p, _p, _p],
+    "scail_conv3d_cl_resid_norm": [_p, _p, _p, _p, _p, _i64, _p, _i64, _p, _p, _p],
     "scail_rms_silu": [_p, _p, _p, _i64, _i64, _i, _p],
     "scail_softmax_rows": [_p, _i64, _i64, _i64, _f, _p],
     "scail_transpose2d": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],

@@ -184,10 +184,13 @@ class WanVAE_(nn.Module):
         return self._cvae
 
     # ---- blocks (channels-last (T,H,W,C) bf16) ----
-    def _res(self, W, n, x):
+    def _res(self, W, n, x, xn=None, next_gamma=None, need_raw=True):
+        """ResidualBlock (wan_vae.py:180-218).  xn: SiLU(RMS_norm(x) * residual.0.gamma) when x's producer already wrote it.  next_gamma: the norm
+        weights of whatever reads this block's output next; where ONE generated kernel covers "last convolution + shortcut sum + that norm"
+        (ops.conv_resid_norm_generated, the rule of csrc/vae_exec.hip res_block) the block returns (raw | None, normalised), else (raw, None)."""
         T, H, Wd, _ = x.shape
         h = ops.conv3d_cl(x, W[n + ".shortcut"], (T, H, Wd)) if (n + ".shortcut") in W else x
-        y = ops.rms_silu(x, W[n + ".residual.0.gamma"])
+        y = xn if xn is not None else ops.rms_silu(x, W[n + ".residual.0.gamma"])
         if ops.conv_norm_fusable(W[n + ".residual.2"], y.shape[3]) and (ops.conv_norm_generated(W[n + ".residual.2"], y.shape) or
                                                                          not ops.conv_generated(W[n + ".residual.2"], y.shape)):
             # conv -> RMS_norm -> SiLU in one kernel: the generated kernel's norm epilogue (96 channels), or the hipcc halo kernel's for the
@@ -196,7 +199,23 @@ class WanVAE_(nn.Module):
         else:
             y = ops.conv3d_cl(y, W[n + ".residual.2"], (T, H, Wd))
             ops.rms_silu(y, W[n + ".residual.3.gamma"], out=y)
-        return ops.conv3d_cl(y, W[n + ".residual.6"], (T, H, Wd), resid=h)
+        w6 = W[n + ".residual.6"]
+        if next_gamma is not None and tuple(w6["k"]) == (3, 3, 3) and ops.conv_resid_norm_generated(w6, y.shape) and h.shape[3] == w6["N"]:
+            return ops.conv3d_cl_resid_norm(y, w6, h, next_gamma, want_raw=need_raw)
+        return ops.conv3d_cl(y, w6, (T, H, Wd), resid=h), None
+
+    def _stages(self, W, plan, x, down, head_gamma=None):
+        """the stage table of the encoder / decoder; a ResidualBlock followed by another one (or, last in the decoder, by the head's norm) hands
+        its consumer's normalised input along.  Returns (raw | None, normalised | None)."""
+        xn = None
+        for i, (kind, n, a, b) in enumerate(plan):
+            if kind == "res":
+                last = i + 1 == len(plan)
+                nxt = head_gamma if (last and head_gamma is not None) else (W[plan[i + 1][1] + ".residual.0.gamma"] if (not last and plan[i + 1][0] == "res") else None)
+                x, xn = self._res(W, n, x, xn, nxt, need_raw=not (last and head_gamma is not None))
+            else:
+                x = self._down(W, n, x, b) if down else self._up(W, n, x, b)
+        return x, xn
 
     def _attn(self, W, n, x):
         T, H, Wd, C = x.shape
@@ -258,11 +277,10 @@ class WanVAE_(nn.Module):
             return self._c().encode(video.float().to(next(self.parameters()).device).contiguous()).unsqueeze(0)
         x = ops.to_channels_last(video.float().to(next(self.parameters()).device), 8)
         x = ops.conv3d_cl(x, W["encoder.conv1"], (T, H, Wd))
-        for kind, n, a, b in self.encoder_plan():
-            x = self._res(W, n, x) if kind == "res" else self._down(W, n, x, b)
-        x = self._res(W, "encoder.middle.0", x)
+        x, _ = self._stages(W, self.encoder_plan(), x, down=True)
+        x, _ = self._res(W, "encoder.middle.0", x)
         x = self._attn(W, "encoder.middle.1", x)
-        x = self._res(W, "encoder.middle.2", x)
+        x, _ = self._res(W, "encoder.middle.2", x)
         ops.rms_silu(x, W["encoder.head.0.gamma"], out=x)
         x = ops.conv3d_cl(x, W["encoder.head.2"], x.shape[:3])
         x = ops.conv3d_cl(x, W["conv1"], x.shape[:3])
@@ -281,12 +299,14 @@ class WanVAE_(nn.Module):
         x = ops.to_channels_last(z.float().to(next(self.parameters()).device), self.z_dim, a=W["std"], b=W["mean"])
         x = ops.conv3d_cl(x, W["conv2"], x.shape[:3])
         x = ops.conv3d_cl(x, W["decoder.conv1"], x.shape[:3])
-        x = self._res(W, "decoder.middle.0", x)
+        x, _ = self._res(W, "decoder.middle.0", x)
         x = self._attn(W, "decoder.middle.1", x)
-        x = self._res(W, "decoder.middle.2", x)
-        for kind, n, a, b in self.decoder_plan():
-            x = self._res(W, n, x) if kind == "res" else self._up(W, n, x, b)
-        ops.rms_silu(x, W["decoder.head.0.gamma"], out=x)
+        x, _ = self._res(W, "decoder.middle.2", x)
+        x, xn = self._stages(W, self.decoder_plan(), x, down=False, head_gamma=W["decoder.head.0.gamma"])
+        if xn is not None:          # the head's RMS_norm + SiLU came out of the last block's epilogue
+            x = xn
+        else:
+            ops.rms_silu(x, W["decoder.head.0.gamma"], out=x)
         x = ops.conv3d_cl(x, W["decoder.head.2"], x.shape[:3])
         return ops.from_channels_last(x, 3).unsqueeze(0)
 

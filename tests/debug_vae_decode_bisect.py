@@ -69,13 +69,13 @@ def main():
         cmp("conv2", x[..., :16], o)
         x = ops.conv3d_cl(x, W["decoder.conv1"], x.shape[:3]); o = V.causal_conv3d(o, sdg["decoder.conv1.weight"], sdg["decoder.conv1.bias"])
         cmp("decoder.conv1", x, o)
-        x = m._res(W, "decoder.middle.0", x); o = V.residual_block(sdg, "decoder.middle.0", o); cmp("middle.0", x, o)
+        x, _ = m._res(W, "decoder.middle.0", x); o = V.residual_block(sdg, "decoder.middle.0", o); cmp("middle.0", x, o)
         x = m._attn(W, "decoder.middle.1", x); o = V.attention_block(sdg, "decoder.middle.1", o); cmp("middle.1 (attn)", x, o)
-        x = m._res(W, "decoder.middle.2", x); o = V.residual_block(sdg, "decoder.middle.2", o); cmp("middle.2", x, o)
+        x, _ = m._res(W, "decoder.middle.2", x); o = V.residual_block(sdg, "decoder.middle.2", o); cmp("middle.2", x, o)
         for kind, n, a, b in m.decoder_plan():
             x_in = x
             if kind == "res":
-                x = m._res(W, n, x); o = V.residual_block(sdg, n, o)
+                x, _ = m._res(W, n, x); o = V.residual_block(sdg, n, o)
             else:
                 x = m._up(W, n, x, b)
                 mode = "upsample3d" if b else "upsample2d"

@@ -24,7 +24,7 @@ def _cfg(name):
 
 
 def test_conv4_static_hazards():
-    for cfg in conv4.DEFAULTS + conv4.UPSAMPLE + conv4.NARROW + conv4.FUSED + conv4.CONT:
+    for cfg in conv4.DEFAULTS + conv4.UPSAMPLE + conv4.NARROW + conv4.FUSED + conv4.CONT + conv4.RESNORM:
         assert R.check_static(cfg) == [], cfg.name
 
 
@@ -126,3 +126,32 @@ def test_conv4c_emulated_tile_continuation(name, shape):
         ref = R.reference_norm_silu(ref, gam)
     assert not np.isnan(y[..., :N]).any()
     assert np.abs(y[..., :N] - ref).max() <= 2.0 ** -6 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name,shape", [("scail_conv4c_e5", (5, 18, 20, 64, 96)),      # two slices; runs that cross into the next spatial tile (rings restart / continue)
+                                        ("scail_conv4c_e5", (9, 16, 32, 32, 96)),
+                                        ("scail_conv4c_e6", (5, 18, 20, 64, 96)),
+                                        ("scail_conv4c_e6", (21, 16, 16, 32, 96))])
+def test_conv4c_emulated_residual_plus_next_norm(name, shape):
+    """Cfg.epi 5 / 6 (round 6): the LAST convolution of a ResidualBlock (wan_vae.py:180-218: conv + shortcut) with the RMS_norm + SiLU of whatever
+    reads the block's output next (the next block's residual[0..1], or the decoder head :417) in its epilogue.  epi 5 stores the raw sum (the
+    next block's shortcut operand) AND the normalised copy at y + (y2 - y); epi 6 the normalised tensor only.  The norm is applied to the
+    bf16-ROUNDED sum, as the separate rms_silu pass it replaces does; the raw output must equal scail_conv4c_e3's bit for bit."""
+    cfg = [c for c in conv4.RESNORM if c.name == name][0]
+    Ti, H, W, Cin, N = shape
+    x, w, b, r = _case(Ti, H, W, Cin, N, True, seed=8)
+    gam = (1 + 0.1 * np.random.default_rng(5).standard_normal(N)).astype(np.float32)
+    out, _ = R.run(cfg, x, w, b, r, cus=8, gamma=gam)
+    raw_ref = R.reference(x, w, b, r)
+    e3 = [c for c in conv4.CONT if c.name == "scail_conv4c_e3"][0]
+    y3, _ = R.run(e3, x, w, b, r, cus=8)
+    nrm_ref = R.reference_norm_silu(y3, gam)                     # of what the e3 kernel stores (bf16), like rms_silu_kernel reading it back
+    if cfg.epi == 5:
+        raw, nrm = out
+        assert np.array_equal(raw, y3)
+        assert np.abs(raw - raw_ref).max() <= 2.0 ** -6 * max(1.0, np.abs(raw_ref).max())
+    else:
+        nrm = out
+    assert not np.isnan(nrm).any()
+    err = np.abs(nrm - nrm_ref)
+    assert err.max() <= 2.0 ** -7 * max(1.0, np.abs(nrm_ref).max()) and err.mean() <= 1e-3, (float(err.max()), float(err.mean()))

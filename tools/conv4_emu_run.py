@@ -39,16 +39,25 @@ def run(cfg: conv4.Cfg, x, w, bias=None, resid=None, pt=2, To=None, ot_mul=1, ot
     pb = mem.alloc("bias", bias.astype(np.float32)) if bias is not None else 0
     py = mem.alloc("y", np.full((y_frames, H, W, ldc), 0x7FC0, dtype=np.uint16))
     pr = mem.alloc("resid", to_bf16_bits(resid)) if resid is not None else 0
-    if gamma is not None:                                      # epi 4: the `resid` argument carries gamma (fp32 [N])
+    pg = py2 = 0
+    if gamma is not None and cfg.epi == 4:                     # epi 4: the `resid` argument carries gamma (fp32 [N])
         pr = mem.alloc("gamma", gamma.astype(np.float32))
+    elif gamma is not None:                                    # epi 5 / 6: gamma has its own kernel argument; epi 5 writes a second output
+        pg = mem.alloc("gamma", gamma.astype(np.float32))
+        if cfg.epi == 5:
+            py2 = mem.alloc("y2", np.full((y_frames, H, W, ldc), 0x7FC0, dtype=np.uint16))
     prog = conv4.Gen(cfg).program()
-    args = conv4.pack_args(px, pw, pb, py, pr, Ti, To, H, W, Cin, N, wp.shape[1], pt, ot_mul, ot_off, ldc, resid.shape[-1] if resid is not None else 0, cus)
+    args = conv4.pack_args(px, pw, pb, py, pr, Ti, To, H, W, Cin, N, wp.shape[1], pt, ot_mul, ot_off, ldc, resid.shape[-1] if resid is not None else 0, cus,
+                           gamma=pg, y2=py2)
     stats = None
     for wg in (range(conv4.grid_blocks(To, H, W, N, cus)) if wgs is None else wgs):
         emu = E.Emu(prog, mem, n_waves=4, lds_bytes=conv4.LDS_BYTES, lazy=lazy)
         emu.launch(args, block_id=(wg, 0, 0))
         stats = emu.waves[0].stats
-    return from_bf16_bits(mem.read_back("y")).reshape(y_frames, H, W, ldc), stats
+    y = from_bf16_bits(mem.read_back("y")).reshape(y_frames, H, W, ldc)
+    if py2:
+        return (y, from_bf16_bits(mem.read_back("y2")).reshape(y_frames, H, W, ldc)), stats
+    return y, stats
 
 
 def reference(x, w, bias=None, resid=None, pt=2, To=None):

@@ -51,7 +51,7 @@ def trace_both(m, f, inp):
     m.use_c_exec = False
     m._cvae = None
     torch.cuda.empty_cache()
-    o_conv, o_norm, o_rms, o_attn = ops.conv3d_cl, ops.conv3d_cl_norm, ops.rms_silu, m._attn
+    o_conv, o_norm, o_rms, o_attn, o_rn = ops.conv3d_cl, ops.conv3d_cl_norm, ops.rms_silu, m._attn, ops.conv3d_cl_resid_norm
 
     def conv(x, wp, out_shape, **kw):
         y = o_conv(x, wp, out_shape, **kw)
@@ -74,11 +74,18 @@ def trace_both(m, f, inp):
         rec_p.append(("attn", tuple(y.shape), frame_sums(y)))
         return y
 
-    ops.conv3d_cl, ops.conv3d_cl_norm, ops.rms_silu, m._attn = conv, norm, rms, attn
+    def resid_norm(x, wp, resid, gamma, want_raw=True):
+        raw, nrm = o_rn(x, wp, resid, gamma, want_raw=want_raw)
+        if raw is not None:
+            rec_p.append(("conv", tuple(raw.shape), frame_sums(raw)))
+        rec_p.append(("conv_resid_norm", tuple(nrm.shape), frame_sums(nrm)))
+        return raw, nrm
+
+    ops.conv3d_cl, ops.conv3d_cl_norm, ops.rms_silu, m._attn, ops.conv3d_cl_resid_norm = conv, norm, rms, attn, resid_norm
     try:
         f(inp)
     finally:
-        ops.conv3d_cl, ops.conv3d_cl_norm, ops.rms_silu = o_conv, o_norm, o_rms
+        ops.conv3d_cl, ops.conv3d_cl_norm, ops.rms_silu, ops.conv3d_cl_resid_norm = o_conv, o_norm, o_rms, o_rn
         del m._attn
     print(f"launch walk: C executor {len(rec_c)} records, layer path {len(rec_p)} records")
     first = True
