@@ -108,6 +108,8 @@ class Cfg:
                             # 5: y = bf16(resid + conv + bias) AND y2 = SiLU(RMS_norm(y) * gamma) -- the same when the raw sum is still needed (the next
                             # ResidualBlock's shortcut): the block-input rms_silu pass disappears (round 6).  One n tile; gamma: kernel argument 136,
                             # y2 - y: argument 144
+                            # 7: y = conv + bias AND y2 = SiLU(RMS_norm(bf16(y)) * gamma), no residual -- epi 5 for a producer that is not a
+                            # ResidualBlock: Resample's 1x3x3 convolution (kt = 1) in front of the full-resolution blocks of the decoder
     kt: int = 3             # temporal taps: 3 = CausalConv3d 3x3x3;  1 = the 1x3x3 convolution of Resample (behind the nearest 2x upsample when the
                             # kernel argument `pt` -- no padding frames exist for kt = 1 -- is 1: patch voxel (h, w) reads input (h >> 1, w >> 1))
     cont: bool = False      # TILE CONTINUATION (one n tile, kt = 3): when the next tile of a workgroup's run is the next frame pair of the same spatial tile,
@@ -207,8 +209,8 @@ class Gen:
         self.TAPS = 9 * cfg.kt                  # taps of a 32-channel slice
         self.NGRP = self.TAPS // 3              # tap groups (dt, dw) of a slice: the 10 patch rows of a group serve its 3 taps dh
         self.NFR = NF + cfg.kt - 1              # patch frames of a slice
-        assert cfg.nb in (1, 6) and not (cfg.nb == 1 and (cfg.epi != 0 or cfg.kt != 3)) and cfg.epi in (0, 3, 4, 5, 6)
-        assert not (cfg.epi in (5, 6) and (cfg.kt != 3 or cfg.prof))
+        assert cfg.nb in (1, 6) and not (cfg.nb == 1 and (cfg.epi != 0 or cfg.kt != 3)) and cfg.epi in (0, 3, 4, 5, 6, 7)
+        assert not (cfg.epi in (5, 6) and (cfg.kt != 3 or cfg.prof)) and not (cfg.epi == 7 and cfg.prof)
         self.NB = cfg.nb
         self.gs = cfg.nb / 6.0                  # the fillers' target gaps scale with the MFMAs of a tap (48 -> 8)
         assert not (cfg.cont and (cfg.kt != 3 or cfg.prof))
@@ -459,7 +461,7 @@ class Gen:
         if c.epi == 4:      # gamma quads (one n tile: the same 96 channels for every tile of the launch); landed long before the first epilogue
             assert not c.prof
             o += [isa.vop("v_lshlrev_b32", t[1], I32(4), g)] + [isa.global_load(4, V(EPI_GQ + 4 * nb, 4), t[1], 64 * nb, saddr=S_RES) for nb in range(6)]
-        if c.epi in (5, 6):  # the same through the kernel argument of their own (the residual pointer is in use); (5) the distance of the second output
+        if c.epi in (5, 6, 7):  # the same through the kernel argument of their own (the residual pointer is in use); (5) the distance of the second output
             gp, yd = S(ST[6].idx, 2), S(ST[4].idx, 2)
             o += [isa.s_load(2, gp, S_KARG, KARG_GAMMA), isa.s_load(2, yd, S_KARG, KARG_Y2D), isa.waitcnt(lgkmcnt=0),
                   isa.vop("v_mov_b32", V(EPI_Y2D), yd.sub(0)), isa.vop("v_mov_b32", V(EPI_Y2D + 1), yd.sub(1)),
@@ -856,7 +858,7 @@ class Gen:
             return r
 
         e += store_pass(S_YF)
-        if c.epi == 5:
+        if c.epi in (5, 7):
             # second output: the packed sums are still in OUT(., .): normalise them in place and store the row blocks again, y2 - y bytes further
             # (the residual frame base is free since the residual rows arrived)
             e += [isa.vop("v_readfirstlane_b32", ST[0], V(EPI_Y2D)), isa.vop("v_readfirstlane_b32", ST[1], V(EPI_Y2D + 1)),
@@ -975,7 +977,7 @@ FUSED = [Cfg(epi=4, name="scail_conv4f_e4")]
 CONT = [Cfg(epi=0, cont=True, name="scail_conv4c_e0"), Cfg(epi=3, cont=True, name="scail_conv4c_e3"), Cfg(epi=4, cont=True, name="scail_conv4c_e4"),
         Cfg(epi=0, nb=1, cont=True, name="scail_conv4cn_e0")]      # the narrow kernel: no staging strip, the rings simply continue
 # round 6: the last convolution of a 96-channel ResidualBlock with the NEXT consumer's RMS_norm + SiLU (Cfg.epi 5: raw sum + normalised copy; 6: normalised only)
-RESNORM = [Cfg(epi=5, cont=True, name="scail_conv4c_e5"), Cfg(epi=6, cont=True, name="scail_conv4c_e6")]
+RESNORM = [Cfg(epi=5, cont=True, name="scail_conv4c_e5"), Cfg(epi=6, cont=True, name="scail_conv4c_e6"), Cfg(epi=7, kt=1, name="scail_conv4u_e7")]
 
 
 def variant_cfgs():

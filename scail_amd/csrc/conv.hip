@@ -910,9 +910,11 @@ extern "C" int scail_conv3d_kernel_for(const int32_t* geom, int64_t ldc, int64_t
     if (geom == nullptr) return 0;
     ConvParams p;
     conv_params(p, geom);
-    if (fused_norm == 2) // residual sum + the NEXT consumer's RMS_norm + SiLU (scail_conv3d_cl_resid_norm): one n tile of 96 channels, tile continuation on
-        return (g_conv4 && g_conv4_cont && g_conv4_resnorm && g_conv4_suffix.empty() && ldr > 0 && p.N == 96 && ldc == 96 && p.ot_mul == 1 && p.ot_off == 0 &&
-                conv4_eligible(p, ldc, ldr)) ? 4 : 0;
+    if (fused_norm == 2) { // (residual sum +) the NEXT consumer's RMS_norm + SiLU (scail_conv3d_cl_resid_norm): one n tile of 96 channels; with a residual the
+                           // 3x3x3 kernels with tile continuation (scail_conv4c_e5 / e6), without one the kt = 1 kernel (scail_conv4u_e7)
+        if (!(g_conv4 && g_conv4_resnorm && g_conv4_suffix.empty() && p.N == 96 && ldc == 96 && p.ot_mul == 1 && p.ot_off == 0)) return 0;
+        return (ldr > 0 ? (g_conv4_cont && conv4_eligible(p, ldc, ldr)) : conv4u_eligible(p, ldc)) ? 4 : 0;
+    }
     if (fused_norm)      // conv + RMS_norm + SiLU: the generated kernel where one n tile holds a voxel's 96 channels, no residual
         return (g_conv4 && ldr == 0 && p.N == 96 && conv4_eligible(p, ldc, ldc)) ? 4 : 0;
     return (g_conv4 && (conv4_eligible(p, ldc, ldr > 0 ? ldr : ldc) || (ldr == 0 && (conv4u_eligible(p, ldc) || conv4n_eligible(p, ldc))))) ? 4 : 0;
@@ -973,7 +975,7 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         // (measurement build: the "_prof" variant is an e0 kernel that writes its phase timers through the residual pointer)
         const bool prof = g_conv4_suffix.find("prof") != std::string::npos;
         const bool cont = g_conv4_cont && !k1 && !nar && a.tiles_n == 1 && g_conv4_suffix.empty();      // one n tile: runs of frame pairs per workgroup (a measurement-build kernel variant takes precedence)
-        if (int rc = rn ? conv4_function(y != y_norm ? "scail_conv4c_e5" : "scail_conv4c_e6", &fn)
+        if (int rc = rn ? conv4_function(k1 ? "scail_conv4u_e7" : y != y_norm ? "scail_conv4c_e5" : "scail_conv4c_e6", &fn)
                         : k1 ? conv4_function("scail_conv4u_e0", &fn) : nar ? conv4_function(g_conv4_cont && g_conv4_suffix.empty() ? "scail_conv4cn_e0" : "scail_conv4n_e0", &fn)
                         : fnorm ? conv4_function(cont ? "scail_conv4c_e4" : "scail_conv4f_e4", &fn)
                         : cont ? conv4_function(resid ? "scail_conv4c_e3" : "scail_conv4c_e0", &fn)
@@ -1136,8 +1138,10 @@ extern "C" int scail_rms_silu(const scail_bf16* x, scail_bf16* y, const float* g
 
 extern "C" int scail_conv3d_cl_resid_norm(const scail_bf16* x, const scail_bf16* w, const float* bias, scail_bf16* y, scail_bf16* y_norm, int64_t ldc,
                                           const scail_bf16* resid, int64_t ldr, const float* gamma, const int32_t* geom, void* stream) {
-    SCAIL_REQUIRE(x != nullptr && w != nullptr && y_norm != nullptr && resid != nullptr && gamma != nullptr && geom != nullptr, "null argument");
+    SCAIL_REQUIRE(x != nullptr && w != nullptr && y_norm != nullptr && gamma != nullptr && geom != nullptr, "null argument");
     SCAIL_REQUIRE(y != y_norm, "y and y_norm must be different tensors (pass y = NULL when the raw sum is not needed)");
+    SCAIL_REQUIRE(resid != nullptr || y != nullptr, "without a residual the raw output is required (conv + norm alone is scail_conv3d_cl_norm)");
+    if (resid == nullptr) ldr = 0;
     ConvParams p;
     conv_params(p, geom);
     SCAIL_REQUIRE(ldc == p.N && p.ot_mul == 1 && p.ot_off == 0, "scail_conv3d_cl_resid_norm needs dense outputs: ldc == N, ot_mul = 1, ot_off = 0");

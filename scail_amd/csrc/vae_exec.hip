@@ -201,8 +201,9 @@ int down_stage(Arena& a, const scail_vae_stage& s, Tens& x) {
     return 0;
 }
 
-// Resample upsample2d / upsample3d (wan_vae.py:76-85, :100-131); consumes x
-int up_stage(Arena& a, const scail_vae_stage& s, Tens& x) {
+// Resample upsample2d / upsample3d (wan_vae.py:76-85, :100-131); consumes x.  next_gamma / xn as in res_block: where ONE generated kernel covers the
+// resample convolution + the next ResidualBlock's RMS_norm + SiLU, *xn returns that block's normalised input beside the raw output
+int up_stage(Arena& a, const scail_vae_stage& s, Tens& x, Tens* xn = nullptr, const float* next_gamma = nullptr) {
     if (s.temporal && x.T > 1) {
         Tens t2 = a.get(1 + 2 * (x.T - 1), x.H, x.W, x.C); VAE_CHK(a)
         const int64_t fr = x.H * x.W * x.C;
@@ -215,7 +216,18 @@ int up_stage(Arena& a, const scail_vae_stage& s, Tens& x) {
         x = t2;
     }
     Tens out;
-    VAE_TRY(conv(a, x, s.resample, out, x.T, 2 * x.H, 2 * x.W, 1, 1, 1, 0, 1, 1, 1));
+    int32_t geom[21] = {(int32_t)x.T, (int32_t)x.H, (int32_t)x.W, (int32_t)x.C, (int32_t)x.T, (int32_t)(2 * x.H), (int32_t)(2 * x.W),
+                        s.resample.kt, s.resample.kh, s.resample.kw, 1, 1, 1, 0, 1, 1, 1, 1, 0, s.resample.N, s.resample.Kpad};
+    if (xn != nullptr && next_gamma != nullptr && x.C == s.resample.Cin && scail_conv3d_kernel_for(geom, s.resample.N, 0, 2) == 4) {
+        out = a.get(x.T, 2 * x.H, 2 * x.W, s.resample.N); VAE_CHK(a)
+        Tens nrm = a.get(x.T, 2 * x.H, 2 * x.W, s.resample.N); VAE_CHK(a)
+        VAE_TRY(scail_conv3d_cl_resid_norm(x.p, s.resample.w, s.resample.b, out.p, nrm.p, s.resample.N, nullptr, 0, next_gamma, geom, a.stream));
+        a.emit("conv", out);
+        a.emit("conv_resid_norm", nrm);
+        *xn = nrm;
+    } else {
+        VAE_TRY(conv(a, x, s.resample, out, x.T, 2 * x.H, 2 * x.W, 1, 1, 1, 0, 1, 1, 1));
+    }
     a.put(x);
     x = out;
     return 0;
@@ -332,7 +344,7 @@ extern "C" int scail_vae_decode(scail_vae* h, const float* latent, float* video,
         const scail_vae_stage& s = h->dec[i];
         const bool last = i + 1 == h->dec.size();      // the last block feeds the head's norm and nothing else
         if (s.kind == 0) { VAE_TRY(res_block(a, s.res, x, &xn, last ? w.dec_head_gamma : next_res_gamma(h->dec, i), !last)); }
-        else if (s.kind == 2) { VAE_TRY(up_stage(a, s, x)); }
+        else if (s.kind == 2) { VAE_TRY(up_stage(a, s, x, &xn, next_res_gamma(h->dec, i))); }
         else { scail_set_error("scail_vae_decode: downsampling stage in the decoder table"); return 1; }
     }
     if (xn.p != nullptr) {             // the head's RMS_norm + SiLU came out of the last block's epilogue

@@ -393,29 +393,42 @@ def conv3d_cl_norm(x, wp, gamma, out=None):
     return out
 
 
-def conv_resid_norm_generated(wp, x_shape) -> bool:
-    """Whether conv3d_cl_resid_norm of an activation of shape (T, H, W, Cin) runs ONE generated kernel (scail_conv4c_e5 / e6;
-    scail_conv3d_kernel_for(..., fused_norm = 2) == 4) -- the rule csrc/vae_exec.hip and the layer path of wan_vae.py share."""
+def _next_norm_geom(wp, x_shape, out_shape, pad, ups):
     import ctypes as C
-    T, H, W, Cin = x_shape
+    Ti, Hi, Wi, Cin = x_shape
+    To, Ho, Wo = out_shape
     kt, kh, kw = wp["k"]
-    geom = (C.c_int32 * 21)(T, H, W, Cin, T, H, W, kt, kh, kw, 1, 1, 1, kt - 1, kh // 2, kw // 2, 0, 1, 0, wp["N"], wp["Kpad"])
-    return L.load().scail_conv3d_kernel_for(C.cast(geom, C.c_void_p), wp["N"], wp["N"], 2) == 4
+    if pad is None:
+        pad = (kt - 1, kh // 2, kw // 2)
+    return (C.c_int32 * 21)(Ti, Hi, Wi, Cin, To, Ho, Wo, kt, kh, kw, 1, 1, 1, pad[0], pad[1], pad[2], 1 if ups else 0, 1, 0, wp["N"], wp["Kpad"])
 
 
-def conv3d_cl_resid_norm(x, wp, resid, gamma, want_raw=True):
-    """(resid + causal 3x3x3 conv(x), SiLU(RMS_norm(that) * gamma)) in one call (scail_conv3d_cl_resid_norm): the last convolution of a
-    ResidualBlock with the next consumer's norm.  Returns (raw | None, normalised), both (T, H, W, N) bf16."""
+def conv_resid_norm_generated(wp, x_shape, out_shape=None, pad=None, ups=False, resid=True) -> bool:
+    """Whether conv3d_cl_resid_norm of an activation of shape (T, H, W, Cin) runs ONE generated kernel (scail_conv4c_e5 / e6 with a residual,
+    scail_conv4u_e7 without; scail_conv3d_kernel_for(..., fused_norm = 2) == 4) -- the rule csrc/vae_exec.hip and the layer path of wan_vae.py share."""
     import ctypes as C
-    _chk(x, bf16, "conv3d_cl_resid_norm.x"); _chk(resid, bf16, "conv3d_cl_resid_norm.resid"); _chk(gamma, f32, "conv3d_cl_resid_norm.gamma")
-    assert x.is_contiguous() and x.dim() == 4 and x.shape[3] == wp["Cin"] and gamma.numel() == wp["N"] and tuple(wp["k"]) == (3, 3, 3)
-    T, H, W, Cin = x.shape
-    assert resid.is_contiguous() and resid.shape == (T, H, W, wp["N"])
-    raw = torch.empty(T, H, W, wp["N"], device=x.device, dtype=bf16) if want_raw else None
-    nrm = torch.empty(T, H, W, wp["N"], device=x.device, dtype=bf16)
-    geom = (C.c_int32 * 21)(T, H, W, Cin, T, H, W, 3, 3, 3, 1, 1, 1, 2, 1, 1, 0, 1, 0, wp["N"], wp["Kpad"])
+    geom = _next_norm_geom(wp, x_shape, out_shape or tuple(x_shape[:3]), pad, ups)
+    return L.load().scail_conv3d_kernel_for(C.cast(geom, C.c_void_p), wp["N"], wp["N"] if resid else 0, 2) == 4
+
+
+def conv3d_cl_resid_norm(x, wp, resid, gamma, want_raw=True, out_shape=None, pad=None, ups=False):
+    """(resid + conv(x), SiLU(RMS_norm(that) * gamma)) in one call (scail_conv3d_cl_resid_norm): the last convolution of a ResidualBlock -- or, with
+    resid = None, any stride-1 convolution such as Resample's behind the 2x upsample -- with the next consumer's norm.  Returns
+    (raw | None, normalised), both (To, Ho, Wo, N) bf16."""
+    import ctypes as C
+    _chk(x, bf16, "conv3d_cl_resid_norm.x"); _chk(gamma, f32, "conv3d_cl_resid_norm.gamma")
+    assert x.is_contiguous() and x.dim() == 4 and x.shape[3] == wp["Cin"] and gamma.numel() == wp["N"]
+    To, Ho, Wo = out_shape or tuple(x.shape[:3])
+    if resid is not None:
+        _chk(resid, bf16, "conv3d_cl_resid_norm.resid")
+        assert resid.is_contiguous() and resid.shape == (To, Ho, Wo, wp["N"])
+    else:
+        assert want_raw, "without a residual the raw output is part of the contract"
+    raw = torch.empty(To, Ho, Wo, wp["N"], device=x.device, dtype=bf16) if want_raw else None
+    nrm = torch.empty(To, Ho, Wo, wp["N"], device=x.device, dtype=bf16)
+    geom = _next_norm_geom(wp, x.shape, (To, Ho, Wo), pad, ups)
     L.call("scail_conv3d_cl_resid_norm", x.data_ptr(), wp["w"].data_ptr(), wp["b"].data_ptr(), _ptr(raw), nrm.data_ptr(), wp["N"],
-           resid.data_ptr(), resid.shape[3], gamma.data_ptr(), C.cast(geom, C.c_void_p), _stream())
+           _ptr(resid), resid.shape[3] if resid is not None else 0, gamma.data_ptr(), C.cast(geom, C.c_void_p), _stream())
     return raw, nrm
 
 

@@ -213,8 +213,11 @@ class WanVAE_(nn.Module):
                 last = i + 1 == len(plan)
                 nxt = head_gamma if (last and head_gamma is not None) else (W[plan[i + 1][1] + ".residual.0.gamma"] if (not last and plan[i + 1][0] == "res") else None)
                 x, xn = self._res(W, n, x, xn, nxt, need_raw=not (last and head_gamma is not None))
+            elif down:
+                x = self._down(W, n, x, b)
             else:
-                x = self._down(W, n, x, b) if down else self._up(W, n, x, b)
+                nxt = W[plan[i + 1][1] + ".residual.0.gamma"] if (i + 1 < len(plan) and plan[i + 1][0] == "res") else None
+                x, xn = self._up(W, n, x, b, nxt) if nxt is not None else (self._up(W, n, x, b), None)
         return x, xn
 
     def _attn(self, W, n, x):
@@ -251,7 +254,8 @@ class WanVAE_(nn.Module):
             y = out
         return y
 
-    def _up(self, W, n, x, temporal):
+    def _up(self, W, n, x, temporal, next_gamma=None):
+        """Resample upsample2d / upsample3d; with next_gamma (the next ResidualBlock's residual.0 norm) returns (raw, normalised | None)."""
         T, H, Wd, C = x.shape
         if temporal and T > 1:
             t2 = torch.empty(1 + 2 * (T - 1), H, Wd, C, device=x.device, dtype=torch.bfloat16)
@@ -260,7 +264,11 @@ class WanVAE_(nn.Module):
             for p in (0, 1):
                 ops.conv3d_cl(tail, W[n + f".time_conv#{p}"], (T - 1, H, Wd), out=t2, ot_mul=2, ot_off=1 + p)
             x, T = t2, t2.shape[0]
-        return ops.conv3d_cl(x, W[n + ".resample.1"], (T, 2 * H, 2 * Wd), pad=(0, 1, 1), ups=True)
+        wr = W[n + ".resample.1"]
+        if next_gamma is not None and ops.conv_resid_norm_generated(wr, x.shape, (T, 2 * H, 2 * Wd), pad=(0, 1, 1), ups=True, resid=False):
+            return ops.conv3d_cl_resid_norm(x, wr, None, next_gamma, out_shape=(T, 2 * H, 2 * Wd), pad=(0, 1, 1), ups=True)
+        y = ops.conv3d_cl(x, wr, (T, 2 * H, 2 * Wd), pad=(0, 1, 1), ups=True)
+        return (y, None) if next_gamma is not None else y
 
     # ---- public: one video / one latent, planar fp32 in and out (reference layout) ----
     @torch.no_grad()

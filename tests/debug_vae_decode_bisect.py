@@ -77,7 +77,7 @@ def main():
             if kind == "res":
                 x, _ = m._res(W, n, x); o = V.residual_block(sdg, n, o)
             else:
-                x = m._up(W, n, x, b)
+                x = m._up(W, n, x, b)        # (no next_gamma: plain raw output)
                 mode = "upsample3d" if b else "upsample2d"
                 o = V.upsample(sdg, n, o, mode)
             c = cmp(f"{kind} {n} {b if kind != 'res' else ''}", x, o)

@@ -138,6 +138,7 @@ def test_conv4c_emulated_residual_plus_next_norm(name, shape):
     next block's shortcut operand) AND the normalised copy at y + (y2 - y); epi 6 the normalised tensor only.  The norm is applied to the
     bf16-ROUNDED sum, as the separate rms_silu pass it replaces does; the raw output must equal scail_conv4c_e3's bit for bit."""
     cfg = [c for c in conv4.RESNORM if c.name == name][0]
+    assert cfg.kt == 3
     Ti, H, W, Cin, N = shape
     x, w, b, r = _case(Ti, H, W, Cin, N, True, seed=8)
     gam = (1 + 0.1 * np.random.default_rng(5).standard_normal(N)).astype(np.float32)
@@ -155,3 +156,23 @@ def test_conv4c_emulated_residual_plus_next_norm(name, shape):
     assert not np.isnan(nrm).any()
     err = np.abs(nrm - nrm_ref)
     assert err.max() <= 2.0 ** -7 * max(1.0, np.abs(nrm_ref).max()) and err.mean() <= 1e-3, (float(err.max()), float(err.mean()))
+
+
+@pytest.mark.parametrize("ups,shape,cus", [(1, (2, 8, 8, 64, 96), 256), (1, (3, 9, 12, 96, 96), 8), (0, (3, 18, 20, 96, 96), 256)])
+def test_conv4u_emulated_dual_output_next_norm(ups, shape, cus):
+    """scail_conv4u_e7 (Cfg.epi 7, kt = 1): Resample's 1 x 3 x 3 convolution behind the nearest 2x upsample (wan_vae.py:76-85) with the RMS_norm + SiLU
+    of the ResidualBlock that reads it next: the raw output (that block's shortcut operand) bit-identical to scail_conv4u_e0's, the normalised
+    copy = the separate pass on the bf16-rounded output."""
+    cfg = [c for c in conv4.RESNORM if c.name == "scail_conv4u_e7"][0]
+    T, Hi, Wi, Cin, N = shape
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((T, Hi, Wi, Cin)).astype(np.float32)
+    w = (rng.standard_normal((N, Cin, 1, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    gam = (1 + 0.1 * rng.standard_normal(N)).astype(np.float32)
+    (raw, nrm), _ = R.run_k1(cfg, x, w, b, ups, cus=cus, gamma=gam)
+    y0, _ = R.run_k1(conv4.UPSAMPLE[0], x, w, b, ups, cus=cus)
+    assert np.array_equal(raw, y0) and not np.isnan(nrm).any()
+    ref = R.reference_norm_silu(y0, gam)
+    err = np.abs(nrm - ref)
+    assert err.max() <= 2.0 ** -7 * max(1.0, np.abs(ref).max()) and err.mean() <= 1e-3, (float(err.max()), float(err.mean()))

@@ -496,6 +496,36 @@ def test_conv3d_cl_resid_norm_against_the_two_calls(thw, want_raw):
     assert torch.equal(nrm0, n2) and (raw0 is None or torch.equal(raw0, y))
 
 
+@pytest.mark.parametrize("thw", [(9, 256, 448), (3, 24, 40)])
+def test_conv3d_cl_resid_norm_without_residual_on_the_upsample_convolution(thw):
+    """scail_conv3d_cl_resid_norm with resid = NULL on Resample's 1 x 3 x 3 convolution behind the nearest 2x upsample (wan_vae.py:76-85; 192 -> 96
+    channels, full resolution out): scail_conv4u_e7 writes the raw output (bit-identical to scail_conv4u_e0's) and the next ResidualBlock's
+    normalised input."""
+    from scail_amd import lib as L, ops
+    T, H, W = thw
+    Cin, C = 192, 96
+    g = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.randn(T, H, W, Cin, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(C, Cin, 1, 3, 3, device=DEV, generator=g) / (9 * Cin) ** 0.5)
+    b = torch.randn(C, device=DEV, generator=g)
+    gam = (1 + 0.1 * torch.randn(C, device=DEV, generator=g)).float()
+    wp = ops.prep_conv_weight(w, b)
+    out_shape = (T, 2 * H, 2 * W)
+    assert ops.conv_resid_norm_generated(wp, x.shape, out_shape, pad=(0, 1, 1), ups=True, resid=False)
+    raw, nrm = ops.conv3d_cl_resid_norm(x, wp, None, gam, out_shape=out_shape, pad=(0, 1, 1), ups=True)
+    y = ops.conv3d_cl(x, wp, out_shape, pad=(0, 1, 1), ups=True)
+    n2 = ops.rms_silu(y, gam)
+    assert torch.equal(raw, y) and torch.isfinite(nrm.float()).all()
+    d = (nrm.float() - n2.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * max(1.0, float(n2.float().abs().max())), float(d.max())
+    L.set_option("conv4_resnorm", 0)
+    try:
+        raw0, nrm0 = ops.conv3d_cl_resid_norm(x, wp, None, gam, out_shape=out_shape, pad=(0, 1, 1), ups=True)
+    finally:
+        L.set_option("conv4_resnorm", 1)
+    assert torch.equal(nrm0, n2) and torch.equal(raw0, y)
+
+
 @pytest.mark.parametrize("C,thw", [(96, (9, 512, 896)), (96, (5, 720, 1280)), (192, (9, 256, 448)), (384, (7, 128, 224))])
 def test_conv4_at_vae_resolutions(C, thw):
     """the generated convolution kernels at the sizes BASELINE config 4 runs them (512 x 896 full / half / quarter resolution; 720 x 1280: 3 600

@@ -95,7 +95,7 @@ def check_static(cfg):
             + sched.check_hazards(body + g.tile_end() + g.tile_setup()))
 
 
-def run_k1(cfg: conv4.Cfg, x, w, bias=None, ups=0, ldc=None, lazy=True, wgs=None, cus=256):
+def run_k1(cfg: conv4.Cfg, x, w, bias=None, ups=0, ldc=None, lazy=True, wgs=None, cus=256, gamma=None):
     """the kt = 1 kernels: x (T, Hi, Wi, Cin), w (N, Cin, 1, 3, 3); output (T, Hi << ups, Wi << ups, N)."""
     T, Hi, Wi, Cin = x.shape
     N = w.shape[0]
@@ -107,14 +107,21 @@ def run_k1(cfg: conv4.Cfg, x, w, bias=None, ups=0, ldc=None, lazy=True, wgs=None
     pw = mem.alloc("w", to_bf16_bits(wp))
     pb = mem.alloc("bias", bias.astype(np.float32)) if bias is not None else 0
     py = mem.alloc("y", np.full((T, H, W, ldc), 0x7FC0, dtype=np.uint16))
+    pg = py2 = 0
+    if gamma is not None:                                      # epi 7: raw + normalised copy
+        pg = mem.alloc("gamma", gamma.astype(np.float32))
+        py2 = mem.alloc("y2", np.full((T, H, W, ldc), 0x7FC0, dtype=np.uint16))
     prog = conv4.Gen(cfg).program()
-    args = conv4.pack_args(px, pw, pb, py, 0, T, T, H, W, Cin, N, wp.shape[1], ups, 1, 0, ldc, 0, cus)
+    args = conv4.pack_args(px, pw, pb, py, 0, T, T, H, W, Cin, N, wp.shape[1], ups, 1, 0, ldc, 0, cus, gamma=pg, y2=py2)
     stats = None
     for wg in (range(conv4.grid_blocks(T, H, W, N, cus)) if wgs is None else wgs):
         emu = E.Emu(prog, mem, n_waves=4, lds_bytes=conv4.LDS_BYTES, lazy=lazy)
         emu.launch(args, block_id=(wg, 0, 0))
         stats = emu.waves[0].stats
-    return from_bf16_bits(mem.read_back("y")).reshape(T, H, W, ldc), stats
+    y = from_bf16_bits(mem.read_back("y")).reshape(T, H, W, ldc)
+    if py2:
+        return (y, from_bf16_bits(mem.read_back("y2")).reshape(T, H, W, ldc)), stats
+    return y, stats
 
 
 def reference_k1(x, w, bias=None, ups=0):
