@@ -27,7 +27,8 @@ struct ConvParams {
     const float* bias; // (N) or null
     u16* y; int64_t ldc;          // output voxel v -> y + v * ldc
     const u16* resid; int64_t ldr;
-    const float* gamma;           // EPI 4 (halo kernel, N <= tile width): RMS_norm gamma, output = SiLU(RMS_norm(conv))
+    const float* gamma;           // EPI 4 (halo kernel, N <= tile width): RMS_norm gamma, output = SiLU(RMS_norm(conv)); conv_direct_kernel<.., true>: the consumer's gamma
+    u16* y2 = nullptr;            // conv_direct_kernel<.., true>: SiLU(RMS_norm(bf16(conv + bias)) * gamma) beside the raw output (same ldc and frame mapping)
     int Ti, Hi, Wi, Cin;
     int To, Ho, Wo;               // output extents covered by this launch (M = To*Ho*Wo)
     int kt, kh, kw, st, sh, sw, pt, ph, pw, ups;
@@ -200,8 +201,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 // ------------------------------------------------------------------------------------------------
 #define CD_THREADS 512
 #define CD_STRIP_LD 104            // elements per staged voxel row: 96 channels + 8 (208 bytes: 16-byte aligned, conflict-light 8-byte writes)
-template <int KS, int NB>
+// DUAL (round 6, NB = 3: the 96 channels of a voxel in one pass): the raw output AND, at y2, SiLU(RMS_norm(bf16(raw)) * gamma) -- the stem convolution of the
+// encoder with the first ResidualBlock's input norm (the arithmetic of rms_silu_kernel on what the plain kernel stores)
+template <int KS, int NB, bool DUAL = false>
 __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p, int wld) {
+    static_assert(!DUAL || NB == 3, "the norm needs every channel of a voxel in one strip pass");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* Ws = smem;                                              // [N][wld]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -307,19 +311,55 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
                         o.x = pack_bf16x2(acc[nb][4 * rr + 0] + bb.x, acc[nb][4 * rr + 1] + bb.y);
                         o.y = pack_bf16x2(acc[nb][4 * rr + 2] + bb.z, acc[nb][4 * rr + 3] + bb.w);
                         *reinterpret_cast<uint2*>(strip + l31 * CD_STRIP_LD + q * 32 + 8 * rr + 4 * g) = o;
+                        if (DUAL) {      // keep what was stored (bf16-rounded) for the norm
+                            acc[nb][4 * rr + 0] = __uint_as_float(o.x << 16); acc[nb][4 * rr + 1] = __uint_as_float(o.x & 0xFFFF0000u);
+                            acc[nb][4 * rr + 2] = __uint_as_float(o.y << 16); acc[nb][4 * rr + 3] = __uint_as_float(o.y & 0xFFFF0000u);
+                        }
                     }
                 }
             }
             // the strip is private to the wave: LDS operations of one wave complete in order, no barrier
             const int cpv = nbs * 4;                                               // 16-byte chunks per voxel in this pass
-            for (int j = lane; j < 32 * cpv; j += 64) {
-                const int v = j / cpv, ch = j - v * cpv;
-                const int64_t mv = vox0 + v;
-                if (mv < p.M) {
-                    const int tv = (int)(mv / HWo);
-                    const int64_t vox = ((int64_t)(tv * p.ot_mul + p.ot_off)) * HWo + (mv - (int64_t)tv * HWo);
-                    *reinterpret_cast<uint4*>(p.y + vox * p.ldc + h * 96 + ch * 8) = *reinterpret_cast<const uint4*>(strip + v * CD_STRIP_LD + ch * 8);
+            auto store_strip = [&](u16* dst) {
+                for (int j = lane; j < 32 * cpv; j += 64) {
+                    const int v = j / cpv, ch = j - v * cpv;
+                    const int64_t mv = vox0 + v;
+                    if (mv < p.M) {
+                        const int tv = (int)(mv / HWo);
+                        const int64_t vox = ((int64_t)(tv * p.ot_mul + p.ot_off)) * HWo + (mv - (int64_t)tv * HWo);
+                        *reinterpret_cast<uint4*>(dst + vox * p.ldc + h * 96 + ch * 8) = *reinterpret_cast<const uint4*>(strip + v * CD_STRIP_LD + ch * 8);
+                    }
                 }
+            };
+            store_strip(p.y);
+            if (DUAL) {
+                // lane (l31, g) holds 48 of voxel l31's 96 channels, lane ^ 32 the others
+                float ss = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ss += acc[nb][e] * acc[nb][e];
+                ss += __shfl_xor(ss, 32, 64);
+                const float inv = sqrtf((float)p.N) * __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ss), 1e-12f));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int n = nb * 32 + 8 * rr + 4 * g;
+                        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + n);
+                        const float g4[4] = {gm.x, gm.y, gm.z, gm.w};
+                        float v4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = acc[nb][4 * rr + e] * inv * g4[e];
+                            v4[e] = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+                        }
+                        uint2 o;
+                        o.x = pack_bf16x2(v4[0], v4[1]);
+                        o.y = pack_bf16x2(v4[2], v4[3]);
+                        *reinterpret_cast<uint2*>(strip + l31 * CD_STRIP_LD + nb * 32 + 8 * rr + 4 * g) = o;
+                    }
+                store_strip(p.y2);
             }
         }
     }
@@ -894,6 +934,17 @@ static bool conv4n_eligible(const ConvParams& p, int64_t ldc) {
            (int64_t)p.Hi * p.Wi * p.Cin * 2 < (1ll << 31) && (int64_t)p.Ho * p.Wo * ldc * 2 < (1ll << 32);
 }
 
+// the direct-gather kernel's dual-output form (conv_direct_kernel<14, 3, true>): 96 output channels, up to 14 k-steps of 16 (the encoder's stem: 3 x 3 x 3 taps
+// of 8 padded channels), no residual, no upsample; shape conditions of the plain dispatch in conv3d_impl
+static bool conv_direct_dual_eligible(const ConvParams& p, int64_t ldc) {
+    const int ksteps = (p.Ktrue + 15) / 16;
+    const int wld = ksteps * 16 + 8;
+    const int lds = (p.N * wld + 8 * 32 * CD_STRIP_LD) * 2;
+    return p.N == 96 && ksteps <= 14 && !p.ups && p.Cin % 8 == 0 && p.kt <= 30 && p.kh <= 31 && p.kw <= 31 && p.Cin < 65536 &&
+           (int64_t)(p.kt + 1) * p.Hi * p.Wi * p.Cin < (1ll << 31) && lds <= 150 * 1024 && ldc % 8 == 0 && p.M >= 4096 && p.M < (1ll << 40) &&
+           p.Ho * (int64_t)p.Wo < (1ll << 31);
+}
+
 static void conv_params(ConvParams& p, const int32_t* geom) {
     p.Ti = geom[0]; p.Hi = geom[1]; p.Wi = geom[2]; p.Cin = geom[3];
     p.To = geom[4]; p.Ho = geom[5]; p.Wo = geom[6];
@@ -913,7 +964,10 @@ extern "C" int scail_conv3d_kernel_for(const int32_t* geom, int64_t ldc, int64_t
     if (fused_norm == 2) { // (residual sum +) the NEXT consumer's RMS_norm + SiLU (scail_conv3d_cl_resid_norm): one n tile of 96 channels; with a residual the
                            // 3x3x3 kernels with tile continuation (scail_conv4c_e5 / e6), without one the kt = 1 kernel (scail_conv4u_e7)
         if (!(g_conv4 && g_conv4_resnorm && g_conv4_suffix.empty() && p.N == 96 && ldc == 96 && p.ot_mul == 1 && p.ot_off == 0)) return 0;
-        return (ldr > 0 ? (g_conv4_cont && conv4_eligible(p, ldc, ldr)) : conv4u_eligible(p, ldc)) ? 4 : 0;
+        if (ldr > 0) return (g_conv4_cont && conv4_eligible(p, ldc, ldr)) ? 4 : 0;
+        if (conv4u_eligible(p, ldc)) return 4;
+        // ... or, answer 2, the hipcc direct-gather kernel's dual-output form (the encoder's stem convolution): not a generated kernel, one launch all the same
+        return (g_conv_direct && !conv4_eligible(p, ldc, ldc) && !conv4n_eligible(p, ldc) && conv_direct_dual_eligible(p, ldc)) ? 2 : 0;
     }
     if (fused_norm)      // conv + RMS_norm + SiLU: the generated kernel where one n tile holds a voxel's 96 channels, no residual
         return (g_conv4 && ldr == 0 && p.N == 96 && conv4_eligible(p, ldc, ldc)) ? 4 : 0;
@@ -989,7 +1043,7 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         }
         return 0;
     }
-    if ((g_conv_halo || fuse) && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups &&
+    if (!rn && (g_conv_halo || fuse) && p.kt == 3 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 1 && p.sw == 1 && !p.ups &&
         p.ph == 1 && p.pw == 1 && p.Ho == p.Hi && p.Wo == p.Wi &&
         p.Cin % ((g_conv_halo == 1 && p.N > 32 && !fuse) ? 48 : 32) == 0 && (fuse || p.N <= 32 || p.N >= 48)) {
 #define HALO_LAUNCH(EPI_, CS_, NWB_, SWZ_, BN_, ...)                                                                        \
@@ -1062,6 +1116,22 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         if (g_conv_direct && !p.ups && resid == nullptr && p.Cin % 8 == 0 && nn % 32 == 0 && shape && lds <= 150 * 1024 && ldc % 8 == 0 &&
             (reinterpret_cast<uintptr_t>(y) & 15) == 0 && p.M >= 4096 && p.M < (1ll << 40) && p.Ho * (int64_t)p.Wo < (1ll << 31)) {
             const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((p.M + 255) / 256, conv4_cu_count()));
+            if (rn) {       // raw output + the consumer's normalised input (scail_conv3d_cl_resid_norm checked conv_direct_dual_eligible)
+                SCAIL_REQUIRE(nb == 3 && nsplit == 1 && ksteps <= 14 && y != y_norm, "conv3d: dual-output direct kernel needs 96 channels, <= 14 k-steps");
+                ConvParams q = p;
+                q.gamma = next_gamma;
+                q.y2 = y_norm;
+                static ScailDeviceOnce attr_;
+                if (attr_.need()) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_direct_kernel<14, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+                        scail_set_error("conv3d: hipFuncSetAttribute failed");
+                        return 2;
+                    }
+                    attr_.done();
+                }
+                hipLaunchKernelGGL((conv_direct_kernel<14, 3, true>), dim3(grid), dim3(CD_THREADS), lds, (hipStream_t)stream, q, wld);
+                return scail_check_launch("conv3d_cl_resid_norm");
+            }
 #define CD_LAUNCH(KS_, NB_)                                                                                                          \
     {                                                                                                                                \
         static ScailDeviceOnce attr_;                                                                                                   \
@@ -1090,6 +1160,7 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
             return scail_check_launch("conv3d_cl");
         }
     }
+    SCAIL_REQUIRE(!rn, "conv3d: the dual-output form was requested for a shape no dual-output kernel covers (scail_conv3d_kernel_for(.., 2) decides)");
     // N tile: of 128 / 96 / 64 the one with the fewest padding columns (ties -> the wider tile)
     int bn = 128;
     {
@@ -1147,7 +1218,7 @@ extern "C" int scail_conv3d_cl_resid_norm(const scail_bf16* x, const scail_bf16*
     SCAIL_REQUIRE(ldc == p.N && p.ot_mul == 1 && p.ot_off == 0, "scail_conv3d_cl_resid_norm needs dense outputs: ldc == N, ot_mul = 1, ot_off = 0");
     const bool aligned = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y_norm) | reinterpret_cast<uintptr_t>(resid) |
                            reinterpret_cast<uintptr_t>(gamma)) & 15) == 0;
-    if (aligned && scail_conv3d_kernel_for(geom, ldc, ldr, 2) == 4)
+    if (aligned && scail_conv3d_kernel_for(geom, ldc, ldr, 2) != 0)       // 4: a generated kernel, 2: the direct-gather kernel's dual-output form
         return conv3d_impl(x, w, bias, y, ldc, resid, ldr, nullptr, geom, stream, gamma, y_norm);
     // everything else: the two separate calls this entry point stands for
     scail_bf16* raw = y != nullptr ? y : y_norm;

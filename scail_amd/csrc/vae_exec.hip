@@ -112,7 +112,7 @@ int res_block(Arena& a, const scail_vae_res& r, Tens& x, Tens* xn = nullptr, con
     }
     int32_t geom6[21] = {(int32_t)y2.T, (int32_t)y2.H, (int32_t)y2.W, (int32_t)y2.C, (int32_t)x.T, (int32_t)x.H, (int32_t)x.W,
                          r.conv6.kt, r.conv6.kh, r.conv6.kw, 1, 1, 1, r.conv6.kt - 1, r.conv6.kh / 2, r.conv6.kw / 2, 0, 1, 0, r.conv6.N, r.conv6.Kpad};
-    if (xn != nullptr && next_gamma != nullptr && y2.C == r.conv6.Cin && scail_conv3d_kernel_for(geom6, r.conv6.N, h.C, 2) == 4) {
+    if (xn != nullptr && next_gamma != nullptr && y2.C == r.conv6.Cin && scail_conv3d_kernel_for(geom6, r.conv6.N, h.C, 2) != 0) {
         Tens nrm = a.get(x.T, x.H, x.W, r.conv6.N); VAE_CHK(a)
         if (need_raw) { out = a.get(x.T, x.H, x.W, r.conv6.N); VAE_CHK(a) }
         VAE_TRY(scail_conv3d_cl_resid_norm(y2.p, r.conv6.w, r.conv6.b, need_raw ? out.p : nullptr, nrm.p, r.conv6.N, h.p, h.C, next_gamma, geom6, a.stream));
@@ -218,7 +218,7 @@ int up_stage(Arena& a, const scail_vae_stage& s, Tens& x, Tens* xn = nullptr, co
     Tens out;
     int32_t geom[21] = {(int32_t)x.T, (int32_t)x.H, (int32_t)x.W, (int32_t)x.C, (int32_t)x.T, (int32_t)(2 * x.H), (int32_t)(2 * x.W),
                         s.resample.kt, s.resample.kh, s.resample.kw, 1, 1, 1, 0, 1, 1, 1, 1, 0, s.resample.N, s.resample.Kpad};
-    if (xn != nullptr && next_gamma != nullptr && x.C == s.resample.Cin && scail_conv3d_kernel_for(geom, s.resample.N, 0, 2) == 4) {
+    if (xn != nullptr && next_gamma != nullptr && x.C == s.resample.Cin && scail_conv3d_kernel_for(geom, s.resample.N, 0, 2) != 0) {
         out = a.get(x.T, 2 * x.H, 2 * x.W, s.resample.N); VAE_CHK(a)
         Tens nrm = a.get(x.T, 2 * x.H, 2 * x.W, s.resample.N); VAE_CHK(a)
         VAE_TRY(scail_conv3d_cl_resid_norm(x.p, s.resample.w, s.resample.b, out.p, nrm.p, s.resample.N, nullptr, 0, next_gamma, geom, a.stream));
@@ -289,10 +289,24 @@ extern "C" int scail_vae_encode(scail_vae* h, const float* video, float* latent,
     Tens x = a.get(T, H, W, 8); VAE_CHK(a)
     VAE_TRY(scail_to_channels_last(video, x.p, nullptr, nullptr, 3, 8, T * H * W, stream));
     Tens y;
-    VAE_TRY(conv(a, x, w.enc_conv1, y, T, H, W));
+    Tens xn;       // the next ResidualBlock's normalised input, when its producer wrote it (res_block, here the stem)
+    {
+        const scail_conv_w& cw = w.enc_conv1;
+        int32_t geom[21] = {(int32_t)T, (int32_t)H, (int32_t)W, (int32_t)x.C, (int32_t)T, (int32_t)H, (int32_t)W,
+                            cw.kt, cw.kh, cw.kw, 1, 1, 1, cw.kt - 1, cw.kh / 2, cw.kw / 2, 0, 1, 0, cw.N, cw.Kpad};
+        const float* g0 = (!h->enc.empty() && h->enc[0].kind == 0) ? h->enc[0].res.gamma0 : nullptr;
+        if (g0 != nullptr && x.C == cw.Cin && scail_conv3d_kernel_for(geom, cw.N, 0, 2) != 0) {
+            y = a.get(T, H, W, cw.N); VAE_CHK(a)
+            xn = a.get(T, H, W, cw.N); VAE_CHK(a)
+            VAE_TRY(scail_conv3d_cl_resid_norm(x.p, cw.w, cw.b, y.p, xn.p, cw.N, nullptr, 0, g0, geom, stream));
+            a.emit("conv", y);
+            a.emit("conv_resid_norm", xn);
+        } else {
+            VAE_TRY(conv(a, x, w.enc_conv1, y, T, H, W));
+        }
+    }
     a.put(x);
     x = y;
-    Tens xn;       // the next ResidualBlock's normalised input, when its producer wrote it (res_block)
     for (size_t i = 0; i < h->enc.size(); ++i) {
         const scail_vae_stage& s = h->enc[i];
         if (s.kind == 0) { VAE_TRY(res_block(a, s.res, x, &xn, next_res_gamma(h->enc, i))); }

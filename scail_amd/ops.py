@@ -408,7 +408,7 @@ def conv_resid_norm_generated(wp, x_shape, out_shape=None, pad=None, ups=False, 
     scail_conv4u_e7 without; scail_conv3d_kernel_for(..., fused_norm = 2) == 4) -- the rule csrc/vae_exec.hip and the layer path of wan_vae.py share."""
     import ctypes as C
     geom = _next_norm_geom(wp, x_shape, out_shape or tuple(x_shape[:3]), pad, ups)
-    return L.load().scail_conv3d_kernel_for(C.cast(geom, C.c_void_p), wp["N"], wp["N"] if resid else 0, 2) == 4
+    return L.load().scail_conv3d_kernel_for(C.cast(geom, C.c_void_p), wp["N"], wp["N"] if resid else 0, 2) != 0       # 4: generated kernel, 2: direct-gather dual form
 
 
 def conv3d_cl_resid_norm(x, wp, resid, gamma, want_raw=True, out_shape=None, pad=None, ups=False):

@@ -204,10 +204,9 @@ class WanVAE_(nn.Module):
             return ops.conv3d_cl_resid_norm(y, w6, h, next_gamma, want_raw=need_raw)
         return ops.conv3d_cl(y, w6, (T, H, Wd), resid=h), None
 
-    def _stages(self, W, plan, x, down, head_gamma=None):
+    def _stages(self, W, plan, x, down, head_gamma=None, xn=None):
         """the stage table of the encoder / decoder; a ResidualBlock followed by another one (or, last in the decoder, by the head's norm) hands
         its consumer's normalised input along.  Returns (raw | None, normalised | None)."""
-        xn = None
         for i, (kind, n, a, b) in enumerate(plan):
             if kind == "res":
                 last = i + 1 == len(plan)
@@ -284,8 +283,14 @@ class WanVAE_(nn.Module):
         if self.use_c_exec:
             return self._c().encode(video.float().to(next(self.parameters()).device).contiguous()).unsqueeze(0)
         x = ops.to_channels_last(video.float().to(next(self.parameters()).device), 8)
-        x = ops.conv3d_cl(x, W["encoder.conv1"], (T, H, Wd))
-        x, _ = self._stages(W, self.encoder_plan(), x, down=True)
+        plan = self.encoder_plan()
+        g0 = W[plan[0][1] + ".residual.0.gamma"] if plan and plan[0][0] == "res" else None
+        xn = None
+        if g0 is not None and ops.conv_resid_norm_generated(W["encoder.conv1"], x.shape, resid=False):
+            x, xn = ops.conv3d_cl_resid_norm(x, W["encoder.conv1"], None, g0)          # the stem with the first block's input norm (csrc/vae_exec.hip)
+        else:
+            x = ops.conv3d_cl(x, W["encoder.conv1"], (T, H, Wd))
+        x, _ = self._stages(W, plan, x, down=True, xn=xn)
         x, _ = self._res(W, "encoder.middle.0", x)
         x = self._attn(W, "encoder.middle.1", x)
         x, _ = self._res(W, "encoder.middle.2", x)

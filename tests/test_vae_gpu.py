@@ -496,6 +496,30 @@ def test_conv3d_cl_resid_norm_against_the_two_calls(thw, want_raw):
     assert torch.equal(nrm0, n2) and (raw0 is None or torch.equal(raw0, y))
 
 
+@pytest.mark.parametrize("thw", [(9, 512, 896), (5, 40, 56)])
+def test_conv3d_cl_resid_norm_on_the_stem_convolution(thw):
+    """the encoder's stem (CausalConv3d(3, 96, 3), wan_vae.py:283; 3 channels padded to 8) with the first ResidualBlock's input norm: the hipcc
+    direct-gather kernel's dual-output form (conv_direct_kernel<14, 3, true>; scail_conv3d_kernel_for(.., 2) == 2) against the two calls."""
+    from scail_amd import lib as L, ops
+    import ctypes as C
+    T, H, W = thw
+    g = torch.Generator(device=DEV).manual_seed(19)
+    x = torch.zeros(T, H, W, 8, device=DEV, dtype=torch.bfloat16)
+    x[..., :3] = torch.randn(T, H, W, 3, device=DEV, generator=g).to(torch.bfloat16)
+    w = torch.randn(96, 3, 3, 3, 3, device=DEV, generator=g) / 81 ** 0.5
+    b = torch.randn(96, device=DEV, generator=g)
+    gam = (1 + 0.1 * torch.randn(96, device=DEV, generator=g)).float()
+    wp = ops.prep_conv_weight(w, b, cin_pad=8)
+    geom = ops._next_norm_geom(wp, x.shape, (T, H, W), None, False)
+    assert L.load().scail_conv3d_kernel_for(C.cast(geom, C.c_void_p), 96, 0, 2) == 2
+    raw, nrm = ops.conv3d_cl_resid_norm(x, wp, None, gam)
+    y = ops.conv3d_cl(x, wp, (T, H, W))
+    n2 = ops.rms_silu(y, gam)
+    assert torch.equal(raw, y) and torch.isfinite(nrm.float()).all()
+    d = (nrm.float() - n2.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * max(1.0, float(n2.float().abs().max())), float(d.max())
+
+
 @pytest.mark.parametrize("thw", [(9, 256, 448), (3, 24, 40)])
 def test_conv3d_cl_resid_norm_without_residual_on_the_upsample_convolution(thw):
     """scail_conv3d_cl_resid_norm with resid = NULL on Resample's 1 x 3 x 3 convolution behind the nearest 2x upsample (wan_vae.py:76-85; 192 -> 96
