@@ -77,7 +77,8 @@ void scail_vae_destroy(scail_vae* h);
  * host with the channels-last bf16 tensor [T][H][W][C] inside the workspace that the launch writes.  The launch is only ENQUEUED at that
  * point: the callback must order itself after the stream (enqueue its own work on the same stream, or synchronise) before reading, and
  * must not write.  The call sequence is the launch order of scail_amd/wan_vae.py's layer-by-layer path (tools/vae_exec_vs_layers.py
- * walks both).  fn == NULL switches it off (the default; nothing is called, nothing synchronises). */
+ * walks both); a launch with two outputs (scail_conv3d_cl_resid_norm: raw sum + the next consumer's normalised input) calls fn once per output
+ * ("conv", then "conv_resid_norm").  fn == NULL switches it off (the default; nothing is called, nothing synchronises). */
 typedef void (*scail_vae_trace_fn)(void* user, int index, const char* op, const void* data, int64_t T, int64_t H, int64_t W, int64_t C);
 int scail_vae_set_trace(scail_vae* h, scail_vae_trace_fn fn, void* user);
 
