@@ -30,6 +30,7 @@ M0_DIST = 2                # s_mov / s_add m0 -> LDS-DMA
 VCC_BRANCH_DIST = 2        # v_cmp -> s_cbranch_vcc*
 SGPR_VALU_TO_VMEM_DIST = 6   # VALU-written SGPR (readfirstlane) -> VMEM / SMEM use: 5 wait states
 MFMA_SRC_WAR_DIST = 2      # overwrite of an MFMA's A / B operand registers after the MFMA
+MFMA_SRCC_WAR_DIST = 12    # overwrite of an MFMA's srcC registers by a non-MFMA instruction (8 passes + 3 wait states, the larger shape's figure)
 
 
 def _slots(i: Instr) -> int:
@@ -69,6 +70,11 @@ def min_distance(p: Instr, c: Instr, kind: str, unit: Tuple[str, int]) -> int:
         return 1
     # war
     if p.cls == isa.MFMA:
+        # the accumulator input (srcC) is read by the matrix pipe after issue: a VALU overwrite of it must keep its distance (the vendor
+        # compiler's rule for VGPR srcC: passes + 3 wait states; 4 passes for the 16x16x32 shape, 8 for 32x32x16)
+        c_src = p.src[2] if len(p.src) > 2 else None
+        if isinstance(c_src, isa.Reg) and unit in c_src.units() and c.cls != isa.MFMA:
+            return MFMA_SRCC_WAR_DIST
         return MFMA_SRC_WAR_DIST
     if p.cls == isa.VMEM_STORE and c.cls in (isa.VALU, isa.TRANS) and unit[0] == "v" and ("dwordx4" in p.op or "dwordx3" in p.op):
         return WIDE_STORE_WAR_DIST

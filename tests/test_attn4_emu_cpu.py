@@ -65,6 +65,11 @@ def test_hazard_table_lane_read_valu_sgpr_and_wide_store_rules():
     assert any("WAR" in e for e in sched.check_hazards(seq)) and sched.check_hazards(sched.pad_hazards(seq)) == []
     seq = [isa.global_store(2, V(20, 2), V(8, 2)), isa.vop("v_mov_b32", V(9), I32(0))]
     assert sched.check_hazards(seq) == []
+    # an MFMA's accumulator INPUT is read after issue: a VALU overwrite keeps its distance (the folded maximum of the attention kernel is such an input)
+    from scail_amd.asmgen.isa import A
+    mf = isa.Instr("v_mfma_f32_16x16x32_bf16", [V(100, 4)], [A(240, 4), A(128, 4), V(212, 4)], cls=isa.MFMA)
+    seq = [mf, isa.vop("v_mov_b32", V(213), I32(0))]
+    assert any("WAR" in e for e in sched.check_hazards(seq)) and sched.check_hazards(sched.pad_hazards(seq)) == []
 
 
 @pytest.mark.parametrize("rd", [4, 2])
