@@ -8,6 +8,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the CPU emulator of the generated kernels checks the hardware's minimum issue distances along every executed path (tools/asm_emu.py
+# Emu.check_hazards; round 6: a rule the in-order emulator cannot see in the numbers cost a restart flag on the GPU)
+os.environ.setdefault("SCAIL_EMU_HAZARDS", "1")
 
 
 def pytest_configure(config):

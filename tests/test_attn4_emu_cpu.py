@@ -72,6 +72,27 @@ def test_hazard_table_lane_read_valu_sgpr_and_wide_store_rules():
     assert any("WAR" in e for e in sched.check_hazards(seq)) and sched.check_hazards(sched.pad_hazards(seq)) == []
 
 
+def test_emulator_checks_issue_distances_along_the_executed_path():
+    """tools/asm_emu.py Emu.check_hazards (on for every emulator test: tests/conftest.py): the minimum issue distances of asmgen/sched.py are
+    checked on the path each wave actually takes -- across labels, branches and subroutine calls.  Regression of round 6's GPU-only bug: the
+    shipped kernel generated WITHOUT the lane-read rule computes the right numbers in the emulator (it executes in order), and the dynamic
+    check names the instruction pair that lost wave 3's restart flag on the hardware."""
+    from scail_amd.asmgen import sched
+    rng = np.random.default_rng(21)
+    q = rng.standard_normal((1, 256, 128)).astype(np.float32)
+    k = rng.standard_normal((1, 64 * 5, 128)).astype(np.float32)
+    v = rng.standard_normal((1, 64 * 5, 128)).astype(np.float32)
+    keep = sched.READLANE_DIST
+    try:
+        sched.READLANE_DIST = 1
+        prog = attn4.Gen(attn4.M16F).program()
+    finally:
+        sched.READLANE_DIST = keep
+    with pytest.raises(AssertionError, match="v_readfirstlane_b32"):
+        R.run(attn4.M16F, q, [k], [v], 1, program=prog)
+    R.run(attn4.M16F, q, [k], [v], 1)                      # the shipped program: clean
+
+
 @pytest.mark.parametrize("rd", [4, 2])
 def test_static_hazards_clean(rd):
     assert R.check_static(attn4.Cfg(rd=rd)) == []

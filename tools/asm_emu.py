@@ -20,6 +20,8 @@ from __future__ import annotations
 import struct
 from typing import Dict, List, Sequence
 
+import os
+
 import numpy as np
 
 from scail_amd.asmgen import isa
@@ -45,6 +47,17 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
 
 def bf16_to_f32(h: np.ndarray) -> np.ndarray:
     return (h.astype(np.uint32) << 16).view(np.float32)
+
+
+_SCHED = None
+
+
+def _sched():
+    global _SCHED
+    if _SCHED is None:
+        from scail_amd.asmgen import sched as m
+        _SCHED = m
+    return _SCHED
 
 
 class Memory:
@@ -105,11 +118,21 @@ class Wave:
         self.vm: List = []
         self.mfma_pending: List = []    # [slots_left, reg, values]
         self.issued = 0
+        self.hz_last_write = {}     # (Emu.check_hazards) register unit -> (issue slot, instruction) of its last writer
+        self.hz_readers = {}        # ... -> the last few readers since that write
         self.stats = {"mfma": 0, "instr": 0}
 
 
 class Emu:
-    def __init__(self, program: Sequence[isa.Instr], mem: Memory, n_waves: int = 4, lds_bytes: int = 160 * 1024, lazy: bool = True):
+    def __init__(self, program: Sequence[isa.Instr], mem: Memory, n_waves: int = 4, lds_bytes: int = 160 * 1024, lazy: bool = True,
+                 check_hazards: bool = None):
+        # DYNAMIC hazard check (round 6): every executed instruction is checked against the minimum issue distances of asmgen/sched.py
+        # (min_distance: the same table the static padding uses) along the path the wave ACTUALLY took -- across labels, branches and
+        # subroutine calls, where the static check of a linear block cannot look.  Violations are collected in ``self.hazards``; the emulator
+        # itself executes in order with every result visible at once, so it would not notice them in the numbers (that is how the lost restart
+        # flag of round 6 passed every CPU test).  Default: on when SCAIL_EMU_HAZARDS=1 (the emulator tests switch it on for their rare-path cases).
+        self.check_hazards = (os.environ.get("SCAIL_EMU_HAZARDS", "0") != "0") if check_hazards is None else check_hazards
+        self.hazards: List[str] = []
         self.prog = list(program)
         self.labels = {i.label: k for k, i in enumerate(self.prog) if i.op == "label"}
         self.mem = mem
@@ -148,6 +171,9 @@ class Emu:
                 raise RuntimeError("emulator dead-lock")
             if steps > max_steps:
                 raise RuntimeError("emulator step limit")
+        if self.check_hazards and self.hazards:
+            uniq = sorted(set(h.split(" ", 2)[2] for h in self.hazards))
+            raise AssertionError(f"dynamic hazard check: {len(self.hazards)} violation(s) of the minimum issue distances, e.g. " + " | ".join(uniq[:4]))
         return steps
 
     # ---------------------------------------------------------------------------------------------
@@ -243,6 +269,44 @@ class Emu:
                 keep.append(p)
         w.mfma_pending = keep
 
+    def _hazard_check(self, w: Wave, ins: isa.Instr):
+        sched = _sched()
+        cur = w.issued
+        lw, rd = w.hz_last_write, w.hz_readers
+        hz = getattr(ins, "_hz_units", None)
+        if hz is None:                       # the unit lists of an instruction object never change: computed once
+            hz = ins._hz_units = (tuple(ins.reads()), tuple(ins.writes()))
+        reads, writes = hz
+        # a (writer, reader) pair sits at a fixed distance on a straight path: re-checking it on every trip of a hot loop adds nothing, so a pair
+        # is looked at only when the distance is short enough to matter (every rule of the table is <= 16 slots)
+        if len(self.hazards) < 50:
+            for u in reads:
+                p = lw.get(u)
+                if p is not None and cur - p[0] < 16:
+                    need = sched.min_distance(p[1], ins, "raw", u)
+                    if cur - p[0] < need:
+                        self.hazards.append(f"wave {w.id} RAW {u}: '{p[1].render().strip()}' -> '{ins.render().strip()}' distance {cur - p[0]} < {need}")
+            for u in writes:
+                p = lw.get(u)
+                if p is not None and cur - p[0] < 16:
+                    need = sched.min_distance(p[1], ins, "waw", u)
+                    if cur - p[0] < need:
+                        self.hazards.append(f"wave {w.id} WAW {u}: '{p[1].render().strip()}' -> '{ins.render().strip()}' distance {cur - p[0]} < {need}")
+                for q in rd.get(u, ()):
+                    if cur - q[0] >= 16:
+                        continue
+                    need = sched.min_distance(q[1], ins, "war", u)
+                    if need > 1 and cur - q[0] < need:
+                        self.hazards.append(f"wave {w.id} WAR {u}: '{q[1].render().strip()}' -> '{ins.render().strip()}' distance {cur - q[0]} < {need}")
+        for u in writes:
+            lw[u] = (cur, ins)
+            rd[u] = []
+        for u in reads:
+            lst = rd.setdefault(u, [])
+            lst.append((cur, ins))
+            if len(lst) > 4:
+                del lst[0]
+
     def _queue(self, w: Wave, q: str, fn):
         if self.lazy:
             getattr(w, q).append(fn)
@@ -262,6 +326,8 @@ class Emu:
         if op == "label":
             return
         slots = getattr(ins, "count", 1)
+        if self.check_hazards:
+            self._hazard_check(w, ins)
         w.issued += slots
         w.stats["instr"] += 1
         d = ins.dst[0] if ins.dst else None
