@@ -261,7 +261,7 @@ def _git_blob_sha1(path):
 VAE_ALG = {"encode": (188.3e12, 148.7e9), "decode": (316.5e12, 229.4e9)}      # SURVEY.md 8d, 81 x 512 x 896
 
 
-def vae_leg(dev):
+def vae_leg(dev, pmc=True):
     """BASELINE config 4 (Wan2.1 VAE encode + decode only, 512p x 81 f) after the timed DiT region: one warm-up and one
     timed call per direction, HIP events on the launch stream; algorithmic 188.3 / 316.5 TFLOP and 148.7 / 229.4 GB
     (every conv reads its input once and writes its output once, norm + SiLU fused)."""
@@ -293,7 +293,82 @@ def vae_leg(dev):
         res["conv_traffic"] = conv or None
     except Exception:
         res["conv_traffic"] = None
+    res["conv_traffic_source"] = "profiles/traffic.json (stamped with the git blob of the kernel source)"
+    if pmc:
+        # ... and from counters read in THIS run: the three dominant 3x3x3 shapes (tools/conv_pmc_probe.py), FETCH_SIZE / WRITE_SIZE one pass each
+        try:
+            t0 = time.time()
+            live = {}
+            for C_, (H_, W_) in ((96, (512, 896)), (192, (256, 448)), (384, (128, 224))):
+                v = {c: max(_pmc_pass([os.path.join(ROOT, "tools", "conv_pmc_probe.py"), str(C_), "2"], c, "scail_conv4").items(), key=lambda kv: kv[1]) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+                live[f"conv4_c{C_}"] = {"traffic_bytes": _kib_to_bytes(v["FETCH_SIZE"][1], v["WRITE_SIZE"][1]), "algorithmic_bytes": 2.0 * 21 * H_ * W_ * C_ * 2 + 27 * C_ * C_ * 2,
+                                        "shape": {"T": 21, "H": H_, "W": W_, "C": C_}, "kernel": v["FETCH_SIZE"][0]}
+            res["conv_traffic_stamped"] = res["conv_traffic"]
+            res["conv_traffic"] = live
+            res["conv_traffic_source"] = f"PMC counters of this run (rocprofv3 --pmc around tools/conv_pmc_probe.py, {time.time() - t0:.0f} s)"
+        except Exception as e:          # noqa: BLE001
+            res["conv_traffic_in_run_error"] = f"{type(e).__name__}: {e}"[:300]
     return res
+
+
+def _pmc_pass(probe_args, counter, like):
+    """ONE rocprofv3 --pmc pass (one counter set, kernel trace only -- the guide's recipe) around a child process that launches kernels on the
+    product library; returns {kernel name: mean of the counter per dispatch (summed over its XCD / channel instances)} for names containing ``like``."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    d = tempfile.mkdtemp(prefix="scail_pmc_", dir="/tmp")
+    try:
+        r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable] + probe_args,
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+        dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+        if r.returncode != 0 or not dbs:
+            raise RuntimeError(f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(dbs)} database(s): " + r.stdout.decode(errors="replace")[-300:])
+        c = sqlite3.connect(dbs[0])
+        cols = [row[1] for row in c.execute("pragma table_info(counters_collection)")]
+        name_col = "kernel_name" if "kernel_name" in cols else "name"
+        cnt_col = "counter_name" if "counter_name" in cols else "counter"
+        val_col = "value" if "value" in cols else "counter_value"
+        q = (f"select {name_col}, avg(v) from (select {name_col}, dispatch_id, sum({val_col}) as v from counters_collection "
+             f"where {name_col} like ? and {cnt_col} = ? group by {name_col}, dispatch_id) group by {name_col}")
+        res = {n.split("(")[0].strip(): float(v) for n, v in c.execute(q, (f"%{like}%", counter))}
+        c.close()
+        if not res:
+            raise RuntimeError(f"no dispatch of *{like}* with {counter} in the database")
+        return res
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _kib_to_bytes(fetch_kib, write_kib):
+    return (2.0 * fetch_kib + write_kib) * 1024.0          # gfx950: 128-byte read requests are tallied at 64 (the guide's correction)
+
+
+def pmc_traffic_leg(expected_attn, expected_gemm):
+    """roofline.traffic / roofline_gemm.traffic from counters read IN THIS RUN: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: one pass each)
+    around child processes that launch (a) the config-2 self-attention (tools/attn_pmc_probe.py: B = 2, 40 heads, L = 48 832 -- the timed
+    region's launch) and (b) the six per-token GEMMs of a block with the executor's shapes and epilogues (tools/gemm_layer_pmc_probe.py).
+    Bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB.  A failure leaves the stamped values of profiles/traffic.json in place."""
+    t0 = time.time()
+    out = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (one pass each) around tools/attn_pmc_probe.py and tools/gemm_layer_pmc_probe.py, in this run"}
+    att = {c: _pmc_pass([os.path.join(ROOT, "tools", "attn_pmc_probe.py"), "prescaled", "2"], c, "scail_attn4_m16f")["scail_attn4_m16f"] for c in ("FETCH_SIZE", "WRITE_SIZE")}
+    out["attention"] = {"traffic_bytes": _kib_to_bytes(att["FETCH_SIZE"], att["WRITE_SIZE"]), "fetch_kib": att["FETCH_SIZE"], "write_kib": att["WRITE_SIZE"],
+                        "stamped_value_of_profiles_traffic_json": expected_attn}
+    try:
+        gm = {c: _pmc_pass([os.path.join(ROOT, "tools", "gemm_layer_pmc_probe.py"), "1"], c, "scail_gemm4_e") for c in ("FETCH_SIZE", "WRITE_SIZE")}
+        n = {"e0": 2, "e1": 1, "e3": 2, "e4": 1}            # launches per layer: qkv + cross q, MLP up, attention out + MLP down, cross out
+        tf = sum(gm["FETCH_SIZE"]["scail_gemm4_" + k] * cnt for k, cnt in n.items())
+        tw = sum(gm["WRITE_SIZE"]["scail_gemm4_" + k] * cnt for k, cnt in n.items())
+        out["gemm"] = {"traffic_bytes_per_launch_mean": _kib_to_bytes(tf, tw) / 6.0, "traffic_bytes_per_layer": _kib_to_bytes(tf, tw),
+                       "stamped_value_of_profiles_traffic_json": expected_gemm}
+    except Exception as e:              # noqa: BLE001
+        out["gemm"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    out["seconds"] = round(time.time() - t0, 1)
+    return out
 
 
 def sp_compute_side_leg(net, p, thw, ctx, clip, dev, t1, args):
@@ -389,6 +464,7 @@ def main():
     ap.add_argument("--cfg-scale", type=float, default=4.0)
     ap.add_argument("--no-cfg-pair", action="store_true", help="A/B: evaluate both CFG elements in layer 0 (no SCAIL_DIT_CFG_PAIR)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip config.sp_compute_side and config.multichar after the timed region")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic (the stamped profiles/traffic.json value is reported then)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -653,8 +729,24 @@ def main():
     if rank == 0 and world == 1 and use_c and args.config == "14b" and args.latent_hw is None and not args.no_extra_legs:
         out["config"]["sp_compute_side"] = leg(sp_compute_side_leg, net, p, (T, H, W), ctx, clip, dev, t_step, args)
         out["config"]["multichar"] = leg(multichar_leg, net, p, (T, H, W), ctx, clip, dev, Lt, Lc, args)
+    if rank == 0 and world == 1 and use_c and args.config == "14b" and args.latent_hw is None and args.layers is None and n_char == 1 and not args.no_pmc:
+        # fabric traffic of the two big kernels from PMC counters collected in THIS run (the stamped file stays the fallback and the cross-check)
+        pm = leg(pmc_traffic_leg, traffic, out.get("roofline_gemm", {}).get("traffic"))
+        out["roofline"]["traffic_in_run"] = pm
+        stamped = "profiles/traffic.json (stamped with the git blob of the kernel source)"
+        if isinstance(pm, dict) and pm.get("attention", {}).get("traffic_bytes"):
+            out["roofline"]["traffic"] = pm["attention"]["traffic_bytes"]
+            out["roofline"]["traffic_source"] = "PMC counters of this run (roofline.traffic_in_run)"
+        else:
+            out["roofline"]["traffic_source"] = stamped
+        if "roofline_gemm" in out:
+            if isinstance(pm, dict) and pm.get("gemm", {}).get("traffic_bytes_per_launch_mean"):
+                out["roofline_gemm"]["traffic"] = pm["gemm"]["traffic_bytes_per_launch_mean"]
+                out["roofline_gemm"]["traffic_source"] = "PMC counters of this run (roofline.traffic_in_run.gemm)"
+            else:
+                out["roofline_gemm"]["traffic_source"] = stamped
     if rank == 0 and world == 1 and not args.no_vae:
-        out["config"]["vae"] = leg(vae_leg, dev)
+        out["config"]["vae"] = leg(vae_leg, dev, (not args.no_pmc) and args.config == "14b" and args.layers is None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(p, L)
         t_cpu = p["num_layers"] * cb["t_block"]

@@ -46,7 +46,7 @@ for LEG in "$@"; do
     smoke)       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1; tail -2 "$O/smoke.log" ;;
     bench)       timeout 1200 python bench.py > "$O/bench.log" 2>&1; tail -c 7000 "$O/bench.log" | cut -c1-5000 ;;
     bench-quick) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$O/bench_quick.log" 2>&1; tail -c 5000 "$O/bench_quick.log" | cut -c1-4000 ;;
-    bench-prof)  kstats bench python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vae --no-extra-legs ;;     # (the legs after the timed region launch the same kernels at other shapes)
+    bench-prof)  kstats bench python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vae --no-extra-legs --no-pmc ;;     # (the legs after the timed region launch the same kernels at other shapes)
     bench-2char) timeout 600 python bench.py --config 14b-2char --steps 2 --warmup 1 --no-vae --no-cpu-baseline > "$O/bench_2char.log" 2>&1; grep -o '"ms_per_step": [0-9.]*\|"achieved": [0-9.]*' "$O/bench_2char.log" ;;
     bench-480)   timeout 600 python bench.py --latent-hw 60 104 --steps 2 --warmup 1 --no-vae --no-cpu-baseline > "$O/bench_480x832.log" 2>&1; grep -o '"ms_per_step": [0-9.]*\|"achieved": [0-9.]*' "$O/bench_480x832.log" ;;
     vae-prof)    timeout 900 rocprofv3 --kernel-trace --stats -d "$O/prof_vae" -o vae -- python tools/vae_leg_probe.py > "$O/vae_prof.log" 2>&1

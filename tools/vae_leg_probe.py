@@ -11,4 +11,4 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 torch.cuda.set_device(0)
-print(json.dumps(bench.vae_leg(torch.device("cuda:0"))))
+print(json.dumps(bench.vae_leg(torch.device("cuda:0"), pmc=False)))
