@@ -311,6 +311,9 @@ def vae_leg(dev, pmc=True):
     return res
 
 
+_PMC_BROKEN = []
+
+
 def _pmc_pass(probe_args, counter, like):
     """ONE rocprofv3 --pmc pass (one counter set, kernel trace only -- the guide's recipe) around a child process that launches kernels on the
     product library; returns {kernel name: mean of the counter per dispatch (summed over its XCD / channel instances)} for names containing ``like``."""
@@ -321,12 +324,19 @@ def _pmc_pass(probe_args, counter, like):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
+    if _PMC_BROKEN:                      # one failed / timed-out pass ends the in-run counter collection: the bench must not wait for a profiler
+        raise RuntimeError("an earlier rocprofv3 pass of this run failed: " + _PMC_BROKEN[0])
     d = tempfile.mkdtemp(prefix="scail_pmc_", dir="/tmp")
     try:
-        r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable] + probe_args,
-                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+        try:
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable] + probe_args,
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=90)
+        except Exception as e:          # noqa: BLE001  (timeout, exec failure)
+            _PMC_BROKEN.append(f"{type(e).__name__}: {e}"[:200])
+            raise
         dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
         if r.returncode != 0 or not dbs:
+            _PMC_BROKEN.append(f"rc {r.returncode}, {len(dbs)} database(s)")
             raise RuntimeError(f"rocprofv3 --pmc {counter}: rc {r.returncode}, {len(dbs)} database(s): " + r.stdout.decode(errors="replace")[-300:])
         c = sqlite3.connect(dbs[0])
         cols = [row[1] for row in c.execute("pragma table_info(counters_collection)")]
