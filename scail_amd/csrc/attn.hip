@@ -1012,6 +1012,7 @@ int scail_row_wave_enable(int v);   // rowops.hip
 int scail_conv_direct_enable(int v);   // conv.hip
 int scail_conv4_cont_enable(int v);    // conv.hip
 int scail_conv4_resnorm_enable(int v); // conv.hip
+int scail_conv_s2_enable(int v);       // conv.hip
 extern "C" int scail_set_option(const char* name, int value) {
     const std::string k(name ? name : "");
     if (k == "attn4") { g_attn4_mode = value != 0; return 0; }              // 0: 8-wave kernel for every shape
@@ -1039,6 +1040,7 @@ extern "C" int scail_set_option(const char* name, int value) {
     if (k == "row_wave") return scail_row_wave_enable(value);
     if (k == "conv_direct") return scail_conv_direct_enable(value);
     if (k == "conv4_cont") return scail_conv4_cont_enable(value);           // 1: tile-continuation variants of the generated 96-channel kernels         // 0: the gather kernel for the HBM-bound convolutions too               // 0: block-per-row LayerNorm / RMSNorm kernels for every width
+    if (k == "conv_s2") return scail_conv_s2_enable(value);                 // 0: the gather kernel for Resample's stride-2 convolution; 1 / 2: conv_s2_kernel with one / two frames per workgroup
     if (k == "conv4_resnorm") return scail_conv4_resnorm_enable(value);     // 0: scail_conv3d_cl_resid_norm = the two separate calls for every shape
     if (k == "attn4_thr") {                                                 // lazy-rescale threshold of attn4: P <= 2^value
         SCAIL_REQUIRE(value >= 0 && value <= 64, "attn4_thr must be in [0, 64] (log2 units)");

@@ -629,6 +629,183 @@ __global__ __launch_bounds__(256, ((NWB == 1 || SWZ) ? 2 : 1)) void conv_halo_ke
 }
 
 // ------------------------------------------------------------------------------------------------
+// Halo-tile kernel for Resample's spatial downsampling (round 6): ZeroPad2d((0, 1, 0, 1)) + Conv2d(dim, dim, 3, stride 2) on every frame
+// (wan_vae.py:87-96) = a 1 x 3 x 3 convolution with stride (1, 2, 2) whose padding sits behind the last row / column only.  The gather
+// kernel ran the three of them (96 / 192 / 384 channels) at 360-600 TFLOP/s: one k-tile in flight per workgroup and every input voxel
+// fetched once per tap that reads it.  Here a workgroup owns 8 x 16 output voxels of NF frames x 96 output channels and keeps the
+// (2*8 + 1) x (2*16 + 1) input patch of a 32-channel slice in LDS, COLUMNS SPLIT BY PARITY (a patch row = its 17 even columns, then its 16
+// odd ones): output column c reads input column 2 c + dw = parity dw & 1, index c + (dw >> 1), so the 16 lanes of an output row read 16
+// CONSECUTIVE patch voxels for every tap (the padded 80-byte voxel stride keeps them in distinct bank groups, as in the stride-1 kernel; at a
+// two-voxel stride they would collide in pairs).  W streams per tap row (3 taps x 32 k), register-staged, one row ahead; the NEXT slice's
+// patch is requested right after the current one is in LDS and stays in flight under the slice's 54 x NF MFMAs per wave.  The n tiles of a
+// voxel tile (192 / 384 channels) get workgroup ids on the SAME XCD, next to each other in time: its L2 serves the patch to all of them.
+// ------------------------------------------------------------------------------------------------
+#define S2_TH 8
+#define S2_TW 16
+#define S2_PH (2 * S2_TH + 1)
+#define S2_PW (2 * S2_TW + 1)
+#define S2_FVOX (S2_PH * S2_PW)
+#define S2_CS 32
+#define S2_PS (S2_CS + 8)
+#define S2_WS (3 * S2_CS + 8)
+template <int NF> struct S2Cfg {
+    static constexpr int PVOX = NF * S2_FVOX, PCH = PVOX * (S2_CS / 8), NP = (PCH + 255) / 256;
+    static constexpr int WCH = 96 * 3 * (S2_CS / 8), NWL = (WCH + 255) / 256;
+    static constexpr int LDS = (PVOX * S2_PS + 96 * S2_WS) * 2 + 96 * 4;       // patch, W tap row, the tile's 96 bias values (fp32)
+};
+
+template <int NF>
+__global__ __launch_bounds__(256, (NF == 1 ? 2 : 1)) void conv_s2_kernel(ConvParams p, int vtiles) {
+    using Cfg = S2Cfg<NF>;
+    constexpr int NP = Cfg::NP, NWL = Cfg::NWL, PCH = Cfg::PCH, WCH = Cfg::WCH, CPV = S2_CS / 8, NBLK = 3;
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* Ps = smem;                          // [NF][17][17 even | 16 odd columns][PS]
+    u16* Ws = smem + Cfg::PVOX * S2_PS;      // [96][WS]
+    float* Bs = reinterpret_cast<float*>(Ws + 96 * S2_WS);      // [96]: the epilogue's bias loads would each wait for L2 (hipcc serialises them)
+
+    // workgroup id -> (voxel tile v, n tile): the XCD (id % 8) depends on v only
+    const int tiles_n = p.N / 96;
+    const int q = blockIdx.x >> 3;
+    const int tn = q % tiles_n;
+    int v = (q / tiles_n) * 8 + (blockIdx.x & 7);
+    if (v >= vtiles) return;
+    const int tiles_w = (p.Wo + S2_TW - 1) / S2_TW, tiles_h = (p.Ho + S2_TH - 1) / S2_TH;
+    const int tw = v % tiles_w; v /= tiles_w;
+    const int th = v % tiles_h;
+    const int to = (v / tiles_h) * NF;       // first output (= input) frame of this workgroup
+    const int n0 = tn * 96, h0 = th * S2_TH, w0 = tw * S2_TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, g = lane >> 5;
+
+    // ---- patch chunk c = tid + 256 i (input order: frame, row, column, 16-byte channel chunk): element offset from frame `to`, LDS offset ----
+    const u16* xb = p.x + (int64_t)to * p.Hi * p.Wi * p.Cin;
+    int psrc[NP], pdst[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int c = tid + 256 * i;
+        psrc[i] = -1; pdst[i] = 0;
+        if (c < PCH) {
+            const int vox = c / CPV, ch = c - vox * CPV;
+            const int f = vox / S2_FVOX, rem = vox - f * S2_FVOX;
+            const int rr = rem / S2_PW, cc = rem - rr * S2_PW;
+            const int hi = 2 * h0 + rr, wi = 2 * w0 + cc;
+            if (to + f < p.Ti && hi < p.Hi && wi < p.Wi) psrc[i] = ((f * p.Hi + hi) * p.Wi + wi) * p.Cin + ch * 8;
+            pdst[i] = (f * S2_FVOX + rr * S2_PW + (cc & 1) * (S2_TW + 1) + (cc >> 1)) * S2_PS + ch * 8;
+        }
+    }
+    // ---- W chunk c = tid + 256 i of a tap row: n = c / 12, dw = (c % 12) / 4, 16-byte chunk = c % 4 ----
+    int wsrc[NWL], wdst[NWL];
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+        const int c = tid + 256 * i;
+        const int n = c / (3 * CPV), rem = c - n * (3 * CPV), dw = rem / CPV, ch = rem - dw * CPV;
+        wsrc[i] = (c < WCH) ? (n0 + n) * p.Kpad + dw * p.Cin + ch * 8 : 0;       // (past the tile: loads a valid address, never stored)
+        wdst[i] = n * S2_WS + dw * S2_CS + ch * 8;
+    }
+    const bool wtail = tid + 256 * (NWL - 1) < WCH;                               // the last chunk exists for this thread
+    uint4 pr[NP], wr[3][NWL];                                                      // W: one register set per tap row of a slice, requested two rows ahead
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pr[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) wr[r][i] = make_uint4(0, 0, 0, 0);
+    auto load_patch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pr[i] = psrc[i] >= 0 ? *reinterpret_cast<const uint4*>(xb + psrc[i] + c0) : make_uint4(0, 0, 0, 0);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (tid + 256 * i < PCH) *reinterpret_cast<uint4*>(Ps + pdst[i]) = pr[i];
+    };
+    auto load_w = [&](int r, int k0) {
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) wr[r][i] = *reinterpret_cast<const uint4*>(p.w + wsrc[i] + k0);
+    };
+    auto store_w = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+            if (i + 1 < NWL || wtail) *reinterpret_cast<uint4*>(Ws + wdst[i]) = wr[r][i];
+    };
+
+    // ---- fragment bases: lane = output voxel vloc (row vloc >> 4, column vloc & 15) of the block ----
+    const int vloc = wave * 32 + l31;
+    const u16* pa = Ps + (2 * (vloc >> 4) * S2_PW + (vloc & 15)) * S2_PS + g * 8;       // its patch voxel at tap (0, 0)
+    const u16* wb = Ws + l31 * S2_WS + g * 8;
+
+    f32x16 acc[NF][NBLK];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int a = 0; a < NBLK; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[f][a][e] = 0.f;
+
+    const int nslice = p.Cin / S2_CS;
+    load_patch(0);
+    load_w(0, 0);
+    load_w(1, 3 * p.Cin);
+    if (tid < 96) Bs[tid] = p.bias != nullptr ? p.bias[n0 + tid] : 0.f;
+    for (int sl = 0; sl < nslice; ++sl) {
+        const int c0 = sl * S2_CS;
+        __syncthreads();                             // every wave is done with the previous slice's patch and W tile
+        store_patch();
+        store_w(0);
+        __syncthreads();
+        if (sl + 1 < nslice) load_patch(c0 + S2_CS);   // in flight under this slice's MFMAs
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            // tap row dh + 2 of the slice-major row sequence: row 2 of this slice, rows 0 / 1 of the next
+            if (dh == 0) load_w(2, 6 * p.Cin + c0);
+            else if (sl + 1 < nslice) load_w(dh - 1, (dh - 1) * 3 * p.Cin + c0 + S2_CS);
+            __builtin_amdgcn_sched_barrier(0);       // (hipcc otherwise sinks the requests behind the tap row's MFMAs, right in front of the barrier that waits for them)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int toff = dh * S2_PW + (dw & 1) * (S2_TW + 1) + (dw >> 1);
+#pragma unroll
+                for (int ks = 0; ks < S2_CS / 16; ++ks) {
+                    bf16x8 xf[NF];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(pa + (f * S2_FVOX + toff) * S2_PS + ks * 16);
+#pragma unroll
+                    for (int nb = 0; nb < NBLK; ++nb) {
+                        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wb + nb * 32 * S2_WS + dw * S2_CS + ks * 16);
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) acc[f][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[f], acc[f][nb], 0, 0, 0);
+                    }
+                }
+            }
+            if (dh < 2) {
+                __syncthreads();                     // every wave has read this tap row's W tile
+                store_w(dh + 1);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: lane = voxel vloc, rows n = n0 + nb * 32 + 8 rr + 4 g + e ----
+    const int ho = h0 + (vloc >> 4), wo = w0 + (vloc & 15);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+        if (ho < p.Ho && wo < p.Wo && to + f < p.To) {
+            const int64_t vox = ((int64_t)((to + f) * p.ot_mul + p.ot_off) * p.Ho + ho) * p.Wo + wo;
+#pragma unroll
+            for (int nb = 0; nb < NBLK; ++nb)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int n = n0 + nb * 32 + 8 * rr + 4 * g;
+                    const float4 bb = *reinterpret_cast<const float4*>(Bs + nb * 32 + 8 * rr + 4 * g);
+                    uint2 o;
+                    o.x = pack_bf16x2(acc[f][nb][4 * rr + 0] + bb.x, acc[f][nb][4 * rr + 1] + bb.y);
+                    o.y = pack_bf16x2(acc[f][nb][4 * rr + 2] + bb.z, acc[f][nb][4 * rr + 3] + bb.w);
+                    *reinterpret_cast<uint2*>(p.y + vox * p.ldc + n) = o;
+                }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // RMS_norm over channels (F.normalize * sqrt(C) * gamma, wan_vae.py:39-54) + optional SiLU.
 // LPV lanes per voxel (power of two >= C/8), 64/LPV voxels per wave.
 // ------------------------------------------------------------------------------------------------
@@ -887,6 +1064,8 @@ int scail_conv4_resnorm_enable(int v) { g_conv4_resnorm = v != 0; return 0; }
 static std::atomic<int> g_conv_direct{1};                                  // option "conv_direct": the direct-gather kernel for the HBM-bound convolutions
 int scail_conv_direct_enable(int v) { g_conv_direct = v != 0; return 0; }
 static std::atomic<int> g_conv4{1};                                        // option "conv4": the generated kernels where scail_conv3d_kernel_for says 4
+static std::atomic<int> g_conv_s2{1};                                      // option "conv_s2": the stride-2 halo kernel for Resample's downsampling convolution (n = output frames per workgroup; 0: gather kernel)
+int scail_conv_s2_enable(int v) { g_conv_s2 = v < 0 ? 0 : (v > 2 ? 2 : v); return 0; }
 int scail_conv4_enable(int v) { g_conv4 = v != 0; return 0; }
 #ifdef SCAIL_ABLATIONS
 static int g_conv_halo = 4;                                    // measurement build: A/B of the halo-kernel layouts (comment below)
@@ -1100,6 +1279,31 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
         const int64_t tiles = (int64_t)((p.To + 1) / 2) * ((p.Ho + HT_TH - 1) / HT_TH) * ((p.Wo + HT_TW - 1) / HT_TW) * ((p.N + 95) / 96);
         SCAIL_REQUIRE(tiles < (1ll << 31), "too many tiles");
         if (resid != nullptr) HALO_LAUNCH(3, 32, 1, false, 96, 2, 1, true) else HALO_LAUNCH(0, 32, 1, false, 96, 2, 1, true)
+        return scail_check_launch("conv3d_cl");
+    }
+    // Resample's spatial downsampling: 1 x 3 x 3, stride (1, 2, 2), zero padding behind the last row / column only (conv_s2_kernel)
+    if (g_conv_s2 && !rn && resid == nullptr && p.kt == 1 && p.kh == 3 && p.kw == 3 && p.st == 1 && p.sh == 2 && p.sw == 2 && !p.ups &&
+        p.pt == 0 && p.ph == 0 && p.pw == 0 && p.To == p.Ti && p.Cin % S2_CS == 0 && p.N % 96 == 0 &&
+        2 * (int64_t)p.Hi * p.Wi * p.Cin < (1ll << 31) && (int64_t)p.N * p.Kpad < (1ll << 31)) {
+        const int nf = (g_conv_s2 == 2 && p.To >= 2) ? 2 : 1;
+        const int64_t vtiles = (int64_t)((p.To + nf - 1) / nf) * ((p.Ho + S2_TH - 1) / S2_TH) * ((p.Wo + S2_TW - 1) / S2_TW);
+        const int64_t grid = (vtiles + 7) / 8 * 8 * (p.N / 96);
+        SCAIL_REQUIRE(grid < (1ll << 31), "too many tiles");
+#define S2_LAUNCH(NF_)                                                                                                              \
+    {                                                                                                                               \
+        static ScailDeviceOnce attr_;                                                                                               \
+        if (attr_.need()) {                                                                                                         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_s2_kernel<NF_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    S2Cfg<NF_>::LDS) != hipSuccess) {                                                               \
+                scail_set_error("conv3d: hipFuncSetAttribute failed");                                                              \
+                return 2;                                                                                                           \
+            }                                                                                                                       \
+            attr_.done();                                                                                                           \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((conv_s2_kernel<NF_>), dim3((unsigned)grid), dim3(256), S2Cfg<NF_>::LDS, (hipStream_t)stream, p, (int)vtiles); \
+    }
+        if (nf == 2) S2_LAUNCH(2) else S2_LAUNCH(1)
+#undef S2_LAUNCH
         return scail_check_launch("conv3d_cl");
     }
     // HBM-bound shapes: the direct-gather kernel (comment above conv_direct_kernel); N = 384 as two launches of 192 channels

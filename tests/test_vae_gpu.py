@@ -188,6 +188,38 @@ def test_conv_direct_gather_kernel(name, cin, cout, k, stride, pad, thw):
     assert float((out[1:].float() - old.float()).abs().max()) <= 2.0 ** -6 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,thw", [(96, 96, (4, 40, 56)),          # encoder stage 0's widths: 3 slices, one n tile, whole tiles
+                                          (32, 96, (3, 17, 35)),          # odd extents: the padding row / column is read, ragged tiles, odd frame count
+                                          (192, 192, (5, 34, 50)),        # two n tiles on one XCD, 6 slices
+                                          (64, 384, (2, 16, 16)),         # four n tiles, a single voxel tile
+                                          (96, 96, (1, 64, 96))])         # one frame: the one-frame kernel whatever the option says
+@pytest.mark.parametrize("nf", [1, 2])
+def test_conv_s2_downsample_kernel(cin, cout, thw, nf):
+    """conv_s2_kernel (csrc/conv.hip; option conv_s2 = output frames per workgroup): Resample's ZeroPad2d((0, 1, 0, 1)) + Conv2d(dim, dim, 3, stride 2) per
+    frame (wan_vae.py:87-96) against torch's fp32 convolution of the bf16-rounded operands and against the gather kernel it ran on before (summation
+    order only); frame offset / stride of the output honoured, nothing else written."""
+    from scail_amd import lib as L, ops
+    g = torch.Generator(device=DEV).manual_seed(21)
+    T, H, W = thw
+    x = torch.randn(T, H, W, cin, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (9 * cin) ** 0.5).to(torch.bfloat16).float()
+    b = torch.randn(cout, device=DEV, generator=g)
+    wp = ops.prep_conv_weight(w, b)
+    ref = F.conv2d(F.pad(x.float().permute(0, 3, 1, 2), (0, 1, 0, 1)), w, b, stride=2).permute(0, 2, 3, 1)       # (T, Ho, Wo, cout)
+    Ho, Wo = ref.shape[1:3]
+    out = torch.full((2 * T + 1, Ho, Wo, cout + 8), float("nan"), dtype=torch.bfloat16, device=DEV)
+    L.set_option("conv_s2", nf)
+    try:
+        ops.conv3d_cl(x, wp, (T, Ho, Wo), stride=(1, 2, 2), pad=(0, 0, 0), out=out, ot_mul=2, ot_off=1)
+        L.set_option("conv_s2", 0)
+        old = ops.conv3d_cl(x, wp, (T, Ho, Wo), stride=(1, 2, 2), pad=(0, 0, 0))
+    finally:
+        L.set_option("conv_s2", 1)
+    torch.testing.assert_close(out[1::2, :, :, :cout].float(), ref, rtol=2e-2, atol=2e-2)
+    assert torch.isnan(out[0::2].float()).all() and torch.isnan(out[..., cout:].float()).all(), "nothing else is written"
+    assert float((out[1::2, :, :, :cout].float() - old.float()).abs().max()) <= 2.0 ** -6 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("cin,thw", [(96, (9, 40, 56)), (192, (7, 128, 224)), (96, (21, 256, 448)), (32, (5, 512, 896))])
 def test_conv4c_tile_continuation_is_bit_identical(cin, thw):
     """option conv4_cont (default on): scail_conv4c_e0 / e3 / e4 keep the patch and W rings going across the frame pairs a workgroup walks; the
