@@ -9,14 +9,14 @@ pose video (:355-391), build c / uc (:433-470), ``engine.sample`` (:476-483), VA
 The reference's first VAE encode of [ref + zeros] (:362-365) is skipped: ``concat_images`` only gates a
 branch and is never read by the network -- a zero-size placeholder is passed.
 
-Requests: ``--ref-image ref.jpg --pose-video <frames dir | .npy | animated .webp/.png/.gif> [--conditioning c.pt]`` runs
+Requests: ``--ref-image ref.jpg --pose-video <frames dir | .npy | animated .webp/.png/.gif | Motion-JPEG .mp4> [--conditioning c.pt]`` runs
 the reference's preprocessing (centre crop, [-1, 1], half-resolution pose; scail_amd/preprocess.py) on files, or
 ``--inputs file.pt`` passes tensors directly: ref (3,1,H,W) in [-1,1], pose (3,T,H,W), context (1,Lt,4096),
 uncond_context (1,Lt,4096), clip (1,257,1280); without either synthetic inputs are drawn.  ``--save-dir`` writes
-``0_output_000000.webp`` (lossless animated WebP; ``--format`` for APNG / GIF / .npy / frames) where the reference writes
-mp4.  ``--prompt TEXT --tokenizer <HF dir | spiece.model> [--t5-ckpt ..] [--clip-ckpt ..]`` runs the UMT5 and CLIP encoders
-(scail_amd/umt5.py, clip.py) on the prompt and the reference image.  Offline limits of this image: no mp4 codecs (decord,
-imageio, ffmpeg, cv2), no tokenizer files and no checkpoints -- hence the container formats above, the tokenizer as a path
+``0_output_000000.webp`` (lossless animated WebP; ``--format`` for APNG / GIF / .npy / frames, or ``.mp4`` = the reference's
+file name with Motion-JPEG samples, container written by scail_amd/video_io.py) where the reference writes H.264 mp4.  ``--prompt TEXT --tokenizer <HF dir | spiece.model> [--t5-ckpt ..] [--clip-ckpt ..]`` runs the UMT5 and CLIP encoders
+(scail_amd/umt5.py, clip.py) on the prompt and the reference image.  Offline limits of this image: no H.264 / HEVC codec (decord,
+imageio, ffmpeg, cv2 are absent: an .mp4 with such a track is rejected by the name of its codec), no tokenizer files and no checkpoints -- hence the container formats above, the tokenizer as a path
 argument, and random-init weights unless checkpoints are given."""
 from __future__ import annotations
 
@@ -65,7 +65,7 @@ def synthetic_request(H, W, frames, text_dim, Lt, device, seed=0):
 
 REF_IMAGE_PATTERNS = ["ref.jpg", "ref.png", "ref_image.jpg", "ref_image.png"]                # sample_video.py:289
 # the reference looks for rendered_aligned.mp4 / rendered.mp4 (:296); the containers this image can decode come first
-POSE_PATTERNS = [stem + ext for stem in ("rendered_aligned", "rendered") for ext in ("", ".webp", ".png", ".gif", ".npy", ".pt", ".mp4")]
+POSE_PATTERNS = [stem + ext for stem in ("rendered_aligned", "rendered") for ext in ("", ".webp", ".png", ".gif", ".npy", ".pt", ".mp4")]      # (.mp4 last: the reference's own examples are H.264, which nothing here decodes)
 
 
 def find_file_with_patterns(directory: str, patterns):
@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--t5-ckpt", default=None)
     ap.add_argument("--clip-ckpt", default=None)
     ap.add_argument("--save-dir", default=None, help="write <key>_000000.<ext> like the reference's save_multi_video_grid_and_mp4")
-    ap.add_argument("--format", default=".webp", help=".webp (lossless) | .png (APNG) | .gif | .npy | '' (directory of PNG frames)")
+    ap.add_argument("--format", default=".webp", help=".webp (lossless) | .png (APNG) | .gif | .npy | .mp4 (Motion JPEG) | '' (directory of PNG frames)")
     ap.add_argument("--request", action="append", default=[], help="'<prompt>@@<example_dir>' (the reference's cli input line); repeatable")
     ap.add_argument("--input-file", default=None, help="text file of request lines (the reference's --input-type txt)")
     ap.add_argument("--output-dir", default="outputs", help="results of --request / --input-file go to <output-dir>/<example>/")

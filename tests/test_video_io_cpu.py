@@ -46,11 +46,56 @@ def test_multi_video_grid_layout(tmp_path):
 
 def test_formats_that_need_codecs_fail_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no video encoder"):
-        video_io.save_video_as_grid(_clip(), str(tmp_path), ext=".mp4")
-    f = tmp_path / "rendered.mp4"
+        video_io.save_video_as_grid(_clip(), str(tmp_path), ext=".webm")
+    f = tmp_path / "rendered.mkv"
     f.write_bytes(b"\x00")
     with pytest.raises(RuntimeError, match="no video decoder"):
         video_io.load_video_for_pose_sample(str(f))
+    g = tmp_path / "rendered.mp4"
+    g.write_bytes(b"\x00")
+    with pytest.raises(ValueError, match="not an ISO base media file"):
+        video_io.load_video_for_pose_sample(str(g))
+
+
+def _smooth_clip(T=6, H=48, W=64):
+    t, y, x = torch.meshgrid(torch.arange(T), torch.arange(H), torch.arange(W), indexing="ij")
+    v = torch.stack([0.5 + 0.5 * torch.sin(0.11 * x + 0.3 * t), 0.5 + 0.5 * torch.cos(0.07 * y - 0.2 * t), (x + y + 3.0 * t) / (H + W + 3.0 * T)], 1)
+    return v[None].float()                                               # (1, T, 3, H, W) in [0, 1]
+
+
+def test_mp4_motion_jpeg_round_trip(tmp_path):
+    """The reference writes <index>.mp4 (sample_video.py:201-217); here the container is written / parsed by video_io itself with Motion-JPEG
+    samples (the one codec Pillow has): frame count, size and order survive, pixels to JPEG accuracy; max_frames truncates."""
+    vid = _smooth_clip()
+    p = video_io.save_video_as_grid(vid, str(tmp_path), fps=16, ext=".mp4")[0]
+    assert os.path.basename(p) == "000000.mp4"
+    raw = open(p, "rb").read()
+    assert raw[4:8] == b"ftyp" and b"moov" in raw and b"mp4v" in raw and b"stsz" in raw
+    back = video_io.load_video_for_pose_sample(p)
+    want = (255.0 * vid[0].permute(0, 2, 3, 1)).numpy().astype(np.uint8)
+    assert back.dtype == torch.uint8 and tuple(back.shape) == want.shape
+    err = np.abs(back.numpy().astype(np.int32) - want.astype(np.int32))
+    assert err.max() <= 6 and err.mean() < 1.0, (err.max(), err.mean())
+    # frame ORDER: every decoded frame is closest to the frame of its own index
+    d = np.abs(back.numpy().astype(np.int32)[:, None] - want.astype(np.int32)[None]).mean(axis=(2, 3, 4))
+    assert (d.argmin(axis=1) == np.arange(want.shape[0])).all()
+    assert tuple(video_io.load_video_for_pose_sample(p, max_frames=2).shape) == (2, 48, 64, 3)
+
+
+def test_mp4_with_another_codec_is_rejected_by_name(tmp_path):
+    """An .mp4 whose video track is H.264 (sample entry avc1 -- what the reference's own examples are) names its codec instead of decoding garbage."""
+    p = video_io.save_video_as_grid(_smooth_clip(T=2), str(tmp_path), fps=8, ext=".mp4")[0]
+    raw = open(p, "rb").read()
+    q = tmp_path / "h264.mp4"
+    q.write_bytes(raw.replace(b"mp4v", b"avc1"))
+    with pytest.raises(RuntimeError, match="'avc1'"):
+        video_io.load_video_for_pose_sample(str(q))
+    i = raw.index(b"esds")
+    j = raw.index(b"\x6c\x11", i)                                        # objectTypeIndication 0x6C (JPEG) -> 0x20 (MPEG-4 part 2 video)
+    r = tmp_path / "mpeg4.mp4"
+    r.write_bytes(raw[:j] + b"\x20" + raw[j + 1:])
+    with pytest.raises(RuntimeError, match="mp4v/0x20"):
+        video_io.load_video_for_pose_sample(str(r))
 
 
 def test_request_assembly_from_files(tmp_path):
