@@ -47,7 +47,11 @@ def load_reference():
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    if "MASTER_PORT" not in os.environ:                 # single-process group: any free port (a fixed one collides between parallel test workers)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(so.getsockname()[1])
     if not dist.is_initialized():
         dist.init_process_group("gloo", rank=int(os.environ.get("RANK", 0)),
                                 world_size=int(os.environ.get("WORLD_SIZE", 1)))

@@ -12,6 +12,7 @@
 #   bench-2char      config 5 extension line                            bench-480      480x832x81f line
 #   vae-prof         kernel stats of the VAE leg (tools/vae_leg_probe.py)
 #   pmc-attn | pmc-gemm | pmc-conv    PMC passes (FETCH_SIZE, WRITE_SIZE, busy counters; each its own rocprofv3 run) -> pmc_summary.txt
+#   pmc-s2           FETCH_SIZE / WRITE_SIZE of Resample's stride-2 convolutions, gather kernel vs conv_s2_kernel -> pmc_s2_summary.txt
 #   traffic          tools/update_traffic.py from pmc_summary.txt (run after the pmc legs)
 #   sp               tools/sp_rank_compute.py 1 2 4 8                   sp8-prof | sp4-prof   kernel stats of one rank's launches of an 8- / 4-rank step
 #   py:<script> [..] python tools/<script> (arguments up to the next leg name are NOT supported: wrap them in quotes: "py:gemm_probe.py 4")
@@ -58,6 +59,10 @@ for LEG in "$@"; do
                    DB=$(find "$O/pmcc_${CC}_$C" -name "*.db" | head -1); python tools/rocpd_counters.py "$DB" conv4 | awk -v C=$CC '{print "conv4 C=" C, $(NF-4), $(NF-2)}' >> "$O/pmc_summary.txt" 2>&1
                    rm -rf "$O/pmcc_${CC}_$C"; done; done
                  for C in "$BUSY" "$LDS"; do pmc_pass "conv_$(echo $C | cut -d' ' -f1)" conv4 "$C" -- python tools/conv_pmc_probe.py 96 2; done ;;
+    pmc-s2)      for M in 0 1; do for C in FETCH_SIZE WRITE_SIZE; do      # per-grid means: the two shapes are different grids of the same kernel
+                   timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$O/pmcs2_${M}_$C" -o pmc -- python tools/conv_s2_pmc_probe.py $M > "$O/pmcs2_${M}_$C.log" 2>&1
+                   DB=$(find "$O/pmcs2_${M}_$C" -name "*.db" | head -1); echo "conv_s2 option $M, $C (KiB per launch; x 2 for fetches: the guide's gfx950 correction)" >> "$O/pmc_s2_summary.txt"
+                   python tools/rocpd_counters.py "$DB" conv_ --by-grid | cut -c1-170 >> "$O/pmc_s2_summary.txt" 2>&1; rm -rf "$O/pmcs2_${M}_$C"; done; done; cat "$O/pmc_s2_summary.txt" ;;
     traffic)     python tools/update_traffic.py "$O/pmc_summary.txt" "$TAG (tools/gpu_session.sh)" > "$O/traffic_update.log" 2>&1; cp profiles/traffic.json "$O/traffic.json"; tail -30 "$O/traffic_update.log" ;;
     sp8-prof)    kstats sp8 python tools/sp_rank_compute.py 8 ;;
     sp4-prof)    kstats sp4 python tools/sp_rank_compute.py 4 ;;
