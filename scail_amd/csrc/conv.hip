@@ -210,6 +210,8 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
     u16* Ws = smem;                                              // [N][wld]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u16* strip = smem + (int64_t)p.N * wld + wave * 32 * CD_STRIP_LD;      // [32][CD_STRIP_LD] of this wave
+    float* Bs = reinterpret_cast<float*>(smem + (int64_t)p.N * wld + 8 * 32 * CD_STRIP_LD);     // [N] bias, then [N] gamma (DUAL): per-tile global loads of
+    float* Gs = Bs + p.N;                                                                       // these 2 x 12 quads each waited for L1 / L2 (round 6)
     const int l31 = lane & 31, g = lane >> 5;
     const int ksteps = (p.Ktrue + 15) >> 4;                      // k-steps that hold real taps (<= KS)
     // ---- weights -> LDS, once (rows n, k < 16 ksteps; 16-byte chunks) ----
@@ -218,6 +220,10 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
         for (int c = tid; c < p.N * cpr; c += CD_THREADS) {
             const int n = c / cpr, kc = c - n * cpr;
             *reinterpret_cast<uint4*>(Ws + n * wld + kc * 8) = *reinterpret_cast<const uint4*>(p.w + (int64_t)n * p.Kpad + kc * 8);
+        }
+        for (int n = tid; n < p.N; n += CD_THREADS) {
+            Bs[n] = p.bias != nullptr ? p.bias[n] : 0.f;
+            if (DUAL) Gs[n] = p.gamma[n];
         }
     }
     __syncthreads();
@@ -241,13 +247,15 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
     const int64_t ntile = (p.M + 31) / 32;
     // the fragments of a tile are dead once its MFMAs are issued: the NEXT tile's loads are requested before this tile's epilogue, whose
     // LDS round trip and stores then run under their latency
+    // (frame, offset inside the frame) of a tile's first voxel are carried along instead of divided out: the 64-bit divisions by H * W -- one per lane and
+    // tile here, one per 16-byte chunk in the store loop -- were a third of the stem's time (round 6).  A tile's 32 voxels cross at most one frame
+    // boundary (H * W >= 32: checked by the dispatch).
     uint4 xr[KS];
-    auto load_tile = [&](int64_t tile_) {
+    auto load_tile = [&](int64_t tile_, int tf_, int rem_) {
         const int64_t m = tile_ * 32 + l31;
         const bool ok = m < p.M;
-        const int64_t mm = ok ? m : 0;
-        const int to = (int)(mm / HWo);
-        const int r = (int)(mm - (int64_t)to * HWo);
+        int to = tf_, r = rem_ + l31;
+        if (r >= HWo) { r -= HWo; ++to; }
         const int ho = r / p.Wo, wo = r - ho * p.Wo;
         const int tb = ok ? to * p.st - p.pt : -(1 << 20), hb = ho * p.sh - p.ph, wb = wo * p.sw - p.pw;
         const u16* xb = p.x + (((int64_t)tb * p.Hi + hb) * p.Wi + wb) * p.Cin;      // the voxel's tap (0, 0, 0); one 64-bit address per tile, 32-bit offsets per chunk
@@ -264,8 +272,15 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
     };
     const int64_t tstep = (int64_t)gridDim.x * 8;
     int64_t tile = (int64_t)blockIdx.x * 8 + wave;
-    if (tile < ntile) load_tile(tile);
-    for (; tile < ntile; tile += tstep) {
+    int tf = (int)((tile * 32) / HWo), rem = (int)(tile * 32 - (int64_t)tf * HWo);     // this tile's; (tfn, remn): the next tile's
+    int tfn = tf, remn = rem;
+    auto advance = [&]() {
+        int64_t rr = (int64_t)remn + tstep * 32;
+        while (rr >= HWo) { rr -= HWo; ++tfn; }
+        remn = (int)rr;
+    };
+    if (tile < ntile) load_tile(tile, tf, rem);
+    for (; tile < ntile; tile += tstep, tf = tfn, rem = remn) {
         f32x16 acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -292,7 +307,8 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
                 for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks % (PF + 1)][nb], xf, acc[nb], 0, 0, 0);
             }
         }
-        if (tile + tstep < ntile) load_tile(tile + tstep);
+        advance();
+        if (tile + tstep < ntile) load_tile(tile + tstep, tfn, remn);
         // ---- epilogue: 96 channels at a time through this wave's strip; lane -> (voxel l31, channels 32 nb + 8 rr + 4 g + e) ----
         const int64_t vox0 = tile * 32;
 #pragma unroll
@@ -305,8 +321,7 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int n = nb * 32 + 8 * rr + 4 * g;
-                        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (p.bias != nullptr) bb = *reinterpret_cast<const float4*>(p.bias + n);
+                        const float4 bb = *reinterpret_cast<const float4*>(Bs + n);
                         uint2 o;
                         o.x = pack_bf16x2(acc[nb][4 * rr + 0] + bb.x, acc[nb][4 * rr + 1] + bb.y);
                         o.y = pack_bf16x2(acc[nb][4 * rr + 2] + bb.z, acc[nb][4 * rr + 3] + bb.w);
@@ -325,8 +340,9 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
                     const int v = j / cpv, ch = j - v * cpv;
                     const int64_t mv = vox0 + v;
                     if (mv < p.M) {
-                        const int tv = (int)(mv / HWo);
-                        const int64_t vox = ((int64_t)(tv * p.ot_mul + p.ot_off)) * HWo + (mv - (int64_t)tv * HWo);
+                        int tv = tf, rv = rem + v;
+                        if (rv >= HWo) { rv -= HWo; ++tv; }
+                        const int64_t vox = ((int64_t)(tv * p.ot_mul + p.ot_off)) * HWo + rv;
                         *reinterpret_cast<uint4*>(dst + vox * p.ldc + h * 96 + ch * 8) = *reinterpret_cast<const uint4*>(strip + v * CD_STRIP_LD + ch * 8);
                     }
                 }
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int n = nb * 32 + 8 * rr + 4 * g;
-                        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + n);
+                        const float4 gm = *reinterpret_cast<const float4*>(Gs + n);
                         const float g4[4] = {gm.x, gm.y, gm.z, gm.w};
                         float v4[4];
 #pragma unroll
@@ -1118,10 +1134,10 @@ static bool conv4n_eligible(const ConvParams& p, int64_t ldc) {
 static bool conv_direct_dual_eligible(const ConvParams& p, int64_t ldc) {
     const int ksteps = (p.Ktrue + 15) / 16;
     const int wld = ksteps * 16 + 8;
-    const int lds = (p.N * wld + 8 * 32 * CD_STRIP_LD) * 2;
+    const int lds = (p.N * wld + 8 * 32 * CD_STRIP_LD) * 2 + 2 * p.N * 4;
     return p.N == 96 && ksteps <= 14 && !p.ups && p.Cin % 8 == 0 && p.kt <= 30 && p.kh <= 31 && p.kw <= 31 && p.Cin < 65536 &&
            (int64_t)(p.kt + 1) * p.Hi * p.Wi * p.Cin < (1ll << 31) && lds <= 150 * 1024 && ldc % 8 == 0 && p.M >= 4096 && p.M < (1ll << 40) &&
-           p.Ho * (int64_t)p.Wo < (1ll << 31);
+           p.Ho * (int64_t)p.Wo < (1ll << 31) && p.Ho * (int64_t)p.Wo >= 32;
 }
 
 static void conv_params(ConvParams& p, const int32_t* geom) {
@@ -1316,9 +1332,9 @@ static int conv3d_impl(const scail_bf16* x, const scail_bf16* w, const float* bi
                            p.kt <= 30 && p.kh <= 31 && p.kw <= 31 && p.Cin < 65536 &&
                            (int64_t)(p.kt + 1) * p.Hi * p.Wi * p.Cin < (1ll << 31);
         const int wld = ksteps * 16 + 8;                              // padded W row: 16 consecutive rows start in distinct 16-byte bank groups
-        const int lds = (nn * wld + 8 * 32 * CD_STRIP_LD) * 2;
+        const int lds = (nn * wld + 8 * 32 * CD_STRIP_LD) * 2 + 2 * nn * 4;        // W, the waves' strips, bias + gamma
         if (g_conv_direct && !p.ups && resid == nullptr && p.Cin % 8 == 0 && nn % 32 == 0 && shape && lds <= 150 * 1024 && ldc % 8 == 0 &&
-            (reinterpret_cast<uintptr_t>(y) & 15) == 0 && p.M >= 4096 && p.M < (1ll << 40) && p.Ho * (int64_t)p.Wo < (1ll << 31)) {
+            (reinterpret_cast<uintptr_t>(y) & 15) == 0 && p.M >= 4096 && p.M < (1ll << 40) && p.Ho * (int64_t)p.Wo < (1ll << 31) && p.Ho * (int64_t)p.Wo >= 32) {
             const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((p.M + 255) / 256, conv4_cu_count()));
             if (rn) {       // raw output + the consumer's normalised input (scail_conv3d_cl_resid_norm checked conv_direct_dual_eligible)
                 SCAIL_REQUIRE(nb == 3 && nsplit == 1 && ksteps <= 14 && y != y_norm, "conv3d: dual-output direct kernel needs 96 channels, <= 14 k-steps");
