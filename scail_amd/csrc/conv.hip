@@ -199,6 +199,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_igemm_kernel(ConvParams p) 
 //     voxel rows of neighbouring voxels (1 KB contiguous per wave instruction).
 // KS = k-steps held in registers (16-byte quad each); NB = 32-channel blocks of the output (N = 32 NB <= 192).
 // ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint4 g_conv_zero16 = {0u, 0u, 0u, 0u};     // what an out-of-range tap reads: the gathers need no branch and no zero fill
 #define CD_THREADS 512
 #define CD_STRIP_LD 104            // elements per staged voxel row: 96 channels + 8 (208 bytes: 16-byte aligned, conflict-light 8-byte writes)
 // DUAL (round 6, NB = 3: the 96 channels of a voxel in one pass): the raw output AND, at y2, SiLU(RMS_norm(bf16(raw)) * gamma) -- the stem convolution of the
@@ -261,13 +262,13 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
         const u16* xb = p.x + (((int64_t)tb * p.Hi + hb) * p.Wi + wb) * p.Cin;      // the voxel's tap (0, 0, 0); one 64-bit address per tile, 32-bit offsets per chunk
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            xr[ks] = make_uint4(0, 0, 0, 0);
-            if (ks < ksteps) {
-                const int tc = tapc[ks];
-                const unsigned ti = (unsigned)(tb + (tc >> 26)), hi = (unsigned)(hb + ((tc >> 21) & 31)), wi = (unsigned)(wb + ((tc >> 16) & 31));
-                if ((tc >> 26) != 31 && ti < (unsigned)p.Ti && hi < (unsigned)p.Hi && wi < (unsigned)p.Wi)
-                    xr[ks] = *reinterpret_cast<const uint4*>(xb + offk[ks]);
-            }
+            // every k-step loads: an out-of-range tap (padding, a k-step past Ktrue, a lane past M) reads the 16 zero bytes of g_conv_zero16 -- a select on the
+            // address instead of a divergent branch and four zero-filling moves per k-step (round 6)
+            const int tc = tapc[ks];
+            const unsigned ti = (unsigned)(tb + (tc >> 26)), hi = (unsigned)(hb + ((tc >> 21) & 31)), wi = (unsigned)(wb + ((tc >> 16) & 31));
+            const bool in = ks < ksteps && (tc >> 26) != 31 && ti < (unsigned)p.Ti && hi < (unsigned)p.Hi && wi < (unsigned)p.Wi;
+            const uint4* src = in ? reinterpret_cast<const uint4*>(xb + offk[ks]) : &g_conv_zero16;
+            xr[ks] = *src;
         }
     };
     const int64_t tstep = (int64_t)gridDim.x * 8;
@@ -282,10 +283,6 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
     if (tile < ntile) load_tile(tile, tf, rem);
     for (; tile < ntile; tile += tstep, tf = tfn, rem = remn) {
         f32x16 acc[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
         const u16* wrow = Ws + l31 * wld + g * 8;
         // W fragments two k-steps ahead of their MFMAs (hipcc otherwise issues every ds_read right in front of its MFMA and the LDS
         // latency of all KS x NB reads lines up on the critical path of a tile)
@@ -301,7 +298,12 @@ __global__ __launch_bounds__(CD_THREADS, 1) void conv_direct_kernel(ConvParams p
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) wf[(ks + PF) % (PF + 1)][nb] = *reinterpret_cast<const bf16x8*>(wrow + nb * 32 * wld + (ks + PF) * 16);
             }
-            if (ks < ksteps) {
+            if (ks == 0) {                       // (k-step 0 always exists: its MFMAs take the constant 0 as accumulator input -- no 16 x NB zeroing moves per tile)
+                const bf16x8 xf = __builtin_bit_cast(bf16x8, xr[0]);
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][nb], xf, zero, 0, 0, 0);
+            } else if (ks < ksteps) {
                 const bf16x8 xf = __builtin_bit_cast(bf16x8, xr[ks]);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks % (PF + 1)][nb], xf, acc[nb], 0, 0, 0);
