@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256, (NF == 1 ? 2 : 1)) void conv_s2_kernel(ConvPar
         for (int i = 0; i < NWL; ++i) wr[r][i] = make_uint4(0, 0, 0, 0);
     auto load_patch = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) pr[i] = psrc[i] >= 0 ? *reinterpret_cast<const uint4*>(xb + psrc[i] + c0) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < NP; ++i) pr[i] = *(psrc[i] >= 0 ? reinterpret_cast<const uint4*>(xb + psrc[i] + c0) : &g_conv_zero16);     // (no branch: padding reads a zero block)
     };
     auto store_patch = [&]() {
 #pragma unroll
